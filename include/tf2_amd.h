@@ -1,0 +1,140 @@
+/*
+ * tf2_amd.h -- C ABI of the MI355X-native drop-in for TF2's Runtime_Engine/cnn path.
+ *
+ * The reference has no plugin/FFI API for this path: it sits behind three C++ classes
+ * and a handful of free functions compiled against one network header
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it
+ * replaces (paths relative to /root/reference/Runtime_Engine/cnn).  Plain pointers and
+ * sizes only; no torch / HIP types in signatures (a stream is passed as void*).
+ *
+ * Conventions
+ *   - every function returns 0 (TF2_OK) or a negative tf2_status; it never exits the
+ *     process (the reference's checkError() -> exit(), common/src/AOCLUtils/opencl.cpp:226-250,
+ *     is deliberately not reproduced); tf2_last_error() gives the message (thread-local).
+ *   - "q" arrays hold the RUNTIME values of quantization.cpp:46, i.e. the NEGATED Q-file ints.
+ *   - device pointers are raw HIP device addresses owned by the caller (PyTorch
+ *     allocations); the library allocates no device memory in run calls.
+ */
+#ifndef TF2_AMD_H_
+#define TF2_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int tf2_status;
+enum {
+  TF2_OK = 0,
+  TF2_ERR_ARG = -1,        /* bad argument / inconsistent tables                      */
+  TF2_ERR_STATE = -2,      /* call order (e.g. run before load_model)                 */
+  TF2_ERR_SIZE = -3,       /* buffer too small / model stream length mismatch         */
+  TF2_ERR_HIP = -4,        /* HIP runtime error (message carries hipGetErrorString)   */
+  TF2_ERR_UNSUPPORTED = -5 /* layer shape not supported by any kernel                 */
+};
+
+/* One row of the network program = one row of the k* tables of <net>.h
+ * (host/inc/resnet50.h:119-1372), with the graph edges made explicit
+ * (tf2_amd.config.build_plan).                                                        */
+typedef struct tf2_layer_desc {
+  int32_t src;          /* producer of the input: -1 image, >=0 layer, <=-2 concat -(id+2) (kInputLayer) */
+  int32_t q_in_row;     /* Q-table row of the input channels (kInputLayer)               */
+  int32_t C, H, W;      /* kInputChannels, kInputHeight, kInputWidth                     */
+  int32_t N, k, stride; /* kOutputChannels, kFilterSize, kConvStride                     */
+  int32_t pad_h, pad_w, dil; /* kPadHeight, kPadWidth, (dilation, 1 in the reference)    */
+  int32_t OH, OW;       /* conv output (after conv stride)                               */
+  int32_t bias_en, bn_en, relu, ipool; /* kBiasEnable, kBnEnable, kReluEnable, kIpoolEnable */
+  int32_t pool_en, pool_S, pool_st, pool_pad; /* kPoolEnable, kPoolWindow, kPoolStride2, kPoolPad */
+  int32_t PH, PW;       /* kPoolOutputHeight/Width                                       */
+  int32_t add_src, add_relu; /* kAdditionEnable (+ DDR page plan), kAdditionReluEnable   */
+  int32_t endpool, endpool_mult; /* kEndPoolEnable; 669 for 7x7 (full_size_pool.cl:118)  */
+  int32_t concat, n_start; /* kBranchTail/kConcatLayer, kNStart                          */
+  int32_t model_C, model_k; /* filter dims in the model file (layer 0: INPUT_IMAGE_C, FIRST_FILTER_SIZE) */
+} tf2_layer_desc;
+
+typedef struct tf2_net_desc {
+  int32_t n_layers;       /* NUM_LAYER                                                   */
+  int32_t n_conv;         /* NUM_CONVOLUTIONS                                            */
+  int32_t n_q_rows;       /* NUM_Q_LAYERS                                                */
+  int32_t max_out_channel;/* MAX_OUT_CHANNEL                                             */
+  int32_t image_c, image_h, image_w; /* INPUT_IMAGE_C/H/W                                */
+  int32_t conv1_rewrite;  /* 1: layer 0 runs as 27-ch 3x3 on the 114x114 space-to-depth
+                             image (model_loader.cpp:244-257, input_loader.cpp:98-116)   */
+  int32_t n_concat;       /* number of concat tensors                                    */
+} tf2_net_desc;
+
+typedef struct tf2_net tf2_net;
+
+/* ---- misc ------------------------------------------------------------------------ */
+const char* tf2_last_error(void);
+int tf2_abi_version(void);
+/* 1 if the library was built with the gfx950 HIP kernels (always, for the shipped .so). */
+int tf2_has_device_code(void);
+
+/* ---- load-time numerics (host CPU; replace model_loader.cpp / quantization.cpp) ----- */
+/* Get_real(float, char): model_loader.cpp:98-126 */
+uint8_t tf2_get_real(float w, int8_t expand);
+/* Quantization(q, input, file): quantization.cpp:25-55.  Takes the Q-file TEXT. Fills
+ * q[n_q_rows][max_out_channel] (caller zero-fills) from the net's layer table.        */
+tf2_status tf2_quantization(const tf2_net* net, const char* q_text, size_t q_text_len,
+                            int8_t* q, size_t q_capacity, int32_t* n_values_read);
+
+/* ---- network handle (replaces NetWork::Init / InitNetwork / InitBuffer, network.cpp:22-150) */
+tf2_status tf2_net_create(const tf2_net_desc* nd, const tf2_layer_desc* layers, tf2_net** out);
+void tf2_net_destroy(tf2_net* net);
+/* runtime q table [n_q_rows][max_out_channel] as produced by tf2_quantization */
+tf2_status tf2_net_set_q(tf2_net* net, const int8_t* q, size_t n_bytes);
+/* LoadModel(file, filter_raw, bias_bn, q): model_loader.cpp:129-258.  `model` is the
+ * float32 stream of fpgamodel.bin / param.bin (already in memory).                     */
+tf2_status tf2_net_load_model(tf2_net* net, const float* model, size_t n_floats);
+/* Introspection for per-function parity tests: byte codes [N][C][k][k] of a layer
+ * (layer 0 after the conv1 rewrite: [N][27][3][3]) and its BiasBnParam (types.h:39-43). */
+tf2_status tf2_net_get_codes(const tf2_net* net, int layer, uint8_t* codes, size_t capacity, size_t* n_bytes);
+tf2_status tf2_net_get_bias_bn(const tf2_net* net, int layer, int32_t* bias, int32_t* alpha, int32_t* beta, size_t capacity);
+
+/* ---- packed device image of the weights (what the one-time RCCL broadcast moves) ---- */
+/* Options: conv kernel selection per layer class.  mode: 0 = auto (MFMA where the layer
+ * qualifies, shift-accumulate VALU kernel otherwise), 1 = force the shift-accumulate
+ * kernel for k>1 convs (MFMA for 1x1 only, the north-star split), 2 = shift kernel
+ * everywhere.                                                                           */
+tf2_status tf2_net_pack(tf2_net* net, int mode);
+size_t tf2_net_packed_size(const tf2_net* net);
+tf2_status tf2_net_packed_copy(const tf2_net* net, void* host_dst, size_t capacity);
+/* Adopt a packed image received from another rank (host copy; same tables required).    */
+tf2_status tf2_net_packed_adopt(tf2_net* net, const void* host_src, size_t n_bytes);
+/* Tell the net where the packed image lives on the device (caller copied/broadcast it). */
+tf2_status tf2_net_bind_device(tf2_net* net, const void* packed_dev, size_t n_bytes);
+
+/* ---- running (replaces Runner::Run, runner.cpp:54-198, and the OpenCL device pipeline) */
+/* keep_all != 0: every layer output gets its own buffer (per-layer parity tests).       */
+size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all);
+/* images_dev: float32 [batch][image_c][image_h][image_w] on the device (the preprocessed
+ * CHW floats LoadInputImage reads, input_loader.cpp:76-96).  Quantises with 2^Q0
+ * (runner.cpp:158-164), runs every layer, writes int8 logits [batch][N_last] (dense).   */
+tf2_status tf2_net_run(tf2_net* net, const float* images_dev, int batch, void* workspace_dev,
+                       size_t workspace_bytes, int8_t* logits_dev, void* hip_stream);
+/* Same, from already-quantised int8 images [batch][image_c][image_h][image_w].          */
+tf2_status tf2_net_run_q(tf2_net* net, const int8_t* images_q_dev, int batch, void* workspace_dev,
+                         size_t workspace_bytes, int8_t* logits_dev, void* hip_stream);
+/* After a keep_all run: copy layer `layer`'s output to the host as dense NCHW int8
+ * [batch][N][PH][PW] (or [batch][N] after an end pool).  layer == -1: the quantised,
+ * transformed network input [batch][C0][H0][W0].  Synchronises the stream.              */
+tf2_status tf2_net_read_layer(tf2_net* net, int layer, int batch, const void* workspace_dev,
+                              int8_t* host_dst, size_t capacity, void* hip_stream);
+/* Per-kernel timing hook for bench.py: records HIP events around every conv launch of
+ * the next tf2_net_run calls on `hip_stream`; tf2_net_profile_read returns, per layer,
+ * the accumulated milliseconds and launch count since profiling was enabled.            */
+tf2_status tf2_net_profile(tf2_net* net, int enable);
+tf2_status tf2_net_profile_read(tf2_net* net, float* ms_per_layer, int32_t* launches_per_layer,
+                                int32_t* kernel_kind_per_layer, int capacity);
+
+/* ---- Evaluation (network_helper.cpp:143-207): top-k with the reference's tie rule ---- */
+tf2_status tf2_topk(const int8_t* logits, const int8_t* q_last_row, int n, int k,
+                    int32_t* labels, float* features);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TF2_AMD_H_ */

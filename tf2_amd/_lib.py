@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI library (include/tf2_amd.h).
+
+The product path FAILS LOUDLY when the HIP extension is missing: there is no CPU
+fallback anywhere in tf2_amd (the CPU restatement lives in oracle/ and is test
+infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtf2amd.so")
+
+
+class Tf2Error(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"tf2_amd status {status}: {msg}")
+        self.status = status
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "src", "q_in_row", "C", "H", "W", "N", "k", "stride", "pad_h", "pad_w", "dil", "OH", "OW",
+        "bias_en", "bn_en", "relu", "ipool", "pool_en", "pool_S", "pool_st", "pool_pad", "PH", "PW",
+        "add_src", "add_relu", "endpool", "endpool_mult", "concat", "n_start", "model_C", "model_k")]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_layers", "n_conv", "n_q_rows", "max_out_channel", "image_c", "image_h", "image_w",
+        "conv1_rewrite", "n_concat")]
+
+
+def build(force: bool = False) -> str:
+    """Compile tf2_amd/libtf2amd.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "tf2_amd.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", src_dir])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension was not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C tf2_amd/csrc`). tf2_amd has no CPU fallback by design.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32p, i8p, u8p, fp = C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    L.tf2_last_error.restype = C.c_char_p
+    L.tf2_abi_version.restype = C.c_int
+    L.tf2_has_device_code.restype = C.c_int
+    L.tf2_get_real.restype = C.c_uint8
+    L.tf2_get_real.argtypes = [C.c_float, C.c_int8]
+    L.tf2_net_create.argtypes = [C.POINTER(NetDesc), C.POINTER(LayerDesc), C.POINTER(vp)]
+    L.tf2_net_destroy.argtypes = [vp]
+    L.tf2_net_destroy.restype = None
+    L.tf2_quantization.argtypes = [vp, C.c_char_p, sz, vp, sz, i32p]
+    L.tf2_net_set_q.argtypes = [vp, vp, sz]
+    L.tf2_net_load_model.argtypes = [vp, vp, sz]
+    L.tf2_net_get_codes.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
+    L.tf2_net_get_bias_bn.argtypes = [vp, C.c_int, vp, vp, vp, sz]
+    L.tf2_net_pack.argtypes = [vp, C.c_int]
+    L.tf2_net_packed_size.argtypes = [vp]
+    L.tf2_net_packed_size.restype = sz
+    L.tf2_net_packed_copy.argtypes = [vp, vp, sz]
+    L.tf2_net_packed_adopt.argtypes = [vp, vp, sz]
+    L.tf2_net_bind_device.argtypes = [vp, vp, sz]
+    L.tf2_net_workspace_size.argtypes = [vp, C.c_int, C.c_int]
+    L.tf2_net_workspace_size.restype = sz
+    L.tf2_net_run.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
+    L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
+    L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
+    L.tf2_net_profile.argtypes = [vp, C.c_int]
+    L.tf2_net_profile_read.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.tf2_topk.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+EXPORTED = [
+    "tf2_last_error", "tf2_abi_version", "tf2_has_device_code", "tf2_get_real", "tf2_quantization",
+    "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_net_get_codes",
+    "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
+    "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_run",
+    "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_topk"]
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise Tf2Error(status, lib().tf2_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,167 @@
+// conv_shift.hip -- the literal shift-accumulate convolution on the vector ALUs (gfx950).
+//
+// This is the direct restatement of the reference's PE datapath for ANY weight code:
+//   acc[n,p] = bias[n] + sum_{c,fh,fw} MUL(x, code)     MUL = +-(x << s), s in 0..31
+// (device/src/pe.cl:27-49,144-180), including the reference's quirk that a negative
+// weight negates the activation in int8, so x = -128 stays -128 (pe.cl:32-37).
+//
+// Mapping: lane = output pixel (64 consecutive pixels of the batch per block), the four
+// waves of a block take 8 output channels each, so a weight is WAVE-UNIFORM: it is
+// fetched once through the scalar cache as the integer +-2^s and the whole
+// shift-accumulate for 64 pixels is one v_mad (v_mad_i32_i24 when every shift of the
+// layer is <= 22, a 32-bit multiply-add otherwise: x * 2^s == x << s in Z/2^32).
+// For inputs that may be negative, positive weights multiply x and the magnitudes of
+// negative weights multiply xneg = (int8)(-x) (computed in registers), reproducing the
+// -128 quirk bit for bit; for post-ReLU inputs one signed weight per tap suffices.
+//
+// Input staging: per 16-channel chunk, all taps of the 64 pixels are gathered with
+// coalesced 16-byte loads into LDS (zero padding applied there, sequencer.cl:287); each
+// lane then reads its own 16 bytes per tap (ds_read_b128, lane-linear = conflict-free)
+// and unpacks them once for the 8 output channels of its wave.
+// Epilogue identical to conv_mfma.hip (bias, BN requant, ReLU, residual, 8-byte store).
+#include <hip/hip_runtime.h>
+#include "tf2_internal.h"
+
+namespace tf2 {
+
+using i32x4 = int __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int requant_i8s(int acc, int alpha, int beta, int relu) {
+  long long p = (long long)acc * (long long)alpha;
+  int t = (int)(p >> kAlphaInflat);
+  t = (int)((unsigned)t + (unsigned)beta);
+  int v = ((t >> (kInflat - 1)) + 1) >> 1;
+  v = v > 127 ? 127 : (v < -128 ? -128 : v);
+  if (relu) v = v > 0 ? v : 0;
+  return v;
+}
+
+constexpr int kMaxTaps = 49;   // up to 7x7 filters
+
+template <bool SIGNED_IN, bool MUL24>
+__global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
+  // LDS: [tap][64 pixels][16 bytes]
+  extern __shared__ __attribute__((aligned(16))) int8_t lds_raw[];
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int taps = a.k * a.k;
+  const int px0 = blockIdx.x * 64;
+  const int n0 = (blockIdx.y * 4 + wave) * 8;          // first output channel of this wave
+  const bool wave_active = n0 < a.Np;
+
+  // geometry of this lane's pixel (for the epilogue) and of the pixels this thread stages
+  int acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) acc[r] = 0;
+
+  // staging assignment: item = tap * 64 + pixel, items strided by 256 threads
+  const int n_items = taps * 64;
+
+  for (int cc = 0; cc < a.n_cchunk; cc++) {
+    __syncthreads();
+    // ---- stage x: all taps of this 16-channel chunk for the block's 64 pixels ----
+    for (int it = tid; it < n_items; it += 256) {
+      const int tap = it >> 6, pl = it & 63;
+      const int p = px0 + pl;
+      i32x4 v = {0, 0, 0, 0};
+      if (p < g.n_pix) {
+        int b = p / g.OHW;
+        int rem = p - b * g.OHW;
+        int oh = rem / g.OW, ow = rem - (rem / g.OW) * g.OW;
+        int fh = tap / a.k, fw = tap - fh * a.k;
+        int ih = oh * g.stride - g.pad_h + fh * a.dil;
+        int iw = ow * g.stride - g.pad_w + fw * a.dil;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+          const int8_t* src = a.x + ((size_t)(b * g.H * g.W + ih * g.W + iw) * g.Cp_in + cc * 16);
+          v = *reinterpret_cast<const i32x4*>(src);
+        }
+      }
+      *reinterpret_cast<i32x4*>(lds_raw + (size_t)it * 16) = v;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+    // ---- shift-accumulate ----
+    // weights: [n8 tile][cchunk][tap][half][8 n][8 c] int32
+    const int* wbase = reinterpret_cast<const int*>(a.w) +
+                       ((size_t)(n0 >> 3) * a.n_cchunk + cc) * taps * 128;
+    const int* w2base = SIGNED_IN ? reinterpret_cast<const int*>(a.w2) +
+                                        ((size_t)(n0 >> 3) * a.n_cchunk + cc) * taps * 128
+                                  : nullptr;
+    for (int tap = 0; tap < taps; tap++) {
+      const i32x4 xv = *reinterpret_cast<const i32x4*>(lds_raw + (size_t)(tap * 64 + lane) * 16);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int xs[8], xn[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          int word = xv[h * 2 + (c >> 2)];
+          xs[c] = (int)(signed char)((word >> (8 * (c & 3))) & 0xff);
+          if (SIGNED_IN) xn[c] = (int)(signed char)(-xs[c]);   // int8 negate: -(-128) == -128 (pe.cl:32-37)
+        }
+        const int* wp = wbase + (tap * 2 + h) * 64;      // wave-uniform -> scalar loads
+        const int* wq = SIGNED_IN ? w2base + (tap * 2 + h) * 64 : nullptr;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const int w = wp[r * 8 + c];
+            if (MUL24) acc[r] += __mul24(xs[c], w);
+            else acc[r] = (int)((unsigned)acc[r] + (unsigned)xs[c] * (unsigned)w);
+            if (SIGNED_IN) {
+              const int w2 = wq[r * 8 + c];
+              if (MUL24) acc[r] += __mul24(xn[c], w2);
+              else acc[r] = (int)((unsigned)acc[r] + (unsigned)xn[c] * (unsigned)w2);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (!wave_active) return;
+  const int px = px0 + lane;
+  if (px >= g.n_pix) return;
+  int q[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int v = (int)((unsigned)a.bias[n0 + r] + (unsigned)acc[r]);
+    q[r] = requant_i8s(v, a.alpha[n0 + r], a.beta[n0 + r], g.relu);
+  }
+  if (n0 + 8 > g.y_nvalid) return;                       // padding rows beyond the tensor
+  if (g.has_res) {
+    const int2 rv = *reinterpret_cast<const int2*>(a.res + (size_t)px * g.res_cp + g.res_off + n0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      int word = r < 4 ? rv.x : rv.y;
+      int rr = (int)(signed char)((word >> (8 * (r & 3))) & 0xff);
+      int s = q[r] + rr;
+      s = s > 127 ? 127 : (s < -128 ? -128 : s);
+      if (g.add_relu) s = s > 0 ? s : 0;
+      q[r] = s;
+    }
+  }
+  int2 out;
+  out.x = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
+  out.y = (q[4] & 0xff) | ((q[5] & 0xff) << 8) | ((q[6] & 0xff) << 16) | ((q[7] & 0xff) << 24);
+  *reinterpret_cast<int2*>(a.y + (size_t)px * g.y_cp + g.y_off + n0) = out;
+}
+
+int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int taps = a.k * a.k;
+  if (taps > kMaxTaps) return -2;
+  dim3 grid((a.g.n_pix + 63) / 64, (a.Np / 8 + 3) / 4);
+  size_t lds = (size_t)taps * 64 * 16;
+  if (signed_in) {
+    if (mul24) hipLaunchKernelGGL((conv_shift_kernel<true, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_shift_kernel<true, false>), grid, dim3(256), lds, s, a);
+  } else {
+    if (mul24) hipLaunchKernelGGL((conv_shift_kernel<false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_shift_kernel<false, false>), grid, dim3(256), lds, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace tf2

@@ -1,0 +1,140 @@
+// misc_kernels.hip -- the HBM-bound glue kernels of the cnn path (gfx950).
+//   prep_input : LoadInputImage/feature_trans + input quantisation
+//                (host/src/input_loader.cpp:27-118, host/src/runner.cpp:158-164) fused,
+//                writing the NHWC int8 tensor [x | xneg] the conv kernels consume.
+//   maxpool    : pool.cl:152-260 + pool_tail.cl:91-216 (zero-extended 3x3 / 2x2 max).
+//   global_avg : full_size_pool.cl:95-125.
+// All are one pass over their tensors with 16-byte (pool) or coalesced accesses.
+#include <hip/hip_runtime.h>
+#include "tf2_internal.h"
+
+namespace tf2 {
+
+using i32x4 = int __attribute__((ext_vector_type(4)));
+
+// runner.cpp:158-163: tmp = x * trans ; (int)(tmp > 0 ? tmp + 0.5 : tmp - 0.5) ; clamp.
+// (tmp +- 0.5 is evaluated in double in the reference.)
+__device__ __forceinline__ int quant_input(float x, float trans) {
+  float tmp = x * trans;
+  double t2 = tmp > 0 ? (double)tmp + 0.5 : (double)tmp - 0.5;
+  int v = (int)t2;
+  return v > 127 ? 127 : (v < -128 ? -128 : v);
+}
+
+__global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
+  // one thread per (image, output pixel, channel slot of the x half); slots >= Cl are
+  // the zero padding of the tensor's channel dimension
+  const int Cl = a.rewrite ? a.C * 9 : a.C;
+  const int Cs = a.half;
+  const long long total = (long long)a.B * a.OH * a.OW * Cs;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % Cs);
+    long long pix = idx / Cs;
+    int ow = (int)(pix % a.OW);
+    long long t = pix / a.OW;
+    int oh = (int)(t % a.OH);
+    int b = (int)(t / a.OH);
+    int ci, sr, sc;
+    if (a.rewrite) {
+      // feature_trans (input_loader.cpp:27-73): sub-channel k of image channel ci holds
+      // pad3[2*oh + roff][2*ow + coff] with (roff,coff) = k0(0,0) k1(1,0) k2(0,1) k3(1,1)
+      // k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2).
+      ci = c / 9;
+      int k = c - ci * 9;
+      int roff = k < 6 ? (k & 1) : 2;
+      int coff = k < 6 ? (k >> 1) : (k - 6);
+      sr = 2 * oh + roff - 3;
+      sc = 2 * ow + coff - 3;
+    } else {
+      ci = c; sr = oh; sc = ow;
+    }
+    int v = 0;
+    if (c < Cl && (unsigned)sr < (unsigned)a.H && (unsigned)sc < (unsigned)a.W) {
+      size_t si = ((size_t)(b * a.C + ci) * a.H + sr) * a.W + sc;
+      if (a.src_is_q) v = (int)reinterpret_cast<const int8_t*>(a.img)[si];
+      else v = quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
+    }
+    int8_t* dst = a.y + (size_t)pix * a.y_cp;
+    dst[c] = (int8_t)v;
+    dst[a.half + c] = (int8_t)(-v);          // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
+  // one thread per (output pixel, 16-channel group)
+  const long long total = (long long)a.B * a.PH * a.PW * a.C16;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int cg = (int)(idx % a.C16);
+    long long pix = idx / a.C16;
+    int pw = (int)(pix % a.PW);
+    long long t = pix / a.PW;
+    int ph = (int)(t % a.PH);
+    int b = (int)(t / a.PH);
+    int m[16];
+    const int init = a.S < 3 ? 0 : -128;      // window slots >= S stay 0 (pool.cl:177-186)
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = init;
+    for (int i = 0; i < a.S; i++)
+      for (int j = 0; j < a.S; j++) {
+        int h = ph * a.st - a.pad + i, w = pw * a.st - a.pad + j;
+        i32x4 v = {0, 0, 0, 0};               // zero beyond the valid area (pool.cl:119-140)
+        if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+          v = *reinterpret_cast<const i32x4*>(a.x + ((size_t)(b * a.H + h) * a.W + w) * a.x_cp + a.x_off + cg * 16);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          int x = (int)(signed char)((v[q >> 2] >> (8 * (q & 3))) & 0xff);
+          m[q] = x > m[q] ? x : m[q];
+        }
+      }
+    i32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      o[q] = (m[4 * q] & 0xff) | ((m[4 * q + 1] & 0xff) << 8) | ((m[4 * q + 2] & 0xff) << 16) | ((m[4 * q + 3] & 0xff) << 24);
+    *reinterpret_cast<i32x4*>(a.y + (size_t)pix * a.y_cp + a.y_off + cg * 16) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void global_avg_kernel(AvgArgs a) {
+  // one thread per (image, channel); consecutive threads = consecutive channels (coalesced)
+  const int total = a.B * a.C;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int c = idx % a.C, b = idx / a.C;
+    const int8_t* p = a.x + (size_t)b * a.HW * a.x_cp + a.x_off + c;
+    int s = 0;
+    for (int i = 0; i < a.HW; i++) s += (int)p[(size_t)i * a.x_cp];
+    s = (int)(short)s;                                   // Sreal accumulator (types.h:30)
+    int m = (((s * a.mult) >> 14) + 1) >> 1;             // full_size_pool.cl:118
+    m = m > 127 ? 127 : (m < -128 ? -128 : m);
+    a.y[(size_t)b * a.y_cp + a.y_off + c] = (int8_t)m;
+  }
+}
+
+static inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  long long cap = 256LL * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+int launch_prep_input(const PrepArgs& a, void* stream) {
+  long long total = (long long)a.B * a.OH * a.OW * a.half;
+  hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_maxpool(const PoolArgs& a, void* stream) {
+  long long total = (long long)a.B * a.PH * a.PW * a.C16;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_global_avg(const AvgArgs& a, void* stream) {
+  hipLaunchKernelGGL(global_avg_kernel, dim3(grid_for((long long)a.B * a.C)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+const char* device_last_error() { return hipGetErrorString(hipGetLastError()); }
+
+}  // namespace tf2

@@ -1,0 +1,131 @@
+// Internal declarations shared by the host side (C++) and the HIP kernels.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "../../include/tf2_amd.h"
+
+namespace tf2 {
+
+constexpr int kInflat = 15;        // host/inc/types.h:34
+constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
+constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
+constexpr uint32_t kPackVersion = 3;
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- conv kernel kinds -----------------------------------------------------------
+enum ConvKind : int32_t { KIND_NONE = 0, KIND_MFMA = 1, KIND_SHIFT = 2 };
+
+// Directory entry of the packed weight image, one per layer.  All offsets are relative
+// to the start of the image so that it can be broadcast and bound on any rank.
+struct PackLayer {
+  int32_t kind;        // ConvKind
+  int32_t TM;          // rows (output channels) per block tile: 64 or 128 (MFMA)
+  int32_t n_mtiles;    // ceil(Np / TM)
+  int32_t n_phases;    // Horner phases (MFMA)
+  int32_t nslab;       // 64-byte K slabs = ceil(taps * Cp_in / 64)
+  int32_t Np;          // padded output channels (multiple of 64 for MFMA, 8 for shift)
+  int32_t signed_in;   // input tensor is [x | xneg] (image layers)
+  int32_t Cp_in;       // channels per pixel seen by the K ordering (incl. the xneg half)
+  int32_t max_shift;   // largest shift amount in the layer (shift kernel: mul24 if <= 22)
+  int32_t n_entries;   // number of (mtile, phase, slab) weight tiles stored
+  int32_t n_cchunk;    // shift kernel: channel chunks of 16
+  int32_t pad_;
+  uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
+  uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
+  uint64_t off_entries;  // int32[n_entries] slab id
+  uint64_t off_dir;      // int32[n_mtiles][n_phases + 1] cumulative entry starts
+  uint64_t off_kinfo;    // int2[nslab * 4]  {dh | dw<<16, coff}  (coff < 0: padding segment)
+  uint64_t off_bias;     // int32[Np]
+  uint64_t off_alpha;    // int32[Np]
+  uint64_t off_beta;     // int32[Np]
+  uint64_t off_lo;       // int32[Np]  final left shift of the accumulated sum
+  uint64_t off_dshift;   // int32[n_phases][Np]  Horner shift applied when entering phase p>=1
+};
+
+struct PackHeader {
+  uint32_t magic, version;
+  uint32_t n_layers, dir_bytes;
+  uint64_t total_bytes;
+  uint64_t tables_hash;     // hash of the layer descs the image was packed for
+};
+
+// ---- device-side parameter blocks -------------------------------------------------
+struct ConvGeom {
+  int32_t H, W, Cp_in;       // input tensor geometry (pixels, bytes per pixel)
+  int32_t OH, OW, OHW;       // conv output geometry
+  int32_t stride, pad_h, pad_w;
+  int32_t n_pix;             // batch * OH * OW
+  int32_t y_cp, y_off;       // output bytes per pixel, channel offset of this layer's slice
+  int32_t y_nvalid;          // valid output channels rounded up to the store granule
+  int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
+  int32_t relu, add_relu, has_res;
+  int32_t flags;             // bit0: no permlane swap in the epilogue (debug)
+};
+
+struct ConvArgs {
+  const int8_t* x;
+  int8_t* y;
+  const int8_t* res;
+  const int8_t* w;           // MFMA: int8 tiles; SHIFT: int32 weights
+  const int8_t* w2;          // SHIFT signed: negative magnitudes
+  const int32_t* entries;
+  const int32_t* dir;
+  const int32_t* kinfo;      // 2 ints per segment
+  const int32_t* bias;
+  const int32_t* alpha;
+  const int32_t* beta;
+  const int32_t* lo;
+  const int32_t* dshift;
+  int32_t n_phases, n_mtiles, Np, nslab;
+  int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split
+  ConvGeom g;
+};
+
+struct PoolArgs {
+  const int8_t* x; int8_t* y;
+  int32_t B, H, W, x_cp, x_off;
+  int32_t PH, PW, y_cp, y_off;
+  int32_t S, st, pad, C16;   // C16: number of 16-channel groups to process
+};
+
+struct AvgArgs {
+  const int8_t* x; int8_t* y;
+  int32_t B, HW, x_cp, x_off, y_cp, y_off, C, mult;
+};
+
+struct PrepArgs {
+  const void* img; int8_t* y;
+  int32_t B, C, H, W;         // source image dims
+  int32_t OH, OW, y_cp, half; // destination dims, bytes per pixel, offset of the xneg half
+  int32_t rewrite;            // 1: 7x7/s2 space-to-depth form (27 channels on 114x114)
+  int32_t q0;                 // runtime (negated) Q of image channel 0
+  int32_t src_is_q;           // 1: source already int8
+};
+
+// kernel launchers (tf2_kernels.hip)
+int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
+int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
+int launch_maxpool(const PoolArgs& a, void* stream);
+int launch_global_avg(const AvgArgs& a, void* stream);
+int launch_prep_input(const PrepArgs& a, void* stream);
+const char* device_last_error();
+
+// ---- host model -------------------------------------------------------------------
+struct LayerModel {
+  std::vector<uint8_t> codes;               // [N][C][k][k] (layer 0 rewritten when conv1_rewrite)
+  std::vector<int32_t> bias, alpha, beta;   // BiasBnParam, types.h:39-43
+};
+
+struct Tensor {           // a device activation tensor [B][H][W][Cp]
+  int H = 0, W = 0, C = 0, Cp = 0;
+  size_t offset = 0;      // byte offset inside the workspace (per batch plan)
+  size_t bytes_per_image = 0;
+};
+
+void set_error(const std::string& s);
+uint8_t get_real(float data, int8_t expand);
+
+}  // namespace tf2

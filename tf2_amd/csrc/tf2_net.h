@@ -1,0 +1,80 @@
+// tf2_net.h -- the network handle behind the C ABI (host side).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "tf2_internal.h"
+
+namespace tf2 {
+
+struct TensorPlan {
+  int H = 0, W = 0, C = 0, Cp = 0;
+  size_t bytes = 0;        // for the planned batch
+  size_t offset = 0;
+  int last_use = -1;       // last layer index reading it (n_layers = network output)
+};
+
+struct LayerExec {
+  int in_tensor = -1;      // tensor ids into WorkPlan::tensors
+  int out_tensor = -1;     // final output of the layer (own tensor or concat tensor)
+  int conv_tensor = -1;    // where the conv kernel writes (== out_tensor unless pool/endpool)
+  int res_tensor = -1;
+  int res_off = 0;
+  int out_off = 0;         // channel offset inside out_tensor (concat slice)
+};
+
+struct WorkPlan {
+  int batch = 0;
+  bool keep_all = false;
+  std::vector<TensorPlan> tensors;
+  std::vector<LayerExec> exec;
+  int input_tensor = -1;
+  int final_tensor = -1;
+  size_t total_bytes = 0;
+};
+
+struct Net {
+  tf2_net_desc nd{};
+  std::vector<tf2_layer_desc> layers;
+  std::vector<int8_t> q;                 // [n_q_rows][max_out_channel], runtime (negated)
+  std::vector<LayerModel> models;
+  bool model_loaded = false;
+
+  // packed image (host copy) and its device binding
+  std::vector<uint8_t> packed;
+  bool packed_valid = false;
+  int pack_mode = 0;
+  const uint8_t* packed_dev = nullptr;
+  size_t packed_dev_bytes = 0;
+
+  // physical input layout of every layer (decided once from the graph)
+  struct InLayout { int Cp_in = 0; int half = 0; int signed_in = 0; };
+  std::vector<InLayout> in_layout;
+  std::vector<int> out_Cp;               // channel padding of each layer's own output tensor
+  std::vector<int> concat_C;             // channels of each concat tensor
+
+  std::map<std::pair<int, int>, WorkPlan> plans;   // (batch, keep_all) -> plan
+
+  // profiling
+  bool profiling = false;
+  std::vector<float> prof_ms;
+  std::vector<int32_t> prof_launches;
+  std::vector<std::pair<void*, void*>> prof_events;   // pending (start, stop) hipEvents
+  std::vector<int> prof_event_layer;
+
+  tf2_status init(const tf2_net_desc* nd, const tf2_layer_desc* layers);
+  tf2_status quantization(const char* text, size_t len, int8_t* q, size_t cap, int32_t* n_read) const;
+  tf2_status load_model(const float* model, size_t n_floats);
+  tf2_status pack(int mode);
+  const PackLayer* pack_layer(int l) const;
+  uint64_t tables_hash() const;
+  const WorkPlan* plan(int batch, bool keep_all);
+  tf2_status run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
+                 int8_t* logits, void* stream);
+  tf2_status read_layer(int layer, int batch, const void* ws, int8_t* dst, size_t cap, void* stream);
+  void drain_profile();
+};
+
+const std::string& last_error();
+
+}  // namespace tf2

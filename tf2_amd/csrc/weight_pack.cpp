@@ -1,0 +1,274 @@
+// weight_pack.cpp -- byte codes + BiasBnParam -> the packed device image.
+//
+// The reference re-lays filters for its PE array in FilterConvert
+// (host/src/model_loader.cpp:263-322); this is the MI355X counterpart.  Two layouts:
+//
+//  MFMA  (conv_mfma.hip)  A weight code is the integer +-2^s.  Per output channel n the
+//        shifts that occur are covered, from the largest down, by windows of 7 exponents
+//        [lo_p[n], lo_p[n]+6]; window p becomes an int8 matrix W_p[n][k] = +-2^(s-lo_p[n])
+//        (zero elsewhere).  sum_k x*2^s == sum_p (sum_k x*W_p) << lo_p[n] in Z/2^32, which
+//        the kernel evaluates Horner-style.  K is ordered (tap, physical channel) and cut
+//        into 64-byte slabs; only slabs with a non-zero weight inside an (m-tile, phase)
+//        are stored ("entries").  For image layers the input tensor is [x | xneg] and
+//        negative weights become positive magnitudes on the xneg half (pe.cl:32-37 quirk).
+//  SHIFT (conv_shift.hip) the integer +-2^s itself as int32, ordered
+//        [n/8][c/16][tap][c-half][8 n][8 c] for wave-uniform scalar loads.
+//
+// The image is position independent (offsets relative to its start) so that rank 0 can
+// broadcast it once over RCCL and every rank bind it at its own address.
+#include <algorithm>
+#include <cstring>
+#include "tf2_net.h"
+
+namespace tf2 {
+
+namespace {
+struct Blob {
+  std::vector<uint8_t>& v;
+  explicit Blob(std::vector<uint8_t>& vv) : v(vv) {}
+  uint64_t alloc(size_t bytes) {
+    size_t off = (v.size() + 255) / 256 * 256;
+    v.resize(off + bytes, 0);
+    return off;
+  }
+  template <typename T> T* at(uint64_t off) { return reinterpret_cast<T*>(v.data() + off); }
+};
+
+inline bool code_zero(uint8_t c) { return (c & 0x40) != 0; }
+inline int code_shift(uint8_t c) { return c & 0x1f; }
+inline bool code_neg(uint8_t c) { return (c & 0x80) != 0; }
+}  // namespace
+
+uint64_t Net::tables_hash() const {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  };
+  mix(&nd, sizeof nd);
+  mix(layers.data(), layers.size() * sizeof(tf2_layer_desc));
+  return h;
+}
+
+const PackLayer* Net::pack_layer(int l) const {
+  if (!packed_valid || l < 0 || l >= nd.n_layers) return nullptr;
+  return reinterpret_cast<const PackLayer*>(packed.data() + sizeof(PackHeader)) + l;
+}
+
+tf2_status Net::pack(int mode) {
+  if (!model_loaded) { set_error("tf2_net_pack: load a model first"); return TF2_ERR_STATE; }
+  if (mode < 0 || mode > 2) { set_error("tf2_net_pack: mode must be 0, 1 or 2"); return TF2_ERR_ARG; }
+  const int nl = nd.n_layers;
+  packed.clear();
+  Blob blob(packed);
+  const size_t dir_bytes = sizeof(PackHeader) + (size_t)nl * sizeof(PackLayer);
+  blob.alloc(dir_bytes);
+
+  // Can the tensor feeding layer l hold negative values (=> the -128 negate quirk matters)?
+  std::vector<int> out_signed(nl, 0);
+  std::vector<int> concat_signed(std::max(1, nd.n_concat), 0);
+  auto src_signed = [&](int src) -> int {
+    if (src == -1) return 1;
+    if (src >= 0) return out_signed[src];
+    return concat_signed[-(src + 2)];
+  };
+  for (int l = 0; l < nl; l++) {
+    const tf2_layer_desc& L = layers[l];
+    int s;
+    if (L.ipool) s = src_signed(L.src);
+    else if (L.add_src >= 0) s = L.add_relu ? 0 : 1;
+    else s = L.relu ? 0 : 1;
+    out_signed[l] = s;
+    if (L.concat >= 0 && s) concat_signed[L.concat] = 1;
+  }
+
+  for (int l = 0; l < nl; l++) {
+    const tf2_layer_desc& L = layers[l];
+    PackLayer pl{};
+    if (L.ipool) {
+      pl.kind = KIND_NONE;
+      *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
+      continue;
+    }
+    const LayerModel& m = models[l];
+    const int N = L.N, C = L.C, k = L.k, taps = k * k;
+    const InLayout& il = in_layout[l];
+    const bool in_signed = src_signed(L.src) != 0;
+    const bool is_image = L.src == -1;
+    bool use_mfma;
+    if (mode == 2) use_mfma = false;
+    else if (mode == 1) use_mfma = (k == 1);
+    else use_mfma = true;
+    if (in_signed && !is_image) use_mfma = false;     // no xneg half on mid-network tensors
+    if (taps > 49 && !use_mfma) { set_error("layer " + std::to_string(l) + ": filter larger than 7x7 needs the MFMA path"); return TF2_ERR_UNSUPPORTED; }
+
+    int max_shift = 0;
+    for (uint8_t c : m.codes) if (!code_zero(c)) max_shift = std::max(max_shift, code_shift(c));
+    pl.max_shift = max_shift;
+    pl.signed_in = in_signed ? 1 : 0;
+    pl.Cp_in = il.Cp_in;
+
+    if (use_mfma) {
+      pl.kind = KIND_MFMA;
+      const int Np = round_up(N, 64);
+      const int TM = (Np % 128 == 0) ? 128 : 64;
+      const int n_mtiles = Np / TM;
+      const int Ktot = taps * il.Cp_in;
+      const int nslab = (Ktot + 63) / 64;
+      const int Kp = nslab * 64;
+      // ---- per-row exponent windows ----
+      std::vector<std::vector<int>> row_lo(N);
+      int P = 1;
+      for (int n = 0; n < N; n++) {
+        bool present[32] = {false};
+        const uint8_t* rc = m.codes.data() + (size_t)n * C * taps;
+        for (int i = 0; i < C * taps; i++) if (!code_zero(rc[i])) present[code_shift(rc[i])] = true;
+        int top = 31;
+        while (true) {
+          while (top >= 0 && !present[top]) top--;
+          if (top < 0) break;
+          const int lo = std::max(top - 6, 0);
+          row_lo[n].push_back(lo);
+          top = lo - 1;
+        }
+        P = std::max(P, (int)row_lo[n].size());
+      }
+      // lo[p][n]; rows with fewer windows repeat their last one (Horner shift 0)
+      std::vector<int32_t> lo((size_t)P * Np, 0);
+      for (int n = 0; n < N; n++)
+        for (int p = 0; p < P; p++) {
+          const auto& r = row_lo[n];
+          lo[(size_t)p * Np + n] = r.empty() ? 0 : r[std::min<size_t>(p, r.size() - 1)];
+        }
+      // ---- dense per-phase int8 matrices ----
+      std::vector<int8_t> W((size_t)P * Np * Kp, 0);
+      for (int n = 0; n < N; n++) {
+        const auto& r = row_lo[n];
+        for (int c = 0; c < C; c++)
+          for (int t = 0; t < taps; t++) {
+            const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+            if (code_zero(code)) continue;
+            const int s = code_shift(code);
+            int p = 0;
+            while (p + 1 < (int)r.size() && s < r[p]) p++;
+            const int rel = s - r[p];
+            int kk = t * il.Cp_in + c;
+            int val = 1 << rel;
+            if (code_neg(code)) {
+              if (in_signed) kk += il.half;       // +magnitude on the xneg half
+              else val = -val;
+            }
+            W[((size_t)p * Np + n) * Kp + kk] = (int8_t)val;
+          }
+      }
+      // ---- entries ----
+      std::vector<int32_t> dir((size_t)n_mtiles * (P + 1), 0);
+      std::vector<int32_t> entries;
+      std::vector<int8_t> tiles;
+      for (int mt = 0; mt < n_mtiles; mt++) {
+        for (int p = 0; p < P; p++) {
+          dir[(size_t)mt * (P + 1) + p] = (int32_t)entries.size();
+          for (int sl = 0; sl < nslab; sl++) {
+            bool any = false;
+            for (int r = 0; r < TM && !any; r++) {
+              const int8_t* src = &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64];
+              for (int b = 0; b < 64; b++) if (src[b]) { any = true; break; }
+            }
+            if (!any) continue;
+            entries.push_back(sl);
+            const size_t base = tiles.size();
+            tiles.resize(base + (size_t)TM * 64);
+            for (int r = 0; r < TM; r++)
+              std::memcpy(&tiles[base + (size_t)r * 64], &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64], 64);
+          }
+        }
+        dir[(size_t)mt * (P + 1) + P] = (int32_t)entries.size();
+      }
+      // ---- kinfo ----
+      std::vector<int32_t> kinfo((size_t)nslab * 4 * 2, 0);
+      for (int sl = 0; sl < nslab; sl++)
+        for (int sg = 0; sg < 4; sg++) {
+          const int kk0 = sl * 64 + sg * 16;
+          const int t = kk0 / il.Cp_in, pc = kk0 % il.Cp_in;
+          int32_t* ki = &kinfo[((size_t)sl * 4 + sg) * 2];
+          if (t >= taps) { ki[0] = 0; ki[1] = -1; continue; }
+          const int dh = (t / k) * L.dil, dw = (t % k) * L.dil;
+          ki[0] = (dh & 0xffff) | (dw << 16);
+          ki[1] = pc;
+        }
+      pl.TM = TM; pl.n_mtiles = n_mtiles; pl.n_phases = P; pl.nslab = nslab; pl.Np = Np;
+      pl.n_entries = (int32_t)entries.size();
+      pl.off_w = blob.alloc(std::max<size_t>(tiles.size(), 64));
+      std::memcpy(blob.at<uint8_t>(pl.off_w), tiles.data(), tiles.size());
+      pl.off_entries = blob.alloc(std::max<size_t>(entries.size(), 1) * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_entries), entries.data(), entries.size() * 4);
+      pl.off_dir = blob.alloc(dir.size() * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_dir), dir.data(), dir.size() * 4);
+      pl.off_kinfo = blob.alloc(kinfo.size() * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_kinfo), kinfo.data(), kinfo.size() * 4);
+      std::vector<int32_t> dshift((size_t)P * Np, 0), lo_last(Np, 0);
+      for (int n = 0; n < Np; n++) {
+        for (int p = 1; p < P; p++) dshift[(size_t)p * Np + n] = lo[(size_t)(p - 1) * Np + n] - lo[(size_t)p * Np + n];
+        lo_last[n] = lo[(size_t)(P - 1) * Np + n];
+      }
+      pl.off_lo = blob.alloc((size_t)Np * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_lo), lo_last.data(), (size_t)Np * 4);
+      pl.off_dshift = blob.alloc(dshift.size() * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_dshift), dshift.data(), dshift.size() * 4);
+    } else {
+      pl.kind = KIND_SHIFT;
+      const int Np = round_up(N, 8);
+      const int n_cchunk = (C + 15) / 16;
+      if (n_cchunk * 16 > (in_signed && is_image ? il.half : il.Cp_in)) {
+        set_error("layer " + std::to_string(l) + ": channel chunks exceed the input tensor"); return TF2_ERR_ARG;
+      }
+      pl.Np = Np; pl.n_cchunk = n_cchunk; pl.nslab = 0; pl.n_phases = 1; pl.TM = 8; pl.n_mtiles = Np / 8;
+      const size_t cnt = (size_t)(Np / 8) * n_cchunk * taps * 128;
+      std::vector<int32_t> w(cnt, 0), w2(in_signed ? cnt : 0, 0);
+      for (int n = 0; n < N; n++)
+        for (int c = 0; c < C; c++)
+          for (int t = 0; t < taps; t++) {
+            const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+            if (code_zero(code)) continue;
+            const uint32_t mag = 1u << code_shift(code);
+            const size_t idx = (((size_t)(n >> 3) * n_cchunk + (c >> 4)) * taps + t) * 128 +
+                               (size_t)((c >> 3) & 1) * 64 + (size_t)(n & 7) * 8 + (c & 7);
+            if (code_neg(code)) {
+              if (in_signed) w2[idx] = (int32_t)mag;
+              else w[idx] = (int32_t)(0u - mag);
+            } else {
+              w[idx] = (int32_t)mag;
+            }
+          }
+      pl.off_w = blob.alloc(cnt * 4);
+      std::memcpy(blob.at<uint8_t>(pl.off_w), w.data(), cnt * 4);
+      if (in_signed) {
+        pl.off_w2 = blob.alloc(cnt * 4);
+        std::memcpy(blob.at<uint8_t>(pl.off_w2), w2.data(), cnt * 4);
+      }
+    }
+    // ---- per-channel epilogue parameters (padded rows: all zero => output 0) ----
+    {
+      const int Np = pl.Np;
+      std::vector<int32_t> b(Np, 0), al(Np, 0), be(Np, 0);
+      std::copy(m.bias.begin(), m.bias.end(), b.begin());
+      std::copy(m.alpha.begin(), m.alpha.end(), al.begin());
+      std::copy(m.beta.begin(), m.beta.end(), be.begin());
+      pl.off_bias = blob.alloc((size_t)Np * 4); std::memcpy(blob.at<uint8_t>(pl.off_bias), b.data(), (size_t)Np * 4);
+      pl.off_alpha = blob.alloc((size_t)Np * 4); std::memcpy(blob.at<uint8_t>(pl.off_alpha), al.data(), (size_t)Np * 4);
+      pl.off_beta = blob.alloc((size_t)Np * 4); std::memcpy(blob.at<uint8_t>(pl.off_beta), be.data(), (size_t)Np * 4);
+    }
+    *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
+  }
+  blob.alloc(0);
+  PackHeader h{};
+  h.magic = kPackMagic; h.version = kPackVersion; h.n_layers = (uint32_t)nl; h.dir_bytes = (uint32_t)dir_bytes;
+  h.total_bytes = packed.size(); h.tables_hash = tables_hash();
+  *blob.at<PackHeader>(0) = h;
+  packed_valid = true;
+  pack_mode = mode;
+  packed_dev = nullptr; packed_dev_bytes = 0;
+  return TF2_OK;
+}
+
+}  // namespace tf2

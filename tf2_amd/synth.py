@@ -1,0 +1,106 @@
+"""Seeded synthetic inputs in the reference's own file formats.
+
+The trained weight files (param.bin / fpgamodel.bin) are not part of the reference
+repository (Runtime_Engine/cnn/host/model/README:1-7), so parity and benchmarks use
+INQ-like synthetic weights written in the exact LoadModel stream order
+(model_loader.cpp:139-213; writer caffe2fpga.cpp:91-113): per layer filters
+[N][C][k][k] float32, then [bias], then [mean, variance, scale_factor(1), gamma, beta].
+
+Weights follow the INQ statistics the reference documents (TransForm_Kit/Compression/
+compress_net/core/compress_train_eval.py:54, 4bit_data_format.txt): every layer has 7
+magnitudes 2^e_max ... 2^(e_max-6) plus zero, random sign, ~10 % zeros.  BN statistics
+are chosen so that activations stay inside the int8 range without saturating
+everywhere (variance = the conv output's expected variance).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import config as cfg
+
+
+def synth_q_values(tables: cfg.NetTables, seed: int = 0, lo: int = 2, hi: int = 5, spread: int = 1) -> np.ndarray:
+    """Q-file ints (file order, quantization.cpp:36-53) for networks without a shipped Q
+    file: per tensor a base Q in [lo,hi] with per-channel jitter of `spread`; tensors that
+    are added together (residual) share one Q vector, as in the shipped resnet50_Q."""
+    rng = np.random.default_rng(seed)
+    plan = cfg.build_plan(tables)
+    rows: Dict[int, np.ndarray] = {}
+    vals: List[int] = [2, 2, 2][:3]
+    for L in plan:
+        if L.ipool:
+            continue
+        if L.add_src >= 0 and L.add_src in rows and rows[L.add_src].size == L.N:
+            r = rows[L.add_src]
+        else:
+            base = int(rng.integers(lo, hi + 1))
+            r = np.clip(base - rng.integers(0, spread + 1, size=L.N), 0, 7)
+            if L.index == len(plan) - 1:
+                r = np.full(L.N, base)
+        rows[L.index] = r
+    # a residual source must carry the same Q as the layer that adds onto it
+    for L in plan:
+        if L.add_src >= 0 and not plan[L.add_src].ipool:
+            rows[L.add_src] = rows[L.index]
+    for L in plan:
+        if not L.ipool:
+            vals.extend(int(v) for v in rows[L.index])
+    return np.asarray(vals, np.int32)
+
+
+def q_text(vals) -> bytes:
+    return ("\n".join(str(int(v)) for v in vals) + "\n").encode()
+
+
+def synth_model(tables: cfg.NetTables, q_vals, seed: int = 0, zero_frac: float = 0.1,
+                dtype=np.float32) -> np.ndarray:
+    """float32 model stream in LoadModel order."""
+    rng = np.random.default_rng(seed + 1000)
+    plan = cfg.build_plan(tables)
+    out: List[np.ndarray] = []
+    for L in plan:
+        fan_in = L.model_C * L.model_k * L.model_k
+        if not L.ipool:
+            e_max = -int(rng.integers(1, 5))                     # 2^-1 .. 2^-4
+            if not L.bn_en:
+                # no BN to normalise: scale the weights so the real-unit output RMS is ~1
+                rin0 = 25.0 if L.src == -1 else 1.0
+                e_max = int(np.clip(np.round(-0.5 * np.log2(0.19 * fan_in * rin0 * rin0)), -8, -1))
+            lev = rng.integers(0, 7, size=(L.N, fan_in))
+            mag = np.ldexp(1.0, e_max - lev).astype(np.float32)
+            sign = np.where(rng.random((L.N, fan_in)) < 0.5, -1.0, 1.0).astype(np.float32)
+            w = mag * sign
+            w[rng.random((L.N, fan_in)) < zero_frac] = 0.0
+            out.append(w.ravel())
+            row_energy = (w.astype(np.float64) ** 2).sum(axis=1)
+        else:
+            row_energy = np.ones(L.N)
+        if L.bias_en:
+            out.append(rng.uniform(-0.5, 0.5, size=L.N).astype(np.float32))
+        if L.bn_en:
+            # real-unit input RMS: ~25 for the image layer (8-bit image data), ~1 elsewhere
+            rin = 25.0 if L.src == -1 else 1.0
+            var = np.maximum(row_energy * rin * rin, 1e-3) * rng.uniform(0.7, 1.4, size=L.N)
+            mean = rng.normal(0, 0.05, size=L.N) * np.sqrt(var)
+            gamma = rng.uniform(0.5, 1.5, size=L.N)
+            beta = rng.uniform(-0.5, 0.5, size=L.N)
+            out.append(mean.astype(np.float32)); out.append(var.astype(np.float32))
+            out.append(np.asarray([1.0], np.float32))
+            out.append(gamma.astype(np.float32)); out.append(beta.astype(np.float32))
+    model = np.concatenate(out).astype(dtype)
+    assert model.size == cfg.model_float_count(tables)
+    return model
+
+
+def synth_images(tables: cfg.NetTables, batch: int, seed: int = 0, kind: str = "float") -> np.ndarray:
+    """Preprocessed CHW images like the shipped resnet50_data_label_100.bin (mean-subtracted
+    0..255 data, range about -126..154).  kind="int8": already quantised, uniform over the
+    whole int8 range (exercises the -128 negate quirk)."""
+    rng = np.random.default_rng(seed + 2000)
+    C, H, W = int(tables["INPUT_IMAGE_C"]), int(tables["INPUT_IMAGE_H"]), int(tables["INPUT_IMAGE_W"])
+    if kind == "int8":
+        return rng.integers(-128, 128, size=(batch, C, H, W)).astype(np.int8)
+    x = rng.normal(0.0, 45.0, size=(batch, C, H, W))
+    return np.clip(x, -126.0, 154.0).astype(np.float32)
