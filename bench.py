@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- ResNet50 INT4w/INT8a images/s on N MI355X (BASELINE.json metric).
+
+One process per GPU (torchrun contract), batches sharded with no data-path collective (weak
+scaling: every rank runs `--batch` images per step); the packed weights are broadcast once
+over RCCL before timing.  A "step" = one pass of the whole hot path over one batch already
+resident in HBM: input quantisation + space-to-depth, all 54 layers, logits copy.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and
+`cpu_baseline` are defined."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def layer_ops(plan):
+    """algorithmic int-ops (2/MAC) and activation bytes per image, per layer."""
+    rows = []
+    for L in plan:
+        macs = 0 if L.ipool else L.N * L.C * L.k * L.k * L.OH * L.OW
+        rd = L.C * L.H * L.W
+        wr = L.N * (1 if L.endpool else L.PH * L.PW)
+        res = L.N * L.PH * L.PW if L.add_src >= 0 else 0
+        cls = "fc" if (L.H == 1 and L.W == 1) else ("conv1" if L.src == -1 else ("1x1" if L.k == 1 else f"{L.k}x{L.k}"))
+        rows.append(dict(ops=2 * macs, bytes=rd + wr + res, cls=cls))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto (MFMA), 1 north-star split, 2 shift only")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra-batches", type=str, default="1,64", help="also time these per-GPU batch sizes")
+    args = ap.parse_args()
+
+    import torch
+    from tf2_amd import config as cfg, dist as tdist, network, synth, _lib
+    import ctypes as C
+
+    rank, world = tdist.init_process_group()
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    tables = cfg.resnet50_tables()
+    plan = cfg.build_plan(tables)
+    qfile = os.path.join(ROOT, "tests", "golden", "resnet50_Q")
+    qv = np.loadtxt(qfile, dtype=np.int32)
+    model = synth.synth_model(tables, qv, seed=0) if rank == 0 else None
+    net = network.NetWork(tables)
+    tdist.broadcast_network(net, model, qfile, device, pack_mode=args.mode)
+    runner = network.Runner(None, net)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def timed(batch, steps, warmup):
+        x = torch.from_numpy(synth.synth_images(tables, batch, seed=100 + rank)).to(device)
+        for _ in range(warmup):
+            runner.run_batch(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.run_batch(x)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, x
+
+    dt, x = timed(args.batch, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    sweep = {}
+    for b in [int(v) for v in args.extra_batches.split(",") if v.strip()]:
+        if b == args.batch:
+            continue
+        d2, _ = timed(b, max(3, args.steps // 2), 2)
+        sweep[str(b)] = round(world * b * max(3, args.steps // 2) / d2, 1)
+
+    # ---- roofline: live per-layer HIP-event timing on the launch stream (C-side hook) ----
+    lo = layer_ops(plan)
+    prof_steps = 5
+    _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
+    for _ in range(prof_steps):
+        runner.run_batch(x)
+    torch.cuda.synchronize(device)
+    ms = np.zeros(len(plan), np.float32); nl = np.zeros(len(plan), np.int32); kinds = np.zeros(len(plan), np.int32)
+    _lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kinds.ctypes.data, len(plan)))
+    _lib.check(_lib.lib().tf2_net_profile(net._h, 0))
+    per_layer_ms = ms / np.maximum(nl, 1)
+    classes = {}
+    for i, L in enumerate(plan):
+        c = classes.setdefault(lo[i]["cls"], dict(ops=0, bytes=0, ms=0.0, kernel=set()))
+        c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
+        c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift"}[int(kinds[i])])
+    PEAK_I8 = 5000.0    # TOP/s dense int8 MFMA (MI355X_MICROARCH.md: ~2x the 2.5 PF bf16 dense peak)
+    PEAK_HBM = 8000.0   # GB/s
+    per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), ms=round(v["ms"], 4),
+                         tops=round(v["ops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                         frac_int8_peak=round(v["ops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_I8, 4) if v["ms"] > 0 else None,
+                         gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,
+                         frac_hbm_peak=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4) if v["ms"] > 0 else None)
+                 for k, v in classes.items()}
+    # dominant kernel = the MFMA conv kernel: all its launches of one step
+    mf = [i for i in range(len(plan)) if kinds[i] == 1 and not plan[i].pool_en and not plan[i].endpool]
+    dom_ops = sum(lo[i]["ops"] for i in mf) * args.batch
+    dom_ms = float(sum(per_layer_ms[i] for i in mf))
+    if mf and dom_ms > 0:
+        achieved = dom_ops / (dom_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="conv_mfma_kernel", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
+                        frac=round(achieved / PEAK_I8, 4), traffic=None, launches_per_step=len(mf),
+                        avg_launch_us=round(dom_ms / len(mf) * 1e3, 2),
+                        note="sum of algorithmic int8 ops of the step's conv_mfma launches / sum of their HIP-event durations")
+    else:
+        sh = [i for i in range(len(plan)) if kinds[i] == 2]
+        dom_ops = sum(lo[i]["ops"] for i in sh) * args.batch
+        dom_ms = float(sum(per_layer_ms[i] for i in sh))
+        achieved = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        roofline = dict(bound="mfma", kernel="conv_shift_kernel", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
+                        frac=round(achieved / PEAK_I8, 4), traffic=None, launches_per_step=len(sh))
+    total_bytes = sum(r["bytes"] for r in lo) * args.batch
+    hbm_gbps = total_bytes / (ms_per_step * 1e-3) / 1e9
+
+    # ---- CPU baseline: the oracle (restated reference CPU path) on the host cores, rank 0, N=1 ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import netref, oracle as O
+        ref = netref.RefNet(tables, qv, model)
+        n_done, t_cpu = 0, 0.0
+        imgs = synth.synth_images(tables, 64, seed=100)
+        chunk = max(1, min(8, O.num_threads()))
+        first_logits = None
+        while t_cpu < args.cpu_seconds and n_done + chunk <= 64:
+            t0 = time.perf_counter()
+            outs = ref.run(imgs[n_done:n_done + chunk])
+            t_cpu += time.perf_counter() - t0
+            if first_logits is None:
+                first_logits = ref.logits(outs)
+            n_done += chunk
+        # parity gate: the GPU logits of the same images equal the oracle's
+        got = runner.run_batch(torch.from_numpy(imgs[:first_logits.shape[0]]).to(device)).cpu().numpy()
+        parity = bool((got == first_logits).all())
+        cpu = dict(value=round(n_done / t_cpu, 3), unit="images/s", cores=O.num_threads(), kind="port",
+                   sample=f"{n_done} synthetic 224x224 images, same ResNet50 weights/Q, oracle/tf2_oracle.c (OpenMP) in {t_cpu:.1f} s",
+                   parity_with_gpu_logits=parity)
+
+    if rank == 0:
+        line = dict(metric="images/sec ResNet50 INT4w/INT8a", value=round(value, 1), unit="images/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4), higher_is_better=True,
+                    scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
+                    config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
+                                         f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
+                                global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode),
+                    roofline=roofline, cpu_baseline=cpu,
+                    hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
+                             bytes_per_image=sum(r["bytes"] for r in lo)),
+                    per_layer_class=per_class, images_per_s_by_batch=sweep)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

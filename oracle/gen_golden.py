@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- generates tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python oracle/gen_golden.py
+
+What it writes (all data: inputs + expected outputs, never reference source text):
+  tables_<net>.json        every k* table of the shipped resnet50/googlenet/resnet50_pruned
+                           headers and of the header TF2_auto_config generates from the shipped
+                           fpganetwork.bin, dumped by compiling oracle/ref_dump_tables.cpp
+                           against the reference headers (oracle/Makefile).
+  fpganetwork_resnet50.bin, resnet50_Q, googlenet_Q, resnet50_pruned_Q,
+  resnet50_data_label_100.bin, resnet50_fc1000_label_100.bin
+                           the data files the reference itself ships as its test fixtures.
+  ref_host.npz             outputs of the reference's own compiled host functions
+                           (oracle/_ref/libtf2ref_*.so): Get_real, LoadModel (codes / BiasBnParam,
+                           as CRCs + small layers in full, on the seeded synthetic model of
+                           tf2_amd.synth), filter_trans, feature_trans, Quantization, Evaluation.
+  ref_pyemu.npz            outputs of the reference's Python FPGA emulator functions
+                           (TransForm_Kit/Quantization/debug/...Batch-2.py: Conv2dInt8, BN, FC),
+                           AST-extracted and executed here.
+"""
+import ast
+import ctypes as C
+import json
+import os
+import shutil
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+RE = REF + "/Runtime_Engine"
+OUT = os.path.join(ROOT, "tests", "golden")
+REFOUT = os.path.join(HERE, "_ref")
+
+from tf2_amd import config as cfg, synth  # noqa: E402
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+class BiasBn(C.Structure):
+    _fields_ = [("bias", C.c_int32), ("alpha", C.c_int32), ("beta", C.c_int32)]
+
+
+def ref_lib(net):
+    L = C.CDLL(os.path.join(REFOUT, f"libtf2ref_{net}.so"))
+    L._Z8Get_realfc.restype = C.c_char
+    L._Z8Get_realfc.argtypes = [C.c_float, C.c_char]
+    return L
+
+
+def gen_tables_and_data():
+    for net in ("resnet50", "googlenet", "resnet50_pruned", "gen_resnet50"):
+        shutil.copy(os.path.join(REFOUT, f"tables_{net}.json"), os.path.join(OUT, f"tables_{net}.json"))
+    shutil.copy(RE + "/TF2_auto_config/examples/resnet50/fpganetwork.bin", os.path.join(OUT, "fpganetwork_resnet50.bin"))
+    for f in ("resnet50_Q", "googlenet_Q", "resnet50_pruned_Q"):
+        shutil.copy(RE + "/cnn/host/model/" + f, os.path.join(OUT, f))
+    shutil.copy(RE + "/cnn/host/test_images/resnet50_data_label_100.bin", os.path.join(OUT, "resnet50_data_label_100.bin"))
+    shutil.copy(RE + "/cnn/host/verify/resnet50_fc1000_label_100.bin", os.path.join(OUT, "resnet50_fc1000_label_100.bin"))
+
+
+def gen_ref_host():
+    out = {}
+    L = ref_lib("resnet50")
+    # ---- Get_real ------------------------------------------------------------------
+    rng = np.random.default_rng(7)
+    vals = [0.0, 1e-6, -1e-6, 9.9e-6, 1.01e-5, 0.3, -0.3, 1.5, -2.0, 3.0, 0.75, 1e-3]
+    for i in range(0, 17):
+        for s in (1.0, -1.0):
+            for f in (1.0, 0.9901, 0.9899, 1.0099, 1.0101, 0.995, 1.005):
+                vals.append(s * f * 2.0 ** (-i))
+    vals += list(rng.normal(0, 0.2, 200))
+    vals = np.asarray(vals, np.float32)
+    expands = np.asarray(list(range(-3, 32)) + [40, 100, 127, -128], np.int8)
+    gr = np.empty((vals.size, expands.size), np.uint8)
+    for i, v in enumerate(vals):
+        for j, e in enumerate(expands):
+            r = L._Z8Get_realfc(C.c_float(float(v)), C.c_char(int(e) & 0xff))
+            gr[i, j] = r[0] if isinstance(r, bytes) else (int(r) & 0xff)
+    out.update(getreal_vals=vals, getreal_expands=expands, getreal_codes=gr)
+
+    # ---- Quantization + LoadModel on the seeded synthetic ResNet50 model -----------------
+    tables = cfg.parse_net_header(RE + "/cnn/host/inc/resnet50.h")
+    plan = cfg.build_plan(tables)
+    NL, MAXC = 54, 2048
+    q = np.zeros((55, MAXC), np.int8)
+    dummy = np.zeros(16, np.float32)
+    qfile = (RE + "/cnn/host/model/resnet50_Q").encode()
+    L._Z12QuantizationPcPfS_(q.ctypes.data_as(C.c_void_p), dummy.ctypes.data_as(C.c_void_p), C.c_char_p(qfile))
+    out.update(q_resnet50_crc=np.asarray([crc(q)], np.uint32), q_resnet50_rows=q[[0, 1, 2, 5, 44, 54]].copy())
+    qv = np.loadtxt(RE + "/cnn/host/model/resnet50_Q", dtype=np.int32)
+    model = synth.synth_model(tables, qv, seed=0)
+    MAX_FILTER = 262144 * 64
+    filt = np.full(NL * MAX_FILTER, 0x40, np.uint8)
+    bb = (BiasBn * (NL * 2048))()
+    with tempfile.TemporaryDirectory() as td:
+        mp = os.path.join(td, "model.bin")
+        model.tofile(mp)
+        L._Z9LoadModelPcS_P11BiasBnParamS_(C.c_char_p(mp.encode()), filt.ctypes.data_as(C.c_void_p), bb, q.ctypes.data_as(C.c_void_p))
+    bba = np.frombuffer(bb, dtype=np.int32).reshape(NL, 2048, 3)
+    codes_crc, bias_crc, alpha_crc, beta_crc = [], [], [], []
+    small = {}
+    for l, Lp in enumerate(plan):
+        n_codes = Lp.N * Lp.C * Lp.k * Lp.k
+        c = filt[l * MAX_FILTER: l * MAX_FILTER + n_codes]
+        codes_crc.append(crc(c))
+        bias_crc.append(crc(bba[l, :Lp.N, 0])); alpha_crc.append(crc(bba[l, :Lp.N, 1])); beta_crc.append(crc(bba[l, :Lp.N, 2]))
+        if l in (0, 2, 53):
+            small[f"lm_codes_{l}"] = c.copy() if l != 53 else c[:64 * 2048].copy()
+            small[f"lm_bias_{l}"] = bba[l, :Lp.N, 0].copy(); small[f"lm_alpha_{l}"] = bba[l, :Lp.N, 1].copy()
+            small[f"lm_beta_{l}"] = bba[l, :Lp.N, 2].copy()
+    out.update(lm_seed=np.asarray([0]), lm_codes_crc=np.asarray(codes_crc, np.uint32), lm_bias_crc=np.asarray(bias_crc, np.uint32),
+               lm_alpha_crc=np.asarray(alpha_crc, np.uint32), lm_beta_crc=np.asarray(beta_crc, np.uint32), **small)
+    del filt
+
+    # ---- filter_trans --------------------------------------------------------------------
+    planes = rng.integers(0, 256, size=(16, 49)).astype(np.uint8)
+    ft = np.zeros((16, 81), np.uint8)          # LoadModel pre-clears with memset(0) (model_loader.cpp:246)
+    for i in range(16):
+        L._Z12filter_transPcS_(planes[i].ctypes.data_as(C.c_void_p), ft[i].ctypes.data_as(C.c_void_p))
+    out.update(ft_in=planes, ft_out=ft)
+
+    # ---- feature_trans / LoadInputImage --------------------------------------------------
+    raw = np.zeros(3 * 224 * 224 * 2, np.float32)
+    inp = np.zeros(27 * 114 * 114, np.float32)
+    imgf = (RE + "/cnn/host/test_images/resnet50_data_label_100.bin").encode()
+    L._Z14LoadInputImagePcPfS0_i(C.c_char_p(imgf), inp.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p), 0)
+    out.update(lii_crc=np.asarray([crc(inp)], np.uint32), lii_sample_idx=np.arange(0, inp.size, 9973), lii_sample=inp[::9973].copy())
+    rimg = rng.normal(0, 50, size=(224 * 224,)).astype(np.float32)
+    fo = np.zeros(9 * 115 * 115 + 2048, np.float32)
+    L._Z13feature_transPfS_(rimg.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p))
+    f9 = fo[:9 * 115 * 115].reshape(9, 115, 115)[:, :114, :114]
+    out.update(ftr_seed_plane=rimg, ftr_out_crc=np.asarray([crc(np.ascontiguousarray(f9))], np.uint32))
+
+    # ---- Evaluation (top-5 with ties) ----------------------------------------------------
+    ev_logits, ev_labels = [], []
+    OUTPUT_OFFSET = int(tables["OUTPUT_OFFSET"])
+    ddr_base = int(tables["kDDRWriteBase"][53]) * 128
+    qE = np.zeros((55, MAXC), np.int8)
+    qE[54, :1000] = -np.asarray(rng.integers(0, 4, 1000), np.int8)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            for case in range(6):
+                lg = rng.integers(-128, 128, 1000).astype(np.int8)
+                if case >= 3:
+                    lg = rng.integers(-5, 6, 1000).astype(np.int8)      # many ties
+                buf = np.zeros(2 * OUTPUT_OFFSET + 2048 * 8 + ddr_base + 1024, np.int8)
+                for n in range(1000):
+                    buf[ddr_base + OUTPUT_OFFSET + (n // 16) * 128 + (n % 16)] = lg[n]
+                lab = np.zeros(5, np.int32)
+                L._Z10EvaluationiPcS_Pi(0, qE.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p))
+                ev_logits.append(lg); ev_labels.append(lab.copy())
+        finally:
+            os.chdir(cwd)
+    out.update(ev_q=qE[54, :1000].copy(), ev_logits=np.stack(ev_logits), ev_labels=np.stack(ev_labels))
+
+    # ---- GoogLeNet Quantization (concat mirroring, ipool rows) ---------------------------
+    G = ref_lib("googlenet")
+    gt = cfg.parse_net_header(RE + "/cnn/host/inc/googlenet.h")
+    gq = np.zeros((int(gt["NUM_Q_LAYERS"]), int(gt["MAX_OUT_CHANNEL"])), np.int8)
+    G._Z12QuantizationPcPfS_(gq.ctypes.data_as(C.c_void_p), dummy.ctypes.data_as(C.c_void_p),
+                             C.c_char_p((RE + "/cnn/host/model/googlenet_Q").encode()))
+    out.update(q_googlenet=gq)
+    np.savez_compressed(os.path.join(OUT, "ref_host.npz"), **out)
+
+
+def gen_pyemu():
+    np.lib.pad = np.pad
+    src = open(REF + "/TransForm_Kit/Quantization/debug/Pytorch-ResNet50-Log2QuantizeLoad-FPGA_Quantize-Batch-2.py").read()
+    tree = ast.parse(src)
+    want = {"Conv2dInt8", "BN", "FC"}
+    mod = ast.Module([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], [])
+    import torch
+    ns = {"np": np, "torch": torch, "print": lambda *a, **k: None}
+    exec(compile(mod, "ref_debug", "exec"), ns)
+    rng = np.random.default_rng(11)
+    out = {}
+    for idx, (Cc, N, H, k, stride, pad) in enumerate([(8, 6, 9, 3, 1, 1), (16, 4, 8, 1, 1, 0), (5, 7, 11, 3, 2, 1), (3, 4, 12, 5, 1, 2)]):
+        x = rng.integers(-127, 128, size=(2, Cc, H, H)).astype(np.int8)        # no -128 (Appendix C-1)
+        shift = rng.integers(0, 21, size=(N, Cc, k, k)).astype(np.int32)
+        sign = rng.choice(np.asarray([-1, 0, 1], np.int8), size=(N, Cc, k, k), p=[0.45, 0.1, 0.45]).astype(np.int8)
+        acc = ns["Conv2dInt8"](x, shift, sign, stride, pad)
+        out[f"conv{idx}_x"] = x; out[f"conv{idx}_shift"] = shift; out[f"conv{idx}_sign"] = sign
+        out[f"conv{idx}_geom"] = np.asarray([stride, pad], np.int32); out[f"conv{idx}_acc"] = np.asarray(acc, np.int32)
+    # BN: float emulation vs the integer requant -- keep cases away from .5 ties
+    N = 64
+    Qout = rng.integers(0, 6, N).astype(np.int8)
+    alpha = rng.uniform(0.02, 2.0, N).astype(np.float32)
+    beta = rng.uniform(-1.5, 1.5, N).astype(np.float32)
+    acc = rng.integers(-(1 << 24), 1 << 24, size=(1, N, 6, 6)).astype(np.int32)
+    ns.update(layer_count=0, layer_name_binQ=["k"], Q={"k": [int(v) for v in Qout]}, INFLAT=15)
+    y = ns["BN"](acc, np.zeros(N, np.float32), alpha, beta)
+    exact = (alpha.astype(np.float64)[None, :, None, None] * acc.astype(np.float64) +
+             beta.astype(np.float64)[None, :, None, None] * 2.0 ** (Qout.astype(np.float64) + 15)[None, :, None, None]) * 2.0 ** -15
+    frac = np.abs(exact - np.floor(exact) - 0.5)
+    safe = (frac > 0.02) & (np.abs(exact) < 120)
+    out.update(bn_acc=acc, bn_alpha=alpha, bn_beta=beta, bn_q=Qout, bn_y=np.asarray(y, np.float32), bn_safe=safe)
+    # FC
+    ns["BatchSize"] = 1
+    xf = rng.integers(0, 128, size=(1, 96)).astype(np.int8)
+    sh = rng.integers(0, 16, size=(10, 96)).astype(np.int32)
+    sg = rng.choice(np.asarray([-1, 0, 1], np.int8), size=(10, 96)).astype(np.int8)
+    bias = rng.integers(-(1 << 18), 1 << 18, 10).astype(np.float32)
+    yf = ns["FC"](xf, sh, sg, bias).numpy()
+    out.update(fc_x=xf, fc_shift=sh, fc_sign=sg, fc_bias=bias, fc_y=yf.astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, "ref_pyemu.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    gen_tables_and_data()
+    gen_ref_host()
+    gen_pyemu()
+    print("golden fixtures written to", OUT)

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CPU-side prerequisites: the oracle (plain C) and the C-ABI library (host entry points work
+    # without a GPU; hipcc cross-compiles gfx950).  Built once per session if stale/missing.
+    from oracle import oracle as O
+    O.build()
+    from tf2_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

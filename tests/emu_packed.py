@@ -1,0 +1,131 @@
+"""TEST INFRASTRUCTURE: a numpy model of what the HIP conv kernels compute FROM THE PACKED
+IMAGE (tf2_amd/csrc/weight_pack.cpp layouts), used on the CPU to check the packing logic
+(exponent windows, Horner shifts, slab lists, kinfo gather, [x|xneg] image layout) against
+the oracle before anything runs on a GPU.  It mirrors conv_mfma.hip / conv_shift.hip's
+data flow, not their scheduling."""
+import numpy as np
+
+HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir_bytes", "<u4"),
+                ("total_bytes", "<u8"), ("tables_hash", "<u8")])
+PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
+                                     "max_shift", "n_entries", "n_cchunk", "pad_")] +
+              [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
+                                    "off_alpha", "off_beta", "off_lo", "off_dshift")])
+
+
+def parse(blob: np.ndarray):
+    h = np.frombuffer(blob[:HDR.itemsize].tobytes(), HDR)[0]
+    n = int(h["n_layers"])
+    pls = np.frombuffer(blob[HDR.itemsize:HDR.itemsize + n * PL.itemsize].tobytes(), PL)
+    assert int(h["dir_bytes"]) == HDR.itemsize + n * PL.itemsize
+    return h, pls
+
+
+def i32(blob, off, n):
+    return np.frombuffer(blob[off:off + 4 * n].tobytes(), "<i4")
+
+
+def requant(acc, alpha, beta, relu):
+    acc = acc.astype(np.int64)
+    t = ((acc * alpha.astype(np.int64)) >> 20).astype(np.int64)
+    t = ((t + 2 ** 31) % 2 ** 32 - 2 ** 31)                 # (int) truncation
+    t = ((t + beta.astype(np.int64) + 2 ** 31) % 2 ** 32 - 2 ** 31)
+    v = ((t >> 14) + 1) >> 1
+    v = np.clip(v, -128, 127)
+    if relu:
+        v = np.maximum(v, 0)
+    return v.astype(np.int8)
+
+
+def nhwc(x_nchw, Cp, signed_half=None):
+    """[B,C,H,W] int8 -> [B,H,W,Cp]; with signed_half: [x | (int8)(-x)] halves."""
+    B, C, H, W = x_nchw.shape
+    t = np.zeros((B, H, W, Cp), np.int8)
+    t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))
+    if signed_half is not None:
+        t[..., signed_half:signed_half + C] = (-t[..., :C].astype(np.int16)).astype(np.int8)
+    return t
+
+
+def conv_from_packed(blob, pl, L, x_t, res=None):
+    """L: LayerSpec.  x_t: input tensor [B,H,W,Cp_in] int8.  Returns conv-stage output NCHW
+    [B,N,OH,OW] after requant/relu/residual (before pool / global average)."""
+    B, H, W, Cp = x_t.shape
+    assert Cp == int(pl["Cp_in"]) or int(pl["kind"]) == 2
+    N, OH, OW = L.N, L.OH, L.OW
+    Np = int(pl["Np"])
+    bias = i32(blob, int(pl["off_bias"]), Np).astype(np.int64)
+    alpha = i32(blob, int(pl["off_alpha"]), Np)
+    beta = i32(blob, int(pl["off_beta"]), Np)
+    npix = B * OH * OW
+    if int(pl["kind"]) == 1:
+        TM, P, nslab, nm = int(pl["TM"]), int(pl["n_phases"]), int(pl["nslab"]), int(pl["n_mtiles"])
+        entries = i32(blob, int(pl["off_entries"]), max(1, int(pl["n_entries"])))
+        dirs = i32(blob, int(pl["off_dir"]), nm * (P + 1)).reshape(nm, P + 1)
+        kinfo = i32(blob, int(pl["off_kinfo"]), nslab * 8).reshape(nslab, 4, 2)
+        lo = i32(blob, int(pl["off_lo"]), Np).astype(np.int64)
+        dsh = i32(blob, int(pl["off_dshift"]), P * Np).reshape(P, Np).astype(np.int64)
+        wt = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * TM * 64].tobytes(), np.int8)
+        wt = wt.reshape(-1, TM, 64)
+        # gather all slabs once: Bmat[slab] = [npix, 64]
+        pb, poh, pow_ = np.unravel_index(np.arange(npix), (B, OH, OW))
+        slabs = {}
+
+        def slab(sl):
+            if sl in slabs:
+                return slabs[sl]
+            m = np.zeros((npix, 64), np.int8)
+            for sg in range(4):
+                ki0, coff = int(kinfo[sl, sg, 0]), int(kinfo[sl, sg, 1])
+                if coff < 0:
+                    continue
+                dh = np.int16(ki0 & 0xffff); dw = ki0 >> 16
+                ih = poh * L.stride - L.pad_h + int(dh); iw = pow_ * L.stride - L.pad_w + dw
+                ok = (ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)
+                v = np.zeros((npix, 16), np.int8)
+                v[ok] = x_t[pb[ok], ih[ok], iw[ok], coff:coff + 16]
+                m[:, sg * 16:(sg + 1) * 16] = v
+            slabs[sl] = m
+            return m
+
+        acc = np.zeros((Np, npix), np.int64)
+        for mt in range(nm):
+            a = np.zeros((TM, npix), np.int64)
+            for p in range(P):
+                if p >= 1:
+                    a = (a << dsh[p, mt * TM:(mt + 1) * TM, None]) % 2 ** 32
+                for e in range(dirs[mt, p], dirs[mt, p + 1]):
+                    a = (a + (wt[e].astype(np.float64) @ slab(int(entries[e])).astype(np.float64).T).astype(np.int64)) % 2 ** 32
+            acc[mt * TM:(mt + 1) * TM] = a
+        acc = (bias[:, None] + (acc << lo[:, None])) % 2 ** 32
+    else:
+        k, taps, ncc = L.k, L.k * L.k, int(pl["n_cchunk"])
+        cnt = (Np // 8) * ncc * taps * 128
+        w = i32(blob, int(pl["off_w"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64)
+        w2 = i32(blob, int(pl["off_w2"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64) if int(pl["signed_in"]) else None
+        pb, poh, pow_ = np.unravel_index(np.arange(npix), (B, OH, OW))
+        acc = np.zeros((Np, npix), np.int64)
+        for cc in range(ncc):
+            for t in range(taps):
+                fh, fw = divmod(t, k)
+                ih = poh * L.stride - L.pad_h + fh * L.dil; iw = pow_ * L.stride - L.pad_w + fw * L.dil
+                ok = (ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)
+                xv = np.zeros((npix, 16), np.int64)
+                xv[ok] = x_t[pb[ok], ih[ok], iw[ok], cc * 16:cc * 16 + 16]
+                xn = (-xv).astype(np.int8).astype(np.int64)
+                for n8 in range(Np // 8):
+                    wm = w[n8, cc, t].transpose(1, 0, 2).reshape(8, 16)      # [n][half*8+c]
+                    acc[n8 * 8:(n8 + 1) * 8] += wm @ xv.T          # exact: int64
+                    if w2 is not None:
+                        wm2 = w2[n8, cc, t].transpose(1, 0, 2).reshape(8, 16)
+                        acc[n8 * 8:(n8 + 1) * 8] += wm2 @ xn.T
+        acc = (bias[:, None] + acc) % 2 ** 32
+    acc = ((acc + 2 ** 31) % 2 ** 32 - 2 ** 31)
+    y = requant(acc[:N], alpha[:N, None], beta[:N, None], L.relu)          # [N, npix]
+    y = y.reshape(N, B, OH, OW).transpose(1, 0, 2, 3)
+    if res is not None:
+        s = np.clip(y.astype(np.int16) + res.astype(np.int16), -128, 127)
+        if L.add_relu:
+            s = np.maximum(s, 0)
+        y = s.astype(np.int8)
+    return np.ascontiguousarray(y)

@@ -1,0 +1,170 @@
+"""GPU parity proper: the HIP path, called through the C ABI, against the oracle on the same
+seeded inputs -- bit-exact, layer by layer (the reference's own per-layer Verify practice,
+network_helper.cpp:36-75) and on the final logits / top-5 (Evaluation)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import netref
+from tf2_amd import config as cfg, network, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    return torch
+
+
+class Rig:
+    def __init__(self, tables, q, model, mode):
+        torch = _torch()
+        self.t, self.q, self.model = tables, q, model
+        self.net = network.NetWork(tables)
+        self.net.Init(model, synth.q_text(q), device="cuda:0", pack_mode=mode)
+        self.runner = network.Runner(None, self.net)
+        self.ref = netref.RefNet(tables, q, model)
+
+    def run(self, images, keep_all=True):
+        torch = _torch()
+        x = torch.from_numpy(np.ascontiguousarray(images)).to("cuda:0")
+        logits = self.runner.run_batch(x, keep_all=keep_all)
+        torch.cuda.synchronize()
+        return logits.cpu().numpy()
+
+    def check_all_layers(self, images, layers=None):
+        got_logits = self.run(images, keep_all=True)
+        outs = self.ref.run(images)
+        B = images.shape[0]
+        np.testing.assert_array_equal(self.runner.read_layer(-1, B), outs[-1], err_msg="network input (prep kernel)")
+        for L in self.ref.plan:
+            if layers is not None and L.index not in layers:
+                continue
+            got = self.runner.read_layer(L.index, B)
+            np.testing.assert_array_equal(got, outs[L.index], err_msg=f"layer {L.index}")
+        want = self.ref.logits(outs)
+        np.testing.assert_array_equal(got_logits, want)
+        for b in range(B):
+            lab_g, _ = network.Evaluation(b, self.net.q[len(self.ref.plan)], got_logits)
+            lab_o, _ = self.ref.top5(want[b])
+            assert lab_g == lab_o.tolist()
+        return got_logits
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["float", "int8"])
+def test_tiny_every_layer(mode, kind):
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 5, spread=2)
+    model = synth.synth_model(t, q, 5)
+    x = synth.synth_images(t, 5, 5, kind=kind)
+    if kind == "int8":
+        x[0, :, :2, :] = -128          # the negate quirk of pe.cl:32-37
+    Rig(t, q, model, mode).check_all_layers(x)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_squeezenet_concat(mode):
+    t = cfg.squeezenet11_tables(image_hw=99)
+    q = synth.synth_q_values(t, 6, spread=2)
+    model = synth.synth_model(t, q, 6)
+    x = synth.synth_images(t, 3, 6)
+    Rig(t, q, model, mode).check_all_layers(x)
+
+
+def test_vgg_small_bias_and_2x2_pools():
+    t = cfg.vgg16_tables(32, 10)
+    q = synth.synth_q_values(t, 7)
+    model = synth.synth_model(t, q, 7)
+    x = synth.synth_images(t, 2, 7)
+    Rig(t, q, model, 0).check_all_layers(x)
+
+
+def test_wide_shift_range_phases():
+    t = cfg.tiny_tables(hw=8, widths=(16, 16), classes=8)
+    q = synth.synth_q_values(t, 9, lo=5, hi=7, spread=0)
+    rng = np.random.default_rng(9)
+    model = synth.synth_model(t, q, 9)
+    pos = 0
+    for L in cfg.build_plan(t):
+        n = L.N * L.model_C * L.model_k * L.model_k
+        if L.index == 1:
+            model[pos:pos + n] = np.ldexp(rng.choice([-1.0, 1.0], n), -rng.integers(0, 15, n)).astype(np.float32)
+        pos += n + (L.N if L.bias_en else 0) + (4 * L.N + 1 if L.bn_en else 0)
+    x = synth.synth_images(t, 2, 9)
+    Rig(t, q, model, 0).check_all_layers(x)
+
+
+@pytest.fixture(scope="module")
+def r50(golden_dir):
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    return t, q, model
+
+
+@pytest.fixture(scope="module")
+def r50_rig(r50):
+    return Rig(*r50, 0)
+
+
+def test_resnet50_every_layer_batch2(r50_rig):
+    x = synth.synth_images(r50_rig.t, 2, 0)
+    r50_rig.check_all_layers(x)
+
+
+def test_resnet50_shipped_test_image(r50_rig, golden_dir):
+    """The reference's own fixture image (test_images/resnet50_data_label_100.bin) through the
+    seeded synthetic weights: logits and top-5 identical to the oracle."""
+    img = np.fromfile(os.path.join(golden_dir, "resnet50_data_label_100.bin"), dtype=np.float32).reshape(1, 3, 224, 224)
+    r50_rig.check_all_layers(img, layers={0, 10, 52, 53})
+
+
+def test_resnet50_int8_input_with_minus128(r50_rig):
+    x = synth.synth_images(r50_rig.t, 1, 3, kind="int8")
+    x[0, :, 100:120, 100:120] = -128
+    r50_rig.check_all_layers(x, layers={0, 1, 4, 53})
+
+
+def test_resnet50_full_batch32_logits_and_properties(r50_rig):
+    """BASELINE batch: all 32 logits rows against the oracle; batch invariance (row i of the
+    batch run == the same image run alone); determinism."""
+    x = synth.synth_images(r50_rig.t, 32, 11)
+    got = r50_rig.run(x, keep_all=False)
+    outs = r50_rig.ref.run(x)
+    np.testing.assert_array_equal(got, r50_rig.ref.logits(outs))
+    again = r50_rig.run(x, keep_all=False)
+    np.testing.assert_array_equal(got, again)
+    alone = r50_rig.run(x[7:8], keep_all=False)
+    np.testing.assert_array_equal(alone[0], got[7])
+
+
+def test_resnet50_north_star_split_mode1(r50):
+    """3x3 convs on the shift-accumulate VALU kernel, 1x1 on int8 MFMA."""
+    rig = Rig(*r50, 1)
+    x = synth.synth_images(rig.t, 1, 2)
+    rig.check_all_layers(x, layers={0, 3, 4, 13, 26, 45, 52, 53})
+
+
+def test_epilogue_debug_store_path_matches(r50, monkeypatch):
+    rig = Rig(*r50, 0)
+    x = synth.synth_images(rig.t, 1, 4)
+    a = rig.run(x, keep_all=False)
+    monkeypatch.setenv("TF2_AMD_NOSWAP", "1")
+    b = rig.run(x, keep_all=False)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_runner_run_mirrors_reference_flow(r50_rig, golden_dir):
+    """Runner::Run: image file -> num_images frames -> output + throughput (runner.cpp:54-198)."""
+    net = r50_rig.net
+    net.image_file = os.path.join(golden_dir, "resnet50_data_label_100.bin")
+    net.num_images = 2
+    r = network.Runner(None, net)
+    r.Init()
+    out = r.Run()
+    assert out.shape == (2, 1000) and (out[0] == out[1]).all() and r.throughput_fps > 0
+    err = network.Verify(0, os.path.join(golden_dir, "resnet50_fc1000_label_100.bin"), net.q[54][:1000], out)
+    assert np.isfinite(err)        # synthetic weights: the number is meaningless, the plumbing is what is checked

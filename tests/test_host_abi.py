@@ -1,0 +1,110 @@
+"""The C-ABI library on the CPU: every symbol include/tf2_amd.h declares is exported, the
+host-side (load-time) entry points agree with the oracle on networks the reference ships no
+header for, and errors are status codes, never exit()."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import netref
+from tf2_amd import _lib, config as cfg, network, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tf2_amd.h")).read()
+    declared = set(re.findall(r"\b(tf2_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tf2_status"}
+    L = C.CDLL(_lib.LIB_PATH)
+    assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().tf2_abi_version() == 1 and _lib.lib().tf2_has_device_code() == 1
+
+
+@pytest.mark.parametrize("which", ["tiny", "squeezenet", "vgg_small"])
+def test_host_numerics_match_oracle(which):
+    t = {"tiny": cfg.tiny_tables, "squeezenet": cfg.squeezenet11_tables,
+         "vgg_small": lambda: cfg.vgg16_tables(32, 10)}[which]()
+    q = synth.synth_q_values(t, seed=3)
+    model = synth.synth_model(t, q, seed=3)
+    net = network.NetWork(t)
+    qt = net.Quantization(synth.q_text(q))
+    net.LoadModel(model)
+    R = netref.RefNet(t, q, model)
+    np.testing.assert_array_equal(qt, R.q)
+    for L in R.plan:
+        np.testing.assert_array_equal(net.codes(L.index), R.codes[L.index])
+        for a, b in zip(net.bias_bn(L.index), R.bn[L.index]):
+            np.testing.assert_array_equal(a, b)
+    net.Pack(0)
+    blob = net.packed_host()
+    assert blob.size > 0 and net.workspace_size(4) > 0 and net.workspace_size(4, True) >= net.workspace_size(4)
+    # a second handle with the same tables adopts the image (what non-root ranks do)
+    other = network.NetWork(t)
+    other.Quantization(synth.q_text(q))
+    other.adopt_packed(blob)
+    np.testing.assert_array_equal(other.packed_host(), blob)
+    # ... and one with different tables refuses it
+    t2 = cfg.tiny_tables(hw=16)
+    stranger = network.NetWork(t2)
+    with pytest.raises(_lib.Tf2Error):
+        stranger.adopt_packed(blob)
+
+
+def test_errors_are_status_codes():
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 0)
+    model = synth.synth_model(t, q, 0)
+    net = network.NetWork(t)
+    with pytest.raises(_lib.Tf2Error) as e:
+        net.LoadModel(model)                       # q table not set yet
+    assert e.value.status == -2
+    net.Quantization(synth.q_text(q))
+    with pytest.raises(_lib.Tf2Error) as e:
+        net.LoadModel(model[:-5])                  # truncated stream
+    assert e.value.status == -3 and "short" in str(e.value)
+    with pytest.raises(_lib.Tf2Error) as e:
+        net.LoadModel(np.concatenate([model, model[:3]]))   # trailing floats
+    assert e.value.status == -3
+    with pytest.raises(_lib.Tf2Error):
+        net.Pack(0)                                # no model loaded
+    net.LoadModel(model)
+    with pytest.raises(_lib.Tf2Error):
+        net.Pack(7)
+    # inconsistent tables are rejected at create time
+    bad = cfg.tiny_tables()
+    bad["kInputChannels"][2] = 99
+    with pytest.raises(_lib.Tf2Error):
+        network.NetWork(bad)
+    # short Q files read as zeros like fscanf on EOF (quantization.cpp:45)
+    net2 = network.NetWork(t)
+    net2.Quantization(b"1 2 3\n")
+    assert net2.q_values_read == cfg.q_value_count(t) and (net2.q[1:] == 0).all() and net2.q[0, 2] == -3
+
+
+def test_topk_argument_checks():
+    lg = np.zeros(10, np.int8); q = np.zeros(10, np.int8)
+    lab = np.zeros(5, np.int32)
+    st = _lib.lib().tf2_topk(lg.ctypes.data, q.ctypes.data, 10, 11, lab.ctypes.data, None)
+    assert st == -1
+    q[3] = 1            # Q < 0 for the last layer: the reference shifts by a negative count (UB); we refuse
+    st = _lib.lib().tf2_topk(lg.ctypes.data, q.ctypes.data, 10, 5, lab.ctypes.data, None)
+    assert st == -1
+
+
+def test_pack_modes_and_phase_structure():
+    """mode 0: MFMA everywhere an int8 tile decomposition applies; 1: shift kernel for k>1;
+    2: shift kernel everywhere.  All three pack without error and differ in size."""
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 1)
+    model = synth.synth_model(t, q, 1)
+    sizes = []
+    for mode in (0, 1, 2):
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(mode)
+        sizes.append(net.packed_host().size)
+    assert len(set(sizes)) == 3

@@ -1,0 +1,120 @@
+"""CPU check of the packed weight image (tf2_amd/csrc/weight_pack.cpp): a numpy model of the
+kernels' data flow (tests/emu_packed.py) fed with the packed image must reproduce the oracle
+layer by layer -- exponent windows + Horner recombination are exact in Z/2^32, the slab lists
+drop only all-zero tiles, the kinfo gather implements zero padding/stride/dilation, and the
+[x | xneg] image layout reproduces the -128 negate quirk (pe.cl:32-37)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import netref, oracle as O
+from tf2_amd import config as cfg, network, synth
+from tests import emu_packed as emu
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def check_net(t, q, model, images, mode, layers=None):
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(mode)
+    blob = net.packed_host()
+    hdr, pls = emu.parse(blob)
+    R = netref.RefNet(t, q, model)
+    outs = R.run(images)
+    plan = R.plan
+    concat_c = {}
+    for L in plan:
+        if L.concat >= 0:
+            concat_c[L.concat] = max(concat_c.get(L.concat, 0), L.n_start + L.N)
+    kinds = []
+    for L in plan:
+        if layers is not None and L.index not in layers:
+            continue
+        pl = pls[L.index]
+        kinds.append(int(pl["kind"]))
+        if L.ipool:
+            continue
+        if L.src == -1:
+            half = _round_up(L.C, 16)
+            x_t = emu.nhwc(outs[-1], 2 * half, signed_half=half)
+        elif L.src >= 0:
+            S = plan[L.src]
+            if S.concat >= 0:
+                pytest.skip("concat sources are covered by the GPU tests")
+            x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
+        else:
+            cid = -(L.src + 2)
+            members = [M for M in plan if M.concat == cid]
+            full = np.zeros((images.shape[0], concat_c[cid]) + outs[members[0].index].shape[2:], np.int8)
+            for M in members:
+                full[:, M.n_start:M.n_start + M.N] = outs[M.index]
+            x_t = emu.nhwc(full, _round_up(concat_c[cid], 16))
+        res = outs[L.add_src] if L.add_src >= 0 else None
+        y = emu.conv_from_packed(blob, pl, L, x_t, res)
+        # finish the layer with the oracle's post-ops and compare with the oracle's layer output
+        if L.pool_en:
+            y = np.stack([O.maxpool(yi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for yi in y])
+        if L.endpool:
+            y = np.stack([O.global_avg(yi, L.endpool_mult) for yi in y]).reshape(y.shape[0], L.N, 1, 1)
+        np.testing.assert_array_equal(y, outs[L.index], err_msg=f"layer {L.index} kind {int(pl['kind'])}")
+    return kinds, pls
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["float", "int8"])
+def test_tiny_all_modes(mode, kind):
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 5, spread=2)
+    model = synth.synth_model(t, q, 5)
+    x = synth.synth_images(t, 3, 5, kind=kind)
+    if kind == "int8":
+        x[0, :, :2, :] = -128                     # force the negate quirk
+    kinds, _ = check_net(t, q, model, x, mode)
+    if mode == 0:
+        assert set(kinds) <= {1, 2} and 1 in kinds
+    if mode == 2:
+        assert set(kinds) == {2}
+
+
+def test_squeezenet_small_image():
+    t = cfg.squeezenet11_tables(image_hw=67)
+    q = synth.synth_q_values(t, 6, spread=2)
+    model = synth.synth_model(t, q, 6)
+    x = synth.synth_images(t, 1, 6)
+    check_net(t, q, model, x, 0)
+
+
+def test_resnet50_selected_layers(golden_dir):
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    x = synth.synth_images(t, 1, 0)
+    kinds, pls = check_net(t, q, model, x, 0, layers={0, 1, 3, 4, 11, 13, 14, 46, 52, 53})
+    assert set(kinds) == {1}
+    # the shipped resnet50_Q has per-input-channel Q spreads up to 2 in the early layers: those
+    # need a second exponent window; the uniform-Q late layers need exactly one phase
+    assert int(pls[3]["n_phases"]) == 2 and int(pls[46]["n_phases"]) == 1
+
+
+def test_wide_shift_range_needs_more_windows():
+    """Codes spanning all 32 shift amounts (far beyond INQ's 7 levels): windows of 7 cover
+    them with 5 phases; wrap-around in Z/2^32 must match the oracle bit for bit."""
+    t = cfg.tiny_tables(hw=8, widths=(16, 16), classes=8)
+    q = synth.synth_q_values(t, 9, lo=5, hi=7, spread=0)
+    rng = np.random.default_rng(9)
+    plan = cfg.build_plan(t)
+    model = synth.synth_model(t, q, 9)
+    # overwrite layer 1's weights with powers spanning 2^0 .. 2^-14 (Get_real's whole range)
+    pos = 0
+    for L in plan:
+        n = L.N * L.model_C * L.model_k * L.model_k
+        if L.index == 1:
+            e = rng.integers(0, 15, n)
+            model[pos:pos + n] = np.ldexp(rng.choice([-1.0, 1.0], n), -e).astype(np.float32)
+        pos += n + (L.N if L.bias_en else 0) + (4 * L.N + 1 if L.bn_en else 0)
+    x = synth.synth_images(t, 2, 9)
+    kinds, pls = check_net(t, q, model, x, 0)
+    assert int(pls[1]["n_phases"]) >= 2
