@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-layer HIP-event timing table (ms, TOP/s, GB/s, grid) for ResNet50 at a given batch."""
+import argparse, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from tf2_amd import config as cfg, network, synth, _lib
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import emu_packed as emu
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--mode", type=int, default=0)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
+qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
+model = synth.synth_model(t, qv, 0)
+net = network.NetWork(t); net.Init(model, synth.q_text(qv), device="cuda:0", pack_mode=a.mode)
+_, pls = emu.parse(net.packed_host())
+r = network.Runner(None, net)
+x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
+for _ in range(3): r.run_batch(x)
+torch.cuda.synchronize()
+_lib.check(_lib.lib().tf2_net_profile(net._h, 1))
+for _ in range(a.steps): r.run_batch(x)
+torch.cuda.synchronize()
+n = len(plan); ms = np.zeros(n, np.float32); nl = np.zeros(n, np.int32); kd = np.zeros(n, np.int32)
+_lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kd.ctypes.data, n))
+ms /= np.maximum(nl, 1)
+rows = []
+print(f"{'l':>2} {'k':>1} {'C':>4} {'N':>4} {'HW':>3} s P  ent/mt blocks   us     TOPS   GB/s")
+for i, L in enumerate(plan):
+    pl = pls[i]
+    ops = 2 * L.N * L.C * L.k * L.k * L.OH * L.OW * a.batch
+    byts = (L.C * L.H * L.W + L.N * L.PH * L.PW * (2 if L.add_src >= 0 else 1)) * a.batch
+    TM = int(pl["TM"]); npix = a.batch * L.OH * L.OW
+    blocks = int(pl["n_mtiles"]) * (-(-npix // (128 if TM == 128 else 256))) if int(pl["kind"]) == 1 else 0
+    ent = int(pl["n_entries"]) / max(1, int(pl["n_mtiles"]))
+    us = ms[i] * 1e3
+    rows.append(dict(layer=i, k=L.k, C=L.C, N=L.N, HW=L.OH, stride=L.stride, phases=int(pl["n_phases"]), entries_per_mtile=ent,
+                     blocks=blocks, us=float(us), tops=ops / us / 1e6, gbps=byts / us / 1e3))
+    print(f"{i:>2} {L.k} {L.C:>4} {L.N:>4} {L.OH:>3} {L.stride} {int(pl['n_phases'])} {ent:6.1f} {blocks:>6} {us:7.1f} {ops/us/1e6:7.1f} {byts/us/1e3:7.1f}")
+print("total us", float(ms.sum() * 1e3))
+if a.out:
+    json.dump(rows, open(a.out, "w"), indent=0)
