@@ -217,6 +217,9 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   const uint8_t* pk = packed_dev;
   int flags = 0;
   if (const char* e = getenv("TF2_AMD_NOSWAP")) flags |= (e[0] == '1');
+  bool mfma_v1 = false;
+  if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
+  const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
 
   // input: quantise + (space-to-depth) + [x | xneg]
   {
@@ -259,6 +262,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.bias = (const int32_t*)(pk + pl->off_bias); ca.alpha = (const int32_t*)(pk + pl->off_alpha);
       ca.beta = (const int32_t*)(pk + pl->off_beta); ca.lo = (const int32_t*)(pk + pl->off_lo);
       ca.dshift = (const int32_t*)(pk + pl->off_dshift);
+      ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
       ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;
       ca.k = L.k; ca.dil = L.dil; ca.n_cchunk = pl->n_cchunk; ca.Cp_half = in_layout[l].half;
       ConvGeom& g = ca.g;
@@ -276,7 +280,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       }
       g.flags = flags;
       int rc;
-      if (pl->kind == KIND_MFMA) rc = launch_conv_mfma(ca, pl->TM, stream);
+      if (pl->kind == KIND_MFMA) rc = (mfma_v1 || (flags & 1)) ? launch_conv_mfma(ca, pl->TM, stream) : launch_conv_mfma2(ca, pl->TM, stream);
       else if (pl->kind == KIND_SHIFT) rc = launch_conv_shift(ca, pl->signed_in, pl->max_shift <= 22, stream);
       else { set_error("layer " + std::to_string(l) + " has no packed kernel"); return TF2_ERR_STATE; }
       if (rc) { set_error("conv launch failed at layer " + std::to_string(l) + ": " + device_last_error()); return TF2_ERR_HIP; }

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 3;
+constexpr uint32_t kPackVersion = 4;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -32,7 +32,7 @@ struct PackLayer {
   int32_t max_shift;   // largest shift amount in the layer (shift kernel: mul24 if <= 22)
   int32_t n_entries;   // number of (mtile, phase, slab) weight tiles stored
   int32_t n_cchunk;    // shift kernel: channel chunks of 16
-  int32_t pad_;
+  int32_t max_ent;     // MFMA: largest number of entries of one m-tile (multiple of 4)
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -50,6 +50,7 @@ struct PackHeader {
   uint32_t n_layers, dir_bytes;
   uint64_t total_bytes;
   uint64_t tables_hash;     // hash of the layer descs the image was packed for
+  uint64_t zero_off;        // offset of a 256-byte all-zero block (source of padded taps for LDS-DMA)
 };
 
 // ---- device-side parameter blocks -------------------------------------------------
@@ -79,6 +80,8 @@ struct ConvArgs {
   const int32_t* beta;
   const int32_t* lo;
   const int32_t* dshift;
+  const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
+  int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;
   int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split
   ConvGeom g;
@@ -107,6 +110,7 @@ struct PrepArgs {
 
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
+int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);

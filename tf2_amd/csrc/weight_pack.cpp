@@ -63,6 +63,7 @@ tf2_status Net::pack(int mode) {
   Blob blob(packed);
   const size_t dir_bytes = sizeof(PackHeader) + (size_t)nl * sizeof(PackLayer);
   blob.alloc(dir_bytes);
+  const uint64_t zero_off = blob.alloc(256);
 
   // Can the tensor feeding layer l hold negative values (=> the -128 negate quirk matters)?
   std::vector<int> out_signed(nl, 0);
@@ -111,7 +112,9 @@ tf2_status Net::pack(int mode) {
     if (use_mfma) {
       pl.kind = KIND_MFMA;
       const int Np = round_up(N, 64);
-      const int TM = (Np % 128 == 0) ? 128 : 64;
+      // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output
+      // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
+      const int TM = (Np % 128 == 0 && L.OH * L.OW > 196) ? 128 : 64;
       const int n_mtiles = Np / TM;
       const int Ktot = taps * il.Cp_in;
       const int nslab = (Ktot + 63) / 64;
@@ -183,7 +186,9 @@ tf2_status Net::pack(int mode) {
           }
         }
         dir[(size_t)mt * (P + 1) + P] = (int32_t)entries.size();
+        pl.max_ent = std::max<int32_t>(pl.max_ent, dir[(size_t)mt * (P + 1) + P] - dir[(size_t)mt * (P + 1)]);
       }
+      pl.max_ent = round_up(std::max(pl.max_ent, 1), 4);
       // ---- kinfo ----
       std::vector<int32_t> kinfo((size_t)nslab * 4 * 2, 0);
       for (int sl = 0; sl < nslab; sl++)
@@ -263,7 +268,7 @@ tf2_status Net::pack(int mode) {
   blob.alloc(0);
   PackHeader h{};
   h.magic = kPackMagic; h.version = kPackVersion; h.n_layers = (uint32_t)nl; h.dir_bytes = (uint32_t)dir_bytes;
-  h.total_bytes = packed.size(); h.tables_hash = tables_hash();
+  h.total_bytes = packed.size(); h.tables_hash = tables_hash(); h.zero_off = zero_off;
   *blob.at<PackHeader>(0) = h;
   packed_valid = true;
   pack_mode = mode;

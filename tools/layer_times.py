@@ -45,4 +45,4 @@ for i, L in enumerate(plan):
     print(f"{i:>2} {L.k} {L.C:>4} {L.N:>4} {L.OH:>3} {L.stride} {int(pl['n_phases'])} {ent:6.1f} {blocks:>6} {us:7.1f} {ops/us/1e6:7.1f} {byts/us/1e3:7.1f}")
 print("total us", float(ms.sum() * 1e3))
 if a.out:
-    json.dump(rows, open(a.out, "w"), indent=0)
+    json.dump(rows, open(a.out, "w"), indent=0, default=float)
