@@ -62,7 +62,7 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         TM, P, nslab, nm = int(pl["TM"]), int(pl["n_phases"]), int(pl["nslab"]), int(pl["n_mtiles"])
         entries = i32(blob, int(pl["off_entries"]), max(1, int(pl["n_entries"])))
         dirs = i32(blob, int(pl["off_dir"]), nm * (P + 1)).reshape(nm, P + 1)
-        kinfo = i32(blob, int(pl["off_kinfo"]), nslab * 8).reshape(nslab, 4, 2)
+        kinfo = i32(blob, int(pl["off_kinfo"]), nslab * 4).reshape(nslab, 4)
         lo = i32(blob, int(pl["off_lo"]), Np).astype(np.int64)
         dsh = i32(blob, int(pl["off_dshift"]), P * Np).reshape(P, Np).astype(np.int64)
         wt = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * TM * 64].tobytes(), np.int8)
@@ -76,10 +76,11 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
                 return slabs[sl]
             m = np.zeros((npix, 64), np.int8)
             for sg in range(4):
-                ki0, coff = int(kinfo[sl, sg, 0]), int(kinfo[sl, sg, 1])
-                if coff < 0:
+                ki = int(kinfo[sl, sg]) & 0xffffffff
+                coff = ki & 0xffff
+                if coff == 0xffff:
                     continue
-                dh = np.int16(ki0 & 0xffff); dw = ki0 >> 16
+                dh = (ki >> 16) & 0xff; dw = ki >> 24
                 ih = poh * L.stride - L.pad_h + int(dh); iw = pow_ * L.stride - L.pad_w + dw
                 ok = (ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)
                 v = np.zeros((npix, 16), np.int8)

@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
       int idx = tid + 256 * q;
       areg[q] = *reinterpret_cast<const i32x4*>(wsrc + idx * 16);
     }
-    const int2 ki = *reinterpret_cast<const int2*>(a.kinfo + (slab * 4 + seg) * 2);
-    const int dh = (int)(short)(ki.x & 0xffff);
-    const int dw = ki.x >> 16;
-    const int coff = ki.y;
+    const unsigned ki = (unsigned)a.kinfo[slab * 4 + seg];
+    const int dh = (int)((ki >> 16) & 0xff);
+    const int dw = (int)(ki >> 24);
+    const int coff = (ki & 0xffff) == 0xffff ? -1 : (int)(ki & 0xffff);
 #pragma unroll
     for (int q = 0; q < BQ; q++) {
       int ih = brow_h[q] + dh, iw = brow_w[q] + dw;

@@ -97,8 +97,14 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     prm[i] = a.bias[ch]; prm[TM + i] = a.lo[ch]; prm[2 * TM + i] = a.alpha[ch]; prm[3 * TM + i] = a.beta[ch];
   }
   for (int i = tid; i < P * TM; i += 256) dsh[i] = a.dshift[(size_t)(i / TM) * a.Np + mtile * TM + (i % TM)];
-  for (int i = tid; i < n_ent; i += 256) ent[i] = a.entries[e_begin + i];
-  for (int i = tid; i < a.nslab * 8; i += 256) kin[i] = a.kinfo[i];
+  // slab id | (number of Horner phase steps to take before this entry) << 24: the K loop must not
+  // contain ordinary global loads (they would make hipcc drain the LDS-DMA queue every iteration)
+  for (int i = tid; i < n_ent; i += 256) {
+    int steps = 0;
+    for (int p = 1; p < P; p++) steps += (dirp[p] == e_begin + i && dirp[p] < e_end) ? 1 : 0;
+    ent[i] = a.entries[e_begin + i] | (steps << 24);
+  }
+  for (int i = tid; i < a.nslab * 4; i += 256) kin[i] = a.kinfo[i];
 
   // ---- per-lane gather state ------------------------------------------------------------
   // LDS-DMA lane l of an instruction fills row (l>>2), 16-byte slot (l&3) of a 16-row group;
@@ -135,17 +141,17 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 
   auto issue_stage = [&](int e) {       // e: absolute entry index; fills ring slot (e - e_begin) % S
     int8_t* const slot = lds + ((e - e_begin) % S) * STAGE;
-    const int slab = ent[e - e_begin];
+    const int slab = ent[e - e_begin] & 0xffffff;
+    const unsigned ki = (unsigned)kin[slab * 4 + chunk];
+    const int dh = (int)((ki >> 16) & 0xff);
+    const int dw = (int)(ki >> 24);
+    const int coff = (ki & 0xffff) == 0xffff ? -1 : (int)(ki & 0xffff);
     const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++) {
       const int grp = wave + 4 * j;                          // 16-row group of the A tile
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
     }
-    const int2 ki = *reinterpret_cast<const int2*>(kin + (slab * 4 + chunk) * 2);
-    const int dh = (int)(short)(ki.x & 0xffff);
-    const int dw = ki.x >> 16;
-    const int coff = ki.y;
 #pragma unroll
     for (int j = 0; j < BI; j++) {
       const int grp = wave + 4 * j;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     __builtin_amdgcn_s_barrier();          // every wave's part of stage e landed; slot (e-1)%S is free
     asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
     if (e + S - 1 < e_end) issue_stage(e + S - 1);
-    while (phase + 1 < P && e == dirp[phase + 1]) { phase++; phase_shift(phase); }
+    for (int st = ent[e - e_begin] >> 24; st > 0; st--) { phase++; phase_shift(phase); }
     compute(e);
   }
   while (phase + 1 < P) { phase++; phase_shift(phase); }
@@ -276,7 +282,7 @@ template <int WM, int WN, int WT, int S>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WT, TN = WN * WT;
   constexpr int STAGE = (TM + TN) * 64;
-  const size_t lds = (size_t)S * STAGE + (size_t)(4 + a.n_phases) * TM * 4 + (size_t)a.max_ent * 4 + (size_t)a.nslab * 32 + 64;
+  const size_t lds = (size_t)S * STAGE + (size_t)(4 + a.n_phases) * TM * 4 + (size_t)a.max_ent * 4 + (size_t)a.nslab * 16 + 64;
   static bool attr_set = false;
   auto fn = conv_mfma2_kernel<WM, WN, WT, S>;
   if (!attr_set) {

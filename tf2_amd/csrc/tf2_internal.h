@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 4;
+constexpr uint32_t kPackVersion = 5;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -37,7 +37,7 @@ struct PackLayer {
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
   uint64_t off_dir;      // int32[n_mtiles][n_phases + 1] cumulative entry starts
-  uint64_t off_kinfo;    // int2[nslab * 4]  {dh | dw<<16, coff}  (coff < 0: padding segment)
+  uint64_t off_kinfo;    // int32[nslab * 4]  coff | dh << 16 | dw << 24  (coff == 0xffff: padding segment)
   uint64_t off_bias;     // int32[Np]
   uint64_t off_alpha;    // int32[Np]
   uint64_t off_beta;     // int32[Np]
@@ -74,7 +74,7 @@ struct ConvArgs {
   const int8_t* w2;          // SHIFT signed: negative magnitudes
   const int32_t* entries;
   const int32_t* dir;
-  const int32_t* kinfo;      // 2 ints per segment
+  const int32_t* kinfo;      // one word per 16-byte segment
   const int32_t* bias;
   const int32_t* alpha;
   const int32_t* beta;

@@ -190,16 +190,17 @@ tf2_status Net::pack(int mode) {
       }
       pl.max_ent = round_up(std::max(pl.max_ent, 1), 4);
       // ---- kinfo ----
-      std::vector<int32_t> kinfo((size_t)nslab * 4 * 2, 0);
+      // one 32-bit word per 16-byte segment: coff (16 bits, 0xffff = padding) | dh << 16 | dw << 24
+      std::vector<int32_t> kinfo((size_t)nslab * 4, 0);
+      if (il.Cp_in >= 0xffff || (k - 1) * L.dil > 255) { set_error("layer " + std::to_string(l) + ": geometry exceeds the kinfo encoding"); return TF2_ERR_UNSUPPORTED; }
       for (int sl = 0; sl < nslab; sl++)
         for (int sg = 0; sg < 4; sg++) {
           const int kk0 = sl * 64 + sg * 16;
           const int t = kk0 / il.Cp_in, pc = kk0 % il.Cp_in;
-          int32_t* ki = &kinfo[((size_t)sl * 4 + sg) * 2];
-          if (t >= taps) { ki[0] = 0; ki[1] = -1; continue; }
+          int32_t& ki = kinfo[(size_t)sl * 4 + sg];
+          if (t >= taps) { ki = 0xffff; continue; }
           const int dh = (t / k) * L.dil, dw = (t % k) * L.dil;
-          ki[0] = (dh & 0xffff) | (dw << 16);
-          ki[1] = pc;
+          ki = (int32_t)((uint32_t)pc | ((uint32_t)dh << 16) | ((uint32_t)dw << 24));
         }
       pl.TM = TM; pl.n_mtiles = n_mtiles; pl.n_phases = P; pl.nslab = nslab; pl.Np = Np;
       pl.n_entries = (int32_t)entries.size();
