@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+#define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  TF2_STAMP(0);
   const int P = a.n_phases;
   int* const dsh = prm + 4 * TM;
   int* const ent = dsh + P * TM;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int e_end = dirp[P];
   const int n_ent = e_end - e_begin;
 
+  TF2_STAMP(1);
   // ---- one-time table copy into LDS --------------------------------------------------
   for (int i = tid; i < TM; i += 256) {
     const int ch = mtile * TM + i;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
 
   __syncthreads();     // tables visible; no LDS-DMA outstanding yet, so this is a plain barrier
+  TF2_STAMP(2);
 
   auto issue_stage = [&](int e) {       // e: absolute entry index; fills ring slot (e - e_begin) % S
     int8_t* const slot = lds + ((e - e_begin) % S) * STAGE;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     const int dh = (int)((ki >> 16) & 0xff);
     const int dw = (int)(ki >> 24);
     const int coff = (ki & 0xffff) == 0xffff ? -1 : (int)(ki & 0xffff);
-    const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
+    const int8_t* wsrc = a.w + (size_t)((g.flags & 4) ? e_begin : e) * A_BYTES + a_lane_off;   // bit 2: perf experiment only
 #pragma unroll
     for (int j = 0; j < AI; j++) {
       const int grp = wave + 4 * j;                          // 16-row group of the A tile
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     for (int j = 0; j < BI; j++) {
       const int grp = wave + 4 * j;
       const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
-      const bool ok = coff >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const bool ok = coff >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && !(g.flags & 2);   // bit 1: perf experiment only
       const int8_t* src = ok ? a.x + ((size_t)(brow_base[j] + ih * g.W + iw) * g.Cp_in + coff) : a.zero;
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + A_BYTES + grp * 1024), 16, 0, 0);
     }
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   for (int s = 0; s < S - 1; s++)
     if (e_begin + s < e_end) issue_stage(e_begin + s);
   int phase = 0;
+  TF2_STAMP(3);
   for (int e = e_begin; e < e_end; e++) {
     // stages issued beyond e: min(S-2, e_end-1-e); wait until stage e has landed (per wave)
     const int ahead = (e_end - 1 - e) < (S - 2) ? (e_end - 1 - e) : (S - 2);
@@ -215,12 +221,14 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     else if (S >= 4 && ahead == 1) wait_vmcnt<NI>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // every wave's part of stage e landed; slot (e-1)%S is free
+    if (e == e_begin) TF2_STAMP(4);
     asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
-    if (e + S - 1 < e_end) issue_stage(e + S - 1);
+    if (e + S - 1 < e_end && !(g.flags & 8)) issue_stage(e + S - 1);     // bit 3/4: perf experiments only
     for (int st = ent[e - e_begin] >> 24; st > 0; st--) { phase++; phase_shift(phase); }
-    compute(e);
+    if (!(g.flags & 16)) compute(e);
   }
   while (phase + 1 < P) { phase++; phase_shift(phase); }
+  TF2_STAMP(5);
 
   // ---- epilogue --------------------------------------------------------------------------------
   const int half = lane >> 5;
@@ -276,6 +284,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TF2_STAMP(6);
 }
 
 template <int WM, int WN, int WT, int S>

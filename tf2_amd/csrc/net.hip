@@ -217,6 +217,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   const uint8_t* pk = packed_dev;
   int flags = 0;
   if (const char* e = getenv("TF2_AMD_NOSWAP")) flags |= (e[0] == '1');
+  if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & ~1;   // perf experiments (wrong results!)
   bool mfma_v1 = false;
   if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
@@ -263,6 +264,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.beta = (const int32_t*)(pk + pl->off_beta); ca.lo = (const int32_t*)(pk + pl->off_lo);
       ca.dshift = (const int32_t*)(pk + pl->off_dshift);
       ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
+      if (const char* e = getenv("TF2_AMD_DBGPTR")) ca.dbg = (long long*)strtoull(e, nullptr, 0) + (size_t)l * 16;
       ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;
       ca.k = L.k; ca.dil = L.dil; ca.n_cchunk = pl->n_cchunk; ca.Cp_half = in_layout[l].half;
       ConvGeom& g = ca.g;

@@ -81,6 +81,7 @@ struct ConvArgs {
   const int32_t* lo;
   const int32_t* dshift;
   const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
+  long long* dbg;            // optional: 16 timestamps of block 0 (tools/layer_times.py), else null
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;
   int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split

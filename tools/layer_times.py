@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--out", default=None)
+ap.add_argument("--stamps", action="store_true")
 a = ap.parse_args()
 t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
@@ -22,6 +23,9 @@ net = network.NetWork(t); net.Init(model, synth.q_text(qv), device="cuda:0", pac
 _, pls = emu.parse(net.packed_host())
 r = network.Runner(None, net)
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
+dbg = torch.zeros(64 * 16, dtype=torch.int64, device="cuda:0")
+if a.stamps:
+    os.environ["TF2_AMD_DBGPTR"] = str(dbg.data_ptr())
 for _ in range(3): r.run_batch(x)
 torch.cuda.synchronize()
 _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
@@ -44,5 +48,11 @@ for i, L in enumerate(plan):
                      blocks=blocks, us=float(us), tops=ops / us / 1e6, gbps=byts / us / 1e3))
     print(f"{i:>2} {L.k} {L.C:>4} {L.N:>4} {L.OH:>3} {L.stride} {int(pl['n_phases'])} {ent:6.1f} {blocks:>6} {us:7.1f} {ops/us/1e6:7.1f} {byts/us/1e3:7.1f}")
 print("total us", float(ms.sum() * 1e3))
+if a.stamps:
+    d = dbg.cpu().numpy().reshape(64, 16)
+    print("cycle stamps of block 0 (deltas, 100 MHz ticks?): start->dir, ->tables+barrier, ->prologue issued, ->first stage landed, ->loop end, ->epilogue end")
+    for i in range(n):
+        r = d[i]
+        print(i, [int(r[j + 1] - r[j]) for j in range(6)])
 if a.out:
     json.dump(rows, open(a.out, "w"), indent=0, default=float)
