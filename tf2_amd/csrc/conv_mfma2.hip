@@ -1,20 +1,29 @@
 // conv_mfma2.hip -- implicit-GEMM INT8 convolution, LDS-DMA pipelined (gfx950).
 //
-// Same arithmetic, operand orientation, LDS swizzle and epilogue as conv_mfma.hip (see the
-// header there for the Z/2^32 exponent-window / Horner argument and the reference
-// citations); what changes is how operands reach the matrix cores:
+// Same arithmetic, operand orientation, LDS swizzle and epilogue semantics as conv_mfma.hip
+// (see the header there for the Z/2^32 exponent-window / Horner argument and the reference
+// citations); what changes is how operands reach the matrix cores and how much latency a
+// block exposes:
 //
-//  * every table the K loop needs (this m-tile's slab list, the per-slab gather table
-//    `kinfo`, the per-channel epilogue parameters and Horner shifts) is copied into LDS
-//    once per block, so the loop has NO dependent global-memory chain (v1 paid three
-//    serial latencies per slab: entries -> kinfo -> activations);
+//  * everything the K loop and the epilogue need per m-tile (bias / final shift / alpha /
+//    beta, Horner shifts, this m-tile's slab list with the phase boundaries encoded, and the
+//    per-segment gather tables) is ONE contiguous header per m-tile in the packed image; it
+//    is pulled into LDS by LDS-DMA at block start, together with the first weight tiles
+//    (whose addresses need no table), so the block pays ONE memory latency before its
+//    first gather instead of a chain (kernarg -> dir -> entries -> kinfo -> activations);
 //  * weight tiles and gathered activation rows go HBM/L2 -> LDS directly with
 //    `global_load_lds_dwordx4` (1 KiB per wave instruction, no VGPR staging) into a ring
 //    of S stages; a stage is waited for with a COUNTED s_waitcnt vmcnt(N) and a raw
 //    s_barrier, so S-1 stages stay in flight across barriers (cdna_hip_programming.md
-//    "Pipelining across barriers").  The LDS destination of an LDS-DMA is lane-linear, so
-//    the XOR swizzle is applied on the per-lane SOURCE address (rule 21) and again on the
-//    ds_read_b128 side; zero padding (sequencer.cl:287) is a read from a zero page;
+//    "Pipelining across barriers").  The K loop contains no ordinary global load and no
+//    64-bit LDS read: either makes hipcc (ROCm 7.2) drain the LDS-DMA queue with vmcnt(0)
+//    every iteration.  The LDS destination of an LDS-DMA is lane-linear, so the XOR swizzle
+//    is applied on the per-lane SOURCE address (rule 21) and again on the ds_read_b128
+//    side; zero padding (sequencer.cl:287) is a read from a zero page;
+//  * within an iteration: ds_read fragments, issue the next stage's DMAs (hides the LDS
+//    latency), then the MFMAs, which keep running while the wave moves on to the next wait;
+//  * the residual tile (feature_writer.cl:88-122) is prefetched into registers before the
+//    loop; the epilogue packs with v_perm and stores 16 contiguous NHWC bytes per lane;
 //  * three tile shapes: 128x128 (2x2 waves of 64x64), 64x256 (1x4 waves, N_out = 64
 //    layers) and 64x64 (2x2 waves of 32x32) for layers whose grid would not fill 256 CUs.
 #include <hip/hip_runtime.h>
@@ -28,18 +37,9 @@ using i32x16 = int __attribute__((ext_vector_type(16)));
 #define TF2_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define TF2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-__device__ __forceinline__ int requant2_i8(int acc, int alpha, int beta, int relu) {
-  long long p = (long long)acc * (long long)alpha;           // pe.cl:191
-  int t = (int)(p >> kAlphaInflat);                          // pe.cl:192
-  t = (int)((unsigned)t + (unsigned)beta);
-  int v = ((t >> (kInflat - 1)) + 1) >> 1;                   // pe.cl:193
-  v = v > 127 ? 127 : (v < -128 ? -128 : v);                 // pe.cl:194
-  if (relu) v = v > 0 ? v : 0;                               // relu.cl:54
-  return v;
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 15, "vmcnt immediate out of the prepared range");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -47,11 +47,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  else static_assert(N < 0, "add the vmcnt immediate");
+  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
 // WM x WN waves (WM*WN == 4), each wave a WT x WT output tile (WT = 64 or 32), S ring stages.
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   constexpr int AI = TM / 64, BI = TN / 64;    // LDS-DMA instructions per wave per stage (A, B)
   constexpr int NI = AI + BI;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  // LDS map: [ring S*STAGE][bias|lo|alpha|beta : 4*TM ints][dshift : P*TM ints][entries][kinfo]
+  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta (4*TM) | dshift (P*TM) | entries | kin_off | kin_hw]
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
 
   const ConvGeom& g = a.g;
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int P = a.n_phases;
   int* const dsh = prm + 4 * TM;
   int* const ent = dsh + P * TM;
-  int* const kin = ent + a.max_ent;
+  int* const kin_off = ent + a.max_ent;
+  int* const kin_hw = kin_off + a.nslab * 4;
 
   // XCD-aware remap: consecutive logical tiles (same pixel tile, all channel tiles) on one XCD
   const int nblk = gridDim.x;
@@ -89,33 +94,41 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int mtile = bid % a.n_mtiles;
   const int ntile = bid / a.n_mtiles;
   const int px0 = ntile * TN;
-  const int* dirp = a.dir + mtile * (P + 1);
-  const int e_begin = dirp[0];
-  const int e_end = dirp[P];
+  const int e_begin = a.e_start[mtile];
+  const int e_end = a.e_start[mtile + 1];
   const int n_ent = e_end - e_begin;
-
   TF2_STAMP(1);
-  // ---- one-time table copy into LDS --------------------------------------------------
-  for (int i = tid; i < TM; i += 256) {
-    const int ch = mtile * TM + i;
-    prm[i] = a.bias[ch]; prm[TM + i] = a.lo[ch]; prm[2 * TM + i] = a.alpha[ch]; prm[3 * TM + i] = a.beta[ch];
-  }
-  for (int i = tid; i < P * TM; i += 256) dsh[i] = a.dshift[(size_t)(i / TM) * a.Np + mtile * TM + (i % TM)];
-  // slab id | (number of Horner phase steps to take before this entry) << 24: the K loop must not
-  // contain ordinary global loads (they would make hipcc drain the LDS-DMA queue every iteration)
-  for (int i = tid; i < n_ent; i += 256) {
-    int steps = 0;
-    for (int p = 1; p < P; p++) steps += (dirp[p] == e_begin + i && dirp[p] < e_end) ? 1 : 0;
-    ent[i] = a.entries[e_begin + i] | (steps << 24);
-  }
-  for (int i = tid; i < a.nslab * 4; i += 256) kin[i] = a.kinfo[i];
 
-  // ---- per-lane gather state ------------------------------------------------------------
   // LDS-DMA lane l of an instruction fills row (l>>2), 16-byte slot (l&3) of a 16-row group;
   // with the XOR swizzle slot c' of row r holds chunk c = c' ^ ((r>>2)&3), and r>>2 == l>>4
   // inside a group, so every lane always fetches the same chunk index:
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  int brow_h[BI], brow_w[BI], brow_base[BI];
+  const int a_lane_off = (lane >> 2) * 64 + chunk * 16;       // inside a 16-row group of a weight tile
+
+  auto issue_A = [&](int e) {
+    int8_t* const slot = lds + ((e - e_begin) % S) * STAGE;
+    const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
+#pragma unroll
+    for (int j = 0; j < AI; j++) {
+      const int grp = wave + 4 * j;                          // 16-row group of the A tile
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- block start: header + first weight tiles by LDS-DMA (one latency), decode meanwhile ----
+  {
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
+    int8_t* hdst = reinterpret_cast<int8_t*>(prm);
+    for (int i = wave; i * 1024 < a.hdr_bytes; i += 4)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < S - 1; s++)
+    if (s < n_ent) issue_A(e_begin + s);
+
+  // per-lane gather state for the B (activation) rows this lane fetches
+  const int8_t* brow_ptr[BI];
+  int brow_h[BI], brow_w[BI];
 #pragma unroll
   for (int j = 0; j < BI; j++) {
     const int p = px0 + (wave + 4 * j) * 16 + (lane >> 2);
@@ -126,12 +139,31 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       const int ow = rem - oh * g.OW;
       brow_h[j] = oh * g.stride - g.pad_h;
       brow_w[j] = ow * g.stride - g.pad_w;
-      brow_base[j] = b * g.H * g.W;
+      brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
     } else {
-      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_base[j] = 0;
+      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero;
     }
   }
-  const int a_lane_off = (lane >> 2) * 64 + chunk * 16;       // inside a 16-row group of a weight tile
+
+  // residual tile prefetch (ordinary loads; they are older than every activation DMA below, so the
+  // counted waits of the loop stay valid; first use is in the epilogue)
+  const int half = lane >> 5;
+  i32x4 resv[NT][NT];
+  asm volatile("" ::: "memory");           // keep the residual loads YOUNGER than the header/weight DMAs above
+#pragma unroll
+  for (int i = 0; i < NT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      resv[i][j] = i32x4{0, 0, 0, 0};
+      if (g.has_res) {                     // wave-uniform; every lane loads (a safe address when masked)
+        const int px = px0 + wn * WT + j * 32 + (lane & 31);
+        const int chl = mtile * TM + wm * WT + i * 32 + 16 * half;
+        const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
+        const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+        resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
+      }
+    }
+  asm volatile("" ::: "memory");
 
   i32x16 acc[NT][NT];
 #pragma unroll
@@ -141,54 +173,25 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
 
-  __syncthreads();     // tables visible; no LDS-DMA outstanding yet, so this is a plain barrier
+  // header and first weight tiles landed (the NT*NT residual loads may stay outstanding)
+  if (g.has_res) wait_vmcnt<NT * NT>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   TF2_STAMP(2);
 
-  auto issue_stage = [&](int e) {       // e: absolute entry index; fills ring slot (e - e_begin) % S
-    int8_t* const slot = lds + ((e - e_begin) % S) * STAGE;
+  auto issue_B = [&](int e) {
+    int8_t* const slot = lds + ((e - e_begin) % S) * STAGE + A_BYTES;
     const int slab = ent[e - e_begin] & 0xffffff;
-    const unsigned ki = (unsigned)kin[slab * 4 + chunk];
-    const int dh = (int)((ki >> 16) & 0xff);
-    const int dw = (int)(ki >> 24);
-    const int coff = (ki & 0xffff) == 0xffff ? -1 : (int)(ki & 0xffff);
-    const int8_t* wsrc = a.w + (size_t)((g.flags & 4) ? e_begin : e) * A_BYTES + a_lane_off;   // bit 2: perf experiment only
-#pragma unroll
-    for (int j = 0; j < AI; j++) {
-      const int grp = wave + 4 * j;                          // 16-row group of the A tile
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
-    }
+    const int off = kin_off[slab * 4 + chunk];
+    const int hw = kin_hw[slab * 4 + chunk];
+    const int dh = hw & 0xffff, dw = hw >> 16;
 #pragma unroll
     for (int j = 0; j < BI; j++) {
       const int grp = wave + 4 * j;
       const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
-      const bool ok = coff >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && !(g.flags & 2);   // bit 1: perf experiment only
-      const int8_t* src = ok ? a.x + ((size_t)(brow_base[j] + ih * g.W + iw) * g.Cp_in + coff) : a.zero;
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + A_BYTES + grp * 1024), 16, 0, 0);
-    }
-  };
-
-  auto compute = [&](int e) {
-    const int8_t* A = lds + ((e - e_begin) % S) * STAGE;
-    const int8_t* B = A + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int c = ks * 2 + (lane >> 5);
-      i32x4 af[NT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < NT; i++) {
-        const int row = wm * WT + i * 32 + (lane & 31);
-        af[i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int row = wn * WT + j * 32 + (lane & 31);
-        bf[j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < NT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+      const bool ok = off >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
     }
   };
 
@@ -209,29 +212,59 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   };
 
   // ---- pipelined K loop ---------------------------------------------------------------------
+  // VMEM queue of a wave: [hdr, A_0..A_{S-2}, residual, B_0..B_{S-2}, then per iteration A_e, B_e]
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
-    if (e_begin + s < e_end) issue_stage(e_begin + s);
-  int phase = 0;
+    if (s < n_ent) issue_B(e_begin + s);
   TF2_STAMP(3);
-  for (int e = e_begin; e < e_end; e++) {
-    // stages issued beyond e: min(S-2, e_end-1-e); wait until stage e has landed (per wave)
-    const int ahead = (e_end - 1 - e) < (S - 2) ? (e_end - 1 - e) : (S - 2);
-    if (ahead >= S - 2) wait_vmcnt<(S - 2) * NI>();
-    else if (S >= 4 && ahead == 1) wait_vmcnt<NI>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();          // every wave's part of stage e landed; slot (e-1)%S is free
-    if (e == e_begin) TF2_STAMP(4);
+  int phase = 0;
+  for (int it = 0; it < n_ent; it++) {
+    const int e = e_begin + it;
+    // operations issued after stage `it` (see the queue above); fewer near the tail -> wait for all
+    if (n_ent - 1 - it >= S - 2) {
+      if (it == 0) wait_vmcnt<(S - 2) * BI>();
+      else if (S == 4 && it == 1) wait_vmcnt<BI + NI>();
+      else wait_vmcnt<(S - 2) * NI>();
+    } else if (S == 4 && n_ent - 1 - it == 1 && it >= 2) {
+      wait_vmcnt<NI>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
     asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
-    if (e + S - 1 < e_end && !(g.flags & 8)) issue_stage(e + S - 1);     // bit 3/4: perf experiments only
-    for (int st = ent[e - e_begin] >> 24; st > 0; st--) { phase++; phase_shift(phase); }
-    if (!(g.flags & 16)) compute(e);
+    for (int st = ent[it] >> 24; st > 0; st--) { phase++; phase_shift(phase); }
+
+    const int8_t* A = lds + (it % S) * STAGE;
+    const int8_t* B = A + A_BYTES;
+    i32x4 af[2][NT], bf[2][NT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        const int row = wm * WT + i * 32 + (lane & 31);
+        af[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const int row = wn * WT + j * 32 + (lane & 31);
+        bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+      }
+    }
+    if (it + S - 1 < n_ent) { issue_A(e + S - 1); issue_B(e + S - 1); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
   }
   while (phase + 1 < P) { phase++; phase_shift(phase); }
   TF2_STAMP(5);
 
   // ---- epilogue --------------------------------------------------------------------------------
-  const int half = lane >> 5;
+  const int lo_bound = g.relu ? 0 : -128;                  // relu.cl:54 folded into the clamp
 #pragma unroll
   for (int i = 0; i < NT; i++) {
     const int rb = wm * WT + i * 32;                         // tile row base inside the block tile
@@ -252,10 +285,16 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int v = (int)((unsigned)bias4[r] + ((unsigned)acc[i][j][G * 4 + r] << (lo4[r] & 31)));
-          q[r] = requant2_i8(v, al4[r], be4[r], g.relu);
+          const long long p = (long long)v * (long long)al4[r];            // pe.cl:191
+          int t = (int)(p >> kAlphaInflat);                                // pe.cl:192
+          t = (int)((unsigned)t + (unsigned)be4[r]);
+          int y = ((t >> (kInflat - 1)) + 1) >> 1;                         // pe.cl:193
+          y = y > 127 ? 127 : y;                                           // pe.cl:194
+          q[r] = y < lo_bound ? lo_bound : y;
         }
-        d[G] = (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) |
-               ((unsigned)(q[3] & 0xff) << 24);
+        const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);   // bytes: q0.b0, q1.b0
+        const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
+        d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
       }
       // d[G] = channel group 2G (lanes 0-31) / 2G+1 (lanes 32-63): two half-wave swaps give
       // lanes 0-31 groups 0..3 and lanes 32-63 groups 4..7 -> 16 contiguous NHWC bytes per lane
@@ -265,16 +304,16 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       const int chl = tile_ch + 16 * half;
       if (pvalid && chl + 16 <= g.y_nvalid) {
         if (g.has_res) {
-          // residual add in int16, clamp, ReLU (feature_writer.cl:119-122) on the packed bytes
-          const i32x4 rv = *reinterpret_cast<const i32x4*>(a.res + (size_t)px * g.res_cp + g.res_off + chl);
+          // residual add in int16, clamp, ReLU (feature_writer.cl:119-122)
+          const int rlo = g.add_relu ? 0 : -128;
+          const i32x4 rv = resv[i][j];
 #pragma unroll
           for (int w = 0; w < 4; w++) {
             int o = 0;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
               int s = (int)(signed char)((out[w] >> (8 * b)) & 0xff) + (int)(signed char)((rv[w] >> (8 * b)) & 0xff);
-              s = s > 127 ? 127 : (s < -128 ? -128 : s);
-              if (g.add_relu) s = s > 0 ? s : 0;
+              s = s > 127 ? 127 : (s < rlo ? rlo : s);
               o |= (s & 0xff) << (8 * b);
             }
             out[w] = o;
@@ -284,15 +323,15 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  TF2_STAMP(6);
+  if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
+#undef TF2_STAMP
 }
 
 template <int WM, int WN, int WT, int S>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WT, TN = WN * WT;
   constexpr int STAGE = (TM + TN) * 64;
-  const size_t lds = (size_t)S * STAGE + (size_t)(4 + a.n_phases) * TM * 4 + (size_t)a.max_ent * 4 + (size_t)a.nslab * 16 + 64;
+  const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
   auto fn = conv_mfma2_kernel<WM, WN, WT, S>;
   if (!attr_set) {
@@ -309,6 +348,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 // that small grids still spread over the 256 CUs.
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.n_mtiles > kMaxMtiles) return -4;
   if (TM == 128) return launch_cfg<2, 2, 64, 3>(a, s);
   if (TM == 64) {
     const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;

@@ -264,6 +264,16 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.beta = (const int32_t*)(pk + pl->off_beta); ca.lo = (const int32_t*)(pk + pl->off_lo);
       ca.dshift = (const int32_t*)(pk + pl->off_dshift);
       ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
+      if (pl->kind == KIND_MFMA) {
+        ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
+        if (pl->n_mtiles <= kMaxMtiles) {
+          const int32_t* hd = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
+          for (int mt = 0; mt < pl->n_mtiles; mt++) ca.e_start[mt] = hd[(size_t)mt * (pl->n_phases + 1)];
+          ca.e_start[pl->n_mtiles] = pl->n_entries;
+        } else {
+          mfma_v1 = true;      // very wide layers: the register-staged kernel has no m-tile limit
+        }
+      }
       if (const char* e = getenv("TF2_AMD_DBGPTR")) ca.dbg = (long long*)strtoull(e, nullptr, 0) + (size_t)l * 16;
       ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;
       ca.k = L.k; ca.dil = L.dil; ca.n_cchunk = pl->n_cchunk; ca.Cp_half = in_layout[l].half;

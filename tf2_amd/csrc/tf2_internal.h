@@ -11,7 +11,8 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 5;
+constexpr uint32_t kPackVersion = 6;
+constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -43,6 +44,8 @@ struct PackLayer {
   uint64_t off_beta;     // int32[Np]
   uint64_t off_lo;       // int32[Np]  final left shift of the accumulated sum
   uint64_t off_dshift;   // int32[n_phases][Np]  Horner shift applied when entering phase p>=1
+  uint64_t off_hdr;      // MFMA: n_mtiles headers of hdr_bytes each (the LDS image conv_mfma2 copies per block)
+  uint64_t hdr_bytes;    // multiple of 1024
 };
 
 struct PackHeader {
@@ -82,6 +85,9 @@ struct ConvArgs {
   const int32_t* dshift;
   const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
   long long* dbg;            // optional: 16 timestamps of block 0 (tools/layer_times.py), else null
+  const int32_t* hdr;        // per-m-tile LDS header images
+  int32_t hdr_bytes;
+  int32_t e_start[kMaxMtiles + 1];   // first entry of every m-tile (+ end)
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;
   int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split

@@ -221,6 +221,43 @@ tf2_status Net::pack(int mode) {
       std::memcpy(blob.at<uint8_t>(pl.off_lo), lo_last.data(), (size_t)Np * 4);
       pl.off_dshift = blob.alloc(dshift.size() * 4);
       std::memcpy(blob.at<uint8_t>(pl.off_dshift), dshift.data(), dshift.size() * 4);
+      // ---- per-m-tile LDS header images for conv_mfma2.hip ----
+      // words: bias[TM] lo[TM] alpha[TM] beta[TM] | dshift[P][TM] | entries[max_ent] (slab | phase steps << 24)
+      //        | kin_off[nslab*4] (byte offset of the segment relative to the pixel's tap origin, -1 = padding)
+      //        | kin_hw[nslab*4] (dh | dw << 16)
+      {
+        const size_t words = (size_t)4 * TM + (size_t)P * TM + pl.max_ent + (size_t)8 * nslab;
+        const size_t hb = (words * 4 + 1023) / 1024 * 1024;
+        pl.hdr_bytes = hb;
+        pl.off_hdr = blob.alloc(hb * n_mtiles);
+        for (int mt = 0; mt < n_mtiles; mt++) {
+          int32_t* h = blob.at<int32_t>(pl.off_hdr + (uint64_t)mt * hb);
+          for (int r = 0; r < TM; r++) {
+            const int n = mt * TM + r;
+            h[r] = n < N ? m.bias[n] : 0; h[TM + r] = lo_last[n];
+            h[2 * TM + r] = n < N ? m.alpha[n] : 0; h[3 * TM + r] = n < N ? m.beta[n] : 0;
+            for (int p = 0; p < P; p++) h[4 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
+          }
+          int32_t* he = h + 4 * TM + P * TM;
+          const int e0 = dir[(size_t)mt * (P + 1)], e1 = dir[(size_t)mt * (P + 1) + P];
+          for (int e = e0; e < e1; e++) {
+            int steps = 0;
+            for (int p = 1; p < P; p++) if (dir[(size_t)mt * (P + 1) + p] == e) steps++;
+            he[e - e0] = entries[e] | (steps << 24);
+          }
+          int32_t* ko = he + pl.max_ent;
+          int32_t* kh = ko + 4 * nslab;
+          for (int sl = 0; sl < nslab; sl++)
+            for (int sg = 0; sg < 4; sg++) {
+              const int kk0 = sl * 64 + sg * 16;
+              const int t = kk0 / il.Cp_in, pc = kk0 % il.Cp_in;
+              if (t >= taps) { ko[sl * 4 + sg] = -1; kh[sl * 4 + sg] = 0; continue; }
+              const int dh = (t / k) * L.dil, dw = (t % k) * L.dil;
+              ko[sl * 4 + sg] = (dh * L.W + dw) * il.Cp_in + pc;
+              kh[sl * 4 + sg] = dh | (dw << 16);
+            }
+        }
+      }
     } else {
       pl.kind = KIND_SHIFT;
       const int Np = round_up(N, 8);

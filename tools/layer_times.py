@@ -50,9 +50,9 @@ for i, L in enumerate(plan):
 print("total us", float(ms.sum() * 1e3))
 if a.stamps:
     d = dbg.cpu().numpy().reshape(64, 16)
-    print("cycle stamps of block 0 (deltas, 100 MHz ticks?): start->dir, ->tables+barrier, ->prologue issued, ->first stage landed, ->loop end, ->epilogue end")
+    print("cycle stamps of block 0 (deltas, 100 MHz ticks?): start->e_start, ->header+A landed+barrier, ->prologue B issued, ->loop end, ->epilogue end")
     for i in range(n):
         r = d[i]
-        print(i, [int(r[j + 1] - r[j]) for j in range(6)])
+        print(i, [int(r[1] - r[0]), int(r[2] - r[1]), int(r[3] - r[2]), int(r[5] - r[3]), int(r[6] - r[5])])
 if a.out:
     json.dump(rows, open(a.out, "w"), indent=0, default=float)
