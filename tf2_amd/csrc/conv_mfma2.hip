@@ -59,7 +59,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // WM x WN waves (WM*WN == 4), each wave a WT x WT output tile (WT = 64 or 32), S ring stages.
-template <int WM, int WN, int WT, int S>
+template <int WM, int WN, int WT, int S, bool PADCHK>
 __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int TM = WM * WT, TN = WN * WT;
   constexpr int NT = WT / 32;                  // 32x32 MFMA tiles per wave and dimension
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   constexpr int AI = TM / 64, BI = TN / 64;    // LDS-DMA instructions per wave per stage (A, B)
   constexpr int NI = AI + BI;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta (4*TM) | dshift (P*TM) | entries | kin_off | kin_hw]
+  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta64.lo|beta64.hi (5*TM) | dshift (P*TM) | steps[max_ent] |
+  //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time)
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
 
   const ConvGeom& g = a.g;
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 #define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
   TF2_STAMP(0);
   const int P = a.n_phases;
-  int* const dsh = prm + 4 * TM;
-  int* const ent = dsh + P * TM;
-  int* const kin_off = ent + a.max_ent;
-  int* const kin_hw = kin_off + a.nslab * 4;
+  int* const dsh = prm + 5 * TM;
+  int* const steps = dsh + P * TM;
+  int* const goff = steps + a.max_ent;
+  int* const ghw = goff + a.max_ent * 4;
 
   // XCD-aware remap: consecutive logical tiles (same pixel tile, all channel tiles) on one XCD
   const int nblk = gridDim.x;
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;       // inside a 16-row group of a weight tile
 
-  auto issue_A = [&](int e) {
-    int8_t* const slot = lds + ((e - e_begin) % S) * STAGE;
+  auto issue_A = [&](int e, int slot_idx) {
+    int8_t* const slot = lds + slot_idx * STAGE;
     const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++) {
@@ -124,11 +125,12 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   }
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
-    if (s < n_ent) issue_A(e_begin + s);
+    if (s < n_ent) issue_A(e_begin + s, s);
 
   // per-lane gather state for the B (activation) rows this lane fetches
   const int8_t* brow_ptr[BI];
   int brow_h[BI], brow_w[BI];
+  bool brow_ok[BI];
 #pragma unroll
   for (int j = 0; j < BI; j++) {
     const int p = px0 + (wave + 4 * j) * 16 + (lane >> 2);
@@ -140,8 +142,9 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       brow_h[j] = oh * g.stride - g.pad_h;
       brow_w[j] = ow * g.stride - g.pad_w;
       brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
+      brow_ok[j] = true;
     } else {
-      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero;
+      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
     }
   }
 
@@ -179,17 +182,19 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   asm volatile("" ::: "memory");
   TF2_STAMP(2);
 
-  auto issue_B = [&](int e) {
-    int8_t* const slot = lds + ((e - e_begin) % S) * STAGE + A_BYTES;
-    const int slab = ent[e - e_begin] & 0xffffff;
-    const int off = kin_off[slab * 4 + chunk];
-    const int hw = kin_hw[slab * 4 + chunk];
-    const int dh = hw & 0xffff, dw = hw >> 16;
+  auto issue_B = [&](int it, int slot_idx) {
+    int8_t* const slot = lds + slot_idx * STAGE + A_BYTES;
+    const int off = goff[it * 4 + chunk];
+    int dh = 0, dw = 0;
+    if (PADCHK) { const int hw = ghw[it * 4 + chunk]; dh = hw & 0xffff; dw = hw >> 16; }
 #pragma unroll
     for (int j = 0; j < BI; j++) {
       const int grp = wave + 4 * j;
-      const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
-      const bool ok = off >= 0 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      bool ok = off >= 0 && brow_ok[j];
+      if (PADCHK) {
+        const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
+        ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      }
       const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
     }
@@ -215,26 +220,16 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   // VMEM queue of a wave: [hdr, A_0..A_{S-2}, residual, B_0..B_{S-2}, then per iteration A_e, B_e]
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
-    if (s < n_ent) issue_B(e_begin + s);
+    if (s < n_ent) issue_B(s, s);
   TF2_STAMP(3);
   int phase = 0;
-  for (int it = 0; it < n_ent; it++) {
-    const int e = e_begin + it;
-    // operations issued after stage `it` (see the queue above); fewer near the tail -> wait for all
-    if (n_ent - 1 - it >= S - 2) {
-      if (it == 0) wait_vmcnt<(S - 2) * BI>();
-      else if (S == 4 && it == 1) wait_vmcnt<BI + NI>();
-      else wait_vmcnt<(S - 2) * NI>();
-    } else if (S == 4 && n_ent - 1 - it == 1 && it >= 2) {
-      wait_vmcnt<NI>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
-    asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
-    for (int st = ent[it] >> 24; st > 0; st--) { phase++; phase_shift(phase); }
+  int cslot = 0;                           // ring slot of the stage being computed
+  int islot = S - 1;                       // ring slot the next issued stage goes to
+  const int n_main = n_ent - (S - 1);      // iterations that still issue a stage S-1 ahead
 
-    const int8_t* A = lds + (it % S) * STAGE;
+  auto body = [&](int it, bool issue) {
+    for (int st = steps[it]; st > 0; st--) { phase++; phase_shift(phase); }
+    const int8_t* A = lds + cslot * STAGE;
     const int8_t* B = A + A_BYTES;
     i32x4 af[2][NT], bf[2][NT];
 #pragma unroll
@@ -251,7 +246,11 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
         bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
       }
     }
-    if (it + S - 1 < n_ent) { issue_A(e + S - 1); issue_B(e + S - 1); }
+    if (issue) {
+      issue_A(e_begin + it + S - 1, islot);
+      issue_B(it + S - 1, islot);
+      islot = islot + 1 == S ? 0 : islot + 1;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -259,12 +258,35 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 #pragma unroll
         for (int j = 0; j < NT; j++)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+    cslot = cslot + 1 == S ? 0 : cslot + 1;
+  };
+
+  int it = 0;
+  for (; it < n_main; it++) {
+    // operations issued after stage `it` in the queue above
+    if (it == 0) wait_vmcnt<(S - 2) * BI>();
+    else if (S == 4 && it == 1) wait_vmcnt<BI + NI>();
+    else wait_vmcnt<(S - 2) * NI>();
+    __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
+    asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
+    body(it, true);
+  }
+  for (; it < n_ent; it++) {               // tail: nothing left to issue, wait for everything
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    body(it, false);
   }
   while (phase + 1 < P) { phase++; phase_shift(phase); }
   TF2_STAMP(5);
 
   // ---- epilogue --------------------------------------------------------------------------------
-  const int lo_bound = g.relu ? 0 : -128;                  // relu.cl:54 folded into the clamp
+  // per output: v = bias + (sum << lo);  x = low32((v*alpha + (beta << 20)) >> 20)   (pe.cl:191-193, the
+  // 32-bit truncation and wrap-around of the reference kept);  y = sat(x + 2^14) >> 15, which equals
+  // ((x >> 14) + 1) >> 1 everywhere except where both clamp to 127;  clamp (+ReLU) (pe.cl:194, relu.cl:54);
+  // residual: int16 add, clamp, ReLU (feature_writer.cl:119-122) in the C/D register layout.
+  const int lo_bound = g.relu ? 0 : -128;
+  const int rlo = g.add_relu ? 0 : -128;
 #pragma unroll
   for (int i = 0; i < NT; i++) {
     const int rb = wm * WT + i * 32;                         // tile row base inside the block tile
@@ -273,6 +295,13 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     for (int j = 0; j < NT; j++) {
       const int px = px0 + wn * WT + j * 32 + (lane & 31);
       const bool pvalid = px < g.n_pix;
+      unsigned rd[4] = {0, 0, 0, 0};
+      if (g.has_res) {
+        // the prefetched 16 contiguous bytes back into the C/D layout (the store swaps are involutions)
+        auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[i][j][0], (unsigned)resv[i][j][1], false, false);
+        auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[i][j][2], (unsigned)resv[i][j][3], false, false);
+        rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
+      }
       unsigned d[4];
 #pragma unroll
       for (int G = 0; G < 4; G++) {
@@ -280,17 +309,24 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
         const i32x4 bias4 = *reinterpret_cast<const i32x4*>(prm + r0);
         const i32x4 lo4 = *reinterpret_cast<const i32x4*>(prm + TM + r0);
         const i32x4 al4 = *reinterpret_cast<const i32x4*>(prm + 2 * TM + r0);
-        const i32x4 be4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
+        const i32x4 bl4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
+        const i32x4 bh4 = *reinterpret_cast<const i32x4*>(prm + 4 * TM + r0);
         int q[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int v = (int)((unsigned)bias4[r] + ((unsigned)acc[i][j][G * 4 + r] << (lo4[r] & 31)));
-          const long long p = (long long)v * (long long)al4[r];            // pe.cl:191
-          int t = (int)(p >> kAlphaInflat);                                // pe.cl:192
-          t = (int)((unsigned)t + (unsigned)be4[r]);
-          int y = ((t >> (kInflat - 1)) + 1) >> 1;                         // pe.cl:193
-          y = y > 127 ? 127 : y;                                           // pe.cl:194
-          q[r] = y < lo_bound ? lo_bound : y;
+          const long long b64 = (long long)(((unsigned long long)(unsigned)bh4[r] << 32) | (unsigned)bl4[r]);
+          const long long p = (long long)v * (long long)al4[r] + b64;
+          const int x = (int)(p >> kAlphaInflat);
+          const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+          int c;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+          if (g.has_res) {
+            const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
+            const int sres = c + rr;
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
+          }
+          q[r] = c;
         }
         const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);   // bytes: q0.b0, q1.b0
         const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
@@ -300,40 +336,23 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
       // lanes 0-31 groups 0..3 and lanes 32-63 groups 4..7 -> 16 contiguous NHWC bytes per lane
       auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
       auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-      i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+      const i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
       const int chl = tile_ch + 16 * half;
-      if (pvalid && chl + 16 <= g.y_nvalid) {
-        if (g.has_res) {
-          // residual add in int16, clamp, ReLU (feature_writer.cl:119-122)
-          const int rlo = g.add_relu ? 0 : -128;
-          const i32x4 rv = resv[i][j];
-#pragma unroll
-          for (int w = 0; w < 4; w++) {
-            int o = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-              int s = (int)(signed char)((out[w] >> (8 * b)) & 0xff) + (int)(signed char)((rv[w] >> (8 * b)) & 0xff);
-              s = s > 127 ? 127 : (s < rlo ? rlo : s);
-              o |= (s & 0xff) << (8 * b);
-            }
-            out[w] = o;
-          }
-        }
+      if (pvalid && chl + 16 <= g.y_nvalid)
         *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
-      }
     }
   }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WT, int S>
-static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+template <int WM, int WN, int WT, int S, bool PADCHK>
+static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WT, TN = WN * WT;
   constexpr int STAGE = (TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
-  auto fn = conv_mfma2_kernel<WM, WN, WT, S>;
+  auto fn = conv_mfma2_kernel<WM, WN, WT, S, PADCHK>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_set = true;
@@ -342,6 +361,12 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
   hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int WM, int WN, int WT, int S>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+  // bounds checks on the gathered taps are only needed for padded convolutions
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WT, S, true>(a, s) : launch_cfg2<WM, WN, WT, S, false>(a, s);
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so

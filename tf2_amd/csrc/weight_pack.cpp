@@ -222,11 +222,12 @@ tf2_status Net::pack(int mode) {
       pl.off_dshift = blob.alloc(dshift.size() * 4);
       std::memcpy(blob.at<uint8_t>(pl.off_dshift), dshift.data(), dshift.size() * 4);
       // ---- per-m-tile LDS header images for conv_mfma2.hip ----
-      // words: bias[TM] lo[TM] alpha[TM] beta[TM] | dshift[P][TM] | entries[max_ent] (slab | phase steps << 24)
-      //        | kin_off[nslab*4] (byte offset of the segment relative to the pixel's tap origin, -1 = padding)
-      //        | kin_hw[nslab*4] (dh | dw << 16)
+      // words: bias[TM] lo[TM] alpha[TM] beta64.lo[TM] beta64.hi[TM] (beta64 = (int64)beta << 20, the addend of
+      //        the 64-bit multiply-add) | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
+      //        the entry) | goff[max_ent][4] (per 16-byte segment: byte offset from the pixel's tap origin,
+      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test)
       {
-        const size_t words = (size_t)4 * TM + (size_t)P * TM + pl.max_ent + (size_t)8 * nslab;
+        const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)9 * pl.max_ent;
         const size_t hb = (words * 4 + 1023) / 1024 * 1024;
         pl.hdr_bytes = hb;
         pl.off_hdr = blob.alloc(hb * n_mtiles);
@@ -234,28 +235,33 @@ tf2_status Net::pack(int mode) {
           int32_t* h = blob.at<int32_t>(pl.off_hdr + (uint64_t)mt * hb);
           for (int r = 0; r < TM; r++) {
             const int n = mt * TM + r;
+            const int64_t b64 = (int64_t)(n < N ? m.beta[n] : 0) << kAlphaInflat;
             h[r] = n < N ? m.bias[n] : 0; h[TM + r] = lo_last[n];
-            h[2 * TM + r] = n < N ? m.alpha[n] : 0; h[3 * TM + r] = n < N ? m.beta[n] : 0;
-            for (int p = 0; p < P; p++) h[4 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
+            h[2 * TM + r] = n < N ? m.alpha[n] : 0;
+            h[3 * TM + r] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
+            h[4 * TM + r] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+            for (int p = 0; p < P; p++) h[5 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
           }
-          int32_t* he = h + 4 * TM + P * TM;
+          int32_t* hs = h + 5 * TM + P * TM;
+          int32_t* ko = hs + pl.max_ent;
+          int32_t* kh = ko + 4 * pl.max_ent;
           const int e0 = dir[(size_t)mt * (P + 1)], e1 = dir[(size_t)mt * (P + 1) + P];
           for (int e = e0; e < e1; e++) {
-            int steps = 0;
-            for (int p = 1; p < P; p++) if (dir[(size_t)mt * (P + 1) + p] == e) steps++;
-            he[e - e0] = entries[e] | (steps << 24);
-          }
-          int32_t* ko = he + pl.max_ent;
-          int32_t* kh = ko + 4 * nslab;
-          for (int sl = 0; sl < nslab; sl++)
+            int st = 0;
+            for (int p = 1; p < P; p++) if (dir[(size_t)mt * (P + 1) + p] == e) st++;
+            hs[e - e0] = st;
+            const int sl = entries[e];
             for (int sg = 0; sg < 4; sg++) {
               const int kk0 = sl * 64 + sg * 16;
               const int t = kk0 / il.Cp_in, pc = kk0 % il.Cp_in;
-              if (t >= taps) { ko[sl * 4 + sg] = -1; kh[sl * 4 + sg] = 0; continue; }
+              int32_t& o = ko[(e - e0) * 4 + sg];
+              int32_t& hw = kh[(e - e0) * 4 + sg];
+              if (t >= taps) { o = -1; hw = 0; continue; }
               const int dh = (t / k) * L.dil, dw = (t % k) * L.dil;
-              ko[sl * 4 + sg] = (dh * L.W + dw) * il.Cp_in + pc;
-              kh[sl * 4 + sg] = dh | (dw << 16);
+              o = (dh * L.W + dw) * il.Cp_in + pc;
+              hw = dh | (dw << 16);
             }
+          }
         }
       }
     } else {
