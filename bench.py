@@ -128,10 +128,25 @@ def main():
     dom_ms = float(sum(per_layer_ms[i] for i in mf))
     if mf and dom_ms > 0:
         achieved = dom_ops / (dom_ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel="conv_mfma_kernel", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
-                        frac=round(achieved / PEAK_I8, 4), traffic=None, launches_per_step=len(mf),
+        # HBM bytes per launch from the committed PMC passes of the same workload (tools/pmc_run.sh ->
+        # tools/pmc_summary.py), when they exist for this batch size
+        traffic, traffic_note = None, "no PMC pass committed for this batch size"
+        pj = os.path.join(ROOT, "profiles", f"r01_pmc_conv_b{args.batch}.json")
+        if os.path.exists(pj):
+            pm = json.load(open(pj))
+            tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in mf)
+            traffic = round(tb / len(mf))
+            traffic_note = f"mean HBM bytes per launch over the step's {len(mf)} launches, rocprofv3 FETCH_SIZE(x2, gfx950)+WRITE_SIZE, {os.path.basename(pj)}"
+        alg_bytes = sum(lo[i]["bytes"] for i in mf) * args.batch
+        roofline = dict(bound="mfma", kernel="conv_mfma2_kernel", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
+                        frac=round(achieved / PEAK_I8, 4), traffic=traffic, traffic_note=traffic_note,
+                        algorithmic_bytes_per_launch=round(alg_bytes / len(mf)), launches_per_step=len(mf),
+                        algorithmic_ops_per_launch=round(dom_ops / len(mf)),
                         avg_launch_us=round(dom_ms / len(mf) * 1e3, 2),
-                        note="sum of algorithmic int8 ops of the step's conv_mfma launches / sum of their HIP-event durations")
+                        hbm_side=dict(achieved_gbps=round(alg_bytes / (dom_ms * 1e-3) / 1e9, 1), peak_gbps=PEAK_HBM,
+                                      frac=round(alg_bytes / (dom_ms * 1e-3) / 1e9 / PEAK_HBM, 4)),
+                        note="achieved = sum of algorithmic int8 ops (2/MAC) of the step's conv launches / sum of their HIP-event "
+                             "durations on the launch stream (per-launch average over the 52 shapes of the network)")
     else:
         sh = [i for i in range(len(plan)) if kinds[i] == 2]
         dom_ops = sum(lo[i]["ops"] for i in sh) * args.batch

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 PMC passes of tools/pmc_run.sh (gpurun_out/pmc/*) into
+profiles/<name>.json: per conv launch of the LAST step -- HBM bytes (FETCH_SIZE / WRITE_SIZE,
+KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes for wide coalesced reads on
+gfx950 -- validated here against layers whose byte count is known), wave cycles and instruction mix."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "pmc")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r01_pmc_conv_b32.json")
+
+def table(d):
+    f = glob.glob(f"{src}/{d}/runc/*_counter_collection.csv")[0]
+    disp = collections.OrderedDict()
+    for x in csv.DictReader(open(f)):
+        e = disp.setdefault(int(x["Dispatch_Id"]), {"kernel": x["Kernel_Name"], "grid": int(x["Grid_Size"]), "vgpr": int(x["VGPR_Count"])})
+        e[x["Counter_Name"]] = float(x["Counter_Value"])
+    return [v for v in disp.values() if "conv_mfma" in v["kernel"]]
+
+n = 54
+sq1, sq2, t1, t2 = (table(d)[-n:] for d in ("sq1", "sq2", "tcc1", "tcc2"))
+rows = []
+for i in range(n):
+    a, b, c, d = sq1[i], sq2[i], t1[i], t2[i]
+    rows.append(dict(layer=i, kernel=a["kernel"].split("(")[0][:60], grid_threads=a["grid"], vgpr=a["vgpr"],
+                     fetch_bytes=2 * c["FETCH_SIZE"] * 1024, fetch_bytes_raw_counter=c["FETCH_SIZE"] * 1024,
+                     write_bytes=d["WRITE_SIZE"] * 1024, waves=a["SQ_WAVES"], wave_cycles_quad=a["SQ_WAVE_CYCLES"],
+                     wait_any=a["SQ_WAIT_ANY"], wait_inst_any=a["SQ_WAIT_INST_ANY"], active_inst_any=a["SQ_ACTIVE_INST_ANY"],
+                     insts_valu=a["SQ_INSTS_VALU"], insts_salu=b["SQ_INSTS_SALU"], insts_lds=b["SQ_INSTS_LDS"],
+                     insts_vmem=b["SQ_INSTS_VMEM"], insts_mfma=b["SQ_INSTS_MFMA"], mfma_busy_cycles=b["SQ_VALU_MFMA_BUSY_CYCLES"],
+                     lds_bank_conflict=b["SQ_LDS_BANK_CONFLICT"]))
+tot = dict(fetch_bytes=sum(r["fetch_bytes"] for r in rows), write_bytes=sum(r["write_bytes"] for r in rows))
+json.dump(dict(note="rocprofv3 --pmc passes (separate runs: SQ x2, FETCH_SIZE+GRBM, WRITE_SIZE), ResNet50 batch 32, one step; "
+                    "fetch_bytes = 2 x FETCH_SIZE KiB (gfx950 correction)", total=tot, layers=rows), open(out, "w"), indent=1)
+print("wrote", out, {k: round(v / 1e6, 1) for k, v in tot.items()}, "MB per step")
