@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra-batches", type=str, default="1,64", help="also time these per-GPU batch sizes")
+    ap.add_argument("--streams", type=int, default=1, help="split each batch over this many concurrent HIP streams")
     args = ap.parse_args()
 
     import torch
@@ -71,14 +72,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else []
+    sub_runners = [network.Runner(None, net) for _ in range(n_streams)] if n_streams > 1 else []
+
+    def step(x, parts):
+        if n_streams == 1 or x.shape[0] < n_streams:
+            runner.run_batch(x)
+            return
+        for st, rn, xp in zip(streams, sub_runners, parts):
+            with torch.cuda.stream(st):
+                rn.run_batch(xp)
+
     def timed(batch, steps, warmup):
         x = torch.from_numpy(synth.synth_images(tables, batch, seed=100 + rank)).to(device)
+        parts = [c.contiguous() for c in torch.chunk(x, n_streams)] if n_streams > 1 and batch >= n_streams else None
+        torch.cuda.synchronize(device)
         for _ in range(warmup):
-            runner.run_batch(x)
+            step(x, parts)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            runner.run_batch(x)
+            step(x, parts)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -186,7 +201,8 @@ def main():
                     scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
                     config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
                                          f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
-                                global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode),
+                                global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
+                                streams_per_gpu=n_streams),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

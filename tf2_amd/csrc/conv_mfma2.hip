@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   constexpr int NI = AI + BI;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta64.lo|beta64.hi (5*TM) | dshift (P*TM) | steps[max_ent] |
-  //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time)
+  //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time;
+  //           steps[p-1] = iteration at which phase p starts, INT_MAX after the last; max_ent includes S spare entries)
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
 
   const ConvGeom& g = a.g;
@@ -182,11 +183,10 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   asm volatile("" ::: "memory");
   TF2_STAMP(2);
 
-  auto issue_B = [&](int it, int slot_idx) {
+  auto issue_B = [&](int off, int hw, int slot_idx) {     // off/hw: this lane's gather words of the stage
     int8_t* const slot = lds + slot_idx * STAGE + A_BYTES;
-    const int off = goff[it * 4 + chunk];
     int dh = 0, dw = 0;
-    if (PADCHK) { const int hw = ghw[it * 4 + chunk]; dh = hw & 0xffff; dw = hw >> 16; }
+    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
 #pragma unroll
     for (int j = 0; j < BI; j++) {
       const int grp = wave + 4 * j;
@@ -220,15 +220,23 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   // VMEM queue of a wave: [hdr, A_0..A_{S-2}, residual, B_0..B_{S-2}, then per iteration A_e, B_e]
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
-    if (s < n_ent) issue_B(s, s);
+    if (s < n_ent) issue_B(goff[s * 4 + chunk], PADCHK ? ghw[s * 4 + chunk] : 0, s);
   TF2_STAMP(3);
   int phase = 0;
   int cslot = 0;                           // ring slot of the stage being computed
   int islot = S - 1;                       // ring slot the next issued stage goes to
   const int n_main = n_ent - (S - 1);      // iterations that still issue a stage S-1 ahead
+  // gather words of the next stage to issue, read one iteration ahead (tables are padded by S entries)
+  int off_nx = goff[(S - 1) * 4 + chunk];
+  int hw_nx = PADCHK ? ghw[(S - 1) * 4 + chunk] : 0;
+  // iteration at which the next Horner phase starts (steps[] holds the P-1 boundaries, then INT_MAX)
+  int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int it, bool issue) {
-    for (int st = steps[it]; st > 0; st--) { phase++; phase_shift(phase); }
+    while (it == next_b) {                 // rare: phase boundary
+      phase++; phase_shift(phase);
+      next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
+    }
     const int8_t* A = lds + cslot * STAGE;
     const int8_t* B = A + A_BYTES;
     i32x4 af[2][NT], bf[2][NT];
@@ -248,8 +256,10 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     }
     if (issue) {
       issue_A(e_begin + it + S - 1, islot);
-      issue_B(it + S - 1, islot);
+      issue_B(off_nx, hw_nx, islot);
       islot = islot + 1 == S ? 0 : islot + 1;
+      off_nx = goff[(it + S) * 4 + chunk];
+      if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     asm volatile("" ::: "memory");
     body(it, false);
   }
-  while (phase + 1 < P) { phase++; phase_shift(phase); }
+  while (phase + 1 < P) { phase++; phase_shift(phase); }      // phases that start after the last entry
   TF2_STAMP(5);
 
   // ---- epilogue --------------------------------------------------------------------------------

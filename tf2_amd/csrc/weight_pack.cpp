@@ -188,7 +188,7 @@ tf2_status Net::pack(int mode) {
         dir[(size_t)mt * (P + 1) + P] = (int32_t)entries.size();
         pl.max_ent = std::max<int32_t>(pl.max_ent, dir[(size_t)mt * (P + 1) + P] - dir[(size_t)mt * (P + 1)]);
       }
-      pl.max_ent = round_up(std::max(pl.max_ent, 1), 4);
+      pl.max_ent = round_up(std::max(pl.max_ent, 1) + 4 + P, 4);   // + spare entries the kernel may read ahead, + phase table
       // ---- kinfo ----
       // one 32-bit word per 16-byte segment: coff (16 bits, 0xffff = padding) | dh << 16 | dw << 24
       std::vector<int32_t> kinfo((size_t)nslab * 4, 0);
@@ -246,10 +246,11 @@ tf2_status Net::pack(int mode) {
           int32_t* ko = hs + pl.max_ent;
           int32_t* kh = ko + 4 * pl.max_ent;
           const int e0 = dir[(size_t)mt * (P + 1)], e1 = dir[(size_t)mt * (P + 1) + P];
+          // steps[p-1] = iteration index (relative to the m-tile's first entry) at which phase p starts
+          for (int i = 0; i < pl.max_ent; i++) hs[i] = 0x7fffffff;
+          for (int p = 1; p < P; p++) hs[p - 1] = dir[(size_t)mt * (P + 1) + p] - e0;
+          for (int i = 0; i < pl.max_ent * 4; i++) { ko[i] = -1; kh[i] = 0; }
           for (int e = e0; e < e1; e++) {
-            int st = 0;
-            for (int p = 1; p < P; p++) if (dir[(size_t)mt * (P + 1) + p] == e) st++;
-            hs[e - e0] = st;
             const int sl = entries[e];
             for (int sg = 0; sg < 4; sg++) {
               const int kk0 = sl * 64 + sg * 16;
