@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra-batches", type=str, default="1,64", help="also time these per-GPU batch sizes")
     ap.add_argument("--streams", type=int, default=1, help="split each batch over this many concurrent HIP streams")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
     args = ap.parse_args()
 
     import torch
@@ -76,9 +77,18 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else []
     sub_runners = [network.Runner(None, net) for _ in range(n_streams)] if n_streams > 1 else []
 
+    graphs = {}
+
     def step(x, parts):
         if n_streams == 1 or x.shape[0] < n_streams:
-            runner.run_batch(x)
+            if args.graph:
+                key = (x.data_ptr(), x.shape[0])
+                if key not in graphs:
+                    graphs[key] = network.Runner(None, net)
+                    graphs[key] = (graphs[key], graphs[key].capture(x))
+                graphs[key][1]()
+            else:
+                runner.run_batch(x)
             return
         for st, rn, xp in zip(streams, sub_runners, parts):
             with torch.cuda.stream(st):
@@ -202,7 +212,7 @@ def main():
                     config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
                                          f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
-                                streams_per_gpu=n_streams),
+                                streams_per_gpu=n_streams, hip_graph=bool(args.graph)),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

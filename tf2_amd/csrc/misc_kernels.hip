@@ -22,43 +22,61 @@ __device__ __forceinline__ int quant_input(float x, float trans) {
 }
 
 __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
-  // one thread per (image, output pixel, channel slot of the x half); slots >= Cl are
-  // the zero padding of the tensor's channel dimension
+  // one thread per (image, output pixel, 16-channel group of the x half): 16 gathered source
+  // values -> one 16-byte store of x and one of xneg.  Channel slots >= Cl are the zero padding.
   const int Cl = a.rewrite ? a.C * 9 : a.C;
-  const int Cs = a.half;
-  const long long total = (long long)a.B * a.OH * a.OW * Cs;
+  const int G16 = a.half / 16;
+  const long long total = (long long)a.B * a.OH * a.OW * G16;
   const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(idx % Cs);
-    long long pix = idx / Cs;
-    int ow = (int)(pix % a.OW);
-    long long t = pix / a.OW;
-    int oh = (int)(t % a.OH);
-    int b = (int)(t / a.OH);
-    int ci, sr, sc;
-    if (a.rewrite) {
-      // feature_trans (input_loader.cpp:27-73): sub-channel k of image channel ci holds
-      // pad3[2*oh + roff][2*ow + coff] with (roff,coff) = k0(0,0) k1(1,0) k2(0,1) k3(1,1)
-      // k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2).
-      ci = c / 9;
-      int k = c - ci * 9;
-      int roff = k < 6 ? (k & 1) : 2;
-      int coff = k < 6 ? (k >> 1) : (k - 6);
-      sr = 2 * oh + roff - 3;
-      sc = 2 * ow + coff - 3;
-    } else {
-      ci = c; sr = oh; sc = ow;
+    const int cg = (int)(idx % G16);
+    const long long pix = idx / G16;
+    const int ow = (int)(pix % a.OW);
+    const long long t = pix / a.OW;
+    const int oh = (int)(t % a.OH);
+    const int b = (int)(t / a.OH);
+    int v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int c = cg * 16 + i;
+      int ci, sr, sc;
+      if (a.rewrite) {
+        // feature_trans (input_loader.cpp:27-73): sub-channel k of image channel ci holds
+        // pad3[2*oh + roff][2*ow + coff] with (roff,coff) = k0(0,0) k1(1,0) k2(0,1) k3(1,1)
+        // k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2).
+        ci = c / 9;
+        const int k = c - ci * 9;
+        const int roff = k < 6 ? (k & 1) : 2;
+        const int coff = k < 6 ? (k >> 1) : (k - 6);
+        sr = 2 * oh + roff - 3;
+        sc = 2 * ow + coff - 3;
+      } else {
+        ci = c; sr = oh; sc = ow;
+      }
+      int q = 0;
+      if (c < Cl && (unsigned)sr < (unsigned)a.H && (unsigned)sc < (unsigned)a.W) {
+        const size_t si = ((size_t)(b * a.C + ci) * a.H + sr) * a.W + sc;
+        if (a.src_is_q) q = (int)reinterpret_cast<const int8_t*>(a.img)[si];
+        else q = quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
+      }
+      v[i] = q;
     }
-    int v = 0;
-    if (c < Cl && (unsigned)sr < (unsigned)a.H && (unsigned)sc < (unsigned)a.W) {
-      size_t si = ((size_t)(b * a.C + ci) * a.H + sr) * a.W + sc;
-      if (a.src_is_q) v = (int)reinterpret_cast<const int8_t*>(a.img)[si];
-      else v = quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
+    i32x4 px, nx;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      int p = 0, n = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = v[4 * w + j];
+        p |= (q & 0xff) << (8 * j);
+        n |= ((-q) & 0xff) << (8 * j);        // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+      }
+      px[w] = p; nx[w] = n;
     }
-    int8_t* dst = a.y + (size_t)pix * a.y_cp;
-    dst[c] = (int8_t)v;
-    dst[a.half + c] = (int8_t)(-v);          // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+    int8_t* dst = a.y + (size_t)pix * a.y_cp + cg * 16;
+    *reinterpret_cast<i32x4*>(dst) = px;
+    *reinterpret_cast<i32x4*>(dst + a.half) = nx;
   }
 }
 
@@ -98,17 +116,34 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
 }
 
 __global__ __launch_bounds__(256) void global_avg_kernel(AvgArgs a) {
-  // one thread per (image, channel); consecutive threads = consecutive channels (coalesced)
-  const int total = a.B * a.C;
+  // one thread per (image, 16-channel group): HW 16-byte loads, 16 int16 sums (Sreal, types.h:30)
+  const int G16 = a.C / 16;
+  const int total = a.B * G16;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int c = idx % a.C, b = idx / a.C;
-    const int8_t* p = a.x + (size_t)b * a.HW * a.x_cp + a.x_off + c;
-    int s = 0;
-    for (int i = 0; i < a.HW; i++) s += (int)p[(size_t)i * a.x_cp];
-    s = (int)(short)s;                                   // Sreal accumulator (types.h:30)
-    int m = (((s * a.mult) >> 14) + 1) >> 1;             // full_size_pool.cl:118
-    m = m > 127 ? 127 : (m < -128 ? -128 : m);
-    a.y[(size_t)b * a.y_cp + a.y_off + c] = (int8_t)m;
+    const int cg = idx % G16, b = idx / G16;
+    const int8_t* p = a.x + (size_t)b * a.HW * a.x_cp + a.x_off + cg * 16;
+    int s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    for (int i = 0; i < a.HW; i++) {
+      const i32x4 v = *reinterpret_cast<const i32x4*>(p + (size_t)i * a.x_cp);
+#pragma unroll
+      for (int q = 0; q < 16; q++) s[q] += (int)(signed char)((v[q >> 2] >> (8 * (q & 3))) & 0xff);
+    }
+    i32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      int word = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int sv = (int)(short)s[4 * w + j];             // int16 accumulator wrap
+        int m = (((sv * a.mult) >> 14) + 1) >> 1;            // full_size_pool.cl:118
+        m = m > 127 ? 127 : (m < -128 ? -128 : m);
+        word |= (m & 0xff) << (8 * j);
+      }
+      o[w] = word;
+    }
+    *reinterpret_cast<i32x4*>(a.y + (size_t)b * a.y_cp + a.y_off + cg * 16) = o;
   }
 }
 
@@ -119,7 +154,7 @@ static inline int grid_for(long long total, int block = 256) {
 }
 
 int launch_prep_input(const PrepArgs& a, void* stream) {
-  long long total = (long long)a.B * a.OH * a.OW * a.half;
+  long long total = (long long)a.B * a.OH * a.OW * (a.half / 16);
   hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -131,7 +166,7 @@ int launch_maxpool(const PoolArgs& a, void* stream) {
 }
 
 int launch_global_avg(const AvgArgs& a, void* stream) {
-  hipLaunchKernelGGL(global_avg_kernel, dim3(grid_for((long long)a.B * a.C)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(global_avg_kernel, dim3(grid_for((long long)a.B * (a.C / 16), 64)), dim3(64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -201,6 +201,24 @@ class Runner:
                       self._logits.data_ptr(), stream))
         return self._logits
 
+    def capture(self, images):
+        """Capture one run_batch(images) into a HIP graph (launch-bound small batches: the ~57
+        launches of a step replay as one graph launch).  `images` is a static input buffer: refill
+        it in place, call the returned function, read `self._logits`."""
+        import torch
+        net = self.network
+        self.run_batch(images)                      # warm-up: lazy attribute setup must not be captured
+        torch.cuda.synchronize(net.device)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=net.device)
+        side.wait_stream(torch.cuda.current_stream(net.device))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                self.run_batch(images)
+        torch.cuda.current_stream(net.device).wait_stream(side)
+        self._graph = g
+        return g.replay
+
     def read_layer(self, layer: int, batch: int) -> np.ndarray:
         """Output of ``layer`` after a keep_all run, as NCHW int8 (per-layer parity tests)."""
         import torch
