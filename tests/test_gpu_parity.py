@@ -148,6 +148,27 @@ def test_resnet50_north_star_split_mode1(r50):
     rig.check_all_layers(x, layers={0, 3, 4, 13, 26, 45, 52, 53})
 
 
+@pytest.mark.parametrize("sk", ["1", "2"])
+def test_split_k_kernel_forced_and_disabled(sk, monkeypatch):
+    """conv_mfma_sk.hip (four waves split the slab list) forced for every 64-row layer, and disabled:
+    both bit-exact, including layers with fewer slabs than waves and several Horner phases."""
+    monkeypatch.setenv("TF2_AMD_SK", sk)
+    t = cfg.squeezenet11_tables(image_hw=67)
+    q = synth.synth_q_values(t, 12, spread=2)
+    model = synth.synth_model(t, q, 12)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 2, 12))
+    t = cfg.tiny_tables(hw=20, widths=(64, 128), classes=100)
+    q = synth.synth_q_values(t, 8, spread=2)
+    model = synth.synth_model(t, q, 8)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
+
+
+def test_resnet50_split_k_forced(r50, monkeypatch):
+    monkeypatch.setenv("TF2_AMD_SK", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 21), layers={26, 28, 32, 45, 47, 52, 53})
+
+
 def test_epilogue_debug_store_path_matches(r50, monkeypatch):
     rig = Rig(*r50, 0)
     x = synth.synth_images(rig.t, 1, 4)

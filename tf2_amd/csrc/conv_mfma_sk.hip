@@ -1,0 +1,338 @@
+// conv_mfma_sk.hip -- implicit-GEMM INT8 convolution for SMALL GRIDS: in-block split-K (gfx950).
+//
+// Same arithmetic, packed image, per-m-tile LDS header and epilogue as conv_mfma2.hip.  When a
+// layer has few output pixels (7x7 / 14x14 maps at small batch) but a long K (3x3 over 256-512
+// channels, 1x1 over 1024-2048), conv_mfma2's grid cannot fill the 256 CUs and every block
+// walks its 36-72 K slabs serially (~0.4 us each: the whole layer takes as long as one block).
+// Here the four waves of a block compute the SAME 64-channel x 64-pixel tile over interleaved
+// quarters of the slab list (wave w takes entries w, w+4, ...), each with its own LDS-DMA ring
+// and its own counted vmcnt -- no block barrier inside the K loop -- and the four int32 partial
+// tiles are summed through LDS at the end.  Exactness: the accumulator of the reference lives
+// in Z/2^32 (pe.cl:43), where the Horner-combined partial sums of disjoint slab subsets simply
+// add; each wave applies the phase shifts to its own partial sum.
+#include <hip/hip_runtime.h>
+#include "tf2_internal.h"
+
+namespace tf2 {
+
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x16 = int __attribute__((ext_vector_type(16)));
+
+#define TF2_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define TF2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int N>
+__device__ __forceinline__ void sk_wait_vmcnt() {
+  static_assert(N == 0 || N == 1 || N == 4 || N == 8, "vmcnt immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <int S, bool PADCHK>
+__global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
+  constexpr int TM = 64, TN = 64;
+  constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
+  constexpr int AI = 4, BI = 4, NI = 8;        // LDS-DMA instructions per wave per stage
+  constexpr int RING = S * STAGE;              // per wave
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  // LDS map: [4 per-wave rings (reused for the 64 KiB reduction)][header as in conv_mfma2.hip]
+  constexpr int RING_ALL = (4 * RING > 65536) ? 4 * RING : 65536;
+  int* const prm = reinterpret_cast<int*>(lds + RING_ALL);
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int P = a.n_phases;
+  int* const dsh = prm + 5 * TM;
+  int* const steps = dsh + P * TM;
+  int* const goff = steps + a.max_ent;
+  int* const ghw = goff + a.max_ent * 4;
+  int8_t* const ring = lds + wave * RING;
+
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int mtile = bid % a.n_mtiles;
+  const int ntile = bid / a.n_mtiles;
+  const int px0 = ntile * TN;
+  const int e_begin = a.e_start[mtile];
+  const int n_ent = a.e_start[mtile + 1] - e_begin;
+  const int n_mine = n_ent > wave ? (n_ent - wave + 3) >> 2 : 0;       // entries wave, wave+4, ...
+
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // see conv_mfma2.hip
+  const int a_lane_off = (lane >> 2) * 64 + chunk * 16;
+
+  auto issue_A = [&](int k, int slot_idx) {                     // k-th entry of this wave
+    int8_t* const slot = ring + slot_idx * STAGE;
+    const int8_t* wsrc = a.w + (size_t)(e_begin + wave + 4 * k) * A_BYTES + a_lane_off;
+#pragma unroll
+    for (int j = 0; j < AI; j++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + j * 1024), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
+  };
+
+  // header (shared by the four waves) + this wave's first weight tiles
+  {
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
+    int8_t* hdst = reinterpret_cast<int8_t*>(prm);
+    for (int i = wave; i * 1024 < a.hdr_bytes; i += 4)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < S - 1; s++)
+    if (s < n_mine) issue_A(s, s);
+
+  const int8_t* brow_ptr[BI];
+  int brow_h[BI], brow_w[BI];
+  bool brow_ok[BI];
+#pragma unroll
+  for (int j = 0; j < BI; j++) {
+    const int p = px0 + j * 16 + (lane >> 2);
+    if (p < g.n_pix) {
+      const int b = p / g.OHW;
+      const int rem = p - b * g.OHW;
+      const int oh = rem / g.OW;
+      const int ow = rem - oh * g.OW;
+      brow_h[j] = oh * g.stride - g.pad_h;
+      brow_w[j] = ow * g.stride - g.pad_w;
+      brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
+      brow_ok[j] = true;
+    } else {
+      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
+    }
+  }
+
+  // residual prefetch for the 32x32 sub-tile this wave finishes in the epilogue
+  const int half = lane >> 5;
+  const int ti = wave >> 1, tj = wave & 1;
+  i32x4 resv = {0, 0, 0, 0};
+  asm volatile("" ::: "memory");
+  if (g.has_res) {
+    const int px = px0 + tj * 32 + (lane & 31);
+    const int chl = mtile * TM + ti * 32 + 16 * half;
+    const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
+    const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+    resv = *reinterpret_cast<const i32x4*>(rp);
+  }
+  asm volatile("" ::: "memory");
+
+  i32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+
+  if (g.has_res) sk_wait_vmcnt<1>(); else sk_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();            // header complete (all four waves' parts)
+  asm volatile("" ::: "memory");
+
+  auto issue_B = [&](int off, int hw, int slot_idx) {
+    int8_t* const slot = ring + slot_idx * STAGE + A_BYTES;
+    int dh = 0, dw = 0;
+    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
+#pragma unroll
+    for (int j = 0; j < BI; j++) {
+      bool ok = off >= 0 && brow_ok[j];
+      if (PADCHK) {
+        const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
+        ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      }
+      const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
+    }
+  };
+
+  auto phase_shift = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int rb = i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + p * TM + rb + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i][j][G * 4 + r] = (int)((unsigned)acc[i][j][G * 4 + r] << (d[r] & 31));
+      }
+    }
+  };
+
+  // ---- per-wave pipelined K loop over entries wave, wave+4, ... (no block barrier) -----------
+  // VMEM queue of a wave: [hdr, A_0..A_{S-2}, residual, B_0..B_{S-2}, then per iteration A, B]
+#pragma unroll
+  for (int s = 0; s < S - 1; s++)
+    if (s < n_mine) {
+      const int e = wave + 4 * s;
+      issue_B(goff[e * 4 + chunk], PADCHK ? ghw[e * 4 + chunk] : 0, s);
+    }
+  int phase = 0;
+  int cslot = 0, islot = S - 1;
+  const int n_main = n_mine - (S - 1);
+  int off_nx = goff[(wave + 4 * (S - 1)) * 4 + chunk];
+  int hw_nx = PADCHK ? ghw[(wave + 4 * (S - 1)) * 4 + chunk] : 0;
+  int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
+
+  auto body = [&](int k, bool issue) {
+    const int e = wave + 4 * k;            // index in the m-tile's entry list
+    while (e >= next_b) {                  // this wave has crossed into the next phase(s)
+      phase++; phase_shift(phase);
+      next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
+    }
+    const int8_t* A = ring + cslot * STAGE;
+    const int8_t* B = A + A_BYTES;
+    i32x4 af[2][2], bf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = i * 32 + (lane & 31);
+        af[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        bf[ks][i] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+      }
+    }
+    if (issue) {
+      issue_A(k + S - 1, islot);
+      issue_B(off_nx, hw_nx, islot);
+      islot = islot + 1 == S ? 0 : islot + 1;
+      off_nx = goff[(wave + 4 * (k + S)) * 4 + chunk];
+      if (PADCHK) hw_nx = ghw[(wave + 4 * (k + S)) * 4 + chunk];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+    cslot = cslot + 1 == S ? 0 : cslot + 1;
+  };
+
+  int k = 0;
+  for (; k < n_main; k++) {
+    if (k == 0) sk_wait_vmcnt<(S - 2) * BI>();
+    else sk_wait_vmcnt<(S - 2) * NI>();
+    asm volatile("" ::: "memory");
+    body(k, true);
+  }
+  for (; k < n_mine; k++) {
+    sk_wait_vmcnt<0>();
+    asm volatile("" ::: "memory");
+    body(k, false);
+  }
+  while (phase + 1 < P) { phase++; phase_shift(phase); }
+
+  // ---- reduce the four partial tiles through LDS (the rings are dead now) ---------------------
+  sk_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    i32x4* red = reinterpret_cast<i32x4*>(lds) + (size_t)wave * 1024;       // 16 KiB per wave
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int G = 0; G < 4; G++) {
+          const i32x4 v = {acc[i][j][G * 4], acc[i][j][G * 4 + 1], acc[i][j][G * 4 + 2], acc[i][j][G * 4 + 3]};
+          red[((i * 2 + j) * 4 + G) * 64 + lane] = v;
+        }
+  }
+  __syncthreads();
+  i32x4 sum[4];
+#pragma unroll
+  for (int G = 0; G < 4; G++) {
+    sum[G] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const i32x4 v = reinterpret_cast<const i32x4*>(lds)[(size_t)w * 1024 + ((ti * 2 + tj) * 4 + G) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; r++) sum[G][r] = (int)((unsigned)sum[G][r] + (unsigned)v[r]);
+    }
+  }
+
+  // ---- epilogue for this wave's 32x32 sub-tile (see conv_mfma2.hip for the arithmetic) ----------
+  const int lo_bound = g.relu ? 0 : -128;
+  const int rlo = g.add_relu ? 0 : -128;
+  const int rb = ti * 32;
+  const int tile_ch = mtile * TM + rb;
+  const int px = px0 + tj * 32 + (lane & 31);
+  unsigned rd[4] = {0, 0, 0, 0};
+  if (g.has_res) {
+    auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[0], (unsigned)resv[1], false, false);
+    auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[2], (unsigned)resv[3], false, false);
+    rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
+  }
+  unsigned d[4];
+#pragma unroll
+  for (int G = 0; G < 4; G++) {
+    const int r0 = rb + 4 * half + 8 * G;
+    const i32x4 bias4 = *reinterpret_cast<const i32x4*>(prm + r0);
+    const i32x4 lo4 = *reinterpret_cast<const i32x4*>(prm + TM + r0);
+    const i32x4 al4 = *reinterpret_cast<const i32x4*>(prm + 2 * TM + r0);
+    const i32x4 bl4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
+    const i32x4 bh4 = *reinterpret_cast<const i32x4*>(prm + 4 * TM + r0);
+    int q[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int v = (int)((unsigned)bias4[r] + ((unsigned)sum[G][r] << (lo4[r] & 31)));
+      const long long b64 = (long long)(((unsigned long long)(unsigned)bh4[r] << 32) | (unsigned)bl4[r]);
+      const long long p = (long long)v * (long long)al4[r] + b64;
+      const int x = (int)(p >> kAlphaInflat);
+      const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+      int c;
+      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+      if (g.has_res) {
+        const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
+        const int sres = c + rr;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
+      }
+      q[r] = c;
+    }
+    const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
+    const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
+    d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+  }
+  auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+  auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+  const i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+  const int chl = tile_ch + 16 * half;
+  if (px < g.n_pix && chl + 16 <= g.y_nvalid)
+    *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
+}
+
+template <int S, bool PADCHK>
+static int launch_sk2(const ConvArgs& a, hipStream_t s) {
+  constexpr int RING_ALL = (4 * S * 8192 > 65536) ? 4 * S * 8192 : 65536;
+  const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
+  static bool attr_set = false;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) return -3;
+  const int ntiles = (a.g.n_pix + 63) / 64;
+  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// For 64-row packed layers with a long slab list and a grid that would not fill the chip.
+int launch_conv_mfma_sk(const ConvArgs& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (a.n_mtiles > kMaxMtiles) return -4;
+  const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
+  const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
+  if (blocks <= 256) return pad ? launch_sk2<3, true>(a, s) : launch_sk2<3, false>(a, s);
+  return pad ? launch_sk2<2, true>(a, s) : launch_sk2<2, false>(a, s);
+}
+
+}  // namespace tf2

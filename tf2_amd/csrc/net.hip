@@ -220,6 +220,8 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & ~1;   // perf experiments (wrong results!)
   bool mfma_v1 = false;
   if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
+  int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
+  if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
 
   // input: quantise + (space-to-depth) + [x | xneg]
@@ -292,7 +294,15 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       }
       g.flags = flags;
       int rc;
-      if (pl->kind == KIND_MFMA) rc = (mfma_v1 || (flags & 1)) ? launch_conv_mfma(ca, pl->TM, stream) : launch_conv_mfma2(ca, pl->TM, stream);
+      if (pl->kind == KIND_MFMA) {
+        // small grid + long slab list: the four waves of a block split K (conv_mfma_sk.hip)
+        const long blocks64 = (long)((g.n_pix + 63) / 64) * pl->n_mtiles;
+        const bool sk = pl->TM == 64 && pl->n_mtiles <= kMaxMtiles && sk_mode != 2 &&
+                        (sk_mode == 1 || (blocks64 <= 512 && pl->n_entries >= 16 * pl->n_mtiles));
+        if (mfma_v1 || (flags & 1)) rc = launch_conv_mfma(ca, pl->TM, stream);
+        else if (sk) rc = launch_conv_mfma_sk(ca, stream);
+        else rc = launch_conv_mfma2(ca, pl->TM, stream);
+      }
       else if (pl->kind == KIND_SHIFT) rc = launch_conv_shift(ca, pl->signed_in, pl->max_shift <= 22, stream);
       else { set_error("layer " + std::to_string(l) + " has no packed kernel"); return TF2_ERR_STATE; }
       if (rc) { set_error("conv launch failed at layer " + std::to_string(l) + ": " + device_last_error()); return TF2_ERR_HIP; }

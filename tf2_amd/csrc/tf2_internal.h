@@ -118,6 +118,7 @@ struct PrepArgs {
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
+int launch_conv_mfma_sk(const ConvArgs& a, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
