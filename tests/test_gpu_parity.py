@@ -163,6 +163,18 @@ def test_split_k_kernel_forced_and_disabled(sk, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
+def test_weight_stationary_kernel_forced(r50, monkeypatch):
+    """conv_mfma_ws.hip (weights resident in LDS, a run of pixel tiles per block, deferred stores) forced
+    onto every short-K pointwise layer: with and without residual, stride 1 and 2, tail tiles."""
+    monkeypatch.setenv("TF2_AMD_WS", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 3, 31), layers={1, 2, 4, 5, 7, 11, 12, 14, 17, 53})
+    t = cfg.tiny_tables(hw=20, widths=(64, 128), classes=100)
+    q = synth.synth_q_values(t, 8, spread=2)
+    model = synth.synth_model(t, q, 8)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 5, 8))
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)

@@ -220,6 +220,8 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & ~1;   // perf experiments (wrong results!)
   bool mfma_v1 = false;
   if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
+  int ws_mode = 0;          // 0 auto, 2 never use the weight-stationary kernel
+  if (const char* e = getenv("TF2_AMD_WS")) ws_mode = atoi(e);
   int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
@@ -301,7 +303,10 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
                         (sk_mode == 1 || (blocks64 <= 512 && pl->n_entries >= 16 * pl->n_mtiles));
         if (mfma_v1 || (flags & 1)) rc = launch_conv_mfma(ca, pl->TM, stream);
         else if (sk) rc = launch_conv_mfma_sk(ca, stream);
-        else rc = launch_conv_mfma2(ca, pl->TM, stream);
+        else {
+          rc = ws_mode == 2 ? 1 : launch_conv_mfma_ws(ca, pl->TM, stream);     // short-K pointwise layers
+          if (rc == 1) rc = launch_conv_mfma2(ca, pl->TM, stream);
+        }
       }
       else if (pl->kind == KIND_SHIFT) rc = launch_conv_shift(ca, pl->signed_in, pl->max_shift <= 22, stream);
       else { set_error("layer " + std::to_string(l) + " has no packed kernel"); return TF2_ERR_STATE; }

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 8;
+constexpr uint32_t kPackVersion = 9;
 constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -119,6 +119,7 @@ struct PrepArgs {
 int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, void* stream);
+int launch_conv_mfma_ws(const ConvArgs& a, int TM, void* stream);   // returns 1 if the layer does not qualify
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);

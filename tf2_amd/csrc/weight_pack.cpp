@@ -225,9 +225,11 @@ tf2_status Net::pack(int mode) {
       // words: bias[TM] lo[TM] alpha[TM] beta64.lo[TM] beta64.hi[TM] (beta64 = (int64)beta << 20, the addend of
       //        the 64-bit multiply-add) | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
       //        the entry) | goff[max_ent][4] (per 16-byte segment: byte offset from the pixel's tap origin,
-      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test)
+      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test) | eslot[max_ent] (entry ->
+      //        index of its slab among the m-tile's DISTINCT slabs) | dfirst[max_ent] (distinct index -> an entry
+      //        using that slab); steps[max_ent-1] = number of distinct slabs (conv_mfma_ws.hip)
       {
-        const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)9 * pl.max_ent;
+        const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)11 * pl.max_ent;
         const size_t hb = (words * 4 + 1023) / 1024 * 1024;
         pl.hdr_bytes = hb;
         pl.off_hdr = blob.alloc(hb * n_mtiles);
@@ -250,6 +252,17 @@ tf2_status Net::pack(int mode) {
           for (int i = 0; i < pl.max_ent; i++) hs[i] = 0x7fffffff;
           for (int p = 1; p < P; p++) hs[p - 1] = dir[(size_t)mt * (P + 1) + p] - e0;
           for (int i = 0; i < pl.max_ent * 4; i++) { ko[i] = -1; kh[i] = 0; }
+          int32_t* es = kh + 4 * pl.max_ent;
+          int32_t* df = es + pl.max_ent;
+          std::vector<int> dist;                              // distinct slabs of this m-tile, first-use order
+          for (int e = e0; e < e1; e++) {
+            const int sl = entries[e];
+            size_t j = 0;
+            while (j < dist.size() && dist[j] != sl) j++;
+            if (j == dist.size()) { dist.push_back(sl); df[j] = e - e0; }
+            es[e - e0] = (int32_t)j;
+          }
+          hs[pl.max_ent - 1] = (int32_t)dist.size();
           for (int e = e0; e < e1; e++) {
             const int sl = entries[e];
             for (int sg = 0; sg < 4; sg++) {
