@@ -27,7 +27,9 @@
 //  * three tile shapes: 128x128 (2x2 waves of 64x64), 64x256 (1x4 waves, N_out = 64
 //    layers) and 64x64 (2x2 waves of 32x32) for layers whose grid would not fill 256 CUs.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "tf2_internal.h"
+#include "requant_epilogue.h"
 
 namespace tf2 {
 
@@ -58,16 +60,24 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
-// WM x WN waves (WM*WN == 4), each wave a WT x WT output tile (WT = 64 or 32), S ring stages.
-template <int WM, int WN, int WT, int S, bool PADCHK>
-__global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(ConvArgs a) {
-  constexpr int TM = WM * WT, TN = WN * WT;
-  constexpr int NT = WT / 32;                  // 32x32 MFMA tiles per wave and dimension
+// WM x WN waves (4 or 8), each wave a WTM x WTN output tile (multiples of 32), S ring stages, OCC blocks per CU
+// the register budget is set for.  A wave's instruction stream issues at most one instruction per ~4 cycles
+// whatever the occupancy (tools/ubench), so the per-wave instruction count of the K loop and of the epilogue
+// is what a block's latency is made of: 8 waves with 32x64 tiles halve both against 4 waves with 64x64.
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
+  constexpr int NW = WM * WN;                  // waves per block
+  constexpr int TM = WM * WTM, TN = WN * WTN;
+  constexpr int NTM = WTM / 32, NTN = WTN / 32;   // 32x32 MFMA tiles per wave (rows, columns)
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int AI = TM / 64, BI = TN / 64;    // LDS-DMA instructions per wave per stage (A, B)
-  constexpr int NI = AI + BI;
+  // LDS-DMA instructions per wave per stage: 16-row groups dealt round-robin to the waves.  The weight tile may
+  // have fewer groups than waves: waves < A_REM issue AI_HI instructions, the others AI_LO (waits are per class).
+  constexpr int AG = TM / 16, BG = TN / 16;
+  static_assert(BG % NW == 0, "activation tile groups must divide over the waves");
+  constexpr int BI = BG / NW;
+  constexpr int AI_LO = AG / NW, A_REM = AG % NW, AI_HI = AI_LO + (A_REM ? 1 : 0);
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta64.lo|beta64.hi (5*TM) | dshift (P*TM) | steps[max_ent] |
+  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta64 (lo,hi) pairs (5*TM) | dshift (P*TM) | steps[max_ent] |
   //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time;
   //           steps[p-1] = iteration at which phase p starts, INT_MAX after the last; max_ent includes S spare entries)
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
@@ -76,9 +86,11 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool a_hi = A_REM == 0 || wave < A_REM;      // wave-uniform DMA class
   const int wm = wave / WN, wn = wave % WN;
   const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-#define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); if (a.dbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TF2_STAMP(0);
   const int P = a.n_phases;
   int* const dsh = prm + 5 * TM;
@@ -111,9 +123,10 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     int8_t* const slot = lds + slot_idx * STAGE;
     const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
 #pragma unroll
-    for (int j = 0; j < AI; j++) {
-      const int grp = wave + 4 * j;                          // 16-row group of the A tile
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
+    for (int j = 0; j < AI_HI; j++) {
+      const int grp = wave + NW * j;                         // 16-row group of the A tile
+      if (j < AI_LO || a_hi)
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
     }
   };
 
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   {
     const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
     int8_t* hdst = reinterpret_cast<int8_t*>(prm);
-    for (int i = wave; i * 1024 < a.hdr_bytes; i += 4)
+    for (int i = wave; i * 1024 < a.hdr_bytes; i += NW)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   }
 #pragma unroll
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   bool brow_ok[BI];
 #pragma unroll
   for (int j = 0; j < BI; j++) {
-    const int p = px0 + (wave + 4 * j) * 16 + (lane >> 2);
+    const int p = px0 + (wave + NW * j) * 16 + (lane >> 2);
     if (p < g.n_pix) {
       const int b = p / g.OHW;
       const int rem = p - b * g.OHW;
@@ -152,16 +165,16 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   // residual tile prefetch (ordinary loads; they are older than every activation DMA below, so the
   // counted waits of the loop stay valid; first use is in the epilogue)
   const int half = lane >> 5;
-  i32x4 resv[NT][NT];
+  i32x4 resv[NTM][NTN];
   asm volatile("" ::: "memory");           // keep the residual loads YOUNGER than the header/weight DMAs above
 #pragma unroll
-  for (int i = 0; i < NT; i++)
+  for (int i = 0; i < NTM; i++)
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
+    for (int j = 0; j < NTN; j++) {
       resv[i][j] = i32x4{0, 0, 0, 0};
       if (g.has_res) {                     // wave-uniform; every lane loads (a safe address when masked)
-        const int px = px0 + wn * WT + j * 32 + (lane & 31);
-        const int chl = mtile * TM + wm * WT + i * 32 + 16 * half;
+        const int px = px0 + wn * WTN + j * 32 + (lane & 31);
+        const int chl = mtile * TM + wm * WTM + i * 32 + 16 * half;
         const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
         const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
         resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
@@ -169,16 +182,16 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     }
   asm volatile("" ::: "memory");
 
-  i32x16 acc[NT][NT];
+  i32x16 acc[NTM][NTN];
 #pragma unroll
-  for (int i = 0; i < NT; i++)
+  for (int i = 0; i < NTM; i++)
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+    for (int j = 0; j < NTN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
 
-  // header and first weight tiles landed (the NT*NT residual loads may stay outstanding)
-  if (g.has_res) wait_vmcnt<NT * NT>(); else wait_vmcnt<0>();
+  // header and first weight tiles landed (the NTM*NTN residual loads may stay outstanding)
+  if (g.has_res) wait_vmcnt<NTM * NTN>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   TF2_STAMP(2);
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
 #pragma unroll
     for (int j = 0; j < BI; j++) {
-      const int grp = wave + 4 * j;
+      const int grp = wave + NW * j;
       bool ok = off >= 0 && brow_ok[j];
       if (PADCHK) {
         const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
@@ -202,15 +215,15 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 
   auto phase_shift = [&](int p) {       // Horner step: acc <<= dshift[p][channel]
 #pragma unroll
-    for (int i = 0; i < NT; i++) {
-      const int rb = wm * WT + i * 32 + 4 * (lane >> 5);
+    for (int i = 0; i < NTM; i++) {
+      const int rb = wm * WTM + i * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int G = 0; G < 4; G++) {
         const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + p * TM + rb + 8 * G);
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-          for (int j = 0; j < NT; j++)
+          for (int j = 0; j < NTN; j++)
             acc[i][j][G * 4 + r] = (int)((unsigned)acc[i][j][G * 4 + r] << (d[r] & 31));
       }
     }
@@ -239,18 +252,18 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
     }
     const int8_t* A = lds + cslot * STAGE;
     const int8_t* B = A + A_BYTES;
-    i32x4 af[2][NT], bf[2][NT];
+    i32x4 af[2][NTM], bf[2][NTN];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       const int c = ks * 2 + (lane >> 5);
 #pragma unroll
-      for (int i = 0; i < NT; i++) {
-        const int row = wm * WT + i * 32 + (lane & 31);
+      for (int i = 0; i < NTM; i++) {
+        const int row = wm * WTM + i * 32 + (lane & 31);
         af[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int row = wn * WT + j * 32 + (lane & 31);
+      for (int j = 0; j < NTN; j++) {
+        const int row = wn * WTN + j * 32 + (lane & 31);
         bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
       }
     }
@@ -264,9 +277,9 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int i = 0; i < NT; i++)
+      for (int i = 0; i < NTM; i++)
 #pragma unroll
-        for (int j = 0; j < NT; j++)
+        for (int j = 0; j < NTN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
@@ -275,8 +288,8 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   for (; it < n_main; it++) {
     // operations issued after stage `it` in the queue above
     if (it == 0) wait_vmcnt<(S - 2) * BI>();
-    else if (S == 4 && it == 1) wait_vmcnt<BI + NI>();
-    else wait_vmcnt<(S - 2) * NI>();
+    else if (S == 4 && it == 1) { if (a_hi) wait_vmcnt<BI + AI_HI + BI>(); else wait_vmcnt<BI + AI_LO + BI>(); }
+    else { if (a_hi) wait_vmcnt<(S - 2) * (AI_HI + BI)>(); else wait_vmcnt<(S - 2) * (AI_LO + BI)>(); }
     __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
     asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
     body(it, true);
@@ -297,98 +310,75 @@ __global__ __launch_bounds__(256, (WT == 64 ? 3 : 4)) void conv_mfma2_kernel(Con
   // residual: int16 add, clamp, ReLU (feature_writer.cl:119-122) in the C/D register layout.
   const int lo_bound = g.relu ? 0 : -128;
   const int rlo = g.add_relu ? 0 : -128;
+  auto epilogue = [&](auto has_res_c) {
+    constexpr bool HAS_RES = decltype(has_res_c)::value;
 #pragma unroll
-  for (int i = 0; i < NT; i++) {
-    const int rb = wm * WT + i * 32;                         // tile row base inside the block tile
-    const int tile_ch = mtile * TM + rb;
+    for (int i = 0; i < NTM; i++) {
+      const int rb = wm * WTM + i * 32;                        // tile row base inside the block tile
+      const int chl = mtile * TM + rb + 16 * half;
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      const int px = px0 + wn * WT + j * 32 + (lane & 31);
-      const bool pvalid = px < g.n_pix;
-      unsigned rd[4] = {0, 0, 0, 0};
-      if (g.has_res) {
-        // the prefetched 16 contiguous bytes back into the C/D layout (the store swaps are involutions)
-        auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[i][j][0], (unsigned)resv[i][j][1], false, false);
-        auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[i][j][2], (unsigned)resv[i][j][3], false, false);
-        rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
-      }
-      unsigned d[4];
+      for (int j = 0; j < NTN; j++) {
+        const int px = px0 + wn * WTN + j * 32 + (lane & 31);
+        int a16[16];
 #pragma unroll
-      for (int G = 0; G < 4; G++) {
-        const int r0 = rb + 4 * half + 8 * G;
-        const i32x4 bias4 = *reinterpret_cast<const i32x4*>(prm + r0);
-        const i32x4 lo4 = *reinterpret_cast<const i32x4*>(prm + TM + r0);
-        const i32x4 al4 = *reinterpret_cast<const i32x4*>(prm + 2 * TM + r0);
-        const i32x4 bl4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
-        const i32x4 bh4 = *reinterpret_cast<const i32x4*>(prm + 4 * TM + r0);
-        int q[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int v = (int)((unsigned)bias4[r] + ((unsigned)acc[i][j][G * 4 + r] << (lo4[r] & 31)));
-          const long long b64 = (long long)(((unsigned long long)(unsigned)bh4[r] << 32) | (unsigned)bl4[r]);
-          const long long p = (long long)v * (long long)al4[r] + b64;
-          const int x = (int)(p >> kAlphaInflat);
-          const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
-          int c;
-          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
-          if (g.has_res) {
-            const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
-            const int sres = c + rr;
-            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
-          }
-          q[r] = c;
+        for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
+        const i32x4 out = requant_tile16<HAS_RES>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
+        if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
+          i32x4* dst = reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl);
+          if (g.flags & 4) __builtin_nontemporal_store(out, dst);
+          else if (g.flags & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+          else if (g.flags & 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(out) : "memory");
+          else *dst = out;
         }
-        const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);   // bytes: q0.b0, q1.b0
-        const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
-        d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
       }
-      // d[G] = channel group 2G (lanes 0-31) / 2G+1 (lanes 32-63): two half-wave swaps give
-      // lanes 0-31 groups 0..3 and lanes 32-63 groups 4..7 -> 16 contiguous NHWC bytes per lane
-      auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-      auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-      const i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
-      const int chl = tile_ch + 16 * half;
-      if (pvalid && chl + 16 <= g.y_nvalid)
-        *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
     }
-  }
+  };
+  if (g.has_res) epilogue(std::true_type{}); else epilogue(std::false_type{});
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
+  if (a.dbg2 && tid == 0) {
+    long long* d = a.dbg2 + (size_t)blockIdx.x * 8;
+    d[0] = tstamp[0]; d[1] = (long long)__builtin_readcyclecounter();
+    d[4] = tstamp[1]; d[5] = tstamp[2]; d[6] = tstamp[3]; d[7] = tstamp[5];
+    d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID (id 4), 32 bits
+    d[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID (id 20)
+  }
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WT, int S, bool PADCHK>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK>
 static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
-  constexpr int TM = WM * WT, TN = WN * WT;
+  constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = (TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
-  auto fn = conv_mfma2_kernel<WM, WN, WT, S, PADCHK>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_set = true;
   }
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
-  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int WM, int WN, int WT, int S>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   // bounds checks on the gathered taps are only needed for padded convolutions
-  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WT, S, true>(a, s) : launch_cfg2<WM, WN, WT, S, false>(a, s);
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false>(a, s);
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so
-// that small grids still spread over the 256 CUs.
+// that small grids still spread over the 256 CUs.  a.g.flags bit 1: the 4-wave shapes (A/B switch).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.n_mtiles > kMaxMtiles) return -4;
-  if (TM == 128) return launch_cfg<2, 2, 64, 3>(a, s);
+  const bool w4 = (a.g.flags & 2) != 0;
+  if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   if (TM == 64) {
     const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
-    if (blocks256 >= 512) return launch_cfg<1, 4, 64, 3>(a, s);
-    return launch_cfg<2, 2, 32, 4>(a, s);
+    if (blocks256 >= 512) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
+    return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }
   return -1;
 }

@@ -12,6 +12,7 @@
 // add; each wave applies the phase shifts to its own partial sum.
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
+#include "requant_epilogue.h"
 
 namespace tf2 {
 
@@ -265,45 +266,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   const int rb = ti * 32;
   const int tile_ch = mtile * TM + rb;
   const int px = px0 + tj * 32 + (lane & 31);
-  unsigned rd[4] = {0, 0, 0, 0};
-  if (g.has_res) {
-    auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[0], (unsigned)resv[1], false, false);
-    auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[2], (unsigned)resv[3], false, false);
-    rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
-  }
-  unsigned d[4];
+  int a16[16];
 #pragma unroll
-  for (int G = 0; G < 4; G++) {
-    const int r0 = rb + 4 * half + 8 * G;
-    const i32x4 bias4 = *reinterpret_cast<const i32x4*>(prm + r0);
-    const i32x4 lo4 = *reinterpret_cast<const i32x4*>(prm + TM + r0);
-    const i32x4 al4 = *reinterpret_cast<const i32x4*>(prm + 2 * TM + r0);
-    const i32x4 bl4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
-    const i32x4 bh4 = *reinterpret_cast<const i32x4*>(prm + 4 * TM + r0);
-    int q[4];
+  for (int G = 0; G < 4; G++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int v = (int)((unsigned)bias4[r] + ((unsigned)sum[G][r] << (lo4[r] & 31)));
-      const long long b64 = (long long)(((unsigned long long)(unsigned)bh4[r] << 32) | (unsigned)bl4[r]);
-      const long long p = (long long)v * (long long)al4[r] + b64;
-      const int x = (int)(p >> kAlphaInflat);
-      const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
-      int c;
-      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
-      if (g.has_res) {
-        const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
-        const int sres = c + rr;
-        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
-      }
-      q[r] = c;
-    }
-    const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
-    const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
-    d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-  }
-  auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-  auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-  const i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+    for (int r = 0; r < 4; r++) a16[G * 4 + r] = sum[G][r];
+  const i32x4 out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
+                              : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
   const int chl = tile_ch + 16 * half;
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
     *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;

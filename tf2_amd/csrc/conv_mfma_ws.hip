@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "tf2_internal.h"
+#include "requant_epilogue.h"
 
 namespace tf2 {
 
@@ -244,46 +245,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ws_kernel(ConvArgs a, WsGeom
       for (int j = 0; j < 2; j++) {
         const int pl = wn * 64 + j * 32 + (lane & 31);
         const int px = px0 + pl;
-        unsigned rd[4] = {0, 0, 0, 0};
-        if (g.has_res) {
-          const i32x4 rv = *reinterpret_cast<const i32x4*>(Rbase + (size_t)buf * R_BYTES + (size_t)pl * TM + rb + 16 * half);
-          auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)rv[0], (unsigned)rv[1], false, false);
-          auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)rv[2], (unsigned)rv[3], false, false);
-          rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
-        }
-        unsigned d[4];
+        i32x4 rv = {0, 0, 0, 0};
+        if (g.has_res) rv = *reinterpret_cast<const i32x4*>(Rbase + (size_t)buf * R_BYTES + (size_t)pl * TM + rb + 16 * half);
+        int a16[16];
 #pragma unroll
-        for (int G = 0; G < 4; G++) {
-          const int r0 = rb + 4 * half + 8 * G;
-          const i32x4 bias4 = *reinterpret_cast<const i32x4*>(prm + r0);
-          const i32x4 lo4 = *reinterpret_cast<const i32x4*>(prm + TM + r0);
-          const i32x4 al4 = *reinterpret_cast<const i32x4*>(prm + 2 * TM + r0);
-          const i32x4 bl4 = *reinterpret_cast<const i32x4*>(prm + 3 * TM + r0);
-          const i32x4 bh4 = *reinterpret_cast<const i32x4*>(prm + 4 * TM + r0);
-          int q[4];
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int v = (int)((unsigned)bias4[r] + ((unsigned)acc[i][j][G * 4 + r] << (lo4[r] & 31)));
-            const long long b64 = (long long)(((unsigned long long)(unsigned)bh4[r] << 32) | (unsigned)bl4[r]);
-            const long long p = (long long)v * (long long)al4[r] + b64;
-            const int x = (int)(p >> kAlphaInflat);
-            const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
-            int c;
-            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
-            if (g.has_res) {
-              const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
-              const int sres = c + rr;
-              asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
-            }
-            q[r] = c;
-          }
-          const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
-          const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
-          d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-        }
-        auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-        auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-        pend[i][j] = i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+        for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
+        pend[i][j] = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv)
+                               : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv);
         (void)px; (void)tile_ch;
       }
     }

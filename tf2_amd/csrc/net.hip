@@ -220,7 +220,9 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & ~1;   // perf experiments (wrong results!)
   bool mfma_v1 = false;
   if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
-  int ws_mode = 0;          // 0 auto, 2 never use the weight-stationary kernel
+  // weight-stationary kernel for short-K pointwise layers: measured slower than conv_mfma2 at batch 32-128
+  // on MI355X so far, hence opt-in (TF2_AMD_WS=3 auto, =1 forced with short runs for the tests)
+  int ws_mode = 2;
   if (const char* e = getenv("TF2_AMD_WS")) ws_mode = atoi(e);
   int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
@@ -277,6 +279,10 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
         } else {
           mfma_v1 = true;      // very wide layers: the register-staged kernel has no m-tile limit
         }
+      }
+      if (const char* e = getenv("TF2_AMD_DBGPTR2")) {
+        const char* el = getenv("TF2_AMD_DBGLAYER");
+        if (el && atoi(el) == l) ca.dbg2 = (long long*)strtoull(e, nullptr, 0);
       }
       if (const char* e = getenv("TF2_AMD_DBGPTR")) ca.dbg = (long long*)strtoull(e, nullptr, 0) + (size_t)l * 16;
       ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;

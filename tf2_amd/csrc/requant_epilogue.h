@@ -1,0 +1,78 @@
+// Shared epilogue arithmetic of the MFMA convolution kernels (conv_mfma2 / conv_mfma_sk / conv_mfma_ws).
+//
+// Reference semantics (device/src/pe.cl:191-194, relu.cl:54, feature_writer.cl:119-122), 32-bit truncation
+// and wrap-around kept:
+//   v = bias + (sum << lo)                                  (int32 wrap)
+//   x = low32((v * alpha + (beta << 20)) >> 20)             == (int)((int64)v * alpha >> 20) + beta (wrapped)
+//   y = sat32(x + 2^14) >> 15                               == ((x >> 14) + 1) >> 1 wherever either is < 2^16,
+//                                                              and both clamp to 127 where they differ
+//   c = clamp(y, relu ? 0 : -128, 127);  with a residual:  c = clamp(c + res, add_relu ? 0 : -128, 127)
+//
+// The epilogue is VALU-issue bound on the short-K layers (measured: ~13.5 issue slots per output before this
+// header existed, 8.1k of a block's 15.6k cycles at 3 waves/SIMD), so the per-output instruction count is the
+// thing to watch here: lshl_add, mad_i64_i32, alignbit, add clamp, ashr, med3 (+ sdwa add, med3 with a
+// residual) + 0.75 perm.  The per-m-tile LDS header keeps beta64 as adjacent (lo,hi) words so that the 64-bit
+// addend needs no register moves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tf2_internal.h"
+
+namespace tf2 {
+
+typedef int rq_i32x4 __attribute__((ext_vector_type(4)));
+typedef long long rq_i64x2 __attribute__((ext_vector_type(2)));
+
+// LDS header parameter block of one m-tile (weight_pack.cpp): bias[TM] | lo[TM] | alpha[TM] | beta64[TM] (lo,hi pairs)
+constexpr int kPrmWordsPerRow = 5;
+
+// One 32x32 C/D tile: this lane holds rows (reg&3) + 8*(reg>>2) + 4*half of column (lane&31) in a16[reg].
+// Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
+// resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
+template <bool HAS_RES>
+__device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
+                                                   int lo_bound, int rlo, const rq_i32x4& resv) {
+  unsigned rd[4] = {0, 0, 0, 0};
+  if (HAS_RES) {
+    // the prefetched 16 contiguous bytes back into the C/D layout (the store swaps are involutions)
+    auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[0], (unsigned)resv[1], false, false);
+    auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[2], (unsigned)resv[3], false, false);
+    rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
+  }
+  unsigned d[4];
+#pragma unroll
+  for (int G = 0; G < 4; G++) {
+    const int r0 = row0 + 8 * G;
+    const rq_i32x4 bias4 = *reinterpret_cast<const rq_i32x4*>(prm + r0);
+    const rq_i32x4 lo4 = *reinterpret_cast<const rq_i32x4*>(prm + TM + r0);
+    const rq_i32x4 al4 = *reinterpret_cast<const rq_i32x4*>(prm + 2 * TM + r0);
+    const rq_i64x2 b01 = *reinterpret_cast<const rq_i64x2*>(prm + 3 * TM + 2 * r0);
+    const rq_i64x2 b23 = *reinterpret_cast<const rq_i64x2*>(prm + 3 * TM + 2 * r0 + 4);
+    int q[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int v = (int)((unsigned)bias4[r] + ((unsigned)a16[G * 4 + r] << (lo4[r] & 31)));
+      const long long b64 = r < 2 ? b01[r & 1] : b23[r & 1];
+      const long long p = (long long)v * (long long)al4[r] + b64;
+      const int x = (int)(p >> kAlphaInflat);
+      const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+      int c;
+      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+      if (HAS_RES) {
+        const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
+        const int sres = c + rr;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
+      }
+      q[r] = c;
+    }
+    const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);   // bytes: q0.b0, q1.b0
+    const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
+    d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+  }
+  // d[G] = channel group 2G (lanes 0-31) / 2G+1 (lanes 32-63): two half-wave swaps give lanes 0-31 groups
+  // 0..3 and lanes 32-63 groups 4..7 -> 16 contiguous NHWC bytes per lane
+  auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+  auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+  return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+}
+
+}  // namespace tf2

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 9;
+constexpr uint32_t kPackVersion = 10;
 constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -85,6 +85,7 @@ struct ConvArgs {
   const int32_t* dshift;
   const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
   long long* dbg;            // optional: 16 timestamps of block 0 (tools/layer_times.py), else null
+  long long* dbg2;           // optional: per-block {start, end, hw id, xcc id} of one chosen layer
   const int32_t* hdr;        // per-m-tile LDS header images
   int32_t hdr_bytes;
   int32_t e_start[kMaxMtiles + 1];   // first entry of every m-tile (+ end)
