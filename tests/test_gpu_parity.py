@@ -175,6 +175,33 @@ def test_weight_stationary_kernel_forced(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 5, 8))
 
 
+@pytest.mark.parametrize("wshape", ["0", "2", "4"])
+def test_mfma2_wave_shapes(r50, monkeypatch, wshape):
+    """conv_mfma2.hip block shapes: 8-wave (default, 32x64 wave tiles), 4-wave (64x64) and 16-wave (32x32) blocks."""
+    monkeypatch.setenv("TF2_AMD_P", "0")
+    monkeypatch.setenv("TF2_AMD_EXP", wshape)
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 17), layers={0, 1, 2, 3, 4, 11, 12, 13, 14, 24, 25, 53})
+
+
+def test_persistent_kernel_forced(r50, monkeypatch):
+    """conv_mfma_p.hip (persistent blocks streaming pixel tiles, residual by LDS-DMA, exact vmcnt bookkeeping with
+    stores in the queue) forced onto every layer the split-K kernel does not take: several tiles per block (batch
+    5 at 56x56), blocks with one tile, a ragged last tile, 1x1 / 3x3 / strided, with and without residual, one
+    and two Horner phases; then a small net whose layers have fewer tiles than resident blocks."""
+    monkeypatch.setenv("TF2_AMD_P", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 5, 41))
+    t = cfg.tiny_tables(hw=20, widths=(64, 128), classes=100)
+    q = synth.synth_q_values(t, 8, spread=2)
+    model = synth.synth_model(t, q, 8)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
+    t = cfg.squeezenet11_tables(image_hw=67)
+    q = synth.synth_q_values(t, 12, spread=2)
+    model = synth.synth_model(t, q, 12)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 2, 12))
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)

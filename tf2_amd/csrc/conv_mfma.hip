@@ -25,6 +25,7 @@
 // ReLU (relu.cl:54); residual add in int16 + clamp + ReLU (feature_writer.cl:119-122).
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 
 namespace tf2 {
 
@@ -83,9 +84,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   for (int q = 0; q < BQ; q++) {
     int p = px0 + (tid >> 2) + 64 * q;
     if (p < g.n_pix) {
-      int b = p / g.OHW;
+      int b = fast_div(p, g.ohw_m, g.ohw_s);
       int rem = p - b * g.OHW;
-      int oh = rem / g.OW;
+      int oh = fast_div(rem, g.ow_m, g.ow_s);
       int ow = rem - oh * g.OW;
       brow_h[q] = oh * g.stride - g.pad_h;
       brow_w[q] = ow * g.stride - g.pad_w;

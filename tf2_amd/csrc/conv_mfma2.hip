@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 #include "requant_epilogue.h"
 
 namespace tf2 {
@@ -60,24 +61,25 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
-// WM x WN waves (4 or 8), each wave a WTM x WTN output tile (multiples of 32), S ring stages, OCC blocks per CU
-// the register budget is set for.  A wave's instruction stream issues at most one instruction per ~4 cycles
-// whatever the occupancy (tools/ubench), so the per-wave instruction count of the K loop and of the epilogue
-// is what a block's latency is made of: 8 waves with 32x64 tiles halve both against 4 waves with 64x64.
+// WM x WN waves (4, 8 or 16), each wave a WTM x WTN output tile (multiples of 32), S ring stages, OCC blocks
+// per CU the register budget is set for.  A wave's instruction stream issues one instruction per ~5 ticks
+// (2.1 ns) whatever the occupancy up to 8 waves/SIMD (tools/ubench/valu_peak.hip), so a block's latency is
+// its per-wave instruction count: many light waves (32x32 or 32x64 tiles) beat four waves with 64x64 tiles.
 template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int NTM = WTM / 32, NTN = WTN / 32;   // 32x32 MFMA tiles per wave (rows, columns)
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;
-  // LDS-DMA instructions per wave per stage: 16-row groups dealt round-robin to the waves.  The weight tile may
-  // have fewer groups than waves: waves < A_REM issue AI_HI instructions, the others AI_LO (waits are per class).
-  constexpr int AG = TM / 16, BG = TN / 16;
-  static_assert(BG % NW == 0, "activation tile groups must divide over the waves");
-  constexpr int BI = BG / NW;
-  constexpr int AI_LO = AG / NW, A_REM = AG % NW, AI_HI = AI_LO + (A_REM ? 1 : 0);
+  // LDS-DMA work of one stage: AG weight + BG activation 16-row groups (1 KiB, one wave instruction each), dealt
+  // round-robin to the waves: wave w owns groups w, w + NW, ...  Waves < REM own NI_HI groups, the others NI_LO;
+  // the counted waits are per class (wave-uniform branch).
+  constexpr int AG = TM / 16, BG = TN / 16, NG = AG + BG;
+  constexpr int NI_LO = NG / NW, REM = NG % NW, NI_HI = NI_LO + (REM ? 1 : 0);
+  constexpr int NR = NTM * NTN;                // residual loads per lane
+  static_assert((S - 2) * NI_HI <= 15, "vmcnt immediate range");
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  // LDS map: [ring S*STAGE][header: bias|lo|alpha|beta64 (lo,hi) pairs (5*TM) | dshift (P*TM) | steps[max_ent] |
+  // LDS map: [ring S*STAGE][header: rows {bias, alpha, beta64.lo, beta64.hi} (4*TM) | lo (TM) | dshift (P*TM) | steps[max_ent] |
   //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time;
   //           steps[p-1] = iteration at which phase p starts, INT_MAX after the last; max_ent includes S spare entries)
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
@@ -86,14 +88,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool a_hi = A_REM == 0 || wave < A_REM;      // wave-uniform DMA class
+  const bool ni_hi = REM == 0 || wave < REM;         // wave-uniform DMA class
   const int wm = wave / WN, wn = wave % WN;
   const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
 #define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); if (a.dbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
   long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TF2_STAMP(0);
   const int P = a.n_phases;
-  int* const dsh = prm + 5 * TM;
+  int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
   int* const goff = steps + a.max_ent;
   int* const ghw = goff + a.max_ent * 4;
@@ -111,7 +113,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   const int e_begin = a.e_start[mtile];
   const int e_end = a.e_start[mtile + 1];
   const int n_ent = e_end - e_begin;
-  TF2_STAMP(1);
 
   // LDS-DMA lane l of an instruction fills row (l>>2), 16-byte slot (l&3) of a 16-row group;
   // with the XOR swizzle slot c' of row r holds chunk c = c' ^ ((r>>2)&3), and r>>2 == l>>4
@@ -119,68 +120,101 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;       // inside a 16-row group of a weight tile
 
-  auto issue_A = [&](int e, int slot_idx) {
+  // The gather words of the first S-1 stages straight from the header image in global memory with SCALAR loads
+  // (constant address space, uniform address): they arrive with the kernel arguments' latency class, so the
+  // first activation DMAs do not wait for the header to land in LDS (one memory latency less per block).
+  typedef const __attribute__((address_space(4))) i32x4* cvec_p;
+  const size_t hdr_words = (size_t)mtile * (size_t)(a.hdr_bytes >> 2);
+  cvec_p const hg = (cvec_p)(unsigned long long)(a.hdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a.max_ent);
+  int pro_off[S - 1], pro_hw[S - 1];
+#pragma unroll
+  for (int s = 0; s < S - 1; s++) {
+    const i32x4 o = hg[s];                               // s_load_dwordx4, unconditional
+    pro_off[s] = chunk == 0 ? o[0] : chunk == 1 ? o[1] : chunk == 2 ? o[2] : o[3];
+    pro_hw[s] = 0;
+    if (PADCHK) {
+      const i32x4 h = hg[a.max_ent + s];
+      pro_hw[s] = chunk == 0 ? h[0] : chunk == 1 ? h[1] : chunk == 2 ? h[2] : h[3];
+    }
+  }
+  TF2_STAMP(1);
+
+  // residual tile prefetch FIRST (ordinary loads, the oldest entries of this wave's VMEM queue: every counted
+  // wait below covers them; first use is in the epilogue)
+  const int half = lane >> 5;
+  i32x4 resv[NTM][NTN];
+#pragma unroll
+  for (int i = 0; i < NTM; i++)
+#pragma unroll
+    for (int j = 0; j < NTN; j++) {
+      // no branch around the load (a join would make hipcc wait for it here): without a residual, or when
+      // masked, every lane reads the zero page
+      const int px = px0 + wn * WTN + j * 32 + (lane & 31);
+      const int chl = mtile * TM + wm * WTM + i * 32 + 16 * half;
+      const bool ok = g.has_res && px < g.n_pix && chl + 16 <= g.y_nvalid;
+      const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+      resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
+    }
+  asm volatile("" ::: "memory");           // keep the residual loads OLDER than every DMA below
+
+  // per-lane gather state of the activation row groups this wave owns
+  const int8_t* brow_ptr[NI_HI];
+  int brow_h[NI_HI], brow_w[NI_HI];
+  bool brow_ok[NI_HI];
+#pragma unroll
+  for (int j = 0; j < NI_HI; j++) {
+    const int gi = wave + NW * j;            // group index: < AG weights, else activations
+    brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
+    if (gi >= AG && gi < NG) {
+      const int p = px0 + (gi - AG) * 16 + (lane >> 2);
+      if (p < g.n_pix) {
+        const int b = fast_div(p, g.ohw_m, g.ohw_s);
+        const int rem = p - b * g.OHW;
+        const int oh = fast_div(rem, g.ow_m, g.ow_s);
+        const int ow = rem - oh * g.OW;
+        brow_h[j] = oh * g.stride - g.pad_h;
+        brow_w[j] = ow * g.stride - g.pad_w;
+        brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
+        brow_ok[j] = true;
+      }
+    }
+  }
+
+  // one stage = entry e (weights) + this lane's gather words off/hw (activations) into ring slot slot_idx
+  auto issue_stage = [&](int e, int off, int hw, int slot_idx) {
     int8_t* const slot = lds + slot_idx * STAGE;
     const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
+    int dh = 0, dw = 0;
+    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
 #pragma unroll
-    for (int j = 0; j < AI_HI; j++) {
-      const int grp = wave + NW * j;                         // 16-row group of the A tile
-      if (j < AI_LO || a_hi)
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + grp * 1024), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
+    for (int j = 0; j < NI_HI; j++) {
+      const int gi = wave + NW * j;
+      if (gi < AG) {
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + gi * 1024), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
+      } else if (j < NI_LO || ni_hi) {
+        bool ok = off >= 0 && brow_ok[j];
+        if (PADCHK) {
+          const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
+          ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        }
+        const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
+      }
     }
   };
 
-  // ---- block start: header + first weight tiles by LDS-DMA (one latency), decode meanwhile ----
+  // ---- block start: header, then the first S-1 stages, all by LDS-DMA and all in flight together ----
+  // VMEM queue of a wave: [residual, header, stage 0 .. stage S-2, then one stage per loop iteration]
   {
-    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + hdr_words * 4 + lane * 16;
     int8_t* hdst = reinterpret_cast<int8_t*>(prm);
     for (int i = wave; i * 1024 < a.hdr_bytes; i += NW)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   }
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
-    if (s < n_ent) issue_A(e_begin + s, s);
-
-  // per-lane gather state for the B (activation) rows this lane fetches
-  const int8_t* brow_ptr[BI];
-  int brow_h[BI], brow_w[BI];
-  bool brow_ok[BI];
-#pragma unroll
-  for (int j = 0; j < BI; j++) {
-    const int p = px0 + (wave + NW * j) * 16 + (lane >> 2);
-    if (p < g.n_pix) {
-      const int b = p / g.OHW;
-      const int rem = p - b * g.OHW;
-      const int oh = rem / g.OW;
-      const int ow = rem - oh * g.OW;
-      brow_h[j] = oh * g.stride - g.pad_h;
-      brow_w[j] = ow * g.stride - g.pad_w;
-      brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
-      brow_ok[j] = true;
-    } else {
-      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
-    }
-  }
-
-  // residual tile prefetch (ordinary loads; they are older than every activation DMA below, so the
-  // counted waits of the loop stay valid; first use is in the epilogue)
-  const int half = lane >> 5;
-  i32x4 resv[NTM][NTN];
-  asm volatile("" ::: "memory");           // keep the residual loads YOUNGER than the header/weight DMAs above
-#pragma unroll
-  for (int i = 0; i < NTM; i++)
-#pragma unroll
-    for (int j = 0; j < NTN; j++) {
-      resv[i][j] = i32x4{0, 0, 0, 0};
-      if (g.has_res) {                     // wave-uniform; every lane loads (a safe address when masked)
-        const int px = px0 + wn * WTN + j * 32 + (lane & 31);
-        const int chl = mtile * TM + wm * WTM + i * 32 + 16 * half;
-        const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
-        const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
-        resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
-      }
-    }
-  asm volatile("" ::: "memory");
+    if (s < n_ent) issue_stage(e_begin + s, pro_off[s], pro_hw[s], s);
+  TF2_STAMP(2);
 
   i32x16 acc[NTM][NTN];
 #pragma unroll
@@ -189,29 +223,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     for (int j = 0; j < NTN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
-
-  // header and first weight tiles landed (the NTM*NTN residual loads may stay outstanding)
-  if (g.has_res) wait_vmcnt<NTM * NTN>(); else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  TF2_STAMP(2);
-
-  auto issue_B = [&](int off, int hw, int slot_idx) {     // off/hw: this lane's gather words of the stage
-    int8_t* const slot = lds + slot_idx * STAGE + A_BYTES;
-    int dh = 0, dw = 0;
-    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
-#pragma unroll
-    for (int j = 0; j < BI; j++) {
-      const int grp = wave + NW * j;
-      bool ok = off >= 0 && brow_ok[j];
-      if (PADCHK) {
-        const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
-        ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-      }
-      const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + grp * 1024), 16, 0, 0);
-    }
-  };
 
   auto phase_shift = [&](int p) {       // Horner step: acc <<= dshift[p][channel]
 #pragma unroll
@@ -230,15 +241,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   };
 
   // ---- pipelined K loop ---------------------------------------------------------------------
-  // VMEM queue of a wave: [hdr, A_0..A_{S-2}, residual, B_0..B_{S-2}, then per iteration A_e, B_e]
-#pragma unroll
-  for (int s = 0; s < S - 1; s++)
-    if (s < n_ent) issue_B(goff[s * 4 + chunk], PADCHK ? ghw[s * 4 + chunk] : 0, s);
+  const int n_main = n_ent - (S - 1);      // iterations that still issue a stage S-1 ahead
+  auto wait_main = [&]() {                 // stage `it` (and everything older) landed; S-2 younger stages may fly
+    if (ni_hi) wait_vmcnt<(S - 2) * NI_HI>(); else wait_vmcnt<(S - 2) * NI_LO>();
+  };
+  // header + stage 0
+  if (n_main > 0) wait_main(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   TF2_STAMP(3);
   int phase = 0;
   int cslot = 0;                           // ring slot of the stage being computed
   int islot = S - 1;                       // ring slot the next issued stage goes to
-  const int n_main = n_ent - (S - 1);      // iterations that still issue a stage S-1 ahead
   // gather words of the next stage to issue, read one iteration ahead (tables are padded by S entries)
   int off_nx = goff[(S - 1) * 4 + chunk];
   int hw_nx = PADCHK ? ghw[(S - 1) * 4 + chunk] : 0;
@@ -268,8 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
       }
     }
     if (issue) {
-      issue_A(e_begin + it + S - 1, islot);
-      issue_B(off_nx, hw_nx, islot);
+      issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot);
       islot = islot + 1 == S ? 0 : islot + 1;
       off_nx = goff[(it + S) * 4 + chunk];
       if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
@@ -286,18 +299,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 
   int it = 0;
   for (; it < n_main; it++) {
-    // operations issued after stage `it` in the queue above
-    if (it == 0) wait_vmcnt<(S - 2) * BI>();
-    else if (S == 4 && it == 1) { if (a_hi) wait_vmcnt<BI + AI_HI + BI>(); else wait_vmcnt<BI + AI_LO + BI>(); }
-    else { if (a_hi) wait_vmcnt<(S - 2) * (AI_HI + BI)>(); else wait_vmcnt<(S - 2) * (AI_LO + BI)>(); }
-    __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
-    asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
+    if (it) {
+      wait_main();
+      __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
+      asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
+    }
     body(it, true);
   }
   for (; it < n_ent; it++) {               // tail: nothing left to issue, wait for everything
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if (it) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     body(it, false);
   }
   while (phase + 1 < P) { phase++; phase_shift(phase); }      // phases that start after the last entry
@@ -325,10 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         const i32x4 out = requant_tile16<HAS_RES>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl);
-          if (g.flags & 4) __builtin_nontemporal_store(out, dst);
-          else if (g.flags & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
-          else if (g.flags & 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(out) : "memory");
-          else *dst = out;
+          *dst = out;
         }
       }
     }
@@ -369,15 +380,17 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so
-// that small grids still spread over the 256 CUs.  a.g.flags bit 1: the 4-wave shapes (A/B switch).
+// that small grids still spread over the 256 CUs.  Default: 8-wave blocks with 32x64 wave tiles (measured best);
+// a.g.flags bit 1 / bit 2: the 4-wave (64x64 tiles) / 16-wave (32x32) shapes (A/B switches).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.n_mtiles > kMaxMtiles) return -4;
   const bool w4 = (a.g.flags & 2) != 0;
-  if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
+  const bool w16 = (a.g.flags & 4) != 0;
+  if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   if (TM == 64) {
     const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
-    if (blocks256 >= 512) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
+    if (blocks256 >= 512) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }
   return -1;

@@ -12,6 +12,7 @@
 // add; each wave applies the phase shifts to its own partial sum.
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 #include "requant_epilogue.h"
 
 namespace tf2 {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = a.n_phases;
-  int* const dsh = prm + 5 * TM;
+  int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
   int* const goff = steps + a.max_ent;
   int* const ghw = goff + a.max_ent * 4;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   for (int j = 0; j < BI; j++) {
     const int p = px0 + j * 16 + (lane >> 2);
     if (p < g.n_pix) {
-      const int b = p / g.OHW;
+      const int b = fast_div(p, g.ohw_m, g.ohw_s);
       const int rem = p - b * g.OHW;
-      const int oh = rem / g.OW;
+      const int oh = fast_div(rem, g.ow_m, g.ow_s);
       const int ow = rem - oh * g.OW;
       brow_h[j] = oh * g.stride - g.pad_h;
       brow_w[j] = ow * g.stride - g.pad_w;

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 #include "requant_epilogue.h"
 
 namespace tf2 {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ws_kernel(ConvArgs a, WsGeom
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int P = a.n_phases;
-  int* const dsh = prm + 5 * TM;
+  int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
   int* const goff = steps + a.max_ent;
   int* const eslot = goff + 8 * a.max_ent;           // after goff[4*max_ent] and ghw[4*max_ent]
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ws_kernel(ConvArgs a, WsGeom
         bptr[j] = a.x + (size_t)(bok[j] ? p : 0) * g.Cp_in;
       } else {
         const int pp = bok[j] ? p : 0;
-        const int b = pp / g.OHW;
+        const int b = fast_div(pp, g.ohw_m, g.ohw_s);
         const int rem = pp - b * g.OHW;
-        const int oh = rem / g.OW;
+        const int oh = fast_div(rem, g.ow_m, g.ow_s);
         const int ow = rem - oh * g.OW;
         bptr[j] = a.x + ((long long)b * g.H * g.W + (long long)(oh * g.stride) * g.W + ow * g.stride) * g.Cp_in;
       }

@@ -21,6 +21,7 @@
 // Epilogue identical to conv_mfma.hip (bias, BN requant, ReLU, residual, 8-byte store).
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 
 namespace tf2 {
 
@@ -67,9 +68,9 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
       const int p = px0 + pl;
       i32x4 v = {0, 0, 0, 0};
       if (p < g.n_pix) {
-        int b = p / g.OHW;
+        int b = fast_div(p, g.ohw_m, g.ohw_s);
         int rem = p - b * g.OHW;
-        int oh = rem / g.OW, ow = rem - (rem / g.OW) * g.OW;
+        int oh = fast_div(rem, g.ow_m, g.ow_s), ow = rem - (fast_div(rem, g.ow_m, g.ow_s)) * g.OW;
         int fh = tap / a.k, fw = tap - fh * a.k;
         int ih = oh * g.stride - g.pad_h + fh * a.dil;
         int iw = ow * g.stride - g.pad_w + fw * a.dil;

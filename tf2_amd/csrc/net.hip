@@ -189,7 +189,8 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           release(wp.tensors[t].offset, wp.tensors[t].bytes); freed[t] = 1;
         }
   }
-  wp.total_bytes = top;
+  wp.dump_off = (top + 255) / 256 * 256;      // 16 KiB scratch: where masked lanes of conv_mfma_p.hip store
+  wp.total_bytes = wp.dump_off + 16384;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
@@ -224,6 +225,11 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   // on MI355X so far, hence opt-in (TF2_AMD_WS=3 auto, =1 forced with short runs for the tests)
   int ws_mode = 2;
   if (const char* e = getenv("TF2_AMD_WS")) ws_mode = atoi(e);
+  // persistent tile-streaming kernel (conv_mfma_p.hip): 0 (default) never, 1 whenever the layer is not a split-K
+  // one, 2 when every resident block gets at least two pixel tiles.  Measured no faster than conv_mfma2 so far:
+  // both are bound by VALU issue (4 cycles per wave64 instruction per SIMD), not by the latency it hides.
+  int p_mode = 0;
+  if (const char* e = getenv("TF2_AMD_P")) p_mode = atoi(e);
   int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
@@ -270,6 +276,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.beta = (const int32_t*)(pk + pl->off_beta); ca.lo = (const int32_t*)(pk + pl->off_lo);
       ca.dshift = (const int32_t*)(pk + pl->off_dshift);
       ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
+      ca.dump = base + wp->dump_off;
       if (pl->kind == KIND_MFMA) {
         ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
         if (pl->n_mtiles <= kMaxMtiles) {
@@ -290,6 +297,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ConvGeom& g = ca.g;
       g.H = L.H; g.W = L.W; g.Cp_in = ti.Cp;
       g.OH = L.OH; g.OW = L.OW; g.OHW = L.OH * L.OW;
+      set_fast_div((uint32_t)g.OHW, &g.ohw_m, &g.ohw_s); set_fast_div((uint32_t)g.OW, &g.ow_m, &g.ow_s);
       g.stride = L.stride; g.pad_h = L.pad_h; g.pad_w = L.pad_w;
       g.n_pix = batch * L.OH * L.OW;
       const bool direct = E.conv_tensor == E.out_tensor;
@@ -309,7 +317,10 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
                         (sk_mode == 1 || (blocks64 <= 512 && pl->n_entries >= 16 * pl->n_mtiles));
         if (mfma_v1 || (flags & 1)) rc = launch_conv_mfma(ca, pl->TM, stream);
         else if (sk) rc = launch_conv_mfma_sk(ca, stream);
-        else {
+        else if (p_mode == 1 || (p_mode == 2 && (long)((g.n_pix + (pl->TM == 128 ? 127 : 255)) / (pl->TM == 128 ? 128 : 256)) * pl->n_mtiles >= 1024 && pl->n_mtiles <= 64))
+          rc = launch_conv_mfma_p(ca, pl->TM, stream);
+        else rc = 1;
+        if (rc == 1 && !sk && !(mfma_v1 || (flags & 1))) {
           rc = ws_mode == 2 ? 1 : launch_conv_mfma_ws(ca, pl->TM, stream);     // short-K pointwise layers
           if (rc == 1) rc = launch_conv_mfma2(ca, pl->TM, stream);
         }

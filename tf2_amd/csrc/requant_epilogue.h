@@ -22,13 +22,15 @@ namespace tf2 {
 typedef int rq_i32x4 __attribute__((ext_vector_type(4)));
 typedef long long rq_i64x2 __attribute__((ext_vector_type(2)));
 
-// LDS header parameter block of one m-tile (weight_pack.cpp): bias[TM] | lo[TM] | alpha[TM] | beta64[TM] (lo,hi pairs)
+// LDS header parameter block of one m-tile (weight_pack.cpp): TM rows of {bias, alpha, beta64.lo, beta64.hi}
+// (one 16-byte read per output row, the 64-bit addend already in an aligned register pair), then lo[TM].
 constexpr int kPrmWordsPerRow = 5;
 
 // One 32x32 C/D tile: this lane holds rows (reg&3) + 8*(reg>>2) + 4*half of column (lane&31) in a16[reg].
 // Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
+// LEAN (1 or 2): for kernels compiled for 8 waves/SIMD (64 registers); the number of rows read ahead.
 // resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
-template <bool HAS_RES>
+template <bool HAS_RES, int LEAN = 0>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
                                                    int lo_bound, int rlo, const rq_i32x4& resv) {
   unsigned rd[4] = {0, 0, 0, 0};
@@ -39,20 +41,31 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
     rd[0] = r02[0]; rd[2] = r02[1]; rd[1] = r13[0]; rd[3] = r13[1];
   }
   unsigned d[4];
+  const rq_i32x4* rowp = reinterpret_cast<const rq_i32x4*>(prm) + row0;
+  const int* lop = prm + 4 * TM + row0;
+  // LEAN (kernels built for 64 registers): the rows are processed strictly in order with the parameters of the
+  // next LEAN rows in flight, instead of letting the scheduler hoist all sixteen reads
+  rq_i32x4 pq[3];
+  if (LEAN) { pq[0] = rowp[0]; if (LEAN > 1) pq[1] = rowp[1]; }
 #pragma unroll
   for (int G = 0; G < 4; G++) {
-    const int r0 = row0 + 8 * G;
-    const rq_i32x4 bias4 = *reinterpret_cast<const rq_i32x4*>(prm + r0);
-    const rq_i32x4 lo4 = *reinterpret_cast<const rq_i32x4*>(prm + TM + r0);
-    const rq_i32x4 al4 = *reinterpret_cast<const rq_i32x4*>(prm + 2 * TM + r0);
-    const rq_i64x2 b01 = *reinterpret_cast<const rq_i64x2*>(prm + 3 * TM + 2 * r0);
-    const rq_i64x2 b23 = *reinterpret_cast<const rq_i64x2*>(prm + 3 * TM + 2 * r0 + 4);
+    const rq_i32x4 lo4 = *reinterpret_cast<const rq_i32x4*>(lop + 8 * G);
     int q[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int v = (int)((unsigned)bias4[r] + ((unsigned)a16[G * 4 + r] << (lo4[r] & 31)));
-      const long long b64 = r < 2 ? b01[r & 1] : b23[r & 1];
-      const long long p = (long long)v * (long long)al4[r] + b64;
+      const int k = G * 4 + r;                             // 0..15, row = row0 + 8 * (k / 4) + k % 4
+      rq_i32x4 pr;
+      if (LEAN) {
+        constexpr int NB = LEAN + 1;                       // row buffers: LEAN rows in flight ahead of the current
+        if (k + LEAN < 16) pq[(k + LEAN) % NB] = rowp[8 * ((k + LEAN) / 4) + (k + LEAN) % 4];
+        __builtin_amdgcn_sched_barrier(0);
+        pr = pq[k % NB];
+      } else {
+        pr = rowp[8 * G + r];
+      }
+      const int v = (int)((unsigned)pr[0] + ((unsigned)a16[k] << (lo4[r] & 31)));
+      const long long b64 = (long long)(((unsigned long long)(unsigned)pr[3] << 32) | (unsigned)pr[2]);
+      const long long p = (long long)v * (long long)pr[1] + b64;
       const int x = (int)(p >> kAlphaInflat);
       const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
       int c;

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 10;
+constexpr uint32_t kPackVersion = 12;
 constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -60,6 +60,8 @@ struct PackHeader {
 struct ConvGeom {
   int32_t H, W, Cp_in;       // input tensor geometry (pixels, bytes per pixel)
   int32_t OH, OW, OHW;       // conv output geometry
+  uint32_t ohw_m, ow_m;      // pixel decode without integer division: n / d == umulhi(n, m) >> s for n < 2^31
+  int32_t ohw_s, ow_s;       //   (set_fast_div below; s < 0 means d == 1)
   int32_t stride, pad_h, pad_w;
   int32_t n_pix;             // batch * OH * OW
   int32_t y_cp, y_off;       // output bytes per pixel, channel offset of this layer's slice
@@ -68,6 +70,17 @@ struct ConvGeom {
   int32_t relu, add_relu, has_res;
   int32_t flags;             // bit0: no permlane swap in the epilogue (debug)
 };
+
+// n / d for 0 <= n < 2^31 as one 32x32->hi multiply and a shift: L = ceil(log2 d), m = floor(2^(31+L) / d) + 1,
+// q = umulhi(n, m) >> (L - 1).  (m*d = 2^(31+L) + e, 0 < e <= d, so n*m / 2^(31+L) = n/d + err with err < 2^-L <= 1/d,
+// which cannot carry frac(n/d) <= (d-1)/d over 1.)
+inline void set_fast_div(uint32_t d, uint32_t* m, int32_t* s) {
+  if (d <= 1) { *m = 0; *s = -1; return; }
+  int L = 0;
+  while ((1ull << L) < d) L++;
+  *m = (uint32_t)(((1ull << (31 + L)) / d) + 1);
+  *s = L - 1;
+}
 
 struct ConvArgs {
   const int8_t* x;
@@ -85,6 +98,7 @@ struct ConvArgs {
   const int32_t* dshift;
   const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
   long long* dbg;            // optional: 16 timestamps of block 0 (tools/layer_times.py), else null
+  int8_t* dump;              // 16 KiB of writable scratch for masked stores (conv_mfma_p.hip)
   long long* dbg2;           // optional: per-block {start, end, hw id, xcc id} of one chosen layer
   const int32_t* hdr;        // per-m-tile LDS header images
   int32_t hdr_bytes;
@@ -120,6 +134,7 @@ struct PrepArgs {
 int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, void* stream);
+int launch_conv_mfma_p(const ConvArgs& a, int TM, void* stream);    // persistent tile-streaming kernel
 int launch_conv_mfma_ws(const ConvArgs& a, int TM, void* stream);   // returns 1 if the layer does not qualify
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_maxpool(const PoolArgs& a, void* stream);

@@ -31,6 +31,7 @@ struct WorkPlan {
   int input_tensor = -1;
   int final_tensor = -1;
   size_t total_bytes = 0;
+  size_t dump_off = 0;        // 16 KiB scratch for masked stores (conv_mfma_p.hip)
 };
 
 struct Net {

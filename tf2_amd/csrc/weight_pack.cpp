@@ -222,8 +222,8 @@ tf2_status Net::pack(int mode) {
       pl.off_dshift = blob.alloc(dshift.size() * 4);
       std::memcpy(blob.at<uint8_t>(pl.off_dshift), dshift.data(), dshift.size() * 4);
       // ---- per-m-tile LDS header images for conv_mfma2.hip ----
-      // words: bias[TM] lo[TM] alpha[TM] beta64[TM] as adjacent (lo,hi) words (beta64 = (int64)beta << 20, the addend of
-      //        the 64-bit multiply-add) | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
+      // words: per row {bias, alpha, beta64.lo, beta64.hi} (4*TM; beta64 = (int64)beta << 20, the addend of the
+      //        64-bit multiply-add; one 16-byte read per output row) | lo[TM] | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
       //        the entry) | goff[max_ent][4] (per 16-byte segment: byte offset from the pixel's tap origin,
       //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test) | eslot[max_ent] (entry ->
       //        index of its slab among the m-tile's DISTINCT slabs) | dfirst[max_ent] (distinct index -> an entry
@@ -238,10 +238,11 @@ tf2_status Net::pack(int mode) {
           for (int r = 0; r < TM; r++) {
             const int n = mt * TM + r;
             const int64_t b64 = (int64_t)(n < N ? m.beta[n] : 0) << kAlphaInflat;
-            h[r] = n < N ? m.bias[n] : 0; h[TM + r] = lo_last[n];
-            h[2 * TM + r] = n < N ? m.alpha[n] : 0;
-            h[3 * TM + 2 * r] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
-            h[3 * TM + 2 * r + 1] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+            int32_t* pr = h + 4 * r;                       // one row's parameters: one 16-byte LDS read
+            pr[0] = n < N ? m.bias[n] : 0; pr[1] = n < N ? m.alpha[n] : 0;
+            pr[2] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
+            pr[3] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+            h[4 * TM + r] = lo_last[n];
             for (int p = 0; p < P; p++) h[5 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
           }
           int32_t* hs = h + 5 * TM + P * TM;

@@ -30,7 +30,7 @@ cuid = xcc * 1000 + se * 100 + sh * 16 + cu
 print("blocks", n, "kernel span cycles", en.max(), "distinct CUs", len(set(cuid.tolist())))
 life = en - st
 seg = np.stack([d[:,4]-d[:,0], d[:,5]-d[:,4], d[:,6]-d[:,5], d[:,7]-d[:,6], d[:,1]-d[:,7]], 1)
-print("segment medians (start->e_start, ->hdr+A landed, ->B prologue issued, ->loop end, ->end):", np.median(seg,0).astype(int).tolist())
+print("segment medians (start->gather words, ->prologue DMAs issued, ->hdr+stage0 landed, ->loop end, ->end):", np.median(seg,0).astype(int).tolist())
 print("segment means:", seg.mean(0).astype(int).tolist())
 first = np.argsort(d[:,0])[:256]
 print("segments, mean of 256 earliest blocks:", seg[first].mean(0).astype(int).tolist())
