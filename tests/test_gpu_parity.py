@@ -202,6 +202,18 @@ def test_persistent_kernel_forced(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 2, 12))
 
 
+def test_generic_requant_forced(r50, monkeypatch):
+    """TF2_AMD_NOFAST=1 at pack time: every layer takes the 6-instruction wrap-exact requantisation instead of the
+    range-proven 3-instruction one (most synthetic ResNet-50 layers qualify for the latter); same bits."""
+    monkeypatch.setenv("TF2_AMD_NOFAST", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 23), layers={1, 2, 3, 4, 11, 13, 26, 28, 45, 52, 53})
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 5, spread=2)
+    model = synth.synth_model(t, q, 5)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 2, 5))
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)

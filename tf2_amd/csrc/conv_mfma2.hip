@@ -27,6 +27,7 @@
 //  * three tile shapes: 128x128 (2x2 waves of 64x64), 64x256 (1x4 waves, N_out = 64
 //    layers) and 64x64 (2x2 waves of 32x32) for layers whose grid would not fill 256 CUs.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "tf2_internal.h"
 #include "tf2_device.h"
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); if (a.dbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
   long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TF2_STAMP(0);
+  const long long wall0 = a.dbg2 ? (long long)wall_clock64() : 0;
   const int P = a.n_phases;
   int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
@@ -324,8 +326,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   // residual: int16 add, clamp, ReLU (feature_writer.cl:119-122) in the C/D register layout.
   const int lo_bound = g.relu ? 0 : -128;
   const int rlo = g.add_relu ? 0 : -128;
-  auto epilogue = [&](auto has_res_c) {
+  auto epilogue = [&](auto has_res_c, auto fast_c) {
     constexpr bool HAS_RES = decltype(has_res_c)::value;
+    constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
     for (int i = 0; i < NTM; i++) {
       const int rb = wm * WTM + i * 32;                        // tile row base inside the block tile
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-        const i32x4 out = requant_tile16<HAS_RES>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
+        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl);
           *dst = out;
@@ -344,14 +347,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
       }
     }
   };
-  if (g.has_res) epilogue(std::true_type{}); else epilogue(std::false_type{});
+  if (g.fast) { if (g.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
+  else { if (g.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
   if (a.dbg2 && tid == 0) {
     long long* d = a.dbg2 + (size_t)blockIdx.x * 8;
     d[0] = tstamp[0]; d[1] = (long long)__builtin_readcyclecounter();
-    d[4] = tstamp[1]; d[5] = tstamp[2]; d[6] = tstamp[3]; d[7] = tstamp[5];
+    d[4] = tstamp[1]; d[5] = tstamp[2]; d[6] = tstamp[3];
     d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID (id 4), 32 bits
-    d[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID (id 20)
+    d[3] = wall0; d[7] = (long long)wall_clock64();                        // 100 MHz, chip-wide
   }
 #undef TF2_STAMP
 }
@@ -390,7 +394,8 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   if (TM == 64) {
     const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
-    if (blocks256 >= 512) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
+    static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
+    if (blocks256 >= t256) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }
   return -1;

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 2) / 4) void conv_mfma_p_k
           for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
           i32x4 rv = {0, 0, 0, 0};
           if (HAS_RES) rv = *reinterpret_cast<const i32x4*>(res_lds + (i * NTN + j) * 1024 + lane_e * 16);
-          const i32x4 out = requant_tile16<HAS_RES, (HAS_RES ? 1 : 2)>(a16, prm, TM, rb + 4 * half_e, lo_bound, rlo, rv);
+          const i32x4 out = g.fast ? requant_tile16<HAS_RES, (HAS_RES ? 1 : 2), true>(a16, prm, TM, rb + 4 * half_e, lo_bound, rlo, rv)
+                                   : requant_tile16<HAS_RES, (HAS_RES ? 1 : 2), false>(a16, prm, TM, rb + 4 * half_e, lo_bound, rlo, rv);
           // every lane stores (a dump line when masked) so that the count of VMEM operations is static
           const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid && !(g.flags & 8);     // flags 8/16: timing experiments
           int8_t* dst = ok ? a.y + (size_t)px * g.y_cp + g.y_off + chl : a.dump + (size_t)(wave * 64 + lane_e) * 16;

@@ -272,8 +272,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   for (int G = 0; G < 4; G++)
 #pragma unroll
     for (int r = 0; r < 4; r++) a16[G * 4 + r] = sum[G][r];
-  const i32x4 out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
-                              : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
+  i32x4 out;
+  if (g.fast) out = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
+                              : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
+  else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
+                       : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
   const int chl = tile_ch + 16 * half;
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
     *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;

@@ -251,8 +251,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ws_kernel(ConvArgs a, WsGeom
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-        pend[i][j] = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv)
-                               : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv);
+        if (g.fast) pend[i][j] = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv)
+                                           : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv);
+        else pend[i][j] = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv)
+                                    : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, rv);
         (void)px; (void)tile_ch;
       }
     }

@@ -304,6 +304,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       g.y_cp = tc.Cp; g.y_off = direct ? E.out_off : 0;
       g.y_nvalid = round_up(L.N, 16);
       g.relu = L.relu; g.add_relu = L.add_relu; g.has_res = L.add_src >= 0;
+      g.fast = pl->fast;
       if (g.has_res) {
         const TensorPlan& tr = T(E.res_tensor);
         ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;

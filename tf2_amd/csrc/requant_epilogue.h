@@ -8,6 +8,9 @@
 //                                                              and both clamp to 127 where they differ
 //   c = clamp(y, relu ? 0 : -128, 127);  with a residual:  c = clamp(c + res, add_relu ? 0 : -128, 127)
 //
+// FAST (PackLayer::fast, proven per layer at pack time): y = (sum * (alpha << lo) + B') >> 35 with
+// B' = bias * alpha + (beta << 20) + 2^34 -- mad_i64_i32, ashr, med3.
+//
 // The epilogue is VALU-issue bound on the short-K layers (measured: ~13.5 issue slots per output before this
 // header existed, 8.1k of a block's 15.6k cycles at 3 waves/SIMD), so the per-output instruction count is the
 // thing to watch here: lshl_add, mad_i64_i32, alignbit, add clamp, ashr, med3 (+ sdwa add, med3 with a
@@ -30,7 +33,7 @@ constexpr int kPrmWordsPerRow = 5;
 // Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
 // LEAN (1 or 2): for kernels compiled for 8 waves/SIMD (64 registers); the number of rows read ahead.
 // resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
-template <bool HAS_RES, int LEAN = 0>
+template <bool HAS_RES, int LEAN = 0, bool FAST = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
                                                    int lo_bound, int rlo, const rq_i32x4& resv) {
   unsigned rd[4] = {0, 0, 0, 0};
@@ -49,7 +52,8 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
   if (LEAN) { pq[0] = rowp[0]; if (LEAN > 1) pq[1] = rowp[1]; }
 #pragma unroll
   for (int G = 0; G < 4; G++) {
-    const rq_i32x4 lo4 = *reinterpret_cast<const rq_i32x4*>(lop + 8 * G);
+    rq_i32x4 lo4 = {0, 0, 0, 0};
+    if (!FAST) lo4 = *reinterpret_cast<const rq_i32x4*>(lop + 8 * G);
     int q[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -63,11 +67,18 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
       } else {
         pr = rowp[8 * G + r];
       }
-      const int v = (int)((unsigned)pr[0] + ((unsigned)a16[k] << (lo4[r] & 31)));
       const long long b64 = (long long)(((unsigned long long)(unsigned)pr[3] << 32) | (unsigned)pr[2]);
-      const long long p = (long long)v * (long long)pr[1] + b64;
-      const int x = (int)(p >> kAlphaInflat);
-      const int y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+      int y;
+      if (FAST) {
+        // rows proven at pack time (weight_pack.cpp): y = (acc * (alpha << lo) + B') >> 35, no wrap anywhere
+        const long long p = (long long)a16[k] * (long long)pr[1] + b64;
+        y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+      } else {
+        const int v = (int)((unsigned)pr[0] + ((unsigned)a16[k] << (lo4[r] & 31)));
+        const long long p = (long long)v * (long long)pr[1] + b64;
+        const int x = (int)(p >> kAlphaInflat);
+        y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+      }
       int c;
       asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
       if (HAS_RES) {

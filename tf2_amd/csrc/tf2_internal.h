@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 12;
+constexpr uint32_t kPackVersion = 13;
 constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -34,6 +34,8 @@ struct PackLayer {
   int32_t n_entries;   // number of (mtile, phase, slab) weight tiles stored
   int32_t n_cchunk;    // shift kernel: channel chunks of 16
   int32_t max_ent;     // MFMA: largest number of entries of one m-tile (multiple of 4)
+  int32_t fast;        // MFMA: every output row passed the range proof of the 3-instruction requantisation
+  int32_t rsv0;
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -68,6 +70,7 @@ struct ConvGeom {
   int32_t y_nvalid;          // valid output channels rounded up to the store granule
   int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
   int32_t relu, add_relu, has_res;
+  int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
   int32_t flags;             // bit0: no permlane swap in the epilogue (debug)
 };
 

@@ -17,6 +17,7 @@
 // The image is position independent (offsets relative to its start) so that rank 0 can
 // broadcast it once over RCCL and every rank bind it at its own address.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "tf2_net.h"
 
@@ -228,6 +229,26 @@ tf2_status Net::pack(int mode) {
       //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test) | eslot[max_ent] (entry ->
       //        index of its slab among the m-tile's DISTINCT slabs) | dfirst[max_ent] (distinct index -> an entry
       //        using that slab); steps[max_ent-1] = number of distinct slabs (conv_mfma_ws.hip)
+      // ---- range proof for the fast requantisation (requant_epilogue.h) ----
+      // With |x| <= 128, |sum| <= amax[n] = 128 * sum |w|.  If for every row  amax + |bias| < 2^31  (no int32 wrap
+      // of v = bias + (acc << lo)),  |alpha| << lo < 2^31,  and  (amax + |bias|) * |alpha| + (|beta| << 20) + 2^34 <
+      // 2^51  (x = p >> 20 fits int32 and x + 2^14 does not saturate), then
+      //   y = (acc * (alpha << lo) + B') >> 35,   B' = bias * alpha + (beta << 20) + 2^34
+      // is the reference result exactly, and the kernels use it (3 VALU instructions per output instead of 6).
+      bool fast = getenv("TF2_AMD_NOFAST") == nullptr;
+      for (int n = 0; n < N && fast; n++) {
+        unsigned __int128 amax = 0;
+        const uint8_t* rc = m.codes.data() + (size_t)n * C * taps;
+        for (int i = 0; i < C * taps; i++) if (!code_zero(rc[i])) amax += (unsigned __int128)128 << code_shift(rc[i]);
+        const unsigned __int128 ab = (unsigned __int128)std::llabs((long long)m.bias[n]);
+        const unsigned __int128 aa = (unsigned __int128)std::llabs((long long)m.alpha[n]);
+        const unsigned __int128 abeta = (unsigned __int128)std::llabs((long long)m.beta[n]);
+        const unsigned __int128 one = 1;
+        if (amax + ab >= (one << 31)) fast = false;
+        else if ((aa << lo_last[n]) >= (one << 31)) fast = false;
+        else if ((amax + ab) * aa + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) fast = false;
+      }
+      pl.fast = fast ? 1 : 0;
       {
         const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)11 * pl.max_ent;
         const size_t hb = (words * 4 + 1023) / 1024 * 1024;
@@ -239,9 +260,17 @@ tf2_status Net::pack(int mode) {
             const int n = mt * TM + r;
             const int64_t b64 = (int64_t)(n < N ? m.beta[n] : 0) << kAlphaInflat;
             int32_t* pr = h + 4 * r;                       // one row's parameters: one 16-byte LDS read
-            pr[0] = n < N ? m.bias[n] : 0; pr[1] = n < N ? m.alpha[n] : 0;
-            pr[2] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
-            pr[3] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+            if (fast) {
+              const int64_t al = n < N ? (int64_t)m.alpha[n] : 0;
+              const int64_t bp = (n < N ? (int64_t)m.bias[n] * al : 0) + b64 + ((int64_t)1 << 34);
+              pr[0] = 0; pr[1] = (int32_t)(al << lo_last[n]);
+              pr[2] = (int32_t)(uint32_t)((uint64_t)bp & 0xffffffffu);
+              pr[3] = (int32_t)(uint32_t)((uint64_t)bp >> 32);
+            } else {
+              pr[0] = n < N ? m.bias[n] : 0; pr[1] = n < N ? m.alpha[n] : 0;
+              pr[2] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
+              pr[3] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+            }
             h[4 * TM + r] = lo_last[n];
             for (int p = 0; p < P; p++) h[5 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
           }

@@ -19,18 +19,26 @@ torch.cuda.synchronize()
 dbg = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda:0")
 os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
 r.run_batch(x); torch.cuda.synchronize()
+from tf2_amd import _lib
+_lib.check(_lib.lib().tf2_net_profile(net._h, 1))
+r.run_batch(x); torch.cuda.synchronize()
+nl_ = len(cfg.build_plan(t)); ms = np.zeros(nl_, np.float32); nn = np.zeros(nl_, np.int32); kd = np.zeros(nl_, np.int32)
+_lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nn.ctypes.data, kd.ctypes.data, nl_))
+print(f"layer {a.layer}: event-timed kernel {ms[a.layer] / max(nn[a.layer], 1) * 1e3:.2f} us")
 d = dbg.cpu().numpy().reshape(-1, 8)
 d = d[d[:, 1] != 0]
 n = len(d)
 t0 = d[:, 0].min()
 st, en = d[:, 0] - t0, d[:, 1] - t0
-hw = d[:, 2]; xcc = d[:, 3] & 0xf
+hw = d[:, 2]; xcc = np.zeros(len(d), np.int64)
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 cuid = xcc * 1000 + se * 100 + sh * 16 + cu
 print("blocks", n, "kernel span cycles", en.max(), "distinct CUs", len(set(cuid.tolist())))
 life = en - st
-seg = np.stack([d[:,4]-d[:,0], d[:,5]-d[:,4], d[:,6]-d[:,5], d[:,7]-d[:,6], d[:,1]-d[:,7]], 1)
-print("segment medians (start->gather words, ->prologue DMAs issued, ->hdr+stage0 landed, ->loop end, ->end):", np.median(seg,0).astype(int).tolist())
+seg = np.stack([d[:,4]-d[:,0], d[:,5]-d[:,4], d[:,6]-d[:,5], d[:,1]-d[:,6]], 1)
+w0, w1 = d[:, 3], d[:, 7]
+print(f'wall clock (100 MHz): first block start -> last block end {(w1.max() - w0.min()) / 100:.2f} us; first->last block START {(w0.max() - w0.min()) / 100:.2f} us; median block {np.median(w1 - w0) / 100:.2f} us')
+print("segment medians (start->gather words, ->prologue DMAs issued, ->hdr+stage0 landed, ->end):", np.median(seg,0).astype(int).tolist())
 print("segment means:", seg.mean(0).astype(int).tolist())
 first = np.argsort(d[:,0])[:256]
 print("segments, mean of 256 earliest blocks:", seg[first].mean(0).astype(int).tolist())

@@ -3,12 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int OP>
-__global__ __launch_bounds__(1024) void k(long long* out, int* sink, int seed) {
+__global__ __launch_bounds__(1024) void k(long long* out, int* sink, int seed, int iters) {
   int a[8]; long long q[8];
   for (int i = 0; i < 8; i++) { a[i] = seed + i + threadIdx.x; q[i] = a[i]; }
   int b = seed * 3 + 1, c = seed + 7;
   long long t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < 256; it++) {
+  for (int it = 0; it < iters; it++) {
     if (OP == 0) {
       asm volatile(
         "v_lshl_add_u32 %0, %0, %8, %9\n v_lshl_add_u32 %1, %1, %8, %9\n v_lshl_add_u32 %2, %2, %8, %9\n v_lshl_add_u32 %3, %3, %8, %9\n"
@@ -34,9 +34,13 @@ template <int OP>
 void run(const char* name, long long* d, int* sink) {
   for (int nthr : {64, 256, 512, 1024}) for (int nblk : {1, 256, 512}) {
     if (nblk == 512 && nthr != 1024) continue;
-    k<OP><<<nblk, nthr>>>(d, sink, 3); k<OP><<<nblk, nthr>>>(d, sink, 3); (void)hipDeviceSynchronize();
+    const int iters = 4096;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<OP><<<nblk, nthr>>>(d, sink, 3, iters); (void)hipEventRecord(e0); k<OP><<<nblk, nthr>>>(d, sink, 3, iters); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     long long h; (void)hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-    double per = (double)h / (256.0 * 16);
+    double per = (double)h / (iters * 16.0);
+    printf("   [wall %.1f us for %d instr per wave -> %.2f ns per instr per wave] ", ms * 1e3, iters * 16, ms * 1e6 / (iters * 16.0));
     double wps = nthr / 256.0 * (nblk == 512 ? 2 : 1);
     printf("%-16s blocks %4d threads %4d (%.2f waves/SIMD): %6.2f ticks per instr per wave -> %5.2f ticks per SIMD-instr\n", name, nblk, nthr, wps, per, per / (wps < 1 ? 1 : wps));
   }
