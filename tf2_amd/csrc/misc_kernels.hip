@@ -116,34 +116,38 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
 }
 
 __global__ __launch_bounds__(256) void global_avg_kernel(AvgArgs a) {
-  // one thread per (image, 16-channel group): HW 16-byte loads, 16 int16 sums (Sreal, types.h:30)
+  // one block per (image, 8 groups of 16 channels = 128 contiguous bytes per pixel); thread = (pixel part, group):
+  // 32 parts stride over the HW pixels with 16-byte loads, partial sums meet in LDS.  The reference accumulates in
+  // int16 with wrap-around (Sreal, types.h:30): addition mod 2^16 is associative, the wrap is applied at the end.
+  __shared__ int part_sum[32][8][17];
   const int G16 = a.C / 16;
-  const int total = a.B * G16;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int cg = idx % G16, b = idx / G16;
-    const int8_t* p = a.x + (size_t)b * a.HW * a.x_cp + a.x_off + cg * 16;
-    int s[16];
+  const int gblocks = (G16 + 7) / 8;
+  const int b = blockIdx.x / gblocks, g0 = (blockIdx.x % gblocks) * 8;
+  const int tid = threadIdx.x, cgl = tid & 7, part = tid >> 3;
+  const int cg = g0 + cgl;
+  int s[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = 0;
-    for (int i = 0; i < a.HW; i++) {
+  for (int i = 0; i < 16; i++) s[i] = 0;
+  if (cg < G16) {
+    const int8_t* p = a.x + (size_t)b * a.HW * a.x_cp + a.x_off + cg * 16;
+    for (int i = part; i < a.HW; i += 32) {
       const i32x4 v = *reinterpret_cast<const i32x4*>(p + (size_t)i * a.x_cp);
 #pragma unroll
       for (int q = 0; q < 16; q++) s[q] += (int)(signed char)((v[q >> 2] >> (8 * (q & 3))) & 0xff);
     }
-    i32x4 o;
+  }
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-      int word = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int sv = (int)(short)s[4 * w + j];             // int16 accumulator wrap
-        int m = (((sv * a.mult) >> 14) + 1) >> 1;            // full_size_pool.cl:118
-        m = m > 127 ? 127 : (m < -128 ? -128 : m);
-        word |= (m & 0xff) << (8 * j);
-      }
-      o[w] = word;
-    }
-    *reinterpret_cast<i32x4*>(a.y + (size_t)b * a.y_cp + a.y_off + cg * 16) = o;
+  for (int q = 0; q < 16; q++) part_sum[part][cgl][q] = s[q];
+  __syncthreads();
+  if (tid < 128) {
+    const int gl = tid >> 4, ch = tid & 15;
+    int t = 0;
+#pragma unroll 8
+    for (int pp = 0; pp < 32; pp++) t += part_sum[pp][gl][ch];
+    const int sv = (int)(short)t;                          // int16 accumulator wrap
+    int m = (((sv * a.mult) >> 14) + 1) >> 1;              // full_size_pool.cl:118
+    m = m > 127 ? 127 : (m < -128 ? -128 : m);
+    if (g0 + gl < G16) a.y[(size_t)b * a.y_cp + a.y_off + (g0 + gl) * 16 + ch] = (int8_t)m;
   }
 }
 
@@ -166,7 +170,7 @@ int launch_maxpool(const PoolArgs& a, void* stream) {
 }
 
 int launch_global_avg(const AvgArgs& a, void* stream) {
-  hipLaunchKernelGGL(global_avg_kernel, dim3(grid_for((long long)a.B * (a.C / 16), 64)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(global_avg_kernel, dim3(a.B * ((a.C / 16 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
