@@ -8,7 +8,7 @@ import numpy as np
 HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir_bytes", "<u4"),
                 ("total_bytes", "<u8"), ("tables_hash", "<u8"), ("zero_off", "<u8")])
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
-                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "rsv0")] +
+                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
                                     "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes")])
 
@@ -65,8 +65,10 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         kinfo = i32(blob, int(pl["off_kinfo"]), nslab * 4).reshape(nslab, 4)
         lo = i32(blob, int(pl["off_lo"]), Np).astype(np.int64)
         dsh = i32(blob, int(pl["off_dshift"]), P * Np).reshape(P, Np).astype(np.int64)
-        wt = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * TM * 64].tobytes(), np.int8)
-        wt = wt.reshape(-1, TM, 64)
+        dual = int(pl["dual"])
+        nt = 2 if dual else 1                      # weight tiles per entry
+        wt = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * nt * TM * 64].tobytes(), np.int8)
+        wt = wt.reshape(-1, nt, TM, 64)
         # gather all slabs once: Bmat[slab] = [npix, 64]
         pb, poh, pow_ = np.unravel_index(np.arange(npix), (B, OH, OW))
         slabs = {}
@@ -92,11 +94,21 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         acc = np.zeros((Np, npix), np.int64)
         for mt in range(nm):
             a = np.zeros((TM, npix), np.int64)
-            for p in range(P):
-                if p >= 1:
-                    a = (a << dsh[p, mt * TM:(mt + 1) * TM, None]) % 2 ** 32
-                for e in range(dirs[mt, p], dirs[mt, p + 1]):
-                    a = (a + (wt[e].astype(np.float64) @ slab(int(entries[e])).astype(np.float64).T).astype(np.int64)) % 2 ** 32
+            if dual:
+                # both exponent windows per entry: (hi << dshift[1]) + lo, combined once (weight_pack.cpp)
+                assert P == 2 and dirs[mt, 1] == dirs[mt, 2]
+                lo_acc = np.zeros((TM, npix), np.int64)
+                for e in range(dirs[mt, 0], dirs[mt, 2]):
+                    sb = slab(int(entries[e])).astype(np.float64).T
+                    a = (a + (wt[e, 0].astype(np.float64) @ sb).astype(np.int64)) % 2 ** 32
+                    lo_acc = (lo_acc + (wt[e, 1].astype(np.float64) @ sb).astype(np.int64)) % 2 ** 32
+                a = ((a << dsh[1, mt * TM:(mt + 1) * TM, None]) + lo_acc) % 2 ** 32
+            else:
+                for p in range(P):
+                    if p >= 1:
+                        a = (a << dsh[p, mt * TM:(mt + 1) * TM, None]) % 2 ** 32
+                    for e in range(dirs[mt, p], dirs[mt, p + 1]):
+                        a = (a + (wt[e, 0].astype(np.float64) @ slab(int(entries[e])).astype(np.float64).T).astype(np.int64)) % 2 ** 32
             acc[mt * TM:(mt + 1) * TM] = a
         acc = (bias[:, None] + (acc << lo[:, None])) % 2 ** 32
     else:

@@ -214,6 +214,14 @@ def test_generic_requant_forced(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 2, 5))
 
 
+def test_single_window_packing_forced(r50, monkeypatch):
+    """TF2_AMD_NODUAL=1 at pack time: two-phase layers keep the Horner form (one exponent window per entry, accumulators
+    shifted at the phase boundary) instead of the default dual-window entries; conv_mfma2 and the split-K kernel."""
+    monkeypatch.setenv("TF2_AMD_NODUAL", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 29), layers={0, 1, 2, 3, 4, 11, 13, 24, 26, 27, 29, 47, 53})
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)

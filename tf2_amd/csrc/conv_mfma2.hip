@@ -66,18 +66,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 // per CU the register budget is set for.  A wave's instruction stream issues one instruction per ~5 ticks
 // (2.1 ns) whatever the occupancy up to 8 waves/SIMD (tools/ubench/valu_peak.hip), so a block's latency is
 // its per-wave instruction count: many light waves (32x32 or 32x64 tiles) beat four waves with 64x64 tiles.
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK>
+// DUAL: two-phase layers packed with both exponent windows per entry (weight_pack.cpp): [hi TM rows][lo TM rows] of
+// weights and ONE activation slab per K step, two accumulators, combined once as (hi << dshift[1]) + lo.
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int NTM = WTM / 32, NTN = WTN / 32;   // 32x32 MFMA tiles per wave (rows, columns)
-  constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = (DUAL ? 2 : 1) * TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;
   // LDS-DMA work of one stage: AG weight + BG activation 16-row groups (1 KiB, one wave instruction each), dealt
   // round-robin to the waves: wave w owns groups w, w + NW, ...  Waves < REM own NI_HI groups, the others NI_LO;
   // the counted waits are per class (wave-uniform branch).
-  constexpr int AG = TM / 16, BG = TN / 16, NG = AG + BG;
+  constexpr int AG = A_BYTES / 1024, BG = TN / 16, NG = AG + BG;
   constexpr int NI_LO = NG / NW, REM = NG % NW, NI_HI = NI_LO + (REM ? 1 : 0);
-  constexpr int NR = NTM * NTN;                // residual loads per lane
   static_assert((S - 2) * NI_HI <= 15, "vmcnt immediate range");
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [ring S*STAGE][header: rows {bias, alpha, beta64.lo, beta64.hi} (4*TM) | lo (TM) | dshift (P*TM) | steps[max_ent] |
@@ -218,13 +219,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     if (s < n_ent) issue_stage(e_begin + s, pro_off[s], pro_hw[s], s);
   TF2_STAMP(2);
 
-  i32x16 acc[NTM][NTN];
+  i32x16 acc[NTM][NTN], acc2[DUAL ? NTM : 1][DUAL ? NTN : 1];     // acc2: the low exponent window (DUAL)
 #pragma unroll
   for (int i = 0; i < NTM; i++)
 #pragma unroll
     for (int j = 0; j < NTN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+      for (int r = 0; r < 16; r++) { acc[i][j][r] = 0; if (DUAL) acc2[i][j][r] = 0; }
 
   auto phase_shift = [&](int p) {       // Horner step: acc <<= dshift[p][channel]
 #pragma unroll
@@ -262,40 +263,73 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int it, bool issue) {
-    while (it == next_b) {                 // rare: phase boundary
-      phase++; phase_shift(phase);
-      next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
-    }
+    if (!DUAL)
+      while (it == next_b) {               // rare: phase boundary
+        phase++; phase_shift(phase);
+        next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
+      }
     const int8_t* A = lds + cslot * STAGE;
     const int8_t* B = A + A_BYTES;
-    i32x4 af[2][NTM], bf[2][NTN];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < NTM; i++) {
-        const int row = wm * WTM + i * 32 + (lane & 31);
-        af[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+    auto issue_next = [&]() {
+      if (issue) {
+        issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot);
+        islot = islot + 1 == S ? 0 : islot + 1;
+        off_nx = goff[(it + S) * 4 + chunk];
+        if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
       }
+    };
+    if (DUAL) {
+      // two accumulator sets leave no room for both K halves' fragments: one half at a time
 #pragma unroll
-      for (int j = 0; j < NTN; j++) {
-        const int row = wn * WTN + j * 32 + (lane & 31);
-        bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+      for (int ks = 0; ks < 2; ks++) {
+        const int c = ks * 2 + (lane >> 5);
+        i32x4 af[NTM], af2[NTM], bf[NTN];
+#pragma unroll
+        for (int i = 0; i < NTM; i++) {
+          const int row = wm * WTM + i * 32 + (lane & 31);
+          const int o = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+          af[i] = *reinterpret_cast<const i32x4*>(A + o);
+          af2[i] = *reinterpret_cast<const i32x4*>(A + TM * 64 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; j++) {
+          const int row = wn * WTN + j * 32 + (lane & 31);
+          bf[j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        }
+        if (ks == 0) issue_next();
+#pragma unroll
+        for (int i = 0; i < NTM; i++)
+#pragma unroll
+          for (int j = 0; j < NTN; j++) {
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af2[i], bf[j], acc2[i][j], 0, 0, 0);
+          }
       }
+    } else {
+      i32x4 af[2][NTM], bf[2][NTN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < NTM; i++) {
+          const int row = wm * WTM + i * 32 + (lane & 31);
+          af[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; j++) {
+          const int row = wn * WTN + j * 32 + (lane & 31);
+          bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        }
+      }
+      issue_next();
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < NTM; i++)
+#pragma unroll
+          for (int j = 0; j < NTN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
     }
-    if (issue) {
-      issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot);
-      islot = islot + 1 == S ? 0 : islot + 1;
-      off_nx = goff[(it + S) * 4 + chunk];
-      if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-      for (int i = 0; i < NTM; i++)
-#pragma unroll
-        for (int j = 0; j < NTN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
 
@@ -316,7 +350,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     }
     body(it, false);
   }
-  while (phase + 1 < P) { phase++; phase_shift(phase); }      // phases that start after the last entry
+  if (DUAL) {
+    // combine the two windows: (hi << dshift[1][row]) + lo   (Z/2^32, as the Horner form)
+#pragma unroll
+    for (int i = 0; i < NTM; i++) {
+      const int rb = wm * WTM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + TM + rb + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int j = 0; j < NTN; j++)
+            acc[i][j][G * 4 + r] = (int)(((unsigned)acc[i][j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[i][j][G * 4 + r]);
+      }
+    }
+  } else {
+    while (phase + 1 < P) { phase++; phase_shift(phase); }      // phases that start after the last entry
+  }
   TF2_STAMP(5);
 
   // ---- epilogue --------------------------------------------------------------------------------
@@ -360,13 +411,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
 static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
-  constexpr int STAGE = (TM + TN) * 64;
+  constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
-  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_set = true;
@@ -380,21 +431,31 @@ static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
 template <int WM, int WN, int WTM, int WTN, int S, int OCC>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   // bounds checks on the gathered taps are only needed for padded convolutions
-  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false>(a, s);
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, false>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, false>(a, s);
+}
+
+template <int WM, int WN, int WTM, int WTN, int S, int OCC>
+static int launch_dual(const ConvArgs& a, hipStream_t s) {
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, true>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, true>(a, s);
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so
 // that small grids still spread over the 256 CUs.  Default: 8-wave blocks with 32x64 wave tiles (measured best);
-// a.g.flags bit 1 / bit 2: the 4-wave (64x64 tiles) / 16-wave (32x32) shapes (A/B switches).
+// a.g.flags bit 1 / bit 2: the 4-wave (64x64 tiles) / 16-wave (32x32) shapes (A/B switches, single-window layers).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.n_mtiles > kMaxMtiles) return -4;
   const bool w4 = (a.g.flags & 2) != 0;
   const bool w16 = (a.g.flags & 4) != 0;
+  static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
+  const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
+  if (a.dual) {
+    if (TM == 128) return launch_dual<4, 2, 32, 64, 3, 2>(a, s);
+    if (TM == 64) return blocks256 >= t256 ? launch_dual<2, 4, 32, 64, 3, 2>(a, s) : launch_dual<2, 2, 32, 32, 4, 4>(a, s);
+    return -1;
+  }
   if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   if (TM == 64) {
-    const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
-    static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
     if (blocks256 >= t256) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }

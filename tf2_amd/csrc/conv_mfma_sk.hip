@@ -10,6 +10,11 @@
 // tiles are summed through LDS at the end.  Exactness: the accumulator of the reference lives
 // in Z/2^32 (pe.cl:43), where the Horner-combined partial sums of disjoint slab subsets simply
 // add; each wave applies the phase shifts to its own partial sum.
+//
+// DUAL layers (weight_pack.cpp: both exponent windows per entry) are walked as 2 * n_ent virtual entries
+// v = 2 * e + h: wave w takes v = w, w + 4, ... so h = w & 1 is fixed per wave -- waves 0 and 2 accumulate the high
+// window, waves 1 and 3 the low one, nobody shifts inside the loop, and the reduction is
+// ((p0 + p2) << dshift[1]) + (p1 + p3).
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
 #include "tf2_device.h"
@@ -32,7 +37,7 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int S, bool PADCHK>
+template <int S, bool PADCHK, bool DUAL>
 __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
@@ -65,14 +70,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   const int px0 = ntile * TN;
   const int e_begin = a.e_start[mtile];
   const int n_ent = a.e_start[mtile + 1] - e_begin;
-  const int n_mine = n_ent > wave ? (n_ent - wave + 3) >> 2 : 0;       // entries wave, wave+4, ...
+  const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
+  const int n_mine = n_virt > wave ? (n_virt - wave + 3) >> 2 : 0;     // (virtual) entries wave, wave+4, ...
+  // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
+  auto ent_of = [&](int k) { const int v = wave + 4 * k; return DUAL ? (v >> 1) : v; };
 
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // see conv_mfma2.hip
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;
 
   auto issue_A = [&](int k, int slot_idx) {                     // k-th entry of this wave
     int8_t* const slot = ring + slot_idx * STAGE;
-    const int8_t* wsrc = a.w + (size_t)(e_begin + wave + 4 * k) * A_BYTES + a_lane_off;
+    const int8_t* wsrc = a.w + (size_t)(e_begin + ent_of(k)) * ((DUAL ? 2 : 1) * A_BYTES) + (DUAL ? (wave & 1) * A_BYTES : 0) + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + j * 1024), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
@@ -172,22 +180,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
     if (s < n_mine) {
-      const int e = wave + 4 * s;
+      const int e = ent_of(s);
       issue_B(goff[e * 4 + chunk], PADCHK ? ghw[e * 4 + chunk] : 0, s);
     }
   int phase = 0;
   int cslot = 0, islot = S - 1;
   const int n_main = n_mine - (S - 1);
-  int off_nx = goff[(wave + 4 * (S - 1)) * 4 + chunk];
-  int hw_nx = PADCHK ? ghw[(wave + 4 * (S - 1)) * 4 + chunk] : 0;
+  int off_nx = goff[ent_of(S - 1) * 4 + chunk];
+  int hw_nx = PADCHK ? ghw[ent_of(S - 1) * 4 + chunk] : 0;
   int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int k, bool issue) {
     const int e = wave + 4 * k;            // index in the m-tile's entry list
-    while (e >= next_b) {                  // this wave has crossed into the next phase(s)
-      phase++; phase_shift(phase);
-      next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
-    }
+    if (!DUAL)
+      while (e >= next_b) {                // this wave has crossed into the next phase(s)
+        phase++; phase_shift(phase);
+        next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
+      }
     const int8_t* A = ring + cslot * STAGE;
     const int8_t* B = A + A_BYTES;
     i32x4 af[2][2], bf[2][2];
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
       issue_A(k + S - 1, islot);
       issue_B(off_nx, hw_nx, islot);
       islot = islot + 1 == S ? 0 : islot + 1;
-      off_nx = goff[(wave + 4 * (k + S)) * 4 + chunk];
-      if (PADCHK) hw_nx = ghw[(wave + 4 * (k + S)) * 4 + chunk];
+      off_nx = goff[ent_of(k + S) * 4 + chunk];
+      if (PADCHK) hw_nx = ghw[ent_of(k + S) * 4 + chunk];
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
     asm volatile("" ::: "memory");
     body(k, false);
   }
-  while (phase + 1 < P) { phase++; phase_shift(phase); }
+  if (!DUAL) while (phase + 1 < P) { phase++; phase_shift(phase); }
 
   // ---- reduce the four partial tiles through LDS (the rings are dead now) ---------------------
   sk_wait_vmcnt<0>();
@@ -253,11 +262,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
 #pragma unroll
   for (int G = 0; G < 4; G++) {
     sum[G] = i32x4{0, 0, 0, 0};
+    i32x4 hi = {0, 0, 0, 0};
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const i32x4 v = reinterpret_cast<const i32x4*>(lds)[(size_t)w * 1024 + ((ti * 2 + tj) * 4 + G) * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; r++) sum[G][r] = (int)((unsigned)sum[G][r] + (unsigned)v[r]);
+      for (int r = 0; r < 4; r++) {
+        if (DUAL && !(w & 1)) hi[r] = (int)((unsigned)hi[r] + (unsigned)v[r]);
+        else sum[G][r] = (int)((unsigned)sum[G][r] + (unsigned)v[r]);
+      }
+    }
+    if (DUAL) {
+      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + TM + ti * 32 + 4 * half + 8 * G);
+#pragma unroll
+      for (int r = 0; r < 4; r++) sum[G][r] = (int)(((unsigned)hi[r] << (d[r] & 31)) + (unsigned)sum[G][r]);
     }
   }
 
@@ -282,12 +300,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
     *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
 }
 
-template <int S, bool PADCHK>
+template <int S, bool PADCHK, bool DUAL>
 static int launch_sk2(const ConvArgs& a, hipStream_t s) {
   constexpr int RING_ALL = (4 * S * 8192 > 65536) ? 4 * S * 8192 : 65536;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
-  auto fn = conv_mfma_sk_kernel<S, PADCHK>;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_set = true;
@@ -304,8 +322,12 @@ int launch_conv_mfma_sk(const ConvArgs& a, void* stream) {
   if (a.n_mtiles > kMaxMtiles) return -4;
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
   const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
-  if (blocks <= 256) return pad ? launch_sk2<3, true>(a, s) : launch_sk2<3, false>(a, s);
-  return pad ? launch_sk2<2, true>(a, s) : launch_sk2<2, false>(a, s);
+  if (a.dual) {
+    if (blocks <= 256) return pad ? launch_sk2<3, true, true>(a, s) : launch_sk2<3, false, true>(a, s);
+    return pad ? launch_sk2<2, true, true>(a, s) : launch_sk2<2, false, true>(a, s);
+  }
+  if (blocks <= 256) return pad ? launch_sk2<3, true, false>(a, s) : launch_sk2<3, false, false>(a, s);
+  return pad ? launch_sk2<2, true, false>(a, s) : launch_sk2<2, false, false>(a, s);
 }
 
 }  // namespace tf2

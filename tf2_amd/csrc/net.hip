@@ -277,6 +277,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.dshift = (const int32_t*)(pk + pl->off_dshift);
       ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
       ca.dump = base + wp->dump_off;
+      ca.dual = pl->dual;
       if (pl->kind == KIND_MFMA) {
         ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
         if (pl->n_mtiles <= kMaxMtiles) {
@@ -315,14 +316,16 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
         // small grid + long slab list: the four waves of a block split K (conv_mfma_sk.hip)
         const long blocks64 = (long)((g.n_pix + 63) / 64) * pl->n_mtiles;
         const bool sk = pl->TM == 64 && pl->n_mtiles <= kMaxMtiles && sk_mode != 2 &&
-                        (sk_mode == 1 || (blocks64 <= 512 && pl->n_entries >= 16 * pl->n_mtiles));
-        if (mfma_v1 || (flags & 1)) rc = launch_conv_mfma(ca, pl->TM, stream);
+                        (sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
+        const bool v1 = (mfma_v1 || (flags & 1)) && !pl->dual;      // the register-staged kernel reads single-window tiles
+        if (v1) rc = launch_conv_mfma(ca, pl->TM, stream);
         else if (sk) rc = launch_conv_mfma_sk(ca, stream);
+        else if (pl->dual) rc = 1;                      // dual-window layers: conv_mfma2 / conv_mfma_sk only
         else if (p_mode == 1 || (p_mode == 2 && (long)((g.n_pix + (pl->TM == 128 ? 127 : 255)) / (pl->TM == 128 ? 128 : 256)) * pl->n_mtiles >= 1024 && pl->n_mtiles <= 64))
           rc = launch_conv_mfma_p(ca, pl->TM, stream);
         else rc = 1;
-        if (rc == 1 && !sk && !(mfma_v1 || (flags & 1))) {
-          rc = ws_mode == 2 ? 1 : launch_conv_mfma_ws(ca, pl->TM, stream);     // short-K pointwise layers
+        if (rc == 1 && !sk && !v1) {
+          rc = (ws_mode == 2 || pl->dual) ? 1 : launch_conv_mfma_ws(ca, pl->TM, stream);     // short-K pointwise layers
           if (rc == 1) rc = launch_conv_mfma2(ca, pl->TM, stream);
         }
       }

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 13;
+constexpr uint32_t kPackVersion = 14;
 constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -35,7 +35,8 @@ struct PackLayer {
   int32_t n_cchunk;    // shift kernel: channel chunks of 16
   int32_t max_ent;     // MFMA: largest number of entries of one m-tile (multiple of 4)
   int32_t fast;        // MFMA: every output row passed the range proof of the 3-instruction requantisation
-  int32_t rsv0;
+  int32_t dual;        // MFMA, two-phase layers: every entry holds BOTH exponent windows' tiles ([hi TM rows][lo TM rows],
+                       // one activation slab), accumulated separately and combined once: (hi << dshift[1]) + lo
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -105,6 +106,7 @@ struct ConvArgs {
   long long* dbg2;           // optional: per-block {start, end, hw id, xcc id} of one chosen layer
   const int32_t* hdr;        // per-m-tile LDS header images
   int32_t hdr_bytes;
+  int32_t dual;              // PackLayer::dual
   int32_t e_start[kMaxMtiles + 1];   // first entry of every m-tile (+ end)
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;

@@ -166,27 +166,48 @@ tf2_status Net::pack(int mode) {
           }
       }
       // ---- entries ----
+      // Two-phase layers (the common case with per-channel Q: stages 2-4 of ResNet-50) are stored DUAL: one entry per
+      // slab that is non-zero in either window, holding [hi window TM x 64][lo window TM x 64].  The kernels then
+      // fetch each activation slab once, keep two accumulators and combine them once at the end,
+      // (hi << dshift[1]) + lo -- exact in Z/2^32 like the Horner form -- which halves the K steps.
+      const bool dual = P == 2 && n_mtiles <= kMaxMtiles && getenv("TF2_AMD_NODUAL") == nullptr && getenv("TF2_AMD_MFMA_V1") == nullptr;
+      pl.dual = dual ? 1 : 0;
       std::vector<int32_t> dir((size_t)n_mtiles * (P + 1), 0);
       std::vector<int32_t> entries;
       std::vector<int8_t> tiles;
-      for (int mt = 0; mt < n_mtiles; mt++) {
-        for (int p = 0; p < P; p++) {
-          dir[(size_t)mt * (P + 1) + p] = (int32_t)entries.size();
-          for (int sl = 0; sl < nslab; sl++) {
-            bool any = false;
-            for (int r = 0; r < TM && !any; r++) {
-              const int8_t* src = &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64];
-              for (int b = 0; b < 64; b++) if (src[b]) { any = true; break; }
-            }
-            if (!any) continue;
-            entries.push_back(sl);
-            const size_t base = tiles.size();
-            tiles.resize(base + (size_t)TM * 64);
-            for (int r = 0; r < TM; r++)
-              std::memcpy(&tiles[base + (size_t)r * 64], &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64], 64);
-          }
+      auto slab_nonzero = [&](int p, int mt, int sl) {
+        for (int r = 0; r < TM; r++) {
+          const int8_t* src = &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64];
+          for (int b = 0; b < 64; b++) if (src[b]) return true;
         }
-        dir[(size_t)mt * (P + 1) + P] = (int32_t)entries.size();
+        return false;
+      };
+      auto push_tile = [&](int p, int mt, int sl) {
+        const size_t base = tiles.size();
+        tiles.resize(base + (size_t)TM * 64);
+        for (int r = 0; r < TM; r++)
+          std::memcpy(&tiles[base + (size_t)r * 64], &W[((size_t)p * Np + mt * TM + r) * Kp + sl * 64], 64);
+      };
+      for (int mt = 0; mt < n_mtiles; mt++) {
+        if (dual) {
+          dir[(size_t)mt * (P + 1)] = (int32_t)entries.size();
+          for (int sl = 0; sl < nslab; sl++) {
+            if (!slab_nonzero(0, mt, sl) && !slab_nonzero(1, mt, sl)) continue;
+            entries.push_back(sl);
+            push_tile(0, mt, sl); push_tile(1, mt, sl);
+          }
+          dir[(size_t)mt * (P + 1) + 1] = dir[(size_t)mt * (P + 1) + 2] = (int32_t)entries.size();
+        } else {
+          for (int p = 0; p < P; p++) {
+            dir[(size_t)mt * (P + 1) + p] = (int32_t)entries.size();
+            for (int sl = 0; sl < nslab; sl++) {
+              if (!slab_nonzero(p, mt, sl)) continue;
+              entries.push_back(sl);
+              push_tile(p, mt, sl);
+            }
+          }
+          dir[(size_t)mt * (P + 1) + P] = (int32_t)entries.size();
+        }
         pl.max_ent = std::max<int32_t>(pl.max_ent, dir[(size_t)mt * (P + 1) + P] - dir[(size_t)mt * (P + 1)]);
       }
       pl.max_ent = round_up(std::max(pl.max_ent, 1) + 4 + P, 4);   // + spare entries the kernel may read ahead, + phase table
@@ -280,7 +301,7 @@ tf2_status Net::pack(int mode) {
           const int e0 = dir[(size_t)mt * (P + 1)], e1 = dir[(size_t)mt * (P + 1) + P];
           // steps[p-1] = iteration index (relative to the m-tile's first entry) at which phase p starts
           for (int i = 0; i < pl.max_ent; i++) hs[i] = 0x7fffffff;
-          for (int p = 1; p < P; p++) hs[p - 1] = dir[(size_t)mt * (P + 1) + p] - e0;
+          if (!dual) for (int p = 1; p < P; p++) hs[p - 1] = dir[(size_t)mt * (P + 1) + p] - e0;
           for (int i = 0; i < pl.max_ent * 4; i++) { ko[i] = -1; kh[i] = 0; }
           int32_t* es = kh + 4 * pl.max_ent;
           int32_t* df = es + pl.max_ent;
