@@ -222,6 +222,25 @@ def test_single_window_packing_forced(r50, monkeypatch):
     rig.check_all_layers(synth.synth_images(rig.t, 2, 29), layers={0, 1, 2, 3, 4, 11, 13, 24, 26, 27, 29, 47, 53})
 
 
+def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
+    """conv_pw.hip (weights in registers, activations global -> register -> MFMA, pixel tiles streamed per wave) is the
+    default for dense 1x1 stride-1 layers with K <= 128; TF2_AMD_PW=0 sends them back to conv_mfma2.  Ragged pixel
+    counts (batch 3 and 5), with / without residual, one and two K slabs, single- and dual-window packing."""
+    monkeypatch.setenv("TF2_AMD_PW_SLABS", "2")      # also the two-slab instantiations (default: one slab only)
+    rig = Rig(*r50, 0)
+    pw_layers = {1, 2, 4, 7, 10, 14, 17, 20, 23}
+    for b, seed in ((3, 51), (5, 52)):
+        rig.check_all_layers(synth.synth_images(rig.t, b, seed), layers=pw_layers | {3, 12, 53})
+    monkeypatch.setenv("TF2_AMD_PW", "0")
+    rig.check_all_layers(synth.synth_images(rig.t, 3, 53), layers=pw_layers)
+    monkeypatch.delenv("TF2_AMD_PW")
+    monkeypatch.setenv("TF2_AMD_NODUAL", "1")       # single-window packing: two-phase layers are not eligible, one-phase are
+    t = cfg.tiny_tables(hw=20, widths=(64, 128), classes=100)
+    q = synth.synth_q_values(t, 8, spread=0)
+    model = synth.synth_model(t, q, 8)
+    Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)

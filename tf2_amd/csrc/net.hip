@@ -230,6 +230,8 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   // both are bound by VALU issue (4 cycles per wave64 instruction per SIMD), not by the latency it hides.
   int p_mode = 0;
   if (const char* e = getenv("TF2_AMD_P")) p_mode = atoi(e);
+  int pw_mode = 1;          // register-resident pointwise kernel (conv_pw.hip): 1 auto (default), 0 never
+  if (const char* e = getenv("TF2_AMD_PW")) pw_mode = atoi(e);
   int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
@@ -319,6 +321,15 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
                         (sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
         const bool v1 = (mfma_v1 || (flags & 1)) && !pl->dual;      // the register-staged kernel reads single-window tiles
         if (v1) rc = launch_conv_mfma(ca, pl->TM, stream);
+        else if (pw_mode && L.k == 1 && p_mode == 0 && ws_mode == 2 && sk_mode != 1) {    // no other kernel forced
+          // every m-tile's entry list must be slabs 0..nslab-1 (dense weights): read from the host copy of the image
+          const int32_t* hd = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
+          bool dense = true;
+          for (int mt = 0; mt < pl->n_mtiles && dense; mt++)
+            dense = hd[(size_t)mt * (pl->n_phases + 1) + pl->n_phases] - hd[(size_t)mt * (pl->n_phases + 1)] == pl->nslab;
+          rc = launch_conv_pw(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, stream);
+          if (rc == 1 && sk) rc = launch_conv_mfma_sk(ca, stream);
+        }
         else if (sk) rc = launch_conv_mfma_sk(ca, stream);
         else if (pl->dual) rc = 1;                      // dual-window layers: conv_mfma2 / conv_mfma_sk only
         else if (p_mode == 1 || (p_mode == 2 && (long)((g.n_pix + (pl->TM == 128 ? 127 : 255)) / (pl->TM == 128 ? 128 : 256)) * pl->n_mtiles >= 1024 && pl->n_mtiles <= 64))

@@ -139,6 +139,7 @@ struct PrepArgs {
 int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, void* stream);
+int launch_conv_pw(const ConvArgs& a, int TM, int nslab, int k, int dense, void* stream);   // register-resident pointwise kernel
 int launch_conv_mfma_p(const ConvArgs& a, int TM, void* stream);    // persistent tile-streaming kernel
 int launch_conv_mfma_ws(const ConvArgs& a, int TM, void* stream);   // returns 1 if the layer does not qualify
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
