@@ -89,6 +89,12 @@ tf2_status tf2_net_set_q(tf2_net* net, const int8_t* q, size_t n_bytes);
 /* LoadModel(file, filter_raw, bias_bn, q): model_loader.cpp:129-258.  `model` is the
  * float32 stream of fpgamodel.bin / param.bin (already in memory).                     */
 tf2_status tf2_net_load_model(tf2_net* net, const float* model, size_t n_floats);
+/* The 4-bit packed model file of TransForm_Kit (Compression/compress_net/4bit_data_format.txt:1-44: per tensor
+ * {int8 min_exp, int8 dtype, int16 N,C,H,W}, then 4-bit power-of-two codes in 16-bit words or float32).  The
+ * reference documents the format and ships no reader; these are the canonical ones.  _decode: float32 LoadModel
+ * stream into `floats` (capacity in floats; pass NULL/0 to get the count only).  _load_model_4bit = decode + LoadModel. */
+tf2_status tf2_model4bit_decode(const void* bytes, size_t n_bytes, float* floats, size_t capacity, size_t* n_floats);
+tf2_status tf2_net_load_model_4bit(tf2_net* net, const void* bytes, size_t n_bytes);
 /* Introspection for per-function parity tests: byte codes [N][C][k][k] of a layer
  * (layer 0 after the conv1 rewrite: [N][27][3][3]) and its BiasBnParam (types.h:39-43). */
 tf2_status tf2_net_get_codes(const tf2_net* net, int layer, uint8_t* codes, size_t capacity, size_t* n_bytes);

@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
     L.tf2_quantization.argtypes = [vp, C.c_char_p, sz, vp, sz, i32p]
     L.tf2_net_set_q.argtypes = [vp, vp, sz]
     L.tf2_net_load_model.argtypes = [vp, vp, sz]
+    L.tf2_model4bit_decode.argtypes = [vp, sz, vp, sz, vp]
+    L.tf2_net_load_model_4bit.argtypes = [vp, vp, sz]
     L.tf2_net_get_codes.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
     L.tf2_net_get_bias_bn.argtypes = [vp, C.c_int, vp, vp, vp, sz]
     L.tf2_net_pack.argtypes = [vp, C.c_int]
@@ -90,7 +92,7 @@ def lib() -> C.CDLL:
 
 EXPORTED = [
     "tf2_last_error", "tf2_abi_version", "tf2_has_device_code", "tf2_get_real", "tf2_quantization",
-    "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_net_get_codes",
+    "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_run",
     "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_topk"]

@@ -57,6 +57,29 @@ tf2_status tf2_net_load_model(tf2_net* net, const float* model, size_t n_floats)
   return net->impl.load_model(model, n_floats);
 }
 
+tf2_status tf2_model4bit_decode(const void* bytes, size_t n_bytes, float* floats, size_t capacity, size_t* n_floats) {
+  if (!bytes) { set_error("tf2_model4bit_decode: null input"); return TF2_ERR_ARG; }
+  std::vector<float> out;
+  size_t cnt = 0;
+  const std::string err = tf2::model4bit_decode((const uint8_t*)bytes, n_bytes, floats ? &out : nullptr, &cnt);
+  if (!err.empty()) { set_error(err); return TF2_ERR_ARG; }
+  if (n_floats) *n_floats = cnt;
+  if (floats) {
+    if (capacity < cnt) { set_error("tf2_model4bit_decode: buffer too small"); return TF2_ERR_SIZE; }
+    std::memcpy(floats, out.data(), cnt * sizeof(float));
+  }
+  return TF2_OK;
+}
+
+tf2_status tf2_net_load_model_4bit(tf2_net* net, const void* bytes, size_t n_bytes) {
+  CHECK_NET(net);
+  if (!bytes) { set_error("tf2_net_load_model_4bit: null input"); return TF2_ERR_ARG; }
+  std::vector<float> out;
+  const std::string err = tf2::model4bit_decode((const uint8_t*)bytes, n_bytes, &out, nullptr);
+  if (!err.empty()) { set_error(err); return TF2_ERR_ARG; }
+  return net->impl.load_model(out.data(), out.size());
+}
+
 tf2_status tf2_net_get_codes(const tf2_net* net, int layer, uint8_t* codes, size_t capacity, size_t* n_bytes) {
   CHECK_NET(net);
   const Net& N = net->impl;

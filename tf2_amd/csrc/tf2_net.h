@@ -78,4 +78,7 @@ struct Net {
 
 const std::string& last_error();
 
+// model4bit.cpp: decoder of the 4-bit packed model file; returns an error text (empty = ok)
+std::string model4bit_decode(const uint8_t* bytes, size_t n, std::vector<float>* out, size_t* n_floats);
+
 }  // namespace tf2

@@ -117,6 +117,17 @@ class NetWork:
             model = np.ascontiguousarray(model_file, np.float32).ravel()
         _lib.check(_lib.lib().tf2_net_load_model(self._h, model.ctypes.data, model.size))
 
+    def LoadModel4bit(self, model_file):
+        """The same from TransForm_Kit's 4-bit packed model file (Compression/compress_net/4bit_data_format.txt;
+        path or bytes) -- decoded inside the library, bit-identical to loading the float32 file it was made from."""
+        if isinstance(model_file, (str, os.PathLike)):
+            with open(model_file, "rb") as f:
+                data = f.read()
+        else:
+            data = bytes(model_file)
+        buf = np.frombuffer(data, np.uint8)
+        _lib.check(_lib.lib().tf2_net_load_model_4bit(self._h, buf.ctypes.data, buf.size))
+
     def codes(self, layer: int) -> np.ndarray:
         L = self.plan[layer]
         n = C.c_size_t(0)
