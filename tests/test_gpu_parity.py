@@ -241,6 +241,38 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
+def test_googlenet_ipool_concat_every_layer(golden_dir):
+    """The reference's second shipped network (googlenet.h tables + shipped googlenet_Q): 67 table rows with independent
+    pooling rows (kIpoolEnable), four-way concat slices (kNStart/kBranchTail/kConcatLayer, extra Q rows), 5x5 convs, the
+    7x7 conv1 rewrite and LRN-free inception blocks -- every layer against the oracle."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, "tables_googlenet.json")))
+    t = cfg.NetTables(g)
+    t.setdefault("xConv1Rewrite", 1)
+    qv = np.loadtxt(os.path.join(golden_dir, "googlenet_Q"), dtype=np.int32)
+    model = synth.synth_model(t, qv, 7)
+    rig = Rig(t, qv, model, 0)
+    assert sum(L.ipool for L in rig.ref.plan) == 9
+    rig.check_all_layers(synth.synth_images(t, 2, 3))
+
+
+def test_squeezenet_227_batch32_properties():
+    """BASELINE configs[1] at full size (SqueezeNet 1.1, 32 x 3 x 227 x 227): the oracle checks the first two images in
+    full; the rest through size-independent properties -- every image's logits equal those of the same image run
+    alone-in-a-pair, and a batch permutation permutes the logits."""
+    t = cfg.squeezenet11_tables()
+    q = synth.synth_q_values(t, 21, spread=2)
+    model = synth.synth_model(t, q, 21)
+    rig = Rig(t, q, model, 0)
+    x = synth.synth_images(t, 32, 77)
+    got = rig.run(x, keep_all=False)
+    want2 = rig.ref.logits(rig.ref.run(x[:2]))
+    np.testing.assert_array_equal(got[:2], want2)
+    perm = np.random.default_rng(5).permutation(32)
+    np.testing.assert_array_equal(rig.run(x[perm], keep_all=False), got[perm])
+    np.testing.assert_array_equal(rig.run(x[30:32], keep_all=False), got[30:32])
+
+
 def test_resnet50_split_k_forced(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)
