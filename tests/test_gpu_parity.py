@@ -273,7 +273,10 @@ def test_squeezenet_227_batch32_properties():
     np.testing.assert_array_equal(rig.run(x[30:32], keep_all=False), got[30:32])
 
 
-def test_resnet50_split_k_forced(r50, monkeypatch):
+@pytest.mark.parametrize("sk8", ["0", "100000"])
+def test_resnet50_split_k_forced(r50, monkeypatch, sk8):
+    """4-way and 8-way in-block split-K (TF2_AMD_SK8 = largest grid that takes the 8-wave form)."""
+    monkeypatch.setenv("TF2_AMD_SK8", sk8)
     monkeypatch.setenv("TF2_AMD_SK", "1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 2, 21), layers={26, 28, 32, 45, 47, 52, 53})

@@ -16,6 +16,7 @@
 // window, waves 1 and 3 the low one, nobody shifts inside the loop, and the reduction is
 // ((p0 + p2) << dshift[1]) + (p1 + p3).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "tf2_internal.h"
 #include "tf2_device.h"
 #include "requant_epilogue.h"
@@ -37,15 +38,17 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int S, bool PADCHK, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
+// NWV = 4 or 8 waves split the slab list; with 8 the grid of a 7x7 / 14x14 layer at batch 32 (56..392 blocks) puts
+// twice as many waves on the chip and every wave walks half as many K steps; waves 0-3 run the epilogue.
+template <int S, bool PADCHK, bool DUAL, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
   constexpr int AI = 4, BI = 4, NI = 8;        // LDS-DMA instructions per wave per stage
   constexpr int RING = S * STAGE;              // per wave
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [4 per-wave rings (reused for the 64 KiB reduction)][header as in conv_mfma2.hip]
-  constexpr int RING_ALL = (4 * RING > 65536) ? 4 * RING : 65536;
+  constexpr int RING_ALL = (NWV * RING > NWV * 16384) ? NWV * RING : NWV * 16384;
   int* const prm = reinterpret_cast<int*>(lds + RING_ALL);
 
   const ConvGeom& g = a.g;
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   const int e_begin = a.e_start[mtile];
   const int n_ent = a.e_start[mtile + 1] - e_begin;
   const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
-  const int n_mine = n_virt > wave ? (n_virt - wave + 3) >> 2 : 0;     // (virtual) entries wave, wave+4, ...
+  const int n_mine = n_virt > wave ? (n_virt - wave + NWV - 1) / NWV : 0;     // (virtual) entries wave, wave+NWV, ...
   // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
-  auto ent_of = [&](int k) { const int v = wave + 4 * k; return DUAL ? (v >> 1) : v; };
+  auto ent_of = [&](int k) { const int v = wave + NWV * k; return DUAL ? (v >> 1) : v; };
 
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // see conv_mfma2.hip
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   {
     const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
     int8_t* hdst = reinterpret_cast<int8_t*>(prm);
-    for (int i = wave; i * 1024 < a.hdr_bytes; i += 4)
+    for (int i = wave; i * 1024 < a.hdr_bytes; i += NWV)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   }
 #pragma unroll
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
 
   // residual prefetch for the 32x32 sub-tile this wave finishes in the epilogue
   const int half = lane >> 5;
-  const int ti = wave >> 1, tj = wave & 1;
+  const int ti = (wave >> 1) & 1, tj = wave & 1;     // epilogue sub-tile (waves 0-3)
   i32x4 resv = {0, 0, 0, 0};
   asm volatile("" ::: "memory");
-  if (g.has_res) {
+  if (g.has_res && wave < 4) {
     const int px = px0 + tj * 32 + (lane & 31);
     const int chl = mtile * TM + ti * 32 + 16 * half;
     const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
 
-  if (g.has_res) sk_wait_vmcnt<1>(); else sk_wait_vmcnt<0>();
+  if (g.has_res && wave < 4) sk_wait_vmcnt<1>(); else sk_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();            // header complete (all four waves' parts)
   asm volatile("" ::: "memory");
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
   int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int k, bool issue) {
-    const int e = wave + 4 * k;            // index in the m-tile's entry list
+    const int e = wave + NWV * k;          // index in the m-tile's entry list
     if (!DUAL)
       while (e >= next_b) {                // this wave has crossed into the next phase(s)
         phase++; phase_shift(phase);
@@ -258,13 +261,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
         }
   }
   __syncthreads();
+  if (NWV > 4 && wave >= 4) return;         // partial tile handed over; waves 0-3 finish
   i32x4 sum[4];
 #pragma unroll
   for (int G = 0; G < 4; G++) {
     sum[G] = i32x4{0, 0, 0, 0};
     i32x4 hi = {0, 0, 0, 0};
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NWV; w++) {
       const i32x4 v = reinterpret_cast<const i32x4*>(lds)[(size_t)w * 1024 + ((ti * 2 + tj) * 4 + G) * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -300,19 +304,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_sk_kernel(ConvArgs a) {
     *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
 }
 
-template <int S, bool PADCHK, bool DUAL>
+template <int S, bool PADCHK, bool DUAL, int NWV>
 static int launch_sk2(const ConvArgs& a, hipStream_t s) {
-  constexpr int RING_ALL = (4 * S * 8192 > 65536) ? 4 * S * 8192 : 65536;
+  constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
   static bool attr_set = false;
-  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL>;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_set = true;
   }
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + 63) / 64;
-  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(NWV * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -322,12 +326,21 @@ int launch_conv_mfma_sk(const ConvArgs& a, void* stream) {
   if (a.n_mtiles > kMaxMtiles) return -4;
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
   const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
-  if (a.dual) {
-    if (blocks <= 256) return pad ? launch_sk2<3, true, true>(a, s) : launch_sk2<3, false, true>(a, s);
-    return pad ? launch_sk2<2, true, true>(a, s) : launch_sk2<2, false, true>(a, s);
+  // 8-way split only for grids far below one block per CU (7x7 maps at batch 32: measured 16.0 -> 14.7 us) -- at 392
+  // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
+  static const long sk8_blocks = getenv("TF2_AMD_SK8") ? atol(getenv("TF2_AMD_SK8")) : 128;
+  const long n_virt = (long)(a.e_start[1] - a.e_start[0]) * (a.dual ? 2 : 1);
+  const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
+  if (w8) {
+    if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
+    return pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);
   }
-  if (blocks <= 256) return pad ? launch_sk2<3, true, false>(a, s) : launch_sk2<3, false, false>(a, s);
-  return pad ? launch_sk2<2, true, false>(a, s) : launch_sk2<2, false, false>(a, s);
+  if (a.dual) {
+    if (blocks <= 256) return pad ? launch_sk2<3, true, true, 4>(a, s) : launch_sk2<3, false, true, 4>(a, s);
+    return pad ? launch_sk2<2, true, true, 4>(a, s) : launch_sk2<2, false, true, 4>(a, s);
+  }
+  if (blocks <= 256) return pad ? launch_sk2<3, true, false, 4>(a, s) : launch_sk2<3, false, false, 4>(a, s);
+  return pad ? launch_sk2<2, true, false, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
 }
 
 }  // namespace tf2

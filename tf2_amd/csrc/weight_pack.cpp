@@ -115,7 +115,8 @@ tf2_status Net::pack(int mode) {
       const int Np = round_up(N, 64);
       // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
-      const int TM = (Np % 128 == 0 && L.OH * L.OW > 196) ? 128 : 64;
+      static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
+      const int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
       const int n_mtiles = Np / TM;
       const int Ktot = taps * il.Cp_in;
       const int nslab = (Ktot + 63) / 64;
@@ -210,7 +211,7 @@ tf2_status Net::pack(int mode) {
         }
         pl.max_ent = std::max<int32_t>(pl.max_ent, dir[(size_t)mt * (P + 1) + P] - dir[(size_t)mt * (P + 1)]);
       }
-      pl.max_ent = round_up(std::max(pl.max_ent, 1) + 4 + P, 4);   // + spare entries the kernel may read ahead, + phase table
+      pl.max_ent = round_up(std::max(pl.max_ent, 1) + 8 + P, 4);   // + spare entries the kernels may read ahead (8-way split-K), + phase table
       // ---- kinfo ----
       // one 32-bit word per 16-byte segment: coff (16 bits, 0xffff = padding) | dh << 16 | dw << 24
       std::vector<int32_t> kinfo((size_t)nslab * 4, 0);
