@@ -18,6 +18,7 @@ What it writes (all data: inputs + expected outputs, never reference source text
                            as CRCs + small layers in full, on the seeded synthetic model of
                            tf2_amd.synth), filter_trans, feature_trans, Quantization, Evaluation.
   ref_pyemu.npz            outputs of the reference's Python FPGA emulator functions
+  ref_caq.npz              outputs of the reference's calibrator functions QuantizeForShift / QuantizeChannel
                            (TransForm_Kit/Quantization/debug/...Batch-2.py: Conv2dInt8, BN, FC),
                            AST-extracted and executed here.
 """
@@ -217,6 +218,40 @@ def gen_pyemu():
     np.savez_compressed(os.path.join(OUT, "ref_pyemu.npz"), **out)
 
 
+def gen_caq():
+    """Outputs of the reference's calibrator functions (TransForm_Kit/Quantization/quantization.py:33-72, executed
+    here from the AST -- the module itself needs the dataset/model loaders) on seeded max-|feature| tensors."""
+    src = open(REF + "/TransForm_Kit/Quantization/quantization.py").read()
+    tree = ast.parse(src)
+    want = {"QuantizeForShift", "QuantizeChannel"}
+    mod = ast.Module([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], [])
+    import math
+    ns = {"np": np, "math": math}
+    exec(compile(mod, "ref_caq", "exec"), ns)
+    rng = np.random.default_rng(23)
+    out = {}
+    # single-channel rule: magnitudes across many decades, exact powers of two, tiny, zero
+    mags = np.concatenate([10.0 ** rng.uniform(-4, 4, 300), 127.0 / 2.0 ** np.arange(-8, 9), 2.0 ** np.arange(-10, 10.0),
+                           127.0 * 2.0 ** rng.uniform(-6, 6, 100), [0.0, 1e-30, 126.99, 127.0, 127.01, 63.5, 63.49, 254.0]])
+    qs = []
+    for m in mags:
+        x = np.abs(rng.uniform(0, 1, size=(3, 5))) * m
+        x.flat[rng.integers(0, x.size)] = m                      # the channel's max-|feature|
+        qs.append(ns["QuantizeForShift"](x))
+        out.setdefault("fs_x", []).append(x)
+    out["fs_x"] = np.stack(out["fs_x"]).astype(np.float64); out["fs_q"] = np.asarray(qs, np.float64)
+    # whole tensors: [1, C, H, W] (conv features), [1, C] (fc features) and 1-D
+    for i, shape in enumerate([(1, 16, 6, 6), (1, 64, 3, 3), (1, 10), (12,), (1, 8, 4, 4)]):
+        base = 10.0 ** rng.uniform(-2, 2)
+        x = np.abs(rng.normal(0, 1, size=shape)) * base * 10.0 ** rng.uniform(-1.5, 1.5, size=(shape[1] if len(shape) > 1 else shape[0],)).reshape(
+            (1, -1) + (1,) * (len(shape) - 2) if len(shape) > 1 else (-1,))
+        if i == 4:
+            x[:, 3] = 0.0                                         # an all-zero channel keeps Q = 0
+        out[f"qc{i}_x"] = x.astype(np.float64)
+        out[f"qc{i}_q"] = np.asarray(ns["QuantizeChannel"]("shift", x.copy()), np.float64)
+    np.savez_compressed(os.path.join(OUT, "ref_caq.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if not os.path.isdir(REF):
@@ -224,4 +259,5 @@ if __name__ == "__main__":
     gen_tables_and_data()
     gen_ref_host()
     gen_pyemu()
+    gen_caq()
     print("golden fixtures written to", OUT)
