@@ -273,6 +273,16 @@ def test_squeezenet_227_batch32_properties():
     np.testing.assert_array_equal(rig.run(x[30:32], keep_all=False), got[30:32])
 
 
+def test_vgg16_full_size_batch2_every_layer():
+    """BASELINE configs[3]'s network at full size (VGG16, 224x224: 13 3x3 convs on large maps with 2x2 pools, fc6 as a
+    7x7 convolution over 512 channels = 25088-deep K, fc7/fc8): every layer against the oracle at batch 2."""
+    t = cfg.vgg16_tables()
+    q = synth.synth_q_values(t, 1, spread=1)
+    model = synth.synth_model(t, q, 1)
+    rig = Rig(t, q, model, 0)
+    rig.check_all_layers(synth.synth_images(t, 2, 6))
+
+
 @pytest.mark.parametrize("sk8", ["0", "100000"])
 def test_resnet50_split_k_forced(r50, monkeypatch, sk8):
     """4-way and 8-way in-block split-K (TF2_AMD_SK8 = largest grid that takes the 8-wave form)."""
