@@ -14,7 +14,7 @@ def table(d):
     for x in csv.DictReader(open(f)):
         e = disp.setdefault(int(x["Dispatch_Id"]), {"kernel": x["Kernel_Name"], "grid": int(x["Grid_Size"]), "vgpr": int(x["VGPR_Count"])})
         e[x["Counter_Name"]] = float(x["Counter_Value"])
-    return [v for v in disp.values() if "conv_mfma" in v["kernel"]]
+    return [v for v in disp.values() if "tf2::conv_" in v["kernel"]]
 
 n = 54
 sq1, sq2, t1, t2 = (table(d)[-n:] for d in ("sq1", "sq2", "tcc1", "tcc2"))
