@@ -131,8 +131,12 @@ tf2_status tf2_net_read_layer(tf2_net* net, int layer, int batch, const void* wo
                               int8_t* host_dst, size_t capacity, void* hip_stream);
 /* Per-kernel timing hook for bench.py: records HIP events around every conv launch of
  * the next tf2_net_run calls on `hip_stream`; tf2_net_profile_read returns, per layer,
- * the accumulated milliseconds and launch count since profiling was enabled.            */
+ * the accumulated milliseconds and launch count since profiling was enabled.  enable == 2
+ * records ONE event pair around the whole layer loop instead (tf2_net_profile_loop_read): every
+ * per-layer pair adds its own record handling, the loop pair does not, so callers rescale the
+ * per-layer sum to the loop time.                                                         */
 tf2_status tf2_net_profile(tf2_net* net, int enable);
+tf2_status tf2_net_profile_loop_read(tf2_net* net, float* ms_total, int32_t* runs);
 tf2_status tf2_net_profile_read(tf2_net* net, float* ms_per_layer, int32_t* launches_per_layer,
                                 int32_t* kernel_kind_per_layer, int capacity);
 

@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
     L.tf2_net_profile.argtypes = [vp, C.c_int]
     L.tf2_net_profile_read.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.tf2_net_profile_loop_read.argtypes = [vp, vp, vp]
     L.tf2_topk.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     _lib = L
     return L
@@ -95,7 +96,7 @@ EXPORTED = [
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_run",
-    "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_topk"]
+    "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
 def check(status: int) -> None:

@@ -173,8 +173,9 @@ tf2_status tf2_net_profile(tf2_net* net, int enable) {
   CHECK_NET(net);
   Net& N = net->impl;
   N.drain_profile();
-  if (enable) { std::fill(N.prof_ms.begin(), N.prof_ms.end(), 0.f); std::fill(N.prof_launches.begin(), N.prof_launches.end(), 0); }
-  N.profiling = enable != 0;
+  if (enable) { std::fill(N.prof_ms.begin(), N.prof_ms.end(), 0.f); std::fill(N.prof_launches.begin(), N.prof_launches.end(), 0); N.prof_loop_ms = 0.f; N.prof_loop_n = 0; }
+  N.profiling = enable == 1;
+  N.profiling_loop = enable == 2;
   return TF2_OK;
 }
 
@@ -188,6 +189,15 @@ tf2_status tf2_net_profile_read(tf2_net* net, float* ms, int32_t* launches, int3
     if (launches) launches[l] = N.prof_launches[l];
     if (kinds) { const PackLayer* pl = N.pack_layer(l); kinds[l] = pl ? pl->kind : 0; }
   }
+  return TF2_OK;
+}
+
+tf2_status tf2_net_profile_loop_read(tf2_net* net, float* ms_total, int32_t* runs) {
+  CHECK_NET(net);
+  Net& N = net->impl;
+  N.drain_profile();
+  if (ms_total) *ms_total = N.prof_loop_ms;
+  if (runs) *runs = N.prof_loop_n;
   return TF2_OK;
 }
 

@@ -250,6 +250,11 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     if (launch_prep_input(pa, stream)) { set_error(std::string("prep_input launch: ") + device_last_error()); return TF2_ERR_HIP; }
   }
 
+  hipEvent_t loop0 = nullptr, loop1 = nullptr;
+  if (profiling_loop) {
+    HIP_OK(hipEventCreate(&loop0)); HIP_OK(hipEventCreate(&loop1));
+    HIP_OK(hipEventRecord(loop0, s));
+  }
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
@@ -366,6 +371,11 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       prof_event_layer.push_back(l);
     }
   }
+  if (profiling_loop) {
+    HIP_OK(hipEventRecord(loop1, s));
+    prof_events.emplace_back((void*)loop0, (void*)loop1);
+    prof_event_layer.push_back(-1);
+  }
   // dense logits [batch][N_last]
   if (logits) {
     const TensorPlan& tf = T(wp->final_tensor);
@@ -382,8 +392,12 @@ void Net::drain_profile() {
     hipEvent_t e0 = (hipEvent_t)prof_events[i].first, e1 = (hipEvent_t)prof_events[i].second;
     float ms = 0.f;
     if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
-      prof_ms[prof_event_layer[i]] += ms;
-      prof_launches[prof_event_layer[i]] += 1;
+      if (prof_event_layer[i] < 0) {
+        prof_loop_ms += ms; prof_loop_n++;
+      } else {
+        prof_ms[prof_event_layer[i]] += ms;
+        prof_launches[prof_event_layer[i]] += 1;
+      }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
   }

@@ -61,6 +61,9 @@ struct Net {
   std::vector<float> prof_ms;
   std::vector<int32_t> prof_launches;
   std::vector<std::pair<void*, void*>> prof_events;   // pending (start, stop) hipEvents
+  bool profiling_loop = false; // tf2_net_profile(net, 2): ONE event pair around the whole layer loop
+  float prof_loop_ms = 0.f;    // its accumulated time and count: the per-layer pairs of mode 1 each add their own record
+  int prof_loop_n = 0;         // handling, so bench.py rescales their sum to this
   std::vector<int> prof_event_layer;
 
   tf2_status init(const tf2_net_desc* nd, const tf2_layer_desc* layers);
