@@ -86,22 +86,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   //           steps[p-1] = iteration at which phase p starts, INT_MAX after the last; max_ent includes S spare entries)
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
 
-  const ConvGeom& g = a.g;
+  TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
+  long long* const adbg = a.dbg; long long* const adbg2 = a.dbg2;
+  asm volatile("" :: "s"(adbg), "s"(adbg2));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool ni_hi = REM == 0 || wave < REM;         // wave-uniform DMA class
   const int wm = wave / WN, wn = wave % WN;
-  const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-#define TF2_STAMP(i) do { if (dbg_on) a.dbg[i] = (long long)__builtin_readcyclecounter(); if (a.dbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+  const bool stamps = (adbg != nullptr) | (adbg2 != nullptr);     // one test on the production path
+  const bool dbg_on = adbg != nullptr && blockIdx.x == 0 && tid == 0;
+#define TF2_STAMP(i) do { if (stamps) { if (dbg_on) adbg[i] = (long long)__builtin_readcyclecounter(); if (adbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } } while (0)
   long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TF2_STAMP(0);
-  const long long wall0 = a.dbg2 ? (long long)wall_clock64() : 0;
-  const int P = a.n_phases;
+  const long long wall0 = (stamps && adbg2) ? (long long)wall_clock64() : 0;
   int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
-  int* const goff = steps + a.max_ent;
-  int* const ghw = goff + a.max_ent * 4;
+  int* const goff = steps + a_max_ent;
+  int* const ghw = goff + a_max_ent * 4;
 
   // XCD-aware remap: consecutive logical tiles (same pixel tile, all channel tiles) on one XCD
   const int nblk = gridDim.x;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  const int mtile = bid % a.n_mtiles;
-  const int ntile = bid / a.n_mtiles;
+  const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
+  const int mtile = bid - ntile * a_n_mtiles;
   const int px0 = ntile * TN;
   const int e_begin = a.e_start[mtile];
   const int e_end = a.e_start[mtile + 1];
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   // (constant address space, uniform address): they arrive with the kernel arguments' latency class, so the
   // first activation DMAs do not wait for the header to land in LDS (one memory latency less per block).
   typedef const __attribute__((address_space(4))) i32x4* cvec_p;
-  const size_t hdr_words = (size_t)mtile * (size_t)(a.hdr_bytes >> 2);
-  cvec_p const hg = (cvec_p)(unsigned long long)(a.hdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a.max_ent);
+  const size_t hdr_words = (size_t)mtile * (size_t)(a_hdr_bytes >> 2);
+  cvec_p const hg = (cvec_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent);
   int pro_off[S - 1], pro_hw[S - 1];
 #pragma unroll
   for (int s = 0; s < S - 1; s++) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     pro_off[s] = chunk == 0 ? o[0] : chunk == 1 ? o[1] : chunk == 2 ? o[2] : o[3];
     pro_hw[s] = 0;
     if (PADCHK) {
-      const i32x4 h = hg[a.max_ent + s];
+      const i32x4 h = hg[a_max_ent + s];
       pro_hw[s] = chunk == 0 ? h[0] : chunk == 1 ? h[1] : chunk == 2 ? h[2] : h[3];
     }
   }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
       const int px = px0 + wn * WTN + j * 32 + (lane & 31);
       const int chl = mtile * TM + wm * WTM + i * 32 + 16 * half;
       const bool ok = g.has_res && px < g.n_pix && chl + 16 <= g.y_nvalid;
-      const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+      const int8_t* rp = ok ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
       resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
     }
   asm volatile("" ::: "memory");           // keep the residual loads OLDER than every DMA below
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #pragma unroll
   for (int j = 0; j < NI_HI; j++) {
     const int gi = wave + NW * j;            // group index: < AG weights, else activations
-    brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
+    brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = azero; brow_ok[j] = false;
     if (gi >= AG && gi < NG) {
       const int p = px0 + (gi - AG) * 16 + (lane >> 2);
       if (p < g.n_pix) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         const int ow = rem - oh * g.OW;
         brow_h[j] = oh * g.stride - g.pad_h;
         brow_w[j] = ow * g.stride - g.pad_w;
-        brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
+        brow_ptr[j] = ax + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
         brow_ok[j] = true;
       }
     }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   // one stage = entry e (weights) + this lane's gather words off/hw (activations) into ring slot slot_idx
   auto issue_stage = [&](int e, int off, int hw, int slot_idx) {
     int8_t* const slot = lds + slot_idx * STAGE;
-    const int8_t* wsrc = a.w + (size_t)e * A_BYTES + a_lane_off;
+    const int8_t* wsrc = aw + (size_t)e * A_BYTES + a_lane_off;
     int dh = 0, dw = 0;
     if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
           const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
           ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         }
-        const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
+        const int8_t* src = ok ? brow_ptr[j] + off : azero;
         __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
       }
     }
@@ -209,9 +211,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   // ---- block start: header, then the first S-1 stages, all by LDS-DMA and all in flight together ----
   // VMEM queue of a wave: [residual, header, stage 0 .. stage S-2, then one stage per loop iteration]
   {
-    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + hdr_words * 4 + lane * 16;
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(ahdr) + hdr_words * 4 + lane * 16;
     int8_t* hdst = reinterpret_cast<int8_t*>(prm);
-    for (int i = wave; i * 1024 < a.hdr_bytes; i += NW)
+    for (int i = wave; i * 1024 < a_hdr_bytes; i += NW)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   }
 #pragma unroll
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
         const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
-          i32x4* dst = reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl);
+          i32x4* dst = reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl);
           *dst = out;
         }
       }
@@ -401,8 +403,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   if (g.fast) { if (g.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
-  if (a.dbg2 && tid == 0) {
-    long long* d = a.dbg2 + (size_t)blockIdx.x * 8;
+  if (adbg2 && tid == 0) {
+    long long* d = adbg2 + (size_t)blockIdx.x * 8;
     d[0] = tstamp[0]; d[1] = (long long)__builtin_readcyclecounter();
     d[4] = tstamp[1]; d[5] = tstamp[2]; d[6] = tstamp[3];
     d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID (id 4), 32 bits

@@ -51,15 +51,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   constexpr int RING_ALL = (NWV * RING > NWV * 16384) ? NWV * RING : NWV * 16384;
   int* const prm = reinterpret_cast<int*>(lds + RING_ALL);
 
-  const ConvGeom& g = a.g;
+  TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int P = a.n_phases;
   int* const dsh = prm + kPrmWordsPerRow * TM;
   int* const steps = dsh + P * TM;
-  int* const goff = steps + a.max_ent;
-  int* const ghw = goff + a.max_ent * 4;
+  int* const goff = steps + a_max_ent;
+  int* const ghw = goff + a_max_ent * 4;
   int8_t* const ring = lds + wave * RING;
 
   const int nblk = gridDim.x;
@@ -68,8 +67,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  const int mtile = bid % a.n_mtiles;
-  const int ntile = bid / a.n_mtiles;
+  const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
+  const int mtile = bid - ntile * a_n_mtiles;
   const int px0 = ntile * TN;
   const int e_begin = a.e_start[mtile];
   const int n_ent = a.e_start[mtile + 1] - e_begin;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 
   auto issue_A = [&](int k, int slot_idx) {                     // k-th entry of this wave
     int8_t* const slot = ring + slot_idx * STAGE;
-    const int8_t* wsrc = a.w + (size_t)(e_begin + ent_of(k)) * ((DUAL ? 2 : 1) * A_BYTES) + (DUAL ? (wave & 1) * A_BYTES : 0) + a_lane_off;
+    const int8_t* wsrc = aw + (size_t)(e_begin + ent_of(k)) * ((DUAL ? 2 : 1) * A_BYTES) + (DUAL ? (wave & 1) * A_BYTES : 0) + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + j * 1024), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
@@ -91,9 +90,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 
   // header (shared by the four waves) + this wave's first weight tiles
   {
-    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(ahdr) + (size_t)mtile * a_hdr_bytes + lane * 16;
     int8_t* hdst = reinterpret_cast<int8_t*>(prm);
-    for (int i = wave; i * 1024 < a.hdr_bytes; i += NWV)
+    for (int i = wave; i * 1024 < a_hdr_bytes; i += NWV)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   }
 #pragma unroll
@@ -113,10 +112,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
       const int ow = rem - oh * g.OW;
       brow_h[j] = oh * g.stride - g.pad_h;
       brow_w[j] = ow * g.stride - g.pad_w;
-      brow_ptr[j] = a.x + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
+      brow_ptr[j] = ax + ((long long)b * g.H * g.W + (long long)brow_h[j] * g.W + brow_w[j]) * g.Cp_in;
       brow_ok[j] = true;
     } else {
-      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
+      brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = azero; brow_ok[j] = false;
     }
   }
 
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     const int px = px0 + tj * 32 + (lane & 31);
     const int chl = mtile * TM + ti * 32 + 16 * half;
     const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
-    const int8_t* rp = ok ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+    const int8_t* rp = ok ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
     resv = *reinterpret_cast<const i32x4*>(rp);
   }
   asm volatile("" ::: "memory");
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
         const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
         ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
       }
-      const int8_t* src = ok ? brow_ptr[j] + off : a.zero;
+      const int8_t* src = ok ? brow_ptr[j] + off : azero;
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
     }
   };
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
                        : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
   const int chl = tile_ch + 16 * half;
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
-    *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
+    *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
 }
 
 template <int S, bool PADCHK, bool DUAL, int NWV>

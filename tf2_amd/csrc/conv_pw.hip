@@ -39,7 +39,8 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   int* const prm = reinterpret_cast<int*>(lds);
 
-  const ConvGeom& g = a.g;
+  TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
+  (void)a_max_ent; (void)P; (void)mt_m; (void)mt_s;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
   const int half = lane >> 5;
   int* const dsh = prm + kPrmWordsPerRow * TM;
 
-  const int M = a.n_mtiles;
+  const int M = a_n_mtiles;
   const int b = blockIdx.x;
   const int mtile = (b >> 3) % M;
   const int chunk = (b & 7) + 8 * ((b >> 3) / M);
@@ -57,14 +58,14 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
 
   // header -> LDS (shared by the block)
   {
-    const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mtile * a.hdr_bytes + lane * 16;
-    for (int i = wave; i * 1024 < a.hdr_bytes; i += 8)
+    const int8_t* hsrc = reinterpret_cast<const int8_t*>(ahdr) + (size_t)mtile * a_hdr_bytes + lane * 16;
+    for (int i = wave; i * 1024 < a_hdr_bytes; i += 8)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(lds + i * 1024), 16, 0, 0);
   }
   // this wave's weights -> registers: entry s of the m-tile is slab s (launcher-checked), [window][TM rows][64 B]
   i32x4 wf[NSLAB][NWIN][2];
   {
-    const int8_t* wt = a.w + (size_t)a.e_start[mtile] * (NWIN * TM * 64);
+    const int8_t* wt = aw + (size_t)a.e_start[mtile] * (NWIN * TM * 64);
     const int row = wr * 32 + (lane & 31);
 #pragma unroll
     for (int s = 0; s < NSLAB; s++)
@@ -87,14 +88,14 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
   auto load_tile = [&](int t, Tile& T) {
     int px = t * 32 + (lane & 31);
     px = px > last_px ? last_px : px;                         // clamped: out-of-range pixels are never stored
-    const int8_t* xp = (g.flags & 16) ? a.zero : a.x + (size_t)px * g.Cp_in + half * 16;     // flags 8/16/32: timing experiments
+    const int8_t* xp = (g.flags & 16) ? azero : ax + (size_t)px * g.Cp_in + half * 16;     // flags 8/16/32: timing experiments
 #pragma unroll
     for (int s = 0; s < NSLAB; s++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
         T.bf[s][ks] = *reinterpret_cast<const i32x4*>(xp + s * 64 + ks * 32);
     // unconditional (zero page without a residual): a branch around the load would make hipcc wait at the join
-    const int8_t* rp = (g.has_res && ch_ok) ? a.res + (size_t)px * g.res_cp + g.res_off + chl : a.zero;
+    const int8_t* rp = (g.has_res && ch_ok) ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
     T.res = *reinterpret_cast<const i32x4*>(rp);
   };
   auto compute_tile = [&](int t, const Tile& T) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     if (g.flags & 32) out = i32x4{a16[0], a16[5], a16[10], a16[15]};
     const int px = t * 32 + (lane & 31);
     if (px <= last_px && ch_ok && !(g.flags & 8))
-      *reinterpret_cast<i32x4*>(a.y + (size_t)px * g.y_cp + g.y_off + chl) = out;
+      *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
   };
 
   // ---- stream this wave's pixel tiles: t_begin + wp, + NPW, ... with the next tile always in flight ----

@@ -285,6 +285,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
       ca.dump = base + wp->dump_off;
       ca.dual = pl->dual;
+      set_fast_div((uint32_t)pl->n_mtiles, &ca.mt_m, &ca.mt_s);
       if (pl->kind == KIND_MFMA) {
         ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
         if (pl->n_mtiles <= kMaxMtiles) {

@@ -107,6 +107,7 @@ struct ConvArgs {
   const int32_t* hdr;        // per-m-tile LDS header images
   int32_t hdr_bytes;
   int32_t dual;              // PackLayer::dual
+  uint32_t mt_m; int32_t mt_s; // set_fast_div(n_mtiles): block id -> (pixel tile, channel tile) without a division
   int32_t e_start[kMaxMtiles + 1];   // first entry of every m-tile (+ end)
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;

@@ -15,9 +15,14 @@ ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--out", default=None)
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--uniform-q", action="store_true", help="one Q value per tensor (every layer single-window): the bound for grouped packing")
 a = ap.parse_args()
 t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
+if a.uniform_q:
+    pos = 3
+    for L in plan:
+        qv[pos:pos + L.N] = int(np.round(qv[pos:pos + L.N].mean())); pos += L.N
 model = synth.synth_model(t, qv, 0)
 net = network.NetWork(t); net.Init(model, synth.q_text(qv), device="cuda:0", pack_mode=a.mode)
 _, pls = emu.parse(net.packed_host())
