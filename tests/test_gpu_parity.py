@@ -283,6 +283,27 @@ def test_vgg16_full_size_batch2_every_layer():
     rig.check_all_layers(synth.synth_images(t, 2, 6))
 
 
+def test_input_quantisation_ties_and_extremes(r50_rig):
+    """prep_input_kernel restates runner.cpp:158-164 without double precision: exact .5 ties of both signs, values
+    straddling the int8 clamp, denormals, -0.0, and |x| >= 2^31 / inf / NaN (x86 cvttsd2si -> INT_MIN -> -128 in the
+    reference binary and the oracle) must come out identically."""
+    rig = r50_rig
+    rng = np.random.default_rng(99)
+    x = synth.synth_images(rig.t, 2, 61)
+    q0 = int(rig.net.q[0][0])                      # runtime (negated) Q of image channel 0
+    scale = float(2.0 ** q0) if q0 > 0 else float(2.0 ** q0)
+    flat = x.reshape(-1)
+    ties = (rng.integers(-140, 141, size=20000).astype(np.float32) + 0.5) * np.float32(scale)
+    flat[:20000] = ties
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 127.49, 127.5, -128.5, -128.51, 2147483648.0, -2147483648.0,
+                         4e9, -4e9, 1e30, -1e30, np.inf, -np.inf, np.nan, 2147483520.0, -2147483520.0], np.float32)
+    flat[20000:20000 + specials.size] = specials
+    flat[30000:40000] = (rng.uniform(-200, 200, 10000)).astype(np.float32)
+    rig.run(x, keep_all=True)
+    want = rig.ref.run(x)[-1]
+    np.testing.assert_array_equal(rig.runner.read_layer(-1, 2), want)
+
+
 @pytest.mark.parametrize("sk8", ["0", "100000"])
 def test_resnet50_split_k_forced(r50, monkeypatch, sk8):
     """4-way and 8-way in-block split-K (TF2_AMD_SK8 = largest grid that takes the 8-wave form)."""

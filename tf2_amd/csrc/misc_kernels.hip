@@ -12,13 +12,20 @@ namespace tf2 {
 
 using i32x4 = int __attribute__((ext_vector_type(4)));
 
-// runner.cpp:158-163: tmp = x * trans ; (int)(tmp > 0 ? tmp + 0.5 : tmp - 0.5) ; clamp.
-// (tmp +- 0.5 is evaluated in double in the reference.)
+// runner.cpp:158-163: tmp = x * trans ; (int)(tmp > 0 ? tmp + 0.5 : tmp - 0.5) ; clamp, with tmp +- 0.5 evaluated in
+// double and truncated toward zero.  Restated without double precision (the DP conversions run at a fraction of the
+// VALU rate and this kernel is VALU bound): (double)tmp +- 0.5 is exact, so the result is sign * (floor|tmp| +
+// (frac|tmp| >= 0.5)); floor and the fraction are exact in float.  |tmp| >= 2^31 or NaN: the reference's x86 cvttsd2si
+// returns INT_MIN, which clamps to -128.
 __device__ __forceinline__ int quant_input(float x, float trans) {
-  float tmp = x * trans;
-  double t2 = tmp > 0 ? (double)tmp + 0.5 : (double)tmp - 0.5;
-  int v = (int)t2;
-  return v > 127 ? 127 : (v < -128 ? -128 : v);
+  const float tmp = x * trans;
+  const float m = __builtin_fabsf(tmp);
+  if (!(m < 2147483648.0f)) return -128;
+  const float f = __builtin_floorf(m);
+  float r = f + ((m - f) >= 0.5f ? 1.0f : 0.0f);
+  r = tmp > 0 ? r : -r;
+  r = r > 127.0f ? 127.0f : (r < -128.0f ? -128.0f : r);
+  return (int)r;
 }
 
 __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
@@ -77,6 +84,71 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
     int8_t* dst = a.y + (size_t)pix * a.y_cp + cg * 16;
     *reinterpret_cast<i32x4*>(dst) = px;
     *reinterpret_cast<i32x4*>(dst + a.half) = nx;
+  }
+}
+
+// The 7x7 / stride 2 rewrite of a 3-channel image (ResNet-50 / GoogLeNet conv1), one thread per output pixel, 256 pixels
+// per block.  Sub-channel k of image channel ci is pad3[2*oh + roff][2*ow + coff] with (roff, coff) = k0(0,0) k1(1,0)
+// k2(0,1) k3(1,1) k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2) (feature_trans, input_loader.cpp:27-73): a 3x3 window at
+// stride 2 per channel, 27 loads that neighbouring lanes share in L1, 32-bit index arithmetic.  The 64 bytes of
+// [x | xneg] per pixel go through LDS so that every wave store is 1 KiB of contiguous NHWC bytes.
+template <bool SRC_Q>
+__global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
+  __shared__ __attribute__((aligned(16))) int tile[256][17];        // 64 B per pixel (+1 word: bank spread)
+  const int total = a.B * a.OH * a.OW;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  const int pix0 = blockIdx.x * 256;
+  const int pix = pix0 + (int)threadIdx.x;
+  if (pix < total) {
+    const int ow = pix % a.OW;
+    const int t = pix / a.OW;
+    const int oh = t % a.OH;
+    const int b = t / a.OH;
+    const int r0 = 2 * oh - 3, c0 = 2 * ow - 3;
+    int v[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = 0;
+    bool rok[3], cok[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rok[i] = (unsigned)(r0 + i) < (unsigned)a.H; cok[i] = (unsigned)(c0 + i) < (unsigned)a.W; }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int base = ((b * 3 + ci) * a.H + r0) * a.W + c0;          // < 2^31 for any batch the workspace can hold
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int roff = k < 6 ? (k & 1) : 2;
+        const int coff = k < 6 ? (k >> 1) : (k - 6);
+        int q = 0;
+        if (rok[roff] && cok[coff]) {
+          const int si = base + roff * a.W + coff;
+          if (SRC_Q) q = (int)reinterpret_cast<const int8_t*>(a.img)[si];
+          else q = quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
+        }
+        v[ci * 9 + k] = q;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      int p = 0, n = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = v[4 * w + j];
+        p |= (q & 0xff) << (8 * j);
+        n |= ((-q) & 0xff) << (8 * j);        // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+      }
+      tile[threadIdx.x][w] = p; tile[threadIdx.x][8 + w] = n;
+    }
+  }
+  __syncthreads();
+  // 256 pixels x 64 B = 16 KiB, written as 4 x (256 lanes x 16 B): consecutive lanes -> consecutive 16-byte chunks
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int c = r * 256 + (int)threadIdx.x;          // chunk index inside the block's 16 KiB
+    const int pl = c >> 2, ch = c & 3;
+    if (pix0 + pl < total) {
+      i32x4 o = {tile[pl][ch * 4], tile[pl][ch * 4 + 1], tile[pl][ch * 4 + 2], tile[pl][ch * 4 + 3]};
+      *reinterpret_cast<i32x4*>(a.y + (size_t)(pix0 + pl) * 64 + ch * 16) = o;
+    }
   }
 }
 
@@ -158,6 +230,13 @@ static inline int grid_for(long long total, int block = 256) {
 }
 
 int launch_prep_input(const PrepArgs& a, void* stream) {
+  const long long pixels = (long long)a.B * a.OH * a.OW;
+  if (a.rewrite && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
+    const unsigned grid = (unsigned)((pixels + 255) / 256);
+    if (a.src_is_q) hipLaunchKernelGGL(prep_rewrite3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(prep_rewrite3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   long long total = (long long)a.B * a.OH * a.OW * (a.half / 16);
   hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
