@@ -19,6 +19,7 @@ What it writes (all data: inputs + expected outputs, never reference source text
                            tf2_amd.synth), filter_trans, feature_trans, Quantization, Evaluation.
   ref_pyemu.npz            outputs of the reference's Python FPGA emulator functions
   ref_caq.npz              outputs of the reference's calibrator functions QuantizeForShift / QuantizeChannel
+  ref_ssd.npz              outputs of the reference's SSD PriorBox / decode / nms (+ the L2Norm formula)
                            (TransForm_Kit/Quantization/debug/...Batch-2.py: Conv2dInt8, BN, FC),
                            AST-extracted and executed here.
 """
@@ -252,6 +253,43 @@ def gen_caq():
     np.savez_compressed(os.path.join(OUT, "ref_caq.npz"), **out)
 
 
+def gen_ssd():
+    """Outputs of the reference's SSD post-processing functions (TransForm_Kit/Quantization/models/SSD/layers/
+    functions/prior_box.py, layers/box_utils.py decode / nms, layers/modules/l2norm.py), executed from their AST."""
+    import torch, warnings
+    warnings.filterwarnings("ignore")
+    base = REF + "/TransForm_Kit/Quantization/models/SSD/layers/"
+    ns = {"torch": torch}
+    exec("from math import sqrt as sqrt\nfrom itertools import product as product", ns)
+    tree = ast.parse(open(base + "functions/prior_box.py").read())
+    exec(compile(ast.Module([n for n in tree.body if isinstance(n, ast.ClassDef)], []), "ref_priorbox", "exec"), ns)
+    tree = ast.parse(open(base + "box_utils.py").read())
+    exec(compile(ast.Module([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("decode", "nms")], []), "ref_boxutils", "exec"), ns)
+    cfgsrc = ast.parse(open(REF + "/TransForm_Kit/Quantization/data/SSD/config.py").read())
+    cns = {"os": os}
+    exec(compile(ast.Module([n for n in cfgsrc.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in ("voc", "coco")], []), "ref_ssdcfg", "exec"), cns)
+    out = {}
+    pri = ns["PriorBox"](cns["voc"]).forward()
+    out["priors_voc"] = pri.numpy().astype(np.float32)
+    g = torch.Generator().manual_seed(5)
+    loc = torch.randn(pri.shape[0], 4, generator=g) * 0.7
+    out["loc"] = loc.numpy(); out["decoded"] = ns["decode"](loc, pri, cns["voc"]["variance"]).numpy()
+    for i, (n, thr, topk) in enumerate([(300, 0.45, 200), (50, 0.3, 10), (1, 0.5, 5), (800, 0.45, 200)]):
+        c = torch.rand(n, 2, generator=g) * 0.8
+        wh = torch.rand(n, 2, generator=g) * 0.3 + 0.02
+        boxes = torch.cat([c, c + wh], 1)
+        scores = torch.rand(n, generator=g)
+        keep, count = ns["nms"](boxes, scores, thr, topk)
+        out[f"nms{i}_boxes"] = boxes.numpy(); out[f"nms{i}_scores"] = scores.numpy()
+        out[f"nms{i}_par"] = np.asarray([thr, topk], np.float64); out[f"nms{i}_keep"] = keep[:count].numpy().astype(np.int64)
+    x = torch.randn(2, 16, 5, 5, generator=g)
+    w = torch.rand(16, generator=g) * 20
+    norm = x.pow(2).sum(dim=1, keepdim=True).sqrt() + 1e-10          # l2norm.py:20-24
+    out["l2_x"] = x.numpy(); out["l2_w"] = w.numpy()
+    out["l2_y"] = (w.unsqueeze(0).unsqueeze(2).unsqueeze(3).expand_as(x) * torch.div(x, norm)).numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_ssd.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if not os.path.isdir(REF):
@@ -260,4 +298,5 @@ if __name__ == "__main__":
     gen_ref_host()
     gen_pyemu()
     gen_caq()
+    gen_ssd()
     print("golden fixtures written to", OUT)

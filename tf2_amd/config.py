@@ -677,7 +677,13 @@ class _B:
              add_relu=0, endpool=0, dil=1, endpool_hw=49):
         self.rows.append(dict(src=src, C=C, H=H, W=W, N=N, k=k, stride=stride, pad=pad, relu=relu, bn=bn,
                               bias=bias, pool=pool, add=add, add_relu=add_relu, endpool=endpool, dil=dil,
-                              endpool_hw=endpool_hw))
+                              endpool_hw=endpool_hw, ipool=0))
+        return len(self.rows) - 1
+
+    def pool_only(self, src, C, H, W, pool):
+        """An independent pooling row (kIpoolEnable, as GoogLeNet's inception pools): no filter, no Q row of its own."""
+        self.rows.append(dict(src=src, C=C, H=H, W=W, N=C, k=1, stride=1, pad=0, relu=0, bn=0, bias=0, pool=pool,
+                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=1))
         return len(self.rows) - 1
 
     def tables(self) -> NetTables:
@@ -695,6 +701,7 @@ class _B:
             t["kInputChannels"][i] = r["C"]; t["kOutputChannels"][i] = r["N"]; t["kConvStride"][i] = s
             t["kBiasEnable"][i] = r["bias"]; t["kBnEnable"][i] = r["bn"]; t["kReluEnable"][i] = r["relu"]
             t["xDilation"][i] = d; t["kInputLayer"][i] = r["src"] + 1; t["kNEnd"][i] = r["N"]
+            t["kIpoolEnable"][i] = r.get("ipool", 0)
             oh, ow = (oh1 - 1) // s + 1, (ow1 - 1) // s + 1
             t["kPoolWindow"][i] = 3
             if r["pool"]:
@@ -761,6 +768,59 @@ def vgg16_tables(image_hw: int = 224, num_classes: int = 1000, with_fc: bool = T
         cur = b.conv(cur, 512, H, H, 4096, H, 1, 0, relu=1, bn=0, bias=1)
         cur = b.conv(cur, 4096, 1, 1, 4096, 1, 1, 0, relu=1, bn=0, bias=1)
         b.conv(cur, 4096, 1, 1, num_classes, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1) -> NetTables:
+    """The integer part of SSD300-VGG (TransForm_Kit/Quantization/models/SSD/SSD.py:34-77, 89-151; SURVEY.md section 8f
+    rank 4) as one table program: VGG16 base with the ceil-mode third pool ('C': 75 -> 38), pool5 = 3x3 / stride 1 /
+    pad 1 fused into conv5_3, conv6 = 3x3 pad 6 dilation 6, conv7 = 1x1, the four extra blocks (1x1 then 3x3 with
+    stride 2 / pad 1 twice, then unpadded 3x3 twice), and the twelve multibox head convolutions (3x3 pad 1, no
+    ReLU) reading their six source maps: conv4_3 -- whose L2Norm is a float per-pixel rescale that the host applies
+    outside the integer path, SSD.py:46-47 --, conv7, conv8_2, conv9_2, conv10_2, conv11_2.  Rows are ordered trunk
+    first, heads last (loc then conf per source); every head row's output is a network output
+    (read with tf2_net_read_layer).  `width_div` divides all channel counts (small test nets)."""
+    d = max(1, width_div)
+    b = _B("ssd300", image=(3, image_hw, image_hw), first_filter=3)
+    cfgv = [64, 64, "M", 128, 128, "M", 256, 256, 256, "C", 512, 512, 512, "M", 512, 512, 512]
+    cur, C, H = -1, 3, image_hw
+    sources = []
+    i = 0
+    conv_idx = 0
+    while i < len(cfgv):
+        N = cfgv[i] // d
+        pool, Ho = None, H
+        is_conv4_3 = conv_idx == 9
+        if i + 1 < len(cfgv) and cfgv[i + 1] in ("M", "C") and not is_conv4_3:
+            Ho = H // 2 if cfgv[i + 1] == "M" else -(-H // 2)          # ceil mode: zero-extended window at the edge
+            pool = (2, 2, 0, Ho, Ho)
+            i += 1
+        elif i == len(cfgv) - 1:
+            pool = (3, 1, 1, H, H)                                       # pool5: 3x3, stride 1, pad 1
+        cur = b.conv(cur, C, H, H, N, 3, 1, 1, relu=1, bn=0, bias=1, pool=pool)
+        conv_idx += 1
+        if is_conv4_3:
+            # conv4_3 feeds a multibox head BEFORE pool4: the pool is its own (independent pooling) row
+            sources.append((cur, N, H))
+            Ho = H // 2
+            cur = b.pool_only(cur, N, H, H, (2, 2, 0, Ho, Ho))
+            i += 1
+        C, H = N, Ho
+        i += 1
+    cur = b.conv(cur, C, H, H, 1024 // d, 3, 1, 6, relu=1, bn=0, bias=1, dil=6)      # conv6
+    cur = b.conv(cur, 1024 // d, H, H, 1024 // d, 1, 1, 0, relu=1, bn=0, bias=1)      # conv7
+    C = 1024 // d
+    sources.append((cur, C, H))
+    for mid, out, k2, s2, p2 in ((256, 512, 3, 2, 1), (128, 256, 3, 2, 1), (128, 256, 3, 1, 0), (128, 256, 3, 1, 0)):
+        cur = b.conv(cur, C, H, H, mid // d, 1, 1, 0, relu=1, bn=0, bias=1)
+        Ho = (H + 2 * p2 - 3) // s2 + 1
+        cur = b.conv(cur, mid // d, H, H, out // d, k2, s2, p2, relu=1, bn=0, bias=1)
+        C, H = out // d, Ho
+        sources.append((cur, C, H))
+    mbox = [4, 6, 6, 6, 4, 4]
+    for (src, Cs, Hs), nb in zip(sources, mbox):
+        b.conv(src, Cs, Hs, Hs, nb * 4, 3, 1, 1, relu=0, bn=0, bias=1)                  # loc head
+        b.conv(src, Cs, Hs, Hs, nb * num_classes, 3, 1, 1, relu=0, bn=0, bias=1)        # conf head
     return b.tables()
 
 
