@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 2) / 4) void conv_mfma_p_k
       brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = a.zero; brow_ok[j] = false;
       if (gi >= AG && gi < NG) {
         const int p = px0 + (gi - AG) * 16 + (lane >> 2);
-        if (p < g.n_pix && !(g.flags & 16)) {
+        if (p < g.n_pix) {
           if (linear) {
             brow_h[j] = 0; brow_w[j] = 0;
             brow_ptr[j] = a.x + (long long)p * g.Cp_in;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 2) / 4) void conv_mfma_p_k
           const i32x4 out = g.fast ? requant_tile16<HAS_RES, (HAS_RES ? 1 : 2), true>(a16, prm, TM, rb + 4 * half_e, lo_bound, rlo, rv)
                                    : requant_tile16<HAS_RES, (HAS_RES ? 1 : 2), false>(a16, prm, TM, rb + 4 * half_e, lo_bound, rlo, rv);
           // every lane stores (a dump line when masked) so that the count of VMEM operations is static
-          const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid && !(g.flags & 8);     // flags 8/16: timing experiments
+          const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
           int8_t* dst = ok ? a.y + (size_t)px * g.y_cp + g.y_off + chl : a.dump + (size_t)(wave * 64 + lane_e) * 16;
           asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(out) : "memory");
         }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
   auto load_tile = [&](int t, Tile& T) {
     int px = t * 32 + (lane & 31);
     px = px > last_px ? last_px : px;                         // clamped: out-of-range pixels are never stored
-    const int8_t* xp = (g.flags & 16) ? azero : ax + (size_t)px * g.Cp_in + half * 16;     // flags 8/16/32: timing experiments
+    const int8_t* xp = ax + (size_t)px * g.Cp_in + half * 16;
 #pragma unroll
     for (int s = 0; s < NSLAB; s++)
 #pragma unroll
@@ -129,9 +129,8 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
                                 : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res);
     else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res)
                          : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res);
-    if (g.flags & 32) out = i32x4{a16[0], a16[5], a16[10], a16[15]};
     const int px = t * 32 + (lane & 31);
-    if (px <= last_px && ch_ok && !(g.flags & 8))
+    if (px <= last_px && ch_ok)
       *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
   };
 

@@ -218,7 +218,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   const uint8_t* pk = packed_dev;
   int flags = 0;
   if (const char* e = getenv("TF2_AMD_NOSWAP")) flags |= (e[0] == '1');
-  if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & ~1;   // perf experiments (wrong results!)
+  if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & 6;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
   bool mfma_v1 = false;
   if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
   // weight-stationary kernel for short-K pointwise layers: measured slower than conv_mfma2 at batch 32-128
