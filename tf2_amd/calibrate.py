@@ -24,36 +24,35 @@ from .model4bit import split_model
 
 # ---- the two rules (quantization.py:33-72) -----------------------------------------------------------------
 def quantize_for_shift(x: np.ndarray) -> float:
-    """quantization.py:33-46: Q with x * 2^Q inside [-128, 127]; log2(127 / max) floored when negative, rounded
-    (numpy: half to even) otherwise, then lowered until the scaled data fit."""
-    x = np.asarray(x, np.float64)
-    mx = np.max(np.abs(x)) if x.size else 0.0
-    q = 0.0
-    if mx > 0:
-        q = np.log2(127.0 / mx)
-        q = np.floor(q) if q < 0 else np.round(q)
-        out = x * pow(2, q)
-        while np.max(out) > 127 or np.min(out) < -128:
-            q = q - 1
-            out = x * pow(2, q)
-    return float(q)
+    """Largest power-of-two exponent Q with x * 2^Q inside [-128, 127] (quantization.py:33-46).
+
+    The reference starts from log2(127 / max|x|) -- floored when negative, numpy-rounded (half to even) otherwise --
+    and steps down while the scaled data overflow.  Stated directly: the start value r, then the first Q <= r whose
+    scaled extremes fit; an all-zero channel keeps Q = 0."""
+    v = np.asarray(x, np.float64)
+    peak = float(np.abs(v).max()) if v.size else 0.0
+    if peak <= 0.0:
+        return 0.0
+    r = np.log2(127.0 / peak)
+    q = float(np.floor(r)) if r < 0 else float(np.round(r))
+    hi, lo = float(v.max()), float(v.min())
+    while hi * 2.0 ** q > 127 or lo * 2.0 ** q < -128:
+        q -= 1.0
+    return q
 
 
 def quantize_channels(x: np.ndarray) -> np.ndarray:
-    """quantization.py:48-72, style 'shift': per-channel Q (channel axis 1, or axis 0 of a vector), then every
-    positive Q above the mean drops to floor(mean) and every negative Q below the mean rises to ceil(mean)."""
-    x = np.asarray(x, np.float64)
-    if x.ndim == 1:
-        power = np.array([quantize_for_shift(x[i]) for i in range(x.shape[0])])
-    else:
-        power = np.array([quantize_for_shift(x[:, i]) for i in range(x.shape[1])])
-    mean = power.mean()
-    for i in range(power.shape[0]):
-        if power[i] > 0 and power[i] > mean:
-            power[i] = math.floor(mean)
-        if power[i] < 0 and power[i] < mean:
-            power[i] = math.ceil(mean)
-    return power
+    """Per-channel Q of a feature tensor plus the reference's mean clamp (quantization.py:48-72, style 'shift').
+
+    Channels are axis 1 of an N-D tensor, or the elements of a vector.  After the per-channel rule, positive values
+    above the mean of all channels are pulled down to floor(mean), negative values below it up to ceil(mean)."""
+    v = np.asarray(x, np.float64)
+    per_channel = [v[i] for i in range(v.shape[0])] if v.ndim == 1 else [v[:, i] for i in range(v.shape[1])]
+    q = np.array([quantize_for_shift(c) for c in per_channel])
+    m = q.mean()
+    q = np.where((q > 0) & (q > m), float(math.floor(m)), q)
+    q = np.where((q < 0) & (q < m), float(math.ceil(m)), q)
+    return q
 
 
 # ---- float forward of the table program -----------------------------------------------------------------------

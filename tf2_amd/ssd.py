@@ -17,7 +17,6 @@ No trained SSD weights or datasets ship with the reference, so the mAP of its RE
 """
 from __future__ import annotations
 
-from itertools import product
 from math import sqrt
 from typing import Dict, List, Sequence, Tuple
 
@@ -32,25 +31,29 @@ COCO = dict(num_classes=201, feature_maps=[38, 19, 10, 5, 3, 1], min_dim=300, st
 
 
 def prior_boxes(cfg: dict = VOC):
-    """prior_box.py:28-57: centre-form default boxes [sum f^2 * n_boxes, 4] (8732 for SSD300)."""
+    """Default boxes in centre form, [sum_k f_k^2 * boxes_k, 4] (8732 rows for SSD300), in the reference's order
+    (prior_box.py:28-57): per source map k, per cell (row i, column j): the min-size square, the sqrt(min*max) square,
+    then for every aspect ratio a the (w, h) pairs (s*sqrt(a), s/sqrt(a)) and (s/sqrt(a), s*sqrt(a)); clipped to
+    [0, 1] when cfg['clip'].  Computed per map as a grid of centres times a small table of shapes, in float64 like the
+    reference's Python arithmetic, then stored as float32."""
     import torch
-    mean: List[float] = []
-    size = cfg["min_dim"]
-    for k, f in enumerate(cfg["feature_maps"]):
-        for i, j in product(range(f), repeat=2):
-            f_k = size / cfg["steps"][k]
-            cx, cy = (j + 0.5) / f_k, (i + 0.5) / f_k
-            s_k = cfg["min_sizes"][k] / size
-            mean += [cx, cy, s_k, s_k]
-            s_k_prime = sqrt(s_k * (cfg["max_sizes"][k] / size))
-            mean += [cx, cy, s_k_prime, s_k_prime]
-            for ar in cfg["aspect_ratios"][k]:
-                mean += [cx, cy, s_k * sqrt(ar), s_k / sqrt(ar)]
-                mean += [cx, cy, s_k / sqrt(ar), s_k * sqrt(ar)]
-    out = torch.tensor(mean, dtype=torch.float32).view(-1, 4)
-    if cfg["clip"]:
-        out.clamp_(max=1, min=0)
-    return out
+    size = float(cfg["min_dim"])
+    blocks = []
+    for f, step, smin, smax, ratios in zip(cfg["feature_maps"], cfg["steps"], cfg["min_sizes"], cfg["max_sizes"],
+                                            cfg["aspect_ratios"]):
+        cells = size / step                                   # the reference divides by image_size / step
+        centres = (np.arange(f, dtype=np.float64) + 0.5) / cells
+        cy, cx = np.meshgrid(centres, centres, indexing="ij")
+        s = smin / size
+        shapes = [(s, s), (sqrt(s * (smax / size)),) * 2]
+        for a_r in ratios:
+            shapes += [(s * sqrt(a_r), s / sqrt(a_r)), (s / sqrt(a_r), s * sqrt(a_r))]
+        wh = np.asarray(shapes, np.float64)                   # [boxes_k, 2]
+        grid = np.stack([cx, cy], -1).reshape(f * f, 1, 2)    # [cells, 1, (cx, cy)]
+        blocks.append(np.concatenate([np.broadcast_to(grid, (f * f, len(shapes), 2)),
+                                      np.broadcast_to(wh[None], (f * f, len(shapes), 2))], -1).reshape(-1, 4))
+    out = torch.from_numpy(np.concatenate(blocks, 0).astype(np.float32))
+    return out.clamp_(0, 1) if cfg["clip"] else out
 
 
 def decode(loc, priors, variances: Sequence[float]):
