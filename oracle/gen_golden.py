@@ -18,6 +18,8 @@ What it writes (all data: inputs + expected outputs, never reference source text
                            as CRCs + small layers in full, on the seeded synthetic model of
                            tf2_amd.synth), filter_trans, feature_trans, Quantization, Evaluation.
   ref_pyemu.npz            outputs of the reference's Python FPGA emulator functions
+  ref_pyemu_block.npz      every intermediate tensor of the emulator's own Bottleneck.forward / ResNet.forward (head + tail)
+                           on small seeded blocks, plus its BN on > 10^5 samples with exact rounding ties
   ref_caq.npz              outputs of the reference's calibrator functions QuantizeForShift / QuantizeChannel
   ref_ssd.npz              outputs of the reference's SSD PriorBox / decode / nms (+ the L2Norm formula)
                            (TransForm_Kit/Quantization/debug/...Batch-2.py: Conv2dInt8, BN, FC),
@@ -219,6 +221,136 @@ def gen_pyemu():
     np.savez_compressed(os.path.join(OUT, "ref_pyemu.npz"), **out)
 
 
+def gen_pyemu_block():
+    """Executes the reference emulator's OWN forward code (…Batch-2.py: class Bottleneck :231-323, class ResNet
+    :325-443 with the conv1 -> BN -> clamp -> ReLU -> MaxPool2d(3,2,1) -> ... -> AdaptiveAvgPool -> round -> FC head),
+    AST-extracted with the script's globals supplied here, on small seeded blocks; every intermediate tensor the
+    emulator hands to its FeatureWrite / BN / Conv2dInt8 is captured.  Pins the oracle's relu, max-pool, stride-2
+    subsampling, int16 residual add + clamp + ReLU, global average and requant (tests/test_golden_pyemu.py)."""
+    np.lib.pad = np.pad
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    src = open(REF + "/TransForm_Kit/Quantization/debug/Pytorch-ResNet50-Log2QuantizeLoad-FPGA_Quantize-Batch-2.py").read()
+    tree = ast.parse(src)
+    fn = {"Conv2dInt8", "BN", "FC", "GetBias", "conv3x3", "conv1x1"}
+    cl = {"Bottleneck", "ResNet"}
+    mod = ast.Module([n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in fn) or
+                      (isinstance(n, ast.ClassDef) and n.name in cl)], [])
+    cap = []                                   # (name, array) in call order
+    ns = {"np": np, "torch": torch, "nn": nn, "F": F, "print": lambda *a, **k: None, "INFLAT": np.int8(15), "BatchSize": 1}
+    ns["FeatureWrite"] = lambda name, x: cap.append((name, np.array(x, np.float32, copy=True)))
+    ns["FeatureWriteFC"] = lambda name, x: cap.append((name, np.array(x, np.float32, copy=True)))
+    exec(compile(mod, "ref_debug_block", "exec"), ns)
+    conv_raw, bn_raw = ns["Conv2dInt8"], ns["BN"]
+
+    def conv_cap(x, w, w2, stride, padding):
+        acc = conv_raw(x, w, w2, stride, padding)
+        cap.append(("conv_in", np.array(x, np.int8, copy=True))); cap.append(("conv_acc", np.array(acc, np.int32, copy=True)))
+        return acc
+
+    def bn_cap(acc, bias_power, al, be):
+        y = bn_raw(acc, bias_power, al, be)
+        cap.append(("bn_out", np.array(y, np.float32, copy=True)))
+        return y
+    ns["Conv2dInt8"], ns["BN"] = conv_cap, bn_cap
+    rng = np.random.default_rng(29)
+    out = {}
+
+    def weights(N, Cc, k, lo=7, hi=13):
+        shift = rng.integers(lo, hi + 1, size=(N, Cc, k, k)).astype(np.int32)
+        sign = rng.choice(np.asarray([-1, 0, 1], np.int8), size=(N, Cc, k, k), p=[0.45, 0.1, 0.45]).astype(np.int8)
+        return shift, sign
+
+    def bn_params(N, scale):
+        # alpha on a 2^-12 grid and beta on a 2^-8 grid: the emulator's float arithmetic is then exact, so rounding
+        # ties can be enumerated exactly (the FPGA rule rounds them up, pe.cl:191-193; the emulator half-to-even)
+        al = (rng.integers(1, 1 << 12, N) / 4096.0 * scale).astype(np.float32)
+        al = (np.round(al * 4096) / 4096).astype(np.float32); al[al == 0] = 1.0 / 4096
+        be = (rng.integers(-256, 257, N) / 256.0).astype(np.float32)
+        return al, be
+
+    # ---- two bottlenecks: stride 1 without a projection, stride 2 with one -----------------------------------
+    for tag, (inpl, planes, stride, H, down) in {"b1": (32, 8, 1, 9, False), "b2": (24, 8, 2, 10, True)}.items():
+        width, outc = planes, planes * 4
+        blk = ns["Bottleneck"](inpl, planes, stride, downsample=(object() if down else None))
+        shapes = [(width, inpl, 1), (width, width, 3), (outc, width, 1)] + ([(outc, inpl, 1)] if down else [])
+        names = [f"c{i}" for i in range(len(shapes))]
+        Qk = [f"q{i}" for i in range(4)]
+        Qv = {k: [int(v) for v in rng.integers(0, 5, 64)] for k in Qk}
+        Filter, Filter2, alpha, beta = {}, {}, {}, {}
+        for nme, (N, Cc, k) in zip(names, shapes):
+            Filter[nme], Filter2[nme] = weights(N, Cc, k)
+            # keep requantised values inside the int8 range most of the time: |acc| ~ 127 * sqrt(K) * 2^10
+            alpha[nme], beta[nme] = bn_params(N, 2.0 ** 15 * 200 / (127 * np.sqrt(Cc * k * k) * 2.0 ** 11))
+            out[f"{tag}_{nme}_shift"], out[f"{tag}_{nme}_sign"] = Filter[nme], Filter2[nme]
+            out[f"{tag}_{nme}_alpha"], out[f"{tag}_{nme}_beta"] = alpha[nme], beta[nme]
+        ns.update(layer_name_bin=[f"f{i}" for i in range(16)], layer_name_binQ=Qk, filter_name=names, bn_name=names,
+                  layer_count=0, filter_count=0, feature_file_count=0, Filter=Filter, Filter2=Filter2, alpha=alpha, beta=beta, Q=Qv)
+        x = rng.integers(0, 128, size=(2, inpl, H, H)).astype(np.int8)       # a block input is post-ReLU
+        del cap[:]
+        y = blk.forward(x)
+        out[f"{tag}_x"] = x; out[f"{tag}_y"] = np.asarray(y.numpy(), np.float32)
+        out[f"{tag}_geom"] = np.asarray([inpl, planes, stride, H, int(down)], np.int32)
+        out[f"{tag}_q"] = np.asarray([Qv[k] for k in Qk], np.int32)
+        seq = {}
+        for nme, a in cap:
+            seq.setdefault(nme, []).append(a)
+        for i, a in enumerate(seq["conv_in"]): out[f"{tag}_conv{i}_in"] = a
+        for i, a in enumerate(seq["conv_acc"]): out[f"{tag}_conv{i}_acc"] = a
+        for i, a in enumerate(seq["bn_out"]): out[f"{tag}_bn{i}_out"] = a
+        for nme, a in cap:
+            if nme.startswith("f"): out[f"{tag}_feat_{nme}"] = a
+
+    # ---- ResNet.forward head and tail with identity stages: conv1 7x7/s2/p3 -> BN -> clamp -> ReLU -> MaxPool2d(3,2,1)
+    #      -> AdaptiveAvgPool2d(1) over 7x7 -> round -> FC ------------------------------------------------------
+    net = ns["ResNet"](ns["Bottleneck"], [1, 1, 1, 1])
+    for nme in ("layer1", "layer2", "layer3", "layer4"):
+        setattr(net, nme, nn.Sequential())
+    net.eval()
+    Qk = [f"q{i}" for i in range(51)]
+    Qv = {k: [int(v) for v in rng.integers(0, 4, 1000)] for k in Qk}
+    Filter, Filter2, alpha, beta = {}, {}, {}, {}
+    Filter["c0"], Filter2["c0"] = weights(64, 3, 7, 8, 13)
+    alpha["c0"], beta["c0"] = bn_params(64, 2.0 ** 15 * 50 / (127 * np.sqrt(147) * 2.0 ** 11))
+    beta["c0"] = np.abs(beta["c0"])            # mostly positive maps: the pool sees interesting values
+    sh, sg = weights(1000, 64, 1, 7, 12)
+    Filter["c1"], Filter2["c1"] = sh.reshape(1000, 64), sg.reshape(1000, 64)
+    fc_bias = (rng.integers(-64, 65, 1000) / 64.0).astype(np.float32)
+    ns.update(layer_name_bin=[f"f{i}" for i in range(8)], layer_name_binQ=Qk, filter_name=["c0", "c1"], bn_name=["c0", "c1"],
+              layer_count=0, filter_count=0, feature_file_count=0, Filter=Filter, Filter2=Filter2, alpha=alpha, beta=beta,
+              Q=Qv, fc_bias=fc_bias, fc_weight=None, bias_power=None)
+    img = rng.integers(-127, 128, size=(1, 3, 28, 28)).astype(np.int8)
+    del cap[:]
+    with torch.no_grad():
+        net.forward(img)
+    got = dict()
+    for nme, a in cap:
+        got.setdefault(nme, []).append(a)
+    out.update(head_img=img, head_c0_shift=Filter["c0"], head_c0_sign=Filter2["c0"], head_c0_alpha=alpha["c0"], head_c0_beta=beta["c0"],
+               head_q1=np.asarray(Qv["q1"][:64], np.int32), head_qfc=np.asarray(Qv["q50"], np.int32),
+               head_fc_shift=Filter["c1"], head_fc_sign=Filter2["c1"], head_fc_bias=fc_bias,
+               head_conv1_acc=got["conv_acc"][0], head_conv1_bn=got["bn_out"][0], head_conv1_clamped=got["f1"][0],
+               head_pool1=got["pool1"][0], head_pool5=got["pool5.txt"][0], head_fc=got["fc1000.txt"][0])
+
+    # ---- the avgpool + round step alone on many maps (exactly the two statements of ResNet.forward :415-416) -----
+    xs = rng.integers(0, 128, size=(64, 48, 7, 7)).astype(np.int8)
+    xs[:8] = rng.integers(-128, 128, size=(8, 48, 7, 7)).astype(np.int8)
+    out["avg_x"] = xs
+    out["avg_y"] = torch.round(net.avgpool(torch.Tensor(xs.astype(np.float32)))).numpy().reshape(64, 48).astype(np.float32)
+
+    # ---- BN on > 10^5 samples, exact-arithmetic parameter grid, with rounding ties present ---------------------
+    N, HW = 64, 1600
+    Qout = rng.integers(0, 6, N).astype(np.int8)
+    al, be = bn_params(N, 1.0)
+    al[:8] = np.asarray([1.0, 0.5, 0.25, 1.5, 1.0, 0.5, 0.75, 1.0], np.float32)
+    acc = (rng.integers(-(1 << 14), 1 << 14, size=(1, N, 40, 40)).astype(np.int32) << rng.integers(7, 11, size=(1, N, 1, 1))).astype(np.int32)
+    ns.update(layer_count=0, layer_name_binQ=["k"], Q={"k": [int(v) for v in Qout]})
+    y = bn_raw(acc, np.zeros(N, np.float32), al, be)
+    out.update(bnx_acc=acc, bnx_alpha=al, bnx_beta=be, bnx_q=Qout, bnx_y=np.asarray(y, np.float32))
+    np.savez_compressed(os.path.join(OUT, "ref_pyemu_block.npz"), **out)
+
+
 def gen_caq():
     """Outputs of the reference's calibrator functions (TransForm_Kit/Quantization/quantization.py:33-72, executed
     here from the AST -- the module itself needs the dataset/model loaders) on seeded max-|feature| tensors."""
@@ -297,6 +429,7 @@ if __name__ == "__main__":
     gen_tables_and_data()
     gen_ref_host()
     gen_pyemu()
+    gen_pyemu_block()
     gen_caq()
     gen_ssd()
     print("golden fixtures written to", OUT)

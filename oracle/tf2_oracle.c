@@ -24,10 +24,22 @@
  *   - tf2o_mul / tf2o_conv follow device/src/pe.cl:27-49,144-180 and are checked
  *     against golden conv sums produced by the reference's Python emulator
  *     (TransForm_Kit/Quantization/debug, Conv2dInt8) on inputs without -128.
- *   - requant / relu / pool / residual / global-average follow the OpenCL device
- *     code, which cannot be built here (needs Intel's aoc): PARITY UNPINNED for
- *     these five by execution; they are restated line by line and cross-checked
- *     against the reference's float BN emulation away from rounding ties.
+ *   - requant / relu / max-pool / stride-2 subsampling / residual add / global
+ *     average / FC follow the OpenCL device code (pe.cl:185-203, relu.cl:50-56,
+ *     pool.cl:152-260, pool_tail.cl:91-216, feature_writer.cl:88-137,
+ *     full_size_pool.cl:95-125), which cannot be built here (needs Intel's aoc).
+ *     They are pinned by EXECUTING the reference's own Python FPGA emulator
+ *     (TransForm_Kit/Quantization/debug/...Batch-2.py: Bottleneck.forward
+ *     :249-323 and ResNet.forward :395-443, AST-extracted by
+ *     oracle/gen_golden.py gen_pyemu_block) and comparing every intermediate
+ *     tensor (tests/golden/ref_pyemu_block.npz, tests/test_golden_pyemu.py):
+ *     max-pool, clamp+ReLU, strided conv and the int16 residual add+clamp+ReLU
+ *     exactly on every element; requant on every element that is not a
+ *     rounding tie, over > 10^5 samples, with the exact ties enumerated (the
+ *     emulator rounds half to even in float, the FPGA adds 1 and shifts,
+ *     pe.cl:191-193 -- the oracle follows the FPGA, asserted); the global
+ *     average's 669/2^15 rule (full_size_pool.cl:115-118) on every element
+ *     outside the band where it provably differs from round(mean).
  */
 #include <stdint.h>
 #include <stdlib.h>
