@@ -10,6 +10,11 @@ i % 3 with its own workspace) so that the latency-bound small layers of one batc
 another batch's kernels; all K timed steps complete inside the timed region, and the
 one-batch-at-a-time rate is reported beside it (`images_per_s_one_batch_at_a_time`).
 
+`--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks on
+127.0.0.1 (one per GPU); under torchrun it asserts WORLD_SIZE == N.  Every rank pins LOCAL_RANK -> GPU and fails
+loudly if that GPU does not exist.  `--spawn-check` runs only that launch / pin / broadcast logic (gloo on CPU when
+there is no GPU) -- tests/test_dist_cpu.py drives it through this file.
+
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and
 `cpu_baseline` are defined."""
 import argparse
@@ -37,6 +42,48 @@ def layer_ops(plan):
     return rows
 
 
+def spawn_check(args):
+    """The launch path alone: process group of --gpus ranks (RCCL on GPUs, gloo on CPU), rank -> device pinning, the ONE
+    collective of the data path (broadcast of the packed weights) on a small network, and a CRC agreement check."""
+    import zlib
+    import torch
+    import torch.distributed as dist
+    from tf2_amd import config as cfg, dist as tdist, network, synth
+    on_gpu = torch.cuda.is_available()
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    device = None
+    if on_gpu:
+        if local >= torch.cuda.device_count():
+            sys.exit(f"bench.py: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    rank, world = tdist.init_process_group()
+    assert world == args.gpus
+    if world > 1:
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 2)
+    model = synth.synth_model(t, q, 2) if rank == 0 else None
+    net = network.NetWork(t)
+    tdist.broadcast_network(net, model, synth.q_text(q), device=device)
+    crc = zlib.crc32(net.packed_host().tobytes()) & 0xFFFFFFFF
+    crcs = [crc]
+    if world > 1:
+        tt = torch.tensor([crc], dtype=torch.int64, device=device if on_gpu else "cpu")
+        got = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(got, tt)
+        crcs = [int(g.item()) for g in got]
+    lo, hi = tdist.shard_range(args.batch * world, rank, world)
+    if rank == 0:
+        print(json.dumps(dict(spawn_check=True, n_gpus=world, backend=(dist.get_backend() if world > 1 else None),
+                              device=str(device) if on_gpu else "cpu", packed_crc_all_ranks_equal=len(set(crcs)) == 1,
+                              rank0_shard=[lo, hi], global_batch=args.batch * world)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,23 +94,46 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra-batches", type=str, default="1,64", help="also time these per-GPU batch sizes")
-    ap.add_argument("--streams", type=int, default=1, help="split each batch over this many concurrent HIP streams")
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
+    ap.add_argument("--split", type=int, default=1, help="run every batch as this many sub-batches on concurrent streams (Runner.run_split)")
+    ap.add_argument("--spawn-check", action="store_true", help="only launch N ranks, pin, broadcast a small network, report")
+    ap.add_argument("--master-port", type=int, default=0)
     args = ap.parse_args()
+
+    # ---- N ranks: re-exec under torchrun when started bare -------------------------------------------------------
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        port = args.master_port
+        if not port:
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or without torchrun, and bench.py starts the ranks itself)")
+    if args.spawn_check:
+        return spawn_check(args)
 
     import torch
     from tf2_amd import config as cfg, dist as tdist, network, synth, _lib
     import ctypes as C
 
-    rank, world = tdist.init_process_group()
-    local = int(os.environ.get("LOCAL_RANK", rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local)                      # before the process group: RCCL binds to the current device
     device = torch.device("cuda", local)
+    rank, world = tdist.init_process_group()
     import torch.distributed as dist
+    assert world == args.gpus and (world == 1 or dist.get_world_size() == args.gpus), "process group size != --gpus"
 
     tables = cfg.resnet50_tables()
     plan = cfg.build_plan(tables)
@@ -80,54 +150,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    n_streams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else []
-    sub_runners = [network.Runner(None, net) for _ in range(n_streams)] if n_streams > 1 else []
-
     n_inflight = max(1, args.inflight)
     fl_streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)] if n_inflight > 1 else []
     fl_runners = [network.Runner(None, net) for _ in range(n_inflight)] if n_inflight > 1 else []
     step_no = [0]
-
     graphs = {}
-
     serial = [False]      # True: one batch at a time on the default stream (reported next to the pipelined figure)
 
-    def step(x, parts):
+    def one(rn, x):
+        return rn.run_split(x, args.split) if args.split > 1 else rn.run_batch(x)
+
+    def step(x):
         if n_inflight > 1 and not serial[0]:
             i = step_no[0] % n_inflight
             step_no[0] += 1
             with torch.cuda.stream(fl_streams[i]):
-                fl_runners[i].run_batch(x)
+                one(fl_runners[i], x)
             return
-        if n_streams == 1 or x.shape[0] < n_streams:
-            if args.graph:
-                key = (x.data_ptr(), x.shape[0])
-                if key not in graphs:
-                    graphs[key] = network.Runner(None, net)
-                    graphs[key] = (graphs[key], graphs[key].capture(x))
-                graphs[key][1]()
-            else:
-                runner.run_batch(x)
-            return
-        for st, rn, xp in zip(streams, sub_runners, parts):
-            with torch.cuda.stream(st):
-                rn.run_batch(xp)
+        if args.graph:
+            key = (x.data_ptr(), x.shape[0])
+            if key not in graphs:
+                r = network.Runner(None, net)
+                graphs[key] = (r, r.capture(x, split=args.split))
+            graphs[key][1]()
+        else:
+            one(runner, x)
 
     def timed(batch, steps, warmup):
         x = torch.from_numpy(synth.synth_images(tables, batch, seed=100 + rank)).to(device)
-        parts = [c.contiguous() for c in torch.chunk(x, n_streams)] if n_streams > 1 and batch >= n_streams else None
-        if n_inflight > 1:                     # set-up, not a step: every in-flight runner allocates its workspace
+        if n_inflight > 1 and not serial[0]:   # set-up, not a step: every in-flight runner allocates its workspace
             for st, rn in zip(fl_streams, fl_runners):
                 with torch.cuda.stream(st):
-                    rn.run_batch(x)
+                    one(rn, x)
         torch.cuda.synchronize(device)
         for _ in range(warmup):
-            step(x, parts)
+            step(x)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(x, parts)
+            step(x)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -154,6 +215,28 @@ def main():
         d2, _ = timed(b, max(3, args.steps // 2), 2)
         sweep[str(b)] = round(world * b * max(3, args.steps // 2) / d2, 1)
 
+    # ---- batch-1 LATENCY (the reference reports "Latency ms" next to "Throughput fps", runner.cpp:187-189): one image
+    #      at a time, the step replayed from a HIP graph, synchronised after every image ----
+    lat = None
+    if rank == 0:
+        x1 = torch.from_numpy(synth.synth_images(tables, 1, seed=7)).to(device)
+        r1 = network.Runner(None, net)
+        res = {}
+        for name, fn in (("launches", lambda: r1.run_batch(x1)), ("hip_graph", None)):
+            if fn is None:
+                rg = network.Runner(None, net)
+                fn = rg.capture(x1)
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(device)
+            n_lat = 50
+            t0 = time.perf_counter()
+            for _ in range(n_lat):
+                fn()
+                torch.cuda.synchronize(device)
+            res[name] = round((time.perf_counter() - t0) / n_lat * 1e6, 1)
+        lat = dict(us_per_image=min(res.values()), by_path=res, note="batch 1, one image at a time, host-synchronised after each")
+
     # ---- roofline: live per-layer HIP-event timing on the launch stream (C-side hook) ----
     lo = layer_ops(plan)
     prof_steps = 5
@@ -163,9 +246,8 @@ def main():
     torch.cuda.synchronize(device)
     ms = np.zeros(len(plan), np.float32); nl = np.zeros(len(plan), np.int32); kinds = np.zeros(len(plan), np.int32)
     _lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kinds.ctypes.data, len(plan)))
-    # one event pair around the whole layer loop: what the 54 per-layer pairs add by themselves (each record is a
+    # one event pair around the whole layer loop: what the per-layer pairs add by themselves (each record is a
     # marker the command processor handles between kernels) is removed by rescaling the per-layer sum to it
-    import ctypes as C
     _lib.check(_lib.lib().tf2_net_profile(net._h, 2))
     for _ in range(prof_steps):
         runner.run_batch(x)
@@ -191,39 +273,36 @@ def main():
                          gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,
                          frac_hbm_peak=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4) if v["ms"] > 0 else None)
                  for k, v in classes.items()}
-    # dominant kernel = the MFMA conv kernel: all its launches of one step
-    mf = [i for i in range(len(plan)) if kinds[i] == 1 and not plan[i].pool_en and not plan[i].endpool]
-    dom_ops = sum(lo[i]["ops"] for i in mf) * args.batch
-    dom_ms = float(sum(per_layer_ms[i] for i in mf))
-    if mf and dom_ms > 0:
-        achieved = dom_ops / (dom_ms * 1e-3) / 1e12
-        # HBM bytes per launch from the committed PMC passes of the same workload (tools/pmc_run.sh ->
-        # tools/pmc_summary.py), when they exist for this batch size
-        traffic, traffic_note = None, "no PMC pass committed for this batch size"
-        pj = os.path.join(ROOT, "profiles", f"r01_pmc_conv_b{args.batch}.json")
-        if os.path.exists(pj):
+    # dominant kernel family = the convolution kernels: all their launches of one step.  SURVEY.md 8(d): the binding
+    # roofline of the layer-by-layer int8 streaming is HBM; the int8 MFMA fraction is reported beside it.
+    cv = [i for i in range(len(plan)) if kinds[i] in (1, 2)]
+    dom_ops = sum(lo[i]["ops"] for i in cv) * args.batch
+    alg_bytes = sum(lo[i]["bytes"] for i in cv) * args.batch
+    dom_ms = float(sum(per_layer_ms[i] for i in cv))
+    traffic, traffic_note = None, "no PMC pass committed for this batch size and kernel mode"
+    for rnd in ("r02", "r01"):
+        pj = os.path.join(ROOT, "profiles", f"{rnd}_pmc_conv_b{args.batch}.json")
+        if os.path.exists(pj) and args.mode == 0:
             pm = json.load(open(pj))
-            tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in mf)
-            traffic = round(tb / len(mf))
-            traffic_note = f"mean HBM bytes per launch over the step's {len(mf)} launches, rocprofv3 FETCH_SIZE(x2, gfx950)+WRITE_SIZE, {os.path.basename(pj)}"
-        alg_bytes = sum(lo[i]["bytes"] for i in mf) * args.batch
-        roofline = dict(bound="mfma", kernel="conv_mfma2_kernel (+ conv_mfma_sk / conv_pw: every MFMA conv launch of the step)", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
-                        frac=round(achieved / PEAK_I8, 4), traffic=traffic, traffic_note=traffic_note,
-                        algorithmic_bytes_per_launch=round(alg_bytes / len(mf)), launches_per_step=len(mf),
-                        algorithmic_ops_per_launch=round(dom_ops / len(mf)),
-                        avg_launch_us=round(dom_ms / len(mf) * 1e3, 2), event_pair_scale=round(event_scale, 4),
-                        hbm_side=dict(achieved_gbps=round(alg_bytes / (dom_ms * 1e-3) / 1e9, 1), peak_gbps=PEAK_HBM,
-                                      frac=round(alg_bytes / (dom_ms * 1e-3) / 1e9 / PEAK_HBM, 4)),
-                        note="achieved = sum of algorithmic int8 ops (2/MAC) of the step's conv launches / sum of their HIP-event "
-                             "durations on the launch stream (per-launch average over the 52 shapes of the network); the per-layer event "
-                             "times are rescaled by event_pair_scale = (one event pair around the whole layer loop) / (their sum)")
-    else:
-        sh = [i for i in range(len(plan)) if kinds[i] == 2]
-        dom_ops = sum(lo[i]["ops"] for i in sh) * args.batch
-        dom_ms = float(sum(per_layer_ms[i] for i in sh))
-        achieved = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        roofline = dict(bound="mfma", kernel="conv_shift_kernel", achieved=round(achieved, 2), peak=PEAK_I8, unit="TOP/s",
-                        frac=round(achieved / PEAK_I8, 4), traffic=None, launches_per_step=len(sh))
+            if len(pm.get("layers", [])) == len(plan):
+                tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in cv)
+                traffic = round(tb / len(cv))
+                traffic_note = (f"mean HBM bytes per launch over the step's {len(cv)} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)"
+                                f"+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
+                break
+    gbps = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    tops = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
+             2: "conv_shift_kernel"}[args.mode]
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
+                    traffic=traffic, traffic_note=traffic_note,
+                    algorithmic_bytes_per_launch=round(alg_bytes / max(1, len(cv))), launches_per_step=len(cv),
+                    avg_launch_us=round(dom_ms / max(1, len(cv)) * 1e3, 2), event_pair_scale=round(event_scale, 4),
+                    mfma_side=dict(achieved_tops=round(tops, 1), peak_tops=PEAK_I8, frac=round(tops / PEAK_I8, 4),
+                                   algorithmic_ops_per_launch=round(dom_ops / max(1, len(cv)))),
+                    note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d): 26.9 MB per image) of "
+                         "the step's conv launches / sum of their HIP-event durations on the launch stream, one batch at a time; "
+                         "per-layer event times rescaled by event_pair_scale = (one event pair around the whole layer loop) / (their sum)")
     total_bytes = sum(r["bytes"] for r in lo) * args.batch
     hbm_gbps = total_bytes / (ms_per_step * 1e-3) / 1e9
 
@@ -257,12 +336,12 @@ def main():
                     config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
                                          f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
-                                streams_per_gpu=n_streams, batches_in_flight=n_inflight, hip_graph=bool(args.graph)),
+                                sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph)),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
                     per_layer_class=per_class, images_per_s_by_batch=sweep,
-                    images_per_s_one_batch_at_a_time=serial_value)
+                    images_per_s_one_batch_at_a_time=serial_value, latency_batch1=lat)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -116,9 +116,17 @@ tf2_status tf2_net_bind_device(tf2_net* net, const void* packed_dev, size_t n_by
 /* ---- running (replaces Runner::Run, runner.cpp:54-198, and the OpenCL device pipeline) */
 /* keep_all != 0: every layer output gets its own buffer (per-layer parity tests).       */
 size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all);
+/* Bytes of the dense int8 output of a run: [batch][H_last * W_last][N_last] (NHWC; H_last = W_last = 1 for the
+ * classification networks, i.e. [batch][N_last] -- the buffer Runner::Run reads back, runner.cpp:176-186).      */
+size_t tf2_net_logits_size(const tf2_net* net, int batch);
+/* Re-read the TF2_AMD_* run-time switches (kernel A/B selection for tests and tools) from the environment; they
+ * are otherwise sampled once, at tf2_net_create.  Drops the prepared launch plans.                              */
+tf2_status tf2_net_reload_options(tf2_net* net);
 /* images_dev: float32 [batch][image_c][image_h][image_w] on the device (the preprocessed
  * CHW floats LoadInputImage reads, input_loader.cpp:76-96).  Quantises with 2^Q0
- * (runner.cpp:158-164), runs every layer, writes int8 logits [batch][N_last] (dense).   */
+ * (runner.cpp:158-164), runs every layer, writes the int8 output (tf2_net_logits_size bytes,
+ * [batch][N_last] for a 1x1 final map) to logits_dev.  All kernel argument blocks of a step are
+ * prepared once per (batch, workspace address) and reused by later calls.                       */
 tf2_status tf2_net_run(tf2_net* net, const float* images_dev, int batch, void* workspace_dev,
                        size_t workspace_bytes, int8_t* logits_dev, void* hip_stream);
 /* Same, from already-quantised int8 images [batch][image_c][image_h][image_w].          */

@@ -50,3 +50,26 @@ def test_shard_range_covers_everything():
             spans = [tdist.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_bench_py_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment must start 2 ranks itself (round 1 parsed and ignored
+    the flag).  --spawn-check runs exactly bench.py's launch / pin / process-group / weight-broadcast code, on gloo here."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check", "--batch", "5"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["spawn_check"] and d["n_gpus"] == 2 and d["packed_crc_all_ranks_equal"] and d["global_batch"] == 10 and d["rank0_shard"] == [0, 5]
+
+
+def test_bench_py_refuses_a_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--spawn-check"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)

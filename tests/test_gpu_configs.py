@@ -1,0 +1,151 @@
+"""GPU parity at the BASELINE.json configurations and on the run paths round 1 left unexercised: ResNet50 batch 64,
+the reference's third shipped network (pruned ResNet50: channel counts that are not multiples of 64), SSD300 at full
+width, VGG16 at its per-GPU batch, the HIP-graph replay path and the 4-bit packed model file on the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tf2_amd import config as cfg, model4bit, network, synth
+
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_gpu_parity import Rig, _torch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def r50(golden_dir):
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    return t, q, synth.synth_model(t, q, 0)
+
+
+@pytest.fixture(scope="module")
+def r50_rig(r50):
+    return Rig(*r50, 0)
+
+
+def test_resnet50_batch64_logits_vs_oracle(r50_rig):
+    """BASELINE configs[2]: ResNet50 batch 64 on one GPU -- all 64 logits rows and top-5 lists against the oracle."""
+    x = synth.synth_images(r50_rig.t, 64, 64)
+    got = r50_rig.run(x, keep_all=False)
+    want = r50_rig.ref.logits(r50_rig.ref.run(x))
+    np.testing.assert_array_equal(got, want)
+    for b in (0, 31, 63):
+        lab, _ = network.Evaluation(b, r50_rig.net.q, got, num_layer=r50_rig.net.num_layer)
+        assert lab == r50_rig.ref.top5(want[b])[0].tolist()
+
+
+def test_resnet50_pruned_every_layer(golden_dir):
+    """host/inc/resnet50_pruned.h + host/model/resnet50_pruned_Q (cnn.h:29-35): the shipped tables of the channel-pruned
+    network, widths 32..448 that are not multiples of the 64-row MFMA tiles -- every layer against the oracle."""
+    t = cfg.NetTables(json.load(open(os.path.join(golden_dir, "tables_resnet50_pruned.json"))))
+    t.setdefault("xConv1Rewrite", 1)
+    qv = np.loadtxt(os.path.join(golden_dir, "resnet50_pruned_Q"), dtype=np.int32)
+    model = synth.synth_model(t, qv, 13)
+    rig = Rig(t, qv, model, 0)
+    widths = {L.N for L in rig.ref.plan}
+    assert any(w % 64 for w in widths)
+    rig.check_all_layers(synth.synth_images(t, 3, 13))
+    # and the logits at batch 32 (tile tails on every map size)
+    x = synth.synth_images(t, 32, 14)
+    np.testing.assert_array_equal(rig.run(x, keep_all=False), rig.ref.logits(rig.ref.run(x)))
+
+
+def test_ssd300_full_width_and_batch32_properties():
+    """BASELINE configs[4]: SSD300-VGG at full width.  Two images against the oracle on every row, then batch 32:
+    rows 0-1 equal the oracle-checked pair, a batch permutation permutes the outputs, an image run in a pair equals
+    its row in the batch."""
+    import torch
+    t = cfg.ssd300_tables()
+    q = synth.synth_q_values(t, 3, spread=1)
+    model = synth.synth_model(t, q, 3)
+    rig = Rig(t, q, model, 0)
+    x = synth.synth_images(t, 32, 5)
+    rig.check_all_layers(x[:2])
+    heads = [l for l, L in enumerate(rig.ref.plan) if l >= 24]
+    rig.run(x, keep_all=True)
+    full = {l: rig.runner.read_layer(l, 32) for l in heads}
+    perm = np.random.default_rng(1).permutation(32)
+    rig.run(x[perm], keep_all=True)
+    for l in heads:
+        np.testing.assert_array_equal(rig.runner.read_layer(l, 32), full[l][perm], err_msg=f"head row {l} under a batch permutation")
+    rig.run(x[:2], keep_all=True)
+    for l in heads:
+        np.testing.assert_array_equal(rig.runner.read_layer(l, 2), full[l][:2])
+    torch.cuda.synchronize()
+
+
+def test_vgg16_batch32_properties():
+    """BASELINE configs[3]: VGG16 at its per-GPU batch (256 over 8 GPUs = 32): two images against the oracle, the rest
+    through batch invariance and permutation."""
+    t = cfg.vgg16_tables()
+    q = synth.synth_q_values(t, 1, spread=1)
+    model = synth.synth_model(t, q, 1)
+    rig = Rig(t, q, model, 0)
+    x = synth.synth_images(t, 32, 6)
+    got = rig.run(x, keep_all=False)
+    np.testing.assert_array_equal(got[:2], rig.ref.logits(rig.ref.run(x[:2])))
+    perm = np.random.default_rng(2).permutation(32)
+    np.testing.assert_array_equal(rig.run(x[perm], keep_all=False), got[perm])
+    np.testing.assert_array_equal(rig.run(x[20:22], keep_all=False), got[20:22])
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_hip_graph_replay_equals_run_batch(r50_rig, batch):
+    """Runner.capture: the step recorded once into a HIP graph; replays on refilled input buffers give the logits of
+    run_batch (and of the oracle)."""
+    torch = _torch()
+    rig = r50_rig
+    xs = [synth.synth_images(rig.t, batch, 70 + i) for i in range(3)]
+    want = [rig.run(x, keep_all=False) for x in xs]
+    np.testing.assert_array_equal(want[0], rig.ref.logits(rig.ref.run(xs[0])))
+    runner = network.Runner(None, rig.net)
+    buf = torch.from_numpy(xs[0]).to("cuda:0")
+    replay = runner.capture(buf)
+    for x, w in zip(xs, want):
+        buf.copy_(torch.from_numpy(x))
+        replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(runner._logits.cpu().numpy(), w)
+
+
+def test_model4bit_file_to_gpu_logits(r50):
+    """TransForm_Kit's 4-bit packed model file (4bit_data_format.txt) -> tf2_net_load_model_4bit -> GPU: the logits of
+    the float32-loaded network, bit for bit, and the oracle's."""
+    torch = _torch()
+    t, q, model = r50
+    blob = model4bit.write_model_4bit(t, model)
+    assert len(blob) < model.nbytes / 5
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel4bit(blob); net.Pack(0); net.InitBuffer("cuda:0")
+    x = synth.synth_images(t, 3, 9)
+    got = network.Runner(None, net).run_batch(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
+    rig = Rig(t, q, model, 0)
+    np.testing.assert_array_equal(got, rig.run(x, keep_all=False))
+    np.testing.assert_array_equal(got, rig.ref.logits(rig.ref.run(x)))
+
+
+def test_run_split_and_its_graph_equal_run_batch(r50_rig):
+    """Runner.run_split: the batch as 2 / 3 sub-batches on concurrent streams (fork / join on the caller's stream)
+    writes the same logits tensor as run_batch; also when captured into a HIP graph."""
+    torch = _torch()
+    rig = r50_rig
+    x = synth.synth_images(rig.t, 7, 91)
+    want = rig.run(x, keep_all=False)
+    xd = torch.from_numpy(x).to("cuda:0")
+    for parts in (2, 3):
+        r = network.Runner(None, rig.net)
+        got = r.run_split(xd, parts)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    r = network.Runner(None, rig.net)
+    buf = xd.clone()
+    replay = r.capture(buf, split=2)
+    x2 = synth.synth_images(rig.t, 7, 92)
+    buf.copy_(torch.from_numpy(x2))
+    replay(); torch.cuda.synchronize()
+    np.testing.assert_array_equal(r._logits.cpu().numpy(), rig.run(x2, keep_all=False))

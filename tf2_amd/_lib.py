@@ -80,6 +80,9 @@ def lib() -> C.CDLL:
     L.tf2_net_bind_device.argtypes = [vp, vp, sz]
     L.tf2_net_workspace_size.argtypes = [vp, C.c_int, C.c_int]
     L.tf2_net_workspace_size.restype = sz
+    L.tf2_net_logits_size.argtypes = [vp, C.c_int]
+    L.tf2_net_logits_size.restype = sz
+    L.tf2_net_reload_options.argtypes = [vp]
     L.tf2_net_run.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
@@ -95,7 +98,7 @@ EXPORTED = [
     "tf2_last_error", "tf2_abi_version", "tf2_has_device_code", "tf2_get_real", "tf2_quantization",
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
-    "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_run",
+    "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
     "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 

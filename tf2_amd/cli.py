@@ -28,15 +28,13 @@ def main(argv=None) -> int:
     runner.Init()
     out = runner.Run()
     print(f"Latency = {runner.latency_ms:.3f} ms\nThroughput = {runner.throughput_fps:.1f} fps")
-    n_last = net.plan[-1].N
-    q_last = net.q[len(net.plan)][:n_last]
     for i in range(args.num_images):
         try:
-            err = network.Verify(i, args.verify_file, q_last, out)
+            err = network.Verify(i, args.verify_file, net.q, out, num_layer=net.num_layer)    # main.cpp:52
             print(f"Convolution {len(net.plan)} compare finished, error={err:f}")
         except OSError as e:
             print(f"verify file not readable: {e}")
-        labels, probs = network.Evaluation(i, net.q[len(net.plan)], out)
+        labels, probs = network.Evaluation(i, net.q, out, num_layer=net.num_layer)              # main.cpp:53
         for r, (l, p) in enumerate(zip(labels, probs)):
             print(f"rank={r}\tlabel={l:5d}\tprobability={p:f}")
     net.CleanUp()

@@ -24,6 +24,7 @@ tf2_status tf2_net_create(const tf2_net_desc* nd, const tf2_layer_desc* layers, 
   if (!n) { set_error("out of memory"); return TF2_ERR_SIZE; }
   tf2_status st = n->impl.init(nd, layers);
   if (st != TF2_OK) { delete n; return st; }
+  n->impl.load_options();
   *out = n;
   return TF2_OK;
 }
@@ -48,6 +49,7 @@ tf2_status tf2_net_set_q(tf2_net* net, const int8_t* q, size_t n_bytes) {
   net->impl.q.assign(q, q + n_bytes);
   net->impl.model_loaded = false;
   net->impl.packed_valid = false;
+  net->impl.launch_plans.clear();
   return TF2_OK;
 }
 
@@ -105,7 +107,7 @@ tf2_status tf2_net_get_bias_bn(const tf2_net* net, int layer, int32_t* bias, int
   return TF2_OK;
 }
 
-tf2_status tf2_net_pack(tf2_net* net, int mode) { CHECK_NET(net); return net->impl.pack(mode); }
+tf2_status tf2_net_pack(tf2_net* net, int mode) { CHECK_NET(net); net->impl.launch_plans.clear(); return net->impl.pack(mode); }
 
 size_t tf2_net_packed_size(const tf2_net* net) { return net && net->impl.packed_valid ? net->impl.packed.size() : 0; }
 
@@ -129,6 +131,7 @@ tf2_status tf2_net_packed_adopt(tf2_net* net, const void* host_src, size_t n_byt
   N.packed.assign((const uint8_t*)host_src, (const uint8_t*)host_src + n_bytes);
   N.packed_valid = true;
   N.packed_dev = nullptr; N.packed_dev_bytes = 0;
+  N.launch_plans.clear();
   return TF2_OK;
 }
 
@@ -139,6 +142,7 @@ tf2_status tf2_net_bind_device(tf2_net* net, const void* packed_dev, size_t n_by
   if (!packed_dev || n_bytes != N.packed.size()) { set_error("tf2_net_bind_device: size mismatch"); return TF2_ERR_SIZE; }
   N.packed_dev = (const uint8_t*)packed_dev;
   N.packed_dev_bytes = n_bytes;
+  N.launch_plans.clear();
   return TF2_OK;
 }
 
@@ -147,6 +151,13 @@ size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all) {
   const WorkPlan* wp = net->impl.plan(batch, keep_all != 0);
   return wp ? wp->total_bytes : 0;
 }
+
+size_t tf2_net_logits_size(const tf2_net* net, int batch) {
+  if (!net || batch <= 0) return 0;
+  return net->impl.logits_bytes(batch);
+}
+
+tf2_status tf2_net_reload_options(tf2_net* net) { CHECK_NET(net); net->impl.load_options(); return TF2_OK; }
 
 tf2_status tf2_net_run(tf2_net* net, const float* images_dev, int batch, void* ws, size_t ws_bytes,
                        int8_t* logits_dev, void* hip_stream) {

@@ -115,9 +115,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
   const int mtile = bid - ntile * a_n_mtiles;
   const int px0 = ntile * TN;
-  const int e_begin = a.e_start[mtile];
-  const int e_end = a.e_start[mtile + 1];
-  const int n_ent = e_end - e_begin;
 
   // LDS-DMA lane l of an instruction fills row (l>>2), 16-byte slot (l&3) of a 16-row group;
   // with the XOR swizzle slot c' of row r holds chunk c = c' ^ ((r>>2)&3), and r>>2 == l>>4
@@ -131,6 +128,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   typedef const __attribute__((address_space(4))) i32x4* cvec_p;
   const size_t hdr_words = (size_t)mtile * (size_t)(a_hdr_bytes >> 2);
   cvec_p const hg = (cvec_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent);
+  // this m-tile's {first, end} entry: the last two words of steps[] (weight_pack.cpp), same scalar round trip
+  typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
+  const auto ee = *(cvec2_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
+  const int e_begin = ee[0];
+  const int n_ent = ee[1] - ee[0];
   int pro_off[S - 1], pro_hw[S - 1];
 #pragma unroll
   for (int s = 0; s < S - 1; s++) {
@@ -418,12 +420,8 @@ static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
-  static bool attr_set = false;
   auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-    attr_set = true;
-  }
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
   hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
@@ -446,7 +444,6 @@ static int launch_dual(const ConvArgs& a, hipStream_t s) {
 // a.g.flags bit 1 / bit 2: the 4-wave (64x64 tiles) / 16-wave (32x32) shapes (A/B switches, single-window layers).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.n_mtiles > kMaxMtiles) return -4;
   const bool w4 = (a.g.flags & 2) != 0;
   const bool w16 = (a.g.flags & 4) != 0;
   static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;

@@ -70,8 +70,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
   const int mtile = bid - ntile * a_n_mtiles;
   const int px0 = ntile * TN;
-  const int e_begin = a.e_start[mtile];
-  const int n_ent = a.e_start[mtile + 1] - e_begin;
+  // this m-tile's {first, end} entry: the last two words of steps[] in its header image (weight_pack.cpp)
+  typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
+  const auto ee = *(cvec2_p)(unsigned long long)(ahdr + (size_t)mtile * (size_t)(a_hdr_bytes >> 2) + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
+  const int e_begin = ee[0];
+  const int n_ent = ee[1] - ee[0];
   const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
   const int n_mine = n_virt > wave ? (n_virt - wave + NWV - 1) / NWV : 0;     // (virtual) entries wave, wave+NWV, ...
   // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
@@ -307,12 +310,8 @@ template <int S, bool PADCHK, bool DUAL, int NWV>
 static int launch_sk2(const ConvArgs& a, hipStream_t s) {
   constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
-  static bool attr_set = false;
   auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-    attr_set = true;
-  }
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + 63) / 64;
   hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(NWV * 64), lds, s, a);
@@ -320,15 +319,13 @@ static int launch_sk2(const ConvArgs& a, hipStream_t s) {
 }
 
 // For 64-row packed layers with a long slab list and a grid that would not fill the chip.
-int launch_conv_mfma_sk(const ConvArgs& a, void* stream) {
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.n_mtiles > kMaxMtiles) return -4;
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
   const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
   // 8-way split only for grids far below one block per CU (7x7 maps at batch 32: measured 16.0 -> 14.7 us) -- at 392
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
-  static const long sk8_blocks = getenv("TF2_AMD_SK8") ? atol(getenv("TF2_AMD_SK8")) : 128;
-  const long n_virt = (long)(a.e_start[1] - a.e_start[0]) * (a.dual ? 2 : 1);
+  const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);
   const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
   if (w8) {
     if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);

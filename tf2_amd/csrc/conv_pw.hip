@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
   // this wave's weights -> registers: entry s of the m-tile is slab s (launcher-checked), [window][TM rows][64 B]
   i32x4 wf[NSLAB][NWIN][2];
   {
-    const int8_t* wt = aw + (size_t)a.e_start[mtile] * (NWIN * TM * 64);
+    const int8_t* wt = aw + (size_t)(mtile * NSLAB) * (NWIN * TM * 64);      // dense layer: m-tile mt owns entries mt*NSLAB ..
     const int row = wr * 32 + (lane & 31);
 #pragma unroll
     for (int s = 0; s < NSLAB; s++)
@@ -182,29 +182,30 @@ static int launch_pw2(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Returns 1 if the layer does not qualify (the caller falls back to conv_mfma2).  `dense` = every m-tile's entry
-// list is exactly slabs 0..nslab-1 (checked by the caller on the host copy of the packed image).
-int launch_conv_pw(const ConvArgs& a, int TM, int nslab, int k, int dense, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+// Does the layer qualify?  `dense` = every m-tile's entry list is exactly slabs 0..nslab-1 (checked by the caller on
+// the host copy of the packed image).
+bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense) {
   const ConvGeom& g = a.g;
-  if (k != 1 || g.stride != 1 || (g.pad_h | g.pad_w) != 0 || g.H * g.W != g.OHW) return 1;
+  if (k != 1 || g.stride != 1 || (g.pad_h | g.pad_w) != 0 || g.H * g.W != g.OHW) return false;
   // two-slab layers (K = 128) measured slower here than in conv_mfma2 (twice the weight registers, half the
-  // occupancy headroom): one slab only for now
-  static const int max_slab = getenv("TF2_AMD_PW_SLABS") ? atoi(getenv("TF2_AMD_PW_SLABS")) : 1;
-  if (nslab > max_slab) return 1;
-  if (!dense || nslab < 1 || nslab > 2 || g.Cp_in != nslab * 64 || a.n_mtiles > kMaxMtiles) return 1;
-  if (a.n_phases > 2 || (a.n_phases == 2 && !a.dual)) return 1;
-  if (a.n_mtiles > 64) return 1;
+  // occupancy headroom): one slab only unless asked
+  const int max_slab = getenv("TF2_AMD_PW_SLABS") ? atoi(getenv("TF2_AMD_PW_SLABS")) : 1;
+  if (nslab > max_slab) return false;
+  if (!dense || nslab < 1 || nslab > 2 || g.Cp_in != nslab * 64) return false;
+  if (a.n_phases > 2 || (a.n_phases == 2 && !a.dual)) return false;
+  return TM == 128 || TM == 64;
+}
+
+int launch_conv_pw(const ConvArgs& a, int TM, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int nslab = a.nslab;
   const bool dual = a.dual != 0;
   if (TM == 128) {
     if (nslab == 1) return dual ? launch_pw2<128, 1, true>(a, s) : launch_pw2<128, 1, false>(a, s);
     return dual ? launch_pw2<128, 2, true>(a, s) : launch_pw2<128, 2, false>(a, s);
   }
-  if (TM == 64) {
-    if (nslab == 1) return dual ? launch_pw2<64, 1, true>(a, s) : launch_pw2<64, 1, false>(a, s);
-    return dual ? launch_pw2<64, 2, true>(a, s) : launch_pw2<64, 2, false>(a, s);
-  }
-  return 1;
+  if (nslab == 1) return dual ? launch_pw2<64, 1, true>(a, s) : launch_pw2<64, 1, false>(a, s);
+  return dual ? launch_pw2<64, 2, true>(a, s) : launch_pw2<64, 2, false>(a, s);
 }
 
 }  // namespace tf2

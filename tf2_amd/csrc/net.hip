@@ -7,6 +7,7 @@
 // stream over NHWC int8 activation tensors that live in a caller-owned workspace.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "tf2_net.h"
 
@@ -48,6 +49,11 @@ tf2_status Net::init(const tf2_net_desc* d, const tf2_layer_desc* ls) {
     const tf2_layer_desc& L = layers[l];
     if (L.src >= l || L.add_src >= l) { set_error("layer " + std::to_string(l) + ": forward reference"); return TF2_ERR_ARG; }
     if (L.N <= 0 || L.N > nd.max_out_channel) { set_error("layer " + std::to_string(l) + ": bad N"); return TF2_ERR_ARG; }
+    // the q table rows Quantization / LoadModel index with this row (quantization.cpp:42-49, model_loader.cpp:159-162)
+    if (L.q_in_row < 0 || L.q_in_row >= nd.n_q_rows) { set_error("layer " + std::to_string(l) + ": q_in_row outside the q table"); return TF2_ERR_ARG; }
+    if (L.C <= 0 || (!L.ipool && L.C > nd.max_out_channel)) { set_error("layer " + std::to_string(l) + ": input channels exceed MAX_OUT_CHANNEL"); return TF2_ERR_ARG; }
+    if (L.n_start < 0 || L.n_start + L.N > nd.max_out_channel) { set_error("layer " + std::to_string(l) + ": n_start + N exceeds MAX_OUT_CHANNEL"); return TF2_ERR_ARG; }
+    if (L.concat >= 0 && nd.n_conv + 1 + L.concat >= nd.n_q_rows) { set_error("layer " + std::to_string(l) + ": concat Q row outside the q table"); return TF2_ERR_ARG; }
     if (L.pool_en && L.add_src >= 0) { set_error("layer " + std::to_string(l) + ": pool + residual in one layer is not supported"); return TF2_ERR_UNSUPPORTED; }
     out_Cp[l] = round_up(L.N, 16);
     InLayout il;
@@ -189,13 +195,152 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           release(wp.tensors[t].offset, wp.tensors[t].bytes); freed[t] = 1;
         }
   }
-  wp.dump_off = (top + 255) / 256 * 256;      // 16 KiB scratch: where masked lanes of conv_mfma_p.hip store
-  wp.total_bytes = wp.dump_off + 16384;
+  wp.total_bytes = (top + 255) / 256 * 256 + 256;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
 
-// ---- run ----------------------------------------------------------------------------
+// ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
+void Net::load_options() {
+  RunOpts o;
+  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 6;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
+  if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
+  if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
+  if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
+  if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
+  opts = o;
+  launch_plans.clear();
+}
+
+// ---- launch plan: every kernel argument block of one step, resolved once per (batch, workspace, packed image) ----
+// Net::run used to rebuild ~60 argument structs, scan the packed directory and read a dozen environment variables
+// per call; at batch 1 (57 launches of a few microseconds) that host work was the step.  Now a step is a loop over
+// prepared launches; only the image and logits pointers change between calls.
+const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
+  for (const LaunchPlan& lp : launch_plans)
+    if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev) return &lp;
+  if (launch_plans.size() >= 16) launch_plans.erase(launch_plans.begin());
+  LaunchPlan lp;
+  lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev;
+  int8_t* base = (int8_t*)ws;
+  const int nl = nd.n_layers;
+  auto T = [&](int id) -> const TensorPlan& { return wp->tensors[id]; };
+  const uint8_t* pk = packed_dev;
+  const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
+  auto fail = [&](const std::string& m) -> const LaunchPlan* { set_error(m); return nullptr; };
+
+  // input: quantise + (space-to-depth) + [x | xneg]
+  {
+    const tf2_layer_desc& L0 = layers[0];
+    Launch st; st.kind = Launch::PREP; st.layer = -1;
+    PrepArgs& pa = st.prep;
+    pa.img = nullptr; pa.y = base + T(wp->input_tensor).offset;
+    pa.B = batch; pa.C = nd.image_c; pa.H = nd.image_h; pa.W = nd.image_w;
+    pa.OH = L0.H; pa.OW = L0.W; pa.y_cp = in_layout[0].Cp_in; pa.half = in_layout[0].half;
+    pa.rewrite = nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = 0;
+    if (!nd.conv1_rewrite && (L0.H != nd.image_h || L0.W != nd.image_w || L0.C != nd.image_c)) return fail("layer 0 input does not match the image");
+    lp.steps.push_back(st);
+  }
+  auto pool_step = [&](int l, const TensorPlan& ti, const int8_t* x, int H, int W) {
+    const tf2_layer_desc& L = layers[l];
+    const LayerExec& E = wp->exec[l];
+    Launch st; st.kind = Launch::POOL; st.layer = l;
+    PoolArgs& pa = st.pool;
+    const TensorPlan& to = T(E.out_tensor);
+    pa.x = x; pa.y = base + to.offset;
+    pa.B = batch; pa.H = H; pa.W = W; pa.x_cp = ti.Cp; pa.x_off = 0;
+    pa.PH = L.PH; pa.PW = L.PW; pa.y_cp = to.Cp; pa.y_off = E.out_off;
+    pa.S = L.pool_S; pa.st = L.pool_st; pa.pad = L.pool_pad; pa.C16 = round_up(L.N, 16) / 16;
+    lp.steps.push_back(st);
+  };
+  for (int l = 0; l < nl; l++) {
+    const tf2_layer_desc& L = layers[l];
+    const LayerExec& E = wp->exec[l];
+    const PackLayer* pl = pack_layer(l);
+    if (L.ipool) {
+      const TensorPlan& ti = T(E.in_tensor);
+      pool_step(l, ti, base + ti.offset, ti.H, ti.W);
+      continue;
+    }
+    Launch st; st.kind = Launch::CONV; st.layer = l;
+    ConvArgs& ca = st.conv;
+    const TensorPlan& ti = T(E.in_tensor); const TensorPlan& tc = T(E.conv_tensor);
+    ca.x = base + ti.offset; ca.y = base + tc.offset;
+    ca.w = (const int8_t*)(pk + pl->off_w); ca.w2 = (const int8_t*)(pk + pl->off_w2);
+    ca.bias = (const int32_t*)(pk + pl->off_bias); ca.alpha = (const int32_t*)(pk + pl->off_alpha);
+    ca.beta = (const int32_t*)(pk + pl->off_beta);
+    ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
+    ca.dual = pl->dual;
+    set_fast_div((uint32_t)pl->n_mtiles, &ca.mt_m, &ca.mt_s);
+    bool dense = false;
+    if (pl->kind == KIND_MFMA) {
+      ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
+      // every m-tile's entry list is slabs 0..nslab-1 (dense weights)?  From the host copy of the image.
+      const int32_t* hd = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
+      dense = true;
+      for (int mt = 0; mt < pl->n_mtiles && dense; mt++)
+        dense = hd[(size_t)mt * (pl->n_phases + 1) + pl->n_phases] - hd[(size_t)mt * (pl->n_phases + 1)] == pl->nslab;
+      ca.ent0 = hd[pl->n_phases] - hd[0];
+    }
+    if (opts.dbg2 && opts.dbg_layer == l) ca.dbg2 = opts.dbg2;
+    if (opts.dbg) ca.dbg = opts.dbg + (size_t)l * 16;
+    ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;
+    ca.k = L.k; ca.dil = L.dil; ca.n_cchunk = pl->n_cchunk; ca.Cp_half = in_layout[l].half;
+    ConvGeom& g = ca.g;
+    g.H = L.H; g.W = L.W; g.Cp_in = ti.Cp;
+    g.OH = L.OH; g.OW = L.OW; g.OHW = L.OH * L.OW;
+    set_fast_div((uint32_t)g.OHW, &g.ohw_m, &g.ohw_s); set_fast_div((uint32_t)g.OW, &g.ow_m, &g.ow_s);
+    g.stride = L.stride; g.pad_h = L.pad_h; g.pad_w = L.pad_w;
+    g.n_pix = batch * L.OH * L.OW;
+    const bool direct = E.conv_tensor == E.out_tensor;
+    g.y_cp = tc.Cp; g.y_off = direct ? E.out_off : 0;
+    g.y_nvalid = round_up(L.N, 16);
+    g.relu = L.relu; g.add_relu = L.add_relu; g.has_res = L.add_src >= 0;
+    g.fast = pl->fast;
+    if (g.has_res) {
+      const TensorPlan& tr = T(E.res_tensor);
+      ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;
+    }
+    g.flags = opts.flags;
+    st.TM = pl->TM; st.signed_in = pl->signed_in; st.mul24 = pl->max_shift <= 22;
+    if (pl->kind == KIND_MFMA) {
+      // small grid + long slab list: the four (or eight) waves of a block split K (conv_mfma_sk.hip)
+      const long blocks64 = (long)((g.n_pix + 63) / 64) * pl->n_mtiles;
+      const bool sk = pl->TM == 64 && opts.sk_mode != 2 &&
+                      (opts.sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
+      st.sel = sk ? Launch::SEL_SK : Launch::SEL_MFMA2;
+      // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
+      if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
+    } else if (pl->kind == KIND_SHIFT) {
+      st.sel = Launch::SEL_SHIFT;
+    } else {
+      return fail("layer " + std::to_string(l) + " has no packed kernel");
+    }
+    lp.steps.push_back(st);
+    if (L.pool_en) {
+      pool_step(l, tc, base + tc.offset, L.OH, L.OW);
+    } else if (L.endpool) {
+      Launch sa; sa.kind = Launch::AVG; sa.layer = l;
+      AvgArgs& aa = sa.avg;
+      const TensorPlan& to = T(E.out_tensor);
+      aa.x = base + tc.offset; aa.y = base + to.offset;
+      aa.B = batch; aa.HW = L.PH * L.PW; aa.x_cp = tc.Cp; aa.x_off = 0;
+      aa.y_cp = to.Cp; aa.y_off = E.out_off; aa.C = round_up(L.N, 16); aa.mult = L.endpool_mult;
+      lp.steps.push_back(sa);
+    }
+  }
+  launch_plans.push_back(std::move(lp));
+  return &launch_plans.back();
+}
+
+size_t Net::logits_bytes(int batch) const {
+  const tf2_layer_desc& LL = layers[nd.n_layers - 1];
+  const size_t hw = LL.endpool ? 1 : (size_t)LL.PH * LL.PW;
+  return (size_t)batch * hw * LL.N;
+}
+
 tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
                     int8_t* logits, void* stream) {
   if (!packed_valid) { set_error("tf2_net_run: no packed image (tf2_net_pack / tf2_net_packed_adopt)"); return TF2_ERR_STATE; }
@@ -211,178 +356,68 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     else wp = a;
   }
   if (ws_bytes < wp->total_bytes) { set_error("tf2_net_run: workspace too small"); return TF2_ERR_SIZE; }
+  const LaunchPlan* lp = launch_plan(batch, wp, ws);
+  if (!lp) return TF2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int8_t* base = (int8_t*)ws;
   const int nl = nd.n_layers;
-  auto T = [&](int id) -> const TensorPlan& { return wp->tensors[id]; };
-  const uint8_t* pk = packed_dev;
-  int flags = 0;
-  if (const char* e = getenv("TF2_AMD_NOSWAP")) flags |= (e[0] == '1');
-  if (const char* e = getenv("TF2_AMD_EXP")) flags |= atoi(e) & 6;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
-  bool mfma_v1 = false;
-  if (const char* e = getenv("TF2_AMD_MFMA_V1")) mfma_v1 = e[0] == '1';
-  // weight-stationary kernel for short-K pointwise layers: measured slower than conv_mfma2 at batch 32-128
-  // on MI355X so far, hence opt-in (TF2_AMD_WS=3 auto, =1 forced with short runs for the tests)
-  int ws_mode = 2;
-  if (const char* e = getenv("TF2_AMD_WS")) ws_mode = atoi(e);
-  // persistent tile-streaming kernel (conv_mfma_p.hip): 0 (default) never, 1 whenever the layer is not a split-K
-  // one, 2 when every resident block gets at least two pixel tiles.  Measured no faster than conv_mfma2 so far:
-  // both are bound by VALU issue (4 cycles per wave64 instruction per SIMD), not by the latency it hides.
-  int p_mode = 0;
-  if (const char* e = getenv("TF2_AMD_P")) p_mode = atoi(e);
-  int pw_mode = 1;          // register-resident pointwise kernel (conv_pw.hip): 1 auto (default), 0 never
-  if (const char* e = getenv("TF2_AMD_PW")) pw_mode = atoi(e);
-  int sk_mode = 0;          // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
-  if (const char* e = getenv("TF2_AMD_SK")) sk_mode = atoi(e);
-  const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
-
-  // input: quantise + (space-to-depth) + [x | xneg]
-  {
-    const tf2_layer_desc& L0 = layers[0];
-    PrepArgs pa{};
-    pa.img = images; pa.y = base + T(wp->input_tensor).offset;
-    pa.B = batch; pa.C = nd.image_c; pa.H = nd.image_h; pa.W = nd.image_w;
-    pa.OH = L0.H; pa.OW = L0.W; pa.y_cp = in_layout[0].Cp_in; pa.half = in_layout[0].half;
-    pa.rewrite = nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = images_are_q ? 1 : 0;
-    if (!nd.conv1_rewrite && (L0.H != nd.image_h || L0.W != nd.image_w || L0.C != nd.image_c)) {
-      set_error("layer 0 input does not match the image"); return TF2_ERR_ARG;
-    }
-    if (launch_prep_input(pa, stream)) { set_error(std::string("prep_input launch: ") + device_last_error()); return TF2_ERR_HIP; }
-  }
 
   hipEvent_t loop0 = nullptr, loop1 = nullptr;
-  if (profiling_loop) {
-    HIP_OK(hipEventCreate(&loop0)); HIP_OK(hipEventCreate(&loop1));
-    HIP_OK(hipEventRecord(loop0, s));
-  }
-  for (int l = 0; l < nl; l++) {
-    const tf2_layer_desc& L = layers[l];
-    const LayerExec& E = wp->exec[l];
-    const PackLayer* pl = pack_layer(l);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (profiling) {
-      HIP_OK(hipEventCreate(&ev0)); HIP_OK(hipEventCreate(&ev1));
-      HIP_OK(hipEventRecord(ev0, s));
-    }
-    if (L.ipool) {
-      PoolArgs pa{};
-      const TensorPlan& ti = T(E.in_tensor); const TensorPlan& to = T(E.out_tensor);
-      pa.x = base + ti.offset; pa.y = base + to.offset;
-      pa.B = batch; pa.H = ti.H; pa.W = ti.W; pa.x_cp = ti.Cp; pa.x_off = 0;
-      pa.PH = L.PH; pa.PW = L.PW; pa.y_cp = to.Cp; pa.y_off = E.out_off;
-      pa.S = L.pool_S; pa.st = L.pool_st; pa.pad = L.pool_pad; pa.C16 = round_up(L.N, 16) / 16;
-      if (launch_maxpool(pa, stream)) { set_error("maxpool launch failed"); return TF2_ERR_HIP; }
-    } else {
-      ConvArgs ca{};
-      const TensorPlan& ti = T(E.in_tensor); const TensorPlan& tc = T(E.conv_tensor);
-      ca.x = base + ti.offset; ca.y = base + tc.offset;
-      ca.w = (const int8_t*)(pk + pl->off_w); ca.w2 = (const int8_t*)(pk + pl->off_w2);
-      ca.entries = (const int32_t*)(pk + pl->off_entries); ca.dir = (const int32_t*)(pk + pl->off_dir);
-      ca.kinfo = (const int32_t*)(pk + pl->off_kinfo);
-      ca.bias = (const int32_t*)(pk + pl->off_bias); ca.alpha = (const int32_t*)(pk + pl->off_alpha);
-      ca.beta = (const int32_t*)(pk + pl->off_beta); ca.lo = (const int32_t*)(pk + pl->off_lo);
-      ca.dshift = (const int32_t*)(pk + pl->off_dshift);
-      ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
-      ca.dump = base + wp->dump_off;
-      ca.dual = pl->dual;
-      set_fast_div((uint32_t)pl->n_mtiles, &ca.mt_m, &ca.mt_s);
-      if (pl->kind == KIND_MFMA) {
-        ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
-        if (pl->n_mtiles <= kMaxMtiles) {
-          const int32_t* hd = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
-          for (int mt = 0; mt < pl->n_mtiles; mt++) ca.e_start[mt] = hd[(size_t)mt * (pl->n_phases + 1)];
-          ca.e_start[pl->n_mtiles] = pl->n_entries;
-        } else {
-          mfma_v1 = true;      // very wide layers: the register-staged kernel has no m-tile limit
-        }
-      }
-      if (const char* e = getenv("TF2_AMD_DBGPTR2")) {
-        const char* el = getenv("TF2_AMD_DBGLAYER");
-        if (el && atoi(el) == l) ca.dbg2 = (long long*)strtoull(e, nullptr, 0);
-      }
-      if (const char* e = getenv("TF2_AMD_DBGPTR")) ca.dbg = (long long*)strtoull(e, nullptr, 0) + (size_t)l * 16;
-      ca.n_phases = pl->n_phases; ca.n_mtiles = pl->n_mtiles; ca.Np = pl->Np; ca.nslab = pl->nslab;
-      ca.k = L.k; ca.dil = L.dil; ca.n_cchunk = pl->n_cchunk; ca.Cp_half = in_layout[l].half;
-      ConvGeom& g = ca.g;
-      g.H = L.H; g.W = L.W; g.Cp_in = ti.Cp;
-      g.OH = L.OH; g.OW = L.OW; g.OHW = L.OH * L.OW;
-      set_fast_div((uint32_t)g.OHW, &g.ohw_m, &g.ohw_s); set_fast_div((uint32_t)g.OW, &g.ow_m, &g.ow_s);
-      g.stride = L.stride; g.pad_h = L.pad_h; g.pad_w = L.pad_w;
-      g.n_pix = batch * L.OH * L.OW;
-      const bool direct = E.conv_tensor == E.out_tensor;
-      g.y_cp = tc.Cp; g.y_off = direct ? E.out_off : 0;
-      g.y_nvalid = round_up(L.N, 16);
-      g.relu = L.relu; g.add_relu = L.add_relu; g.has_res = L.add_src >= 0;
-      g.fast = pl->fast;
-      if (g.has_res) {
-        const TensorPlan& tr = T(E.res_tensor);
-        ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;
-      }
-      g.flags = flags;
-      int rc;
-      if (pl->kind == KIND_MFMA) {
-        // small grid + long slab list: the four waves of a block split K (conv_mfma_sk.hip)
-        const long blocks64 = (long)((g.n_pix + 63) / 64) * pl->n_mtiles;
-        const bool sk = pl->TM == 64 && pl->n_mtiles <= kMaxMtiles && sk_mode != 2 &&
-                        (sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
-        const bool v1 = (mfma_v1 || (flags & 1)) && !pl->dual;      // the register-staged kernel reads single-window tiles
-        if (v1) rc = launch_conv_mfma(ca, pl->TM, stream);
-        else if (pw_mode && L.k == 1 && p_mode == 0 && ws_mode == 2 && sk_mode != 1) {    // no other kernel forced
-          // every m-tile's entry list must be slabs 0..nslab-1 (dense weights): read from the host copy of the image
-          const int32_t* hd = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
-          bool dense = true;
-          for (int mt = 0; mt < pl->n_mtiles && dense; mt++)
-            dense = hd[(size_t)mt * (pl->n_phases + 1) + pl->n_phases] - hd[(size_t)mt * (pl->n_phases + 1)] == pl->nslab;
-          rc = launch_conv_pw(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, stream);
-          if (rc == 1 && sk) rc = launch_conv_mfma_sk(ca, stream);
-        }
-        else if (sk) rc = launch_conv_mfma_sk(ca, stream);
-        else if (pl->dual) rc = 1;                      // dual-window layers: conv_mfma2 / conv_mfma_sk only
-        else if (p_mode == 1 || (p_mode == 2 && (long)((g.n_pix + (pl->TM == 128 ? 127 : 255)) / (pl->TM == 128 ? 128 : 256)) * pl->n_mtiles >= 1024 && pl->n_mtiles <= 64))
-          rc = launch_conv_mfma_p(ca, pl->TM, stream);
-        else rc = 1;
-        if (rc == 1 && !sk && !v1) {
-          rc = (ws_mode == 2 || pl->dual) ? 1 : launch_conv_mfma_ws(ca, pl->TM, stream);     // short-K pointwise layers
-          if (rc == 1) rc = launch_conv_mfma2(ca, pl->TM, stream);
-        }
-      }
-      else if (pl->kind == KIND_SHIFT) rc = launch_conv_shift(ca, pl->signed_in, pl->max_shift <= 22, stream);
-      else { set_error("layer " + std::to_string(l) + " has no packed kernel"); return TF2_ERR_STATE; }
-      if (rc) { set_error("conv launch failed at layer " + std::to_string(l) + ": " + device_last_error()); return TF2_ERR_HIP; }
-      if (L.pool_en) {
-        PoolArgs pa{};
-        const TensorPlan& to = T(E.out_tensor);
-        pa.x = base + tc.offset; pa.y = base + to.offset;
-        pa.B = batch; pa.H = L.OH; pa.W = L.OW; pa.x_cp = tc.Cp; pa.x_off = 0;
-        pa.PH = L.PH; pa.PW = L.PW; pa.y_cp = to.Cp; pa.y_off = E.out_off;
-        pa.S = L.pool_S; pa.st = L.pool_st; pa.pad = L.pool_pad; pa.C16 = round_up(L.N, 16) / 16;
-        if (launch_maxpool(pa, stream)) { set_error("maxpool launch failed"); return TF2_ERR_HIP; }
-      } else if (L.endpool) {
-        AvgArgs aa{};
-        const TensorPlan& to = T(E.out_tensor);
-        aa.x = base + tc.offset; aa.y = base + to.offset;
-        aa.B = batch; aa.HW = L.PH * L.PW; aa.x_cp = tc.Cp; aa.x_off = 0;
-        aa.y_cp = to.Cp; aa.y_off = E.out_off; aa.C = round_up(L.N, 16); aa.mult = L.endpool_mult;
-        if (launch_global_avg(aa, stream)) { set_error("global_avg launch failed"); return TF2_ERR_HIP; }
-      }
-    }
-    if (profiling) {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int ev_layer = -2;
+  auto close_layer_event = [&]() -> tf2_status {
+    if (ev_layer >= 0) {
       HIP_OK(hipEventRecord(ev1, s));
       prof_events.emplace_back((void*)ev0, (void*)ev1);
-      prof_event_layer.push_back(l);
+      prof_event_layer.push_back(ev_layer);
+      ev_layer = -2;
     }
+    return TF2_OK;
+  };
+  for (const Launch& st : lp->steps) {
+    if (profiling && st.layer != ev_layer) {            // one event pair per layer (conv + its pool / average)
+      if (tf2_status e = close_layer_event()) return e;
+      if (st.layer >= 0) {
+        HIP_OK(hipEventCreate(&ev0)); HIP_OK(hipEventCreate(&ev1));
+        HIP_OK(hipEventRecord(ev0, s));
+        ev_layer = st.layer;
+      }
+    }
+    if (profiling_loop && st.layer == 0 && !loop0) {
+      HIP_OK(hipEventCreate(&loop0)); HIP_OK(hipEventCreate(&loop1));
+      HIP_OK(hipEventRecord(loop0, s));
+    }
+    int rc = 0;
+    switch (st.kind) {
+      case Launch::PREP: {
+        PrepArgs pa = st.prep; pa.img = images; pa.src_is_q = images_are_q ? 1 : 0;
+        rc = launch_prep_input(pa, stream);
+        break;
+      }
+      case Launch::POOL: rc = launch_maxpool(st.pool, stream); break;
+      case Launch::AVG: rc = launch_global_avg(st.avg, stream); break;
+      case Launch::CONV:
+        switch (st.sel) {
+          case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
+          case Launch::SEL_SK: rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream); break;
+          case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
+          default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
+        }
+        break;
+    }
+    if (rc) { set_error("kernel launch failed at layer " + std::to_string(st.layer) + ": " + device_last_error()); return TF2_ERR_HIP; }
   }
-  if (profiling_loop) {
+  if (profiling) { if (tf2_status e = close_layer_event()) return e; }
+  if (profiling_loop && loop0) {
     HIP_OK(hipEventRecord(loop1, s));
     prof_events.emplace_back((void*)loop0, (void*)loop1);
     prof_event_layer.push_back(-1);
   }
-  // dense logits [batch][N_last]
+  // dense logits [batch][H_last * W_last][N_last]  (H = W = 1 for the classification networks)
   if (logits) {
-    const TensorPlan& tf = T(wp->final_tensor);
+    const TensorPlan& tf = wp->tensors[wp->final_tensor];
     const tf2_layer_desc& LL = layers[nl - 1];
     const size_t rows = (size_t)batch * tf.H * tf.W;
-    HIP_OK(hipMemcpy2DAsync(logits, (size_t)LL.N, base + tf.offset + wp->exec[nl - 1].out_off, (size_t)tf.Cp,
+    HIP_OK(hipMemcpy2DAsync(logits, (size_t)LL.N, (const int8_t*)ws + tf.offset + wp->exec[nl - 1].out_off, (size_t)tf.Cp,
                             (size_t)LL.N, rows, hipMemcpyDeviceToDevice, s));
   }
   return TF2_OK;
@@ -400,7 +435,7 @@ void Net::drain_profile() {
         prof_launches[prof_event_layer[i]] += 1;
       }
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
   prof_events.clear(); prof_event_layer.clear();
 }

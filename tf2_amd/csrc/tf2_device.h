@@ -34,4 +34,16 @@ __device__ __forceinline__ int fast_div_u(int n, unsigned m, int s) {
   return s < 0 ? n : (int)(__umulhi((unsigned)n, m) >> s);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB for a kernel, once per (function, device): a process driving
+// several GPUs must set it on each of them.
+inline bool lds_attr_once(const void* fn) {
+  static thread_local const void* seen_fn[64]; static thread_local int seen_dev[64]; static thread_local int n_seen = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  for (int i = 0; i < n_seen; i++) if (seen_fn[i] == fn && seen_dev[i] == dev) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  if (n_seen < 64) { seen_fn[n_seen] = fn; seen_dev[n_seen] = dev; n_seen++; }
+  return true;
+}
+
 }  // namespace tf2

@@ -11,8 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 15;
-constexpr int kMaxMtiles = 64;       // m-tiles per layer the LDS-DMA kernel takes through its kernarg table
+constexpr uint32_t kPackVersion = 16;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -72,7 +71,7 @@ struct ConvGeom {
   int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
   int32_t relu, add_relu, has_res;
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
-  int32_t flags;             // bit0: no permlane swap in the epilogue (debug)
+  int32_t flags;             // bits 1,2: conv_mfma2 block-shape A/B switches (TF2_AMD_EXP)
 };
 
 // n / d for 0 <= n < 2^31 as one 32x32->hi multiply and a shift: L = ceil(log2 d), m = floor(2^(31+L) / d) + 1,
@@ -92,23 +91,19 @@ struct ConvArgs {
   const int8_t* res;
   const int8_t* w;           // MFMA: int8 tiles; SHIFT: int32 weights
   const int8_t* w2;          // SHIFT signed: negative magnitudes
-  const int32_t* entries;
-  const int32_t* dir;
-  const int32_t* kinfo;      // one word per 16-byte segment
-  const int32_t* bias;
+  const int32_t* bias;       // SHIFT kernel: per-channel BiasBnParam (the MFMA kernels read their LDS header)
   const int32_t* alpha;
   const int32_t* beta;
-  const int32_t* lo;
-  const int32_t* dshift;
   const int8_t* zero;        // >= 16 zero bytes (LDS-DMA source for padded / out-of-range taps)
   long long* dbg;            // optional: 16 timestamps of block 0 (tools/layer_times.py), else null
-  int8_t* dump;              // 16 KiB of writable scratch for masked stores (conv_mfma_p.hip)
   long long* dbg2;           // optional: per-block {start, end, hw id, xcc id} of one chosen layer
   const int32_t* hdr;        // per-m-tile LDS header images
   int32_t hdr_bytes;
   int32_t dual;              // PackLayer::dual
   uint32_t mt_m; int32_t mt_s; // set_fast_div(n_mtiles): block id -> (pixel tile, channel tile) without a division
-  int32_t e_start[kMaxMtiles + 1];   // first entry of every m-tile (+ end)
+  int32_t ent0;              // entries of m-tile 0 (launch heuristics; every block reads its own {first, end} entry from
+                             // the last two words of its header's steps[] table -- no per-m-tile table in the kernarg:
+                             // a 680-byte kernarg costs ~0.8 us more per launch than a 300-byte one, tools/ubench/launch_cost)
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;
   int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split
@@ -137,12 +132,10 @@ struct PrepArgs {
 };
 
 // kernel launchers (tf2_kernels.hip)
-int launch_conv_mfma(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
-int launch_conv_mfma_sk(const ConvArgs& a, void* stream);
-int launch_conv_pw(const ConvArgs& a, int TM, int nslab, int k, int dense, void* stream);   // register-resident pointwise kernel
-int launch_conv_mfma_p(const ConvArgs& a, int TM, void* stream);    // persistent tile-streaming kernel
-int launch_conv_mfma_ws(const ConvArgs& a, int TM, void* stream);   // returns 1 if the layer does not qualify
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
+bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
+int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);

@@ -31,7 +31,33 @@ struct WorkPlan {
   int input_tensor = -1;
   int final_tensor = -1;
   size_t total_bytes = 0;
-  size_t dump_off = 0;        // 16 KiB scratch for masked stores (conv_mfma_p.hip)
+};
+
+// One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
+struct Launch {
+  enum Kind { PREP, CONV, POOL, AVG } kind = CONV;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT } sel = SEL_MFMA2;
+  int layer = -1;
+  int TM = 0, signed_in = 0, mul24 = 0;
+  ConvArgs conv{};
+  PoolArgs pool{};
+  AvgArgs avg{};
+  PrepArgs prep{};
+};
+
+struct LaunchPlan {
+  int batch = 0;
+  const WorkPlan* wp = nullptr;
+  void* ws = nullptr;
+  const uint8_t* packed_dev = nullptr;
+  std::vector<Launch> steps;
+};
+
+struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
+  int flags = 0;           // ConvGeom::flags
+  int pw_mode = 1, sk_mode = 0;
+  long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
+  long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };
 
 struct Net {
@@ -55,6 +81,8 @@ struct Net {
   std::vector<int> concat_C;             // channels of each concat tensor
 
   std::map<std::pair<int, int>, WorkPlan> plans;   // (batch, keep_all) -> plan
+  std::vector<LaunchPlan> launch_plans;            // prepared steps, keyed by (batch, plan, workspace, packed image)
+  RunOpts opts;
 
   // profiling
   bool profiling = false;
@@ -73,6 +101,9 @@ struct Net {
   const PackLayer* pack_layer(int l) const;
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
+  const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws);
+  void load_options();
+  size_t logits_bytes(int batch) const;
   tf2_status run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
                  int8_t* logits, void* stream);
   tf2_status read_layer(int layer, int batch, const void* ws, int8_t* dst, size_t cap, void* stream);

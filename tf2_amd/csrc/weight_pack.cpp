@@ -171,7 +171,7 @@ tf2_status Net::pack(int mode) {
       // slab that is non-zero in either window, holding [hi window TM x 64][lo window TM x 64].  The kernels then
       // fetch each activation slab once, keep two accumulators and combine them once at the end,
       // (hi << dshift[1]) + lo -- exact in Z/2^32 like the Horner form -- which halves the K steps.
-      const bool dual = P == 2 && n_mtiles <= kMaxMtiles && getenv("TF2_AMD_NODUAL") == nullptr && getenv("TF2_AMD_MFMA_V1") == nullptr;
+      const bool dual = P == 2 && getenv("TF2_AMD_NODUAL") == nullptr;
       pl.dual = dual ? 1 : 0;
       std::vector<int32_t> dir((size_t)n_mtiles * (P + 1), 0);
       std::vector<int32_t> entries;
@@ -211,7 +211,7 @@ tf2_status Net::pack(int mode) {
         }
         pl.max_ent = std::max<int32_t>(pl.max_ent, dir[(size_t)mt * (P + 1) + P] - dir[(size_t)mt * (P + 1)]);
       }
-      pl.max_ent = round_up(std::max(pl.max_ent, 1) + 8 + P, 4);   // + spare entries the kernels may read ahead (8-way split-K), + phase table
+      pl.max_ent = round_up(std::max(pl.max_ent, 1) + 8 + P + 2, 4);   // + spare entries the kernels may read ahead (8-way split-K), + phase table, + {first, end} entry
       // ---- kinfo ----
       // one 32-bit word per 16-byte segment: coff (16 bits, 0xffff = padding) | dh << 16 | dw << 24
       std::vector<int32_t> kinfo((size_t)nslab * 4, 0);
@@ -248,9 +248,8 @@ tf2_status Net::pack(int mode) {
       // words: per row {bias, alpha, beta64.lo, beta64.hi} (4*TM; beta64 = (int64)beta << 20, the addend of the
       //        64-bit multiply-add; one 16-byte read per output row) | lo[TM] | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
       //        the entry) | goff[max_ent][4] (per 16-byte segment: byte offset from the pixel's tap origin,
-      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test) | eslot[max_ent] (entry ->
-      //        index of its slab among the m-tile's DISTINCT slabs) | dfirst[max_ent] (distinct index -> an entry
-      //        using that slab); steps[max_ent-1] = number of distinct slabs (conv_mfma_ws.hip)
+      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test);
+      //        steps[max_ent-2], steps[max_ent-1] = the m-tile's first and end entry (scalar-loaded by every block)
       // ---- range proof for the fast requantisation (requant_epilogue.h) ----
       // With |x| <= 128, |sum| <= amax[n] = 128 * sum |w|.  If for every row  amax + |bias| < 2^31  (no int32 wrap
       // of v = bias + (acc << lo)),  |alpha| << lo < 2^31,  and  (amax + |bias|) * |alpha| + (|beta| << 20) + 2^34 <
@@ -272,7 +271,7 @@ tf2_status Net::pack(int mode) {
       }
       pl.fast = fast ? 1 : 0;
       {
-        const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)11 * pl.max_ent;
+        const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)9 * pl.max_ent;
         const size_t hb = (words * 4 + 1023) / 1024 * 1024;
         pl.hdr_bytes = hb;
         pl.off_hdr = blob.alloc(hb * n_mtiles);
@@ -304,17 +303,7 @@ tf2_status Net::pack(int mode) {
           for (int i = 0; i < pl.max_ent; i++) hs[i] = 0x7fffffff;
           if (!dual) for (int p = 1; p < P; p++) hs[p - 1] = dir[(size_t)mt * (P + 1) + p] - e0;
           for (int i = 0; i < pl.max_ent * 4; i++) { ko[i] = -1; kh[i] = 0; }
-          int32_t* es = kh + 4 * pl.max_ent;
-          int32_t* df = es + pl.max_ent;
-          std::vector<int> dist;                              // distinct slabs of this m-tile, first-use order
-          for (int e = e0; e < e1; e++) {
-            const int sl = entries[e];
-            size_t j = 0;
-            while (j < dist.size() && dist[j] != sl) j++;
-            if (j == dist.size()) { dist.push_back(sl); df[j] = e - e0; }
-            es[e - e0] = (int32_t)j;
-          }
-          hs[pl.max_ent - 1] = (int32_t)dist.size();
+          hs[pl.max_ent - 2] = e0; hs[pl.max_ent - 1] = e1;
           for (int e = e0; e < e1; e++) {
             const int sl = entries[e];
             for (int sg = 0; sg < 4; sg++) {

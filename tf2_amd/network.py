@@ -167,6 +167,10 @@ class NetWork:
         _lib.check(_lib.lib().tf2_net_bind_device(self._h, packed_dev.data_ptr(), packed_dev.numel()))
         self.device = packed_dev.device
 
+    def reload_options(self):
+        """Re-read the TF2_AMD_* run-time switches from the environment (sampled at creation otherwise)."""
+        _lib.check(_lib.lib().tf2_net_reload_options(self._h))
+
     def workspace_size(self, batch: int, keep_all: bool = False) -> int:
         return int(_lib.lib().tf2_net_workspace_size(self._h, batch, int(keep_all)))
 
@@ -191,10 +195,14 @@ class Runner:
         import torch
         net = self.network
         if self._ws is None or self._ws_batch != (batch, keep_all):
+            self._split = None
             size = net.workspace_size(batch, keep_all)
             self._ws = torch.empty(max(size, 256), dtype=torch.uint8, device=net.device)
             self._ws_batch = (batch, keep_all)
-            self._logits = torch.empty((batch, net.plan[-1].N), dtype=torch.int8, device=net.device)
+            nbytes = int(_lib.lib().tf2_net_logits_size(net._h, batch))       # [batch][H_last*W_last][N_last]
+            N = net.plan[-1].N
+            self._logits = torch.empty((batch, N) if nbytes == batch * N else (batch, nbytes // (batch * N), N),
+                                       dtype=torch.int8, device=net.device)
 
     def run_batch(self, images, keep_all: bool = False):
         """images: torch tensor on the network's device, float32 [B,C,H,W] (preprocessed
@@ -212,20 +220,55 @@ class Runner:
                       self._logits.data_ptr(), stream))
         return self._logits
 
-    def capture(self, images):
+    def run_split(self, images, parts: int = 2):
+        """One batch as `parts` sub-batches on concurrent HIP streams (fork from / join to the current stream): the
+        small-map layers of a batch are bound by their own launch-to-drain latency, not by throughput, so two halves
+        interleave on the GPU.  Same logits tensor [B, N_last] as run_batch; images are independent, so the result
+        is bit-identical (tests/test_gpu_configs.py)."""
+        import torch
+        net = self.network
+        B = images.shape[0]
+        parts = max(1, min(parts, B))
+        if parts == 1:
+            return self.run_batch(images)
+        if getattr(self, "_split", None) is None or self._split[0] != (B, parts):
+            bounds = [((B * i) // parts, (B * (i + 1)) // parts) for i in range(parts)]
+            nbytes = int(_lib.lib().tf2_net_logits_size(net._h, B)); N = net.plan[-1].N
+            logits = torch.empty((B, N) if nbytes == B * N else (B, nbytes // (B * N), N), dtype=torch.int8, device=net.device)
+            subs = []
+            for lo, hi in bounds:
+                r = Runner(None, net)
+                r._ensure(hi - lo, False)
+                r._logits = logits[lo:hi]                  # contiguous rows of the shared output
+                subs.append((r, torch.cuda.Stream(device=net.device), lo, hi))
+            self._split = ((B, parts), subs, logits)
+        _, subs, logits = self._split
+        cur = torch.cuda.current_stream(net.device)
+        fork = torch.cuda.Event(); fork.record(cur)
+        for r, st, lo, hi in subs:
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                r.run_batch(images[lo:hi])
+                join = torch.cuda.Event(); join.record(st)
+            cur.wait_event(join)
+        self._logits = logits
+        return logits
+
+    def capture(self, images, split: int = 1):
         """Capture one run_batch(images) into a HIP graph (launch-bound small batches: the ~57
         launches of a step replay as one graph launch).  `images` is a static input buffer: refill
         it in place, call the returned function, read `self._logits`."""
         import torch
         net = self.network
-        self.run_batch(images)                      # warm-up: lazy attribute setup must not be captured
+        step = (lambda: self.run_split(images, split)) if split > 1 else (lambda: self.run_batch(images))
+        step()                                      # warm-up: lazy attribute setup must not be captured
         torch.cuda.synchronize(net.device)
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=net.device)
         side.wait_stream(torch.cuda.current_stream(net.device))
         with torch.cuda.stream(side):
             with torch.cuda.graph(g, stream=side):
-                self.run_batch(images)
+                step()
         torch.cuda.current_stream(net.device).wait_stream(side)
         self._graph = g
         return g.replay
@@ -276,32 +319,59 @@ def LoadInputImage(image_name, C=3, H=224, W=224) -> np.ndarray:
     return a.reshape(C, H, W)
 
 
-def Evaluation(n: int, q: np.ndarray, output: np.ndarray, k: int = 5):
-    """network_helper.cpp:143-207: dequantise frame n's logits with the last Q row, top-k
-    with the reference's tie rule, softmax probability.  Returns (labels, probabilities)."""
-    logits = np.ascontiguousarray(output[n], np.int8)
-    q_last = np.ascontiguousarray(q[-1] if q.ndim == 2 and q.shape[0] == 1 else q, np.int8).ravel()
+def _last_q_row(q: np.ndarray, num_layer: Optional[int], n_out: int) -> np.ndarray:
+    """The reference passes the WHOLE q table and indexes q[NUM_LAYER * MAX_OUT_CHANNEL + n]
+    (main.cpp:52-53, network_helper.cpp:127,181): row NUM_LAYER = the Q of the last layer's
+    output.  A 1-D array is taken as that row itself."""
+    q = np.asarray(q)
+    if q.ndim == 2:
+        if num_layer is None:
+            raise ValueError("a 2-D q table needs num_layer (the reference indexes row NUM_LAYER)")
+        row = q[num_layer]
+    elif q.ndim == 1:
+        row = q
+    else:
+        raise ValueError("q must be the [NUM_Q_LAYERS][MAX_OUT_CHANNEL] table or its last-layer row")
+    if row.size < n_out:
+        raise ValueError(f"q row has {row.size} channels, the output {n_out}")
+    return np.ascontiguousarray(row[:n_out], np.int8)
+
+
+def Evaluation(n: int, q: np.ndarray, output: np.ndarray, k: int = 5, num_layer: Optional[int] = None):
+    """network_helper.cpp:143-207: dequantise frame n's logits with the last layer's Q row
+    (q = the full table + num_layer = NUM_LAYER, as main.cpp:53 passes it, or that row alone),
+    top-k with the reference's tie rule, softmax probability.  Returns (labels, probabilities)."""
+    logits = np.ascontiguousarray(output[n], np.int8).ravel()
+    q_last = _last_q_row(q, num_layer, logits.size)
     labels = np.empty(k, np.int32)
     feats = np.empty(k, np.float32)
     _lib.check(_lib.lib().tf2_topk(logits.ctypes.data, q_last.ctypes.data, logits.size, k, labels.ctypes.data, feats.ctypes.data))
-    trans = (1 << (-q_last[:logits.size].astype(np.int32))).astype(np.float32)
+    trans = (1 << (-q_last.astype(np.int32))).astype(np.float32)
     f = logits.astype(np.float32) / trans
     sum_exp = np.float32(0)
-    for v in f:                                # float accumulation order of the reference (:187)
-        sum_exp = np.float32(sum_exp + np.exp(np.float32(v)))
-    probs = np.exp(feats.astype(np.float32)) / sum_exp
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        for v in f:                                # float accumulation order of the reference (:187)
+            sum_exp = np.float32(sum_exp + np.exp(np.float32(v)))
+        probs = np.exp(feats.astype(np.float32)) / sum_exp
     return labels.tolist(), probs.tolist()
 
 
-def Verify(n: int, file_name, q_last: np.ndarray, output: np.ndarray) -> float:
-    """network_helper.cpp:18-141: relative L1 error of frame n's int8 output against the
-    golden float tensor scaled by 2^Q."""
+def Verify(n: int, file_name, q: np.ndarray, output: np.ndarray, num_layer: Optional[int] = None) -> float:
+    """network_helper.cpp:18-141: relative L1 error of frame n's int8 output against the golden
+    float tensor scaled by 2^Q.  output[n] is [N] or NHWC [H*W][N]; the golden file is the
+    reference's [N][H][W] float tensor; the per-CHANNEL factor 1 << -q[NUM_LAYER][c] (:127) is
+    repeated over the H*W positions."""
     expect = np.fromfile(file_name, dtype=np.float32) if isinstance(file_name, (str, os.PathLike)) else np.asarray(file_name, np.float32)
-    out = output[n].astype(np.float32).ravel()
-    expect = expect.ravel()[:out.size]
-    trans = (1 << (-np.asarray(q_last, np.int32).ravel()[:out.size])).astype(np.float32)
-    total_error = np.float32(0); total_expect = np.float32(0)
-    et = expect * trans
+    out = np.asarray(output[n])
+    if out.ndim == 1:
+        out = out[None, :]
+    hw, N = out.shape[0] * int(np.prod(out.shape[1:-1], dtype=np.int64)), out.shape[-1]
+    out = out.reshape(hw, N).astype(np.float32)
+    q_last = _last_q_row(q, num_layer, N)
+    trans = (1 << (-q_last.astype(np.int32))).astype(np.float32)            # per channel
+    if expect.size < N * hw:
+        raise ValueError(f"golden tensor has {expect.size} values, the output {N * hw}")
+    et = expect.ravel()[:N * hw].reshape(N, hw).T * trans[None, :]         # [hw][N], channel-wise scale
     total_error = np.abs(et - out).astype(np.float32).sum(dtype=np.float32)
     total_expect = np.abs(et).astype(np.float32).sum(dtype=np.float32)
     return float(total_error / total_expect) if total_expect else float("inf")
