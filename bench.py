@@ -208,6 +208,39 @@ def main():
         serial[0] = False
         serial_value = round(world * args.batch * args.steps / d1, 1)
 
+    # ---- evidence for the batches-in-flight figure: GPU timestamps (HIP events on each step's own stream, against one
+    #      common base event) of when every step starts and ends.  rocprofv3's kernel trace serialises the dispatches of
+    #      different streams (profiles/r02_overlap_inflight3_rocprof.json: overlap factor 1.0 under the tracer), so the
+    #      overlap is shown here instead: a step's latency is ~n_inflight x the interval at which steps complete.
+    pipe = None
+    if n_inflight > 1 and rank == 0:
+        base_ev = torch.cuda.Event(enable_timing=True)
+        evs = []
+        torch.cuda.synchronize(device)
+        base_ev.record(torch.cuda.current_stream(device))
+        for st in fl_streams:
+            st.wait_event(base_ev)
+        n_ev = 30
+        for k in range(n_ev):
+            i = k % n_inflight
+            with torch.cuda.stream(fl_streams[i]):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(fl_streams[i])
+                one(fl_runners[i], x)
+                e1.record(fl_streams[i])
+            evs.append((e0, e1))
+        torch.cuda.synchronize(device)
+        t0s = np.asarray([base_ev.elapsed_time(a) for a, _ in evs]) * 1e3
+        t1s = np.asarray([base_ev.elapsed_time(b) for _, b in evs]) * 1e3
+        keep = slice(n_inflight * 2, None)                   # steady state
+        lat_us = float(np.mean((t1s - t0s)[keep]))
+        interval_us = float((t1s[-1] - t1s[n_inflight * 2]) / (n_ev - 1 - n_inflight * 2))
+        # steps whose [start, end] GPU intervals contain the end time of step k (concurrently resident batches)
+        resident = float(np.mean([np.sum((t0s < t1s[k]) & (t1s >= t1s[k])) for k in range(n_inflight * 2, n_ev)]))
+        pipe = dict(step_latency_us=round(lat_us, 1), completion_interval_us=round(interval_us, 1),
+                    latency_over_interval=round(lat_us / interval_us, 2), steps_resident_when_one_completes=round(resident, 2),
+                    note="HIP-event GPU timestamps per step on its own stream; serial execution would give latency == interval")
+
     sweep = {}
     for b in [int(v) for v in args.extra_batches.split(",") if v.strip()]:
         if b == args.batch:
@@ -341,7 +374,7 @@ def main():
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
                     per_layer_class=per_class, images_per_s_by_batch=sweep,
-                    images_per_s_one_batch_at_a_time=serial_value, latency_batch1=lat)
+                    images_per_s_one_batch_at_a_time=serial_value, latency_batch1=lat, pipeline_evidence=pipe)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

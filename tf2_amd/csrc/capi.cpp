@@ -76,10 +76,7 @@ tf2_status tf2_model4bit_decode(const void* bytes, size_t n_bytes, float* floats
 tf2_status tf2_net_load_model_4bit(tf2_net* net, const void* bytes, size_t n_bytes) {
   CHECK_NET(net);
   if (!bytes) { set_error("tf2_net_load_model_4bit: null input"); return TF2_ERR_ARG; }
-  std::vector<float> out;
-  const std::string err = tf2::model4bit_decode((const uint8_t*)bytes, n_bytes, &out, nullptr);
-  if (!err.empty()) { set_error(err); return TF2_ERR_ARG; }
-  return net->impl.load_model(out.data(), out.size());
+  return net->impl.load_model_4bit((const uint8_t*)bytes, n_bytes);
 }
 
 tf2_status tf2_net_get_codes(const tf2_net* net, int layer, uint8_t* codes, size_t capacity, size_t* n_bytes) {

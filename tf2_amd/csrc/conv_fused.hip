@@ -15,8 +15,11 @@
 //              usual epilogue with the residual tile (feature_writer.cl:119-122), 16-byte NHWC stores.
 //
 // All four residual tiles are prefetched into registers before phase 1 (they are the oldest entries of the VMEM queue,
-// as in conv_mfma2).  vmcnt retires in issue order across loads and stores on this hardware (tools/ubench/vmcnt_order),
-// so the counted waits of phase 2 include the stores of earlier passes; the counts are compile-time (fully unrolled).
+// as in conv_mfma2); a pass's packed output replaces its residual tile in the same registers and all stores are issued
+// after the last pass, so the counted vmcnt waits of phase 2 only ever see LDS-DMA loads (which retire in order).  A
+// first version stored after every pass and counted the stores in the waits: bit-exact at small batch, wrong under
+// load -- stores may retire ahead of older loads.  The ring is DEEP (5-6 stages where LDS allows): a block walks its
+// 18-36 K steps alone, and a step costs one DMA latency divided by the stages in flight.
 // Arithmetic is bit-identical to running conv_mfma2 twice: same accumulators, same requantisation, and the intermediate
 // is the same int8 tensor (with keep_mid it is also written to HBM so that per-layer parity tests see it).
 #include <hip/hip_runtime.h>
@@ -63,8 +66,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_fused_
   constexpr int NI_LO = NG / NW, REM = NG % NW, NI_HI = NI_LO + (REM ? 1 : 0);
   constexpr int AG2 = A2_BYTES / 1024;
   constexpr int NI2_LO = AG2 / NW, REM2 = AG2 % NW, NI2_HI = NI2_LO + (REM2 ? 1 : 0);
-  constexpr int NST = NTM * NTN;                         // stores per wave per pass
-  static_assert((S - 2) * NI_HI <= 15 && S >= 2, "ring depth");
+  static_assert((S - 2) * NI_HI <= 63 && S >= 2, "ring depth");
   constexpr int MID_BYTES = TN * TM;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [ring S*STAGE][mid TN*TM][header of A (hdr_bytes)][4 headers of B (hdr2_used each)]
@@ -403,14 +405,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_fused_
   auto step2 = [&](auto t_c) {
     constexpr int t = decltype(t_c)::value;
     constexpr int mt = t / NSL2, s = t % NSL2;
-    // VMEM operations younger than this step's weight DMA: the DMAs of the following in-flight steps and the stores of the
-    // passes that finished since it was issued (steps v in [t-S+1, t-1] with v % NSL2 == NSL2-1)
+    // VMEM operations younger than this step's weight DMA: the DMAs of the following in-flight steps (nothing else is
+    // issued during phase 2)
     constexpr int last_issued = (t + S - 2) < (NT2 - 1) ? (t + S - 2) : (NT2 - 1);
     constexpr int n_dma_after = last_issued - t;
-    constexpr int v_lo = (t - S + 1) > 0 ? (t - S + 1) : 0;
-    // count of v in [v_lo, t-1] with (v + 1) % NSL2 == 0  ==  floor(t / NSL2) - floor(v_lo / NSL2)
-    constexpr int n_epi = t / NSL2 - v_lo / NSL2;
-    if (ni2_hi) fz_wait_vmcnt<n_dma_after * NI2_HI + n_epi * NST>(); else fz_wait_vmcnt<n_dma_after * NI2_LO + n_epi * NST>();
+    if (ni2_hi) fz_wait_vmcnt<n_dma_after * NI2_HI>(); else fz_wait_vmcnt<n_dma_after * NI2_LO>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int8_t* A = lds + (t % S) * STAGE;
@@ -433,7 +432,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_fused_
       }
     }
     if (t + S - 1 < NT2) issue2(t + S - 1);
-    asm volatile("" ::: "memory");          // the DMA issue stays ahead of this pass's stores in program order
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -467,20 +465,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_fused_
 #pragma unroll
         for (int i = 0; i < NTM; i++) {
           const int rb = wm * WTM + i * 32;
-          const int chl = mt * TM + rb + 16 * half;
 #pragma unroll
           for (int j = 0; j < NTN; j++) {
-            const int px = px0 + wn * WTN + j * 32 + (lane & 31);
             int a16[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-            const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, pm, TM, rb + 4 * half, lo_bound2, rlo, resv[mt][i][j]);
-            // every wave issues exactly NST store instructions per pass (the vmcnt bookkeeping above relies on it): lanes
-            // outside the tensor write their 16 bytes to a 1 KiB scratch area of the workspace instead of being masked,
-            // so that a fully out-of-range wave still issues the instruction
-            const bool ok = px < g.n_pix && chl + 16 <= f.y2_nvalid;
-            int8_t* dst = ok ? ay2 + (size_t)px * f.y2_cp + f.y2_off + chl : f.dump + lane * 16;
-            *reinterpret_cast<i32x4*>(dst) = out;
+            // the packed 16 output bytes take the place of the residual tile; stored after the last pass
+            resv[mt][i][j] = requant_tile16<HAS_RES, 0, FAST>(a16, pm, TM, rb + 4 * half, lo_bound2, rlo, resv[mt][i][j]);
           }
         }
       };
@@ -496,6 +487,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_fused_
   };
   // fully unrolled: every step has its own compile-time wait count
   fz_static_for<0, NT2>(step2);
+  // ---- all stores: 16 contiguous NHWC bytes per lane and tile ----
+#pragma unroll
+  for (int mt = 0; mt < kFusedPasses; mt++)
+#pragma unroll
+    for (int i = 0; i < NTM; i++)
+#pragma unroll
+      for (int j = 0; j < NTN; j++) {
+        const int px = px0 + wn * WTN + j * 32 + (lane & 31);
+        const int chl = mt * TM + wm * WTM + i * 32 + 16 * half;
+        if (px < g.n_pix && chl + 16 <= f.y2_nvalid)
+          *reinterpret_cast<i32x4*>(ay2 + (size_t)px * f.y2_cp + f.y2_off + chl) = resv[mt][i][j];
+      }
 }
 
 template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DUAL2>
@@ -535,26 +538,27 @@ static size_t fused_lds(const FusedArgs& f, int TM, int TN, int S) {
   return conv_fused_lds_bytes(TM, TN, S, f.a.dual, f.dual2, (size_t)f.a.hdr_bytes, (size_t)f.hdr2_used);
 }
 
-// TM = layer A's padded output channels (64 / 128 / 256).  `shape`: 0 = wide pixel tile (wave tile 32 x 64), 1 = narrow
-// (wave tile 32 x 32: twice the blocks, for small maps).  Returns 1 if no instantiation fits (caller runs the two layers unfused).
+// TM = layer A's padded output channels (128 / 256; 64-channel pairs run faster unfused -- conv_pw takes their expand
+// layer).  `shape`: 0 = wide pixel tile (wave tile 32 x 64), 1 = narrow (32 x 32: twice the blocks, for small maps).  The
+// deepest ring that fits the 160 KiB of LDS is used.  Returns 1 if no instantiation fits.
 int launch_conv_fused(const FusedArgs& f, int TM, int shape, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   constexpr size_t kLds = 160 * 1024;
-  if (TM == 64) {
-    if (shape == 0) return fused_lds(f, 64, 256, 3) <= kLds ? launch_fused_shape<2, 4, 32, 64, 3, 1>(f, s) : 1;
-    return fused_lds(f, 64, 128, 3) <= kLds ? launch_fused_shape<2, 4, 32, 32, 3, 2>(f, s) : 1;
-  }
   if (TM == 128) {
-    if (shape == 0) return fused_lds(f, 128, 128, 3) <= kLds ? launch_fused_shape<4, 2, 32, 64, 3, 1>(f, s) : 1;
+    if (shape == 0) {
+      if (fused_lds(f, 128, 128, 5) <= kLds) return launch_fused_shape<4, 2, 32, 64, 5, 1>(f, s);
+      return fused_lds(f, 128, 128, 3) <= kLds ? launch_fused_shape<4, 2, 32, 64, 3, 1>(f, s) : 1;
+    }
+    if (fused_lds(f, 128, 64, 5) <= kLds) return launch_fused_shape<4, 2, 32, 32, 5, 1>(f, s);
     return fused_lds(f, 128, 64, 3) <= kLds ? launch_fused_shape<4, 2, 32, 32, 3, 1>(f, s) : 1;
   }
   if (TM == 256) {
     if (shape == 0) {
-      if (fused_lds(f, 256, 64, 3) <= kLds) return launch_fused_shape<8, 1, 32, 64, 3, 1>(f, s);
+      if (fused_lds(f, 256, 64, 5) <= kLds) return launch_fused_shape<8, 1, 32, 64, 5, 1>(f, s);
       return fused_lds(f, 256, 64, 2) <= kLds ? launch_fused_shape<8, 1, 32, 64, 2, 1>(f, s) : 1;
     }
-    if (fused_lds(f, 256, 32, 3) <= kLds) return launch_fused_shape<8, 1, 32, 32, 3, 1>(f, s);
-    return fused_lds(f, 256, 32, 2) <= kLds ? launch_fused_shape<8, 1, 32, 32, 2, 1>(f, s) : 1;
+    if (fused_lds(f, 256, 32, 6) <= kLds) return launch_fused_shape<8, 1, 32, 32, 6, 1>(f, s);
+    return fused_lds(f, 256, 32, 3) <= kLds ? launch_fused_shape<8, 1, 32, 32, 3, 1>(f, s) : 1;
   }
   return 1;
 }

@@ -99,6 +99,27 @@ tf2_status Net::quantization(const char* text, size_t len, int8_t* q, size_t cap
   return TF2_OK;
 }
 
+// bias_fix / alpha_fix / beta_fix of one layer (model_loader.cpp:176-188, 215-236); null pointers = disabled
+static void fold_bias_bn(LayerModel& m, int N, const int8_t* q_out, const float* bias_f, const float* mean, const float* var,
+                         float scale_factor, const float* gamma, const float* betaf) {
+  m.bias.assign(N, 0); m.alpha.assign(N, 0); m.beta.assign(N, 0);
+  for (int n = 0; n < N; n++) {
+    const float coe = (float)(1 << (kInflat - q_out[n]));                 // :178,228
+    if (bias_f) m.bias[n] = (int32_t)(bias_f[n] * coe);                   // :181
+    float alpha_data = 1.0f, beta_data = 0.0f;
+    if (mean) {
+      const float eps = 0.00001f;                                         // :221
+      const float a = mean[n] / scale_factor;                             // :223
+      const float b = (float)std::sqrt((double)(var[n] / scale_factor + eps));  // :224
+      alpha_data = gamma[n] / b;                                          // :225
+      beta_data = -(gamma[n] / b * a) + betaf[n];                         // :226
+    }
+    m.alpha[n] = (int32_t)((double)alpha_data * std::pow(2.0, kAlphaInflat));   // :230
+    const double bb = (double)(coe * beta_data);
+    m.beta[n] = (int32_t)(beta_data > 0 ? bb + 0.5 : bb - 0.5);           // :231
+  }
+}
+
 // LoadModel(), model_loader.cpp:129-258, from an in-memory float stream.
 tf2_status Net::load_model(const float* model, size_t n_floats) {
   if (q.empty()) { set_error("tf2_net_load_model: call tf2_net_set_q first"); return TF2_ERR_STATE; }
@@ -124,7 +145,6 @@ tf2_status Net::load_model(const float* model, size_t n_floats) {
         }
       pos += cnt;
     }
-    m.bias.assign(N, 0); m.alpha.assign(N, 0); m.beta.assign(N, 0);
     std::vector<float> bias_f;
     if (L.bias_en) {
       if (!need(N)) { set_error("tf2_net_load_model: model stream too short (bias)"); return TF2_ERR_SIZE; }
@@ -140,26 +160,17 @@ tf2_status Net::load_model(const float* model, size_t n_floats) {
       gamma = model + pos; pos += N;
       betaf = model + pos; pos += N;
     }
-    for (int n = 0; n < N; n++) {
-      const float coe = (float)(1 << (kInflat - q_out[n]));                 // :178,228
-      if (L.bias_en) m.bias[n] = (int32_t)(bias_f[n] * coe);                // :181
-      float alpha_data = 1.0f, beta_data = 0.0f;
-      if (L.bn_en) {
-        const float eps = 0.00001f;                                         // :221
-        const float a = mean[n] / scale_factor;                             // :223
-        const float b = (float)std::sqrt((double)(var[n] / scale_factor + eps));  // :224
-        alpha_data = gamma[n] / b;                                          // :225
-        beta_data = -(gamma[n] / b * a) + betaf[n];                         // :226
-      }
-      m.alpha[n] = (int32_t)((double)alpha_data * std::pow(2.0, kAlphaInflat));   // :230
-      const double bb = (double)(coe * beta_data);
-      m.beta[n] = (int32_t)(beta_data > 0 ? bb + 0.5 : bb - 0.5);           // :231
-    }
+    fold_bias_bn(m, N, q_out, L.bias_en ? bias_f.data() : nullptr, mean, var, scale_factor, gamma, betaf);
   }
   if (pos != n_floats) {
     set_error("tf2_net_load_model: model stream has " + std::to_string(n_floats) + " floats, the tables need " + std::to_string(pos));
     return TF2_ERR_SIZE;
   }
+  return finish_model();
+}
+
+// conv1 rewrite (model_loader.cpp:244-257) and state flags, shared by both loaders
+tf2_status Net::finish_model() {
   if (nd.conv1_rewrite) {                                                   // :244-257
     const tf2_layer_desc& L0 = layers[0];
     if (L0.model_k != 7 || L0.model_C != 3 || L0.k != 3 || L0.C != 27) {
@@ -175,6 +186,79 @@ tf2_status Net::load_model(const float* model, size_t n_floats) {
   model_loaded = true;
   packed_valid = false;
   return TF2_OK;
+}
+
+// LoadModel from TransForm_Kit's 4-bit packed file (4bit_data_format.txt:1-44), tensor by tensor in LoadModel order.  A
+// filter stored as 4-bit codes becomes the reference's byte codes directly: Get_real(value of the code, expand) through
+// a 16-entry table per (tensor, expand) -- the same function on the same values as the float path, hence identical
+// codes, without a float32 copy of the weights.  Bias / BN tensors are float32 in the file.
+tf2_status Net::load_model_4bit(const uint8_t* bytes, size_t n_bytes) {
+  if (q.empty()) { set_error("tf2_net_load_model_4bit: call tf2_net_set_q first"); return TF2_ERR_STATE; }
+  const int M = nd.max_out_channel;
+  M4Cursor cur(bytes, n_bytes);
+  M4Tensor t;
+  auto next = [&](size_t want, const char* what, int l) -> bool {
+    if (cur.done()) { set_error(std::string("tf2_net_load_model_4bit: file ends before the ") + what + " of layer " + std::to_string(l)); return false; }
+    const std::string err = cur.next(&t);
+    if (!err.empty()) { set_error(err); return false; }
+    if (t.cnt != want) {
+      set_error(std::string("tf2_net_load_model_4bit: the ") + what + " of layer " + std::to_string(l) + " has " + std::to_string(t.cnt) +
+                " values, the tables need " + std::to_string(want));
+      return false;
+    }
+    return true;
+  };
+  auto floats = [&](std::vector<float>& v) {            // a small (per-channel) tensor as float32
+    v.resize(t.cnt);
+    for (size_t i = 0; i < t.cnt; i++) v[i] = t.dtype == 1 ? t.f32(i) : m4_code_value(t.code(i), t.min_exp);
+  };
+  models.assign(nd.n_layers, LayerModel());
+  for (int l = 0; l < nd.n_layers; l++) {
+    const tf2_layer_desc& L = layers[l];
+    LayerModel& m = models[l];
+    const int N = L.N, C = L.model_C, K = L.model_k;
+    const int8_t* q_in = q.data() + (size_t)L.q_in_row * M;
+    const int8_t* q_out = q.data() + (size_t)(l + 1) * M;
+    if (!L.ipool) {
+      const size_t cnt = (size_t)N * C * K * K;
+      if (!next(cnt, "filters", l)) return TF2_ERR_SIZE;
+      m.codes.resize(cnt);
+      uint8_t lut[256][16];                                // [expand + 128][4-bit code] -> byte code, filled on demand
+      bool have[256] = {false};
+      for (int n = 0; n < N; n++)
+        for (int c = 0; c < C; c++) {
+          const int8_t expand = (int8_t)(kInflat + q_in[c] - q_out[n]);      // model_loader.cpp:159-162
+          const size_t base = ((size_t)n * C + c) * K * K;
+          if (t.dtype == 0) {
+            uint8_t* lt = lut[(int)expand + 128];
+            if (!have[(int)expand + 128]) {
+              for (int k = 0; k < 16; k++) lt[k] = k == 15 ? 0xff : get_real(m4_code_value(k, t.min_exp), expand);
+              have[(int)expand + 128] = true;
+            }
+            for (int i = 0; i < K * K; i++) {
+              const int k = t.code(base + i);
+              if (k == 15) { set_error("4-bit model: unused code 15 in the filters of layer " + std::to_string(l)); return TF2_ERR_ARG; }
+              m.codes[base + i] = lt[k];
+            }
+          } else {
+            for (int i = 0; i < K * K; i++) m.codes[base + i] = get_real(t.f32(base + i), expand);
+          }
+        }
+    }
+    std::vector<float> bias_f, mean, var, sf, gamma, betaf;
+    if (L.bias_en) { if (!next(N, "bias", l)) return TF2_ERR_SIZE; floats(bias_f); }
+    if (L.bn_en) {
+      if (!next(N, "BN mean", l)) return TF2_ERR_SIZE; floats(mean);
+      if (!next(N, "BN variance", l)) return TF2_ERR_SIZE; floats(var);
+      if (!next(1, "BN scale factor", l)) return TF2_ERR_SIZE; floats(sf);
+      if (!next(N, "scale gamma", l)) return TF2_ERR_SIZE; floats(gamma);
+      if (!next(N, "scale beta", l)) return TF2_ERR_SIZE; floats(betaf);
+    }
+    fold_bias_bn(m, N, q_out, L.bias_en ? bias_f.data() : nullptr, L.bn_en ? mean.data() : nullptr, var.data(),
+                 L.bn_en ? sf[0] : 0.0f, gamma.data(), betaf.data());
+  }
+  if (!cur.done()) { set_error("tf2_net_load_model_4bit: the file holds more tensors than the tables need"); return TF2_ERR_SIZE; }
+  return finish_model();
 }
 
 }  // namespace tf2

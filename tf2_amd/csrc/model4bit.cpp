@@ -13,8 +13,11 @@
 //     [N][C][H] order per word; otherwise every filter ROW of W weights takes floor(W/3) words of 3 codes (W == 2:
 //     one word of 2) plus one word for the remaining W mod 3.  Code j of a word sits in bits [4j, 4j+3]; unused
 //     high nibbles are zero.
-// The decoded float stream is what tf2_net_load_model consumes, so a 4-bit model loads bit-identically to the
-// float32 file it was made from (tests/test_model4bit.py).
+// model4bit_decode gives the float stream tf2_net_load_model consumes (kept for tools / tests).  tf2_net_load_model_4bit
+// does NOT go through it: M4Cursor walks the tensors in place and Net::load_model_4bit (host_model.cpp) turns every 4-bit
+// code straight into the reference's byte code (Get_real applied to the code's value, looked up per tensor in a
+// 16-entry table) -- no float32 copy of the 25.5 M weights is ever allocated.  Either way a 4-bit model loads
+// bit-identically to the float32 file it was made from (tests/test_model4bit.py).
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -28,6 +31,34 @@ static inline float code_value(int code, int min_exp) {
   if (code < 7) return -std::ldexp(1.0f, min_exp + code);
   return std::ldexp(1.0f, min_exp + code - 8);
 }
+
+// ---- in-place tensor cursor ------------------------------------------------------------------------------------
+std::string M4Cursor::next(M4Tensor* t) {
+  if (n - pos < 10) return "4-bit model: truncated tensor header (tensor " + std::to_string(index) + ")";
+  t->min_exp = (int8_t)p[pos];
+  t->dtype = (int8_t)p[pos + 1];
+  int16_t d[4];
+  std::memcpy(d, p + pos + 2, 8);
+  pos += 10;
+  if (d[0] <= 0 || d[1] <= 0 || d[2] <= 0 || d[3] <= 0) return "4-bit model: non-positive dimension in tensor " + std::to_string(index);
+  t->N = d[0]; t->C = d[1]; t->H = d[2]; t->W = d[3];
+  t->cnt = t->N * t->C * t->H * t->W;
+  t->payload = p + pos;
+  size_t bytes;
+  if (t->dtype == 1) bytes = t->cnt * 4;
+  else if (t->dtype == 0) {
+    if (t->min_exp < -40 || t->min_exp > 20) return "4-bit model: implausible minimum exponent in tensor " + std::to_string(index);
+    const size_t rows = t->N * t->C * t->H;
+    t->words_per_row = t->W == 1 ? 0 : (t->W / 3 + (t->W % 3 ? 1 : 0));
+    bytes = 2 * (t->W == 1 ? (rows + 3) / 4 : rows * t->words_per_row);
+  } else return "4-bit model: unknown data type " + std::to_string(t->dtype) + " in tensor " + std::to_string(index);
+  if (n - pos < bytes) return "4-bit model: truncated payload (tensor " + std::to_string(index) + ")";
+  pos += bytes;
+  index++;
+  return std::string();
+}
+
+float m4_code_value(int code, int min_exp) { return code_value(code, min_exp); }
 
 // Appends the decoded floats to `out`; returns an error text (empty = ok).
 std::string model4bit_decode(const uint8_t* p, size_t n, std::vector<float>* out, size_t* n_floats) {

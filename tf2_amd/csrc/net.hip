@@ -195,8 +195,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           release(wp.tensors[t].offset, wp.tensors[t].bytes); freed[t] = 1;
         }
   }
-  wp.dump_off = (top + 255) / 256 * 256;      // 1 KiB scratch for out-of-range lanes of conv_fused.hip
-  wp.total_bytes = wp.dump_off + 1024;
+  wp.total_bytes = (top + 255) / 256 * 256 + 256;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
@@ -344,10 +343,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       f.res = sb.conv.res; f.res_cp = sb.conv.g.res_cp; f.res_off = sb.conv.g.res_off;
       f.add_relu = sb.conv.g.add_relu; f.has_res = sb.conv.g.has_res;
       f.keep_mid = wp->keep_all ? 1 : 0;
-      f.dump = base + wp->dump_off;
       st.sel = Launch::SEL_FUSED;
       // pixel-tile shape: the wide tile when it still gives every CU a block, else the narrow one
-      const int TNw = pl->TM == 64 ? 256 : pl->TM == 128 ? 128 : 64;
+      const int TNw = pl->TM == 128 ? 128 : 64;
       st.shape = opts.fuse_shape >= 0 ? opts.fuse_shape : ((f.a.g.n_pix + TNw - 1) / TNw >= 256 ? 0 : 1);
     }
     lp.steps.push_back(st);

@@ -121,7 +121,6 @@ struct FusedArgs {
   const int32_t* hdr2;       // B's per-m-tile header images (stride hdr2_bytes); the first hdr2_used bytes hold rows | lo | dshift
   int8_t* y2;
   const int8_t* res;
-  int8_t* dump;              // 1 KiB of writable scratch: where lanes outside the tensor store (see the epilogue)
   int32_t hdr2_bytes, hdr2_used, P2, dual2, fast2, relu2;
   int32_t y2_cp, y2_off, y2_nvalid, res_cp, res_off, add_relu, has_res;
   int32_t keep_mid;          // also store A's output tensor (per-layer parity runs)

@@ -1,5 +1,6 @@
 // tf2_net.h -- the network handle behind the C ABI (host side).
 #pragma once
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -31,7 +32,6 @@ struct WorkPlan {
   int input_tensor = -1;
   int final_tensor = -1;
   size_t total_bytes = 0;
-  size_t dump_off = 0;        // 1 KiB scratch (conv_fused.hip stores of out-of-range lanes)
 };
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
@@ -100,6 +100,8 @@ struct Net {
   tf2_status init(const tf2_net_desc* nd, const tf2_layer_desc* layers);
   tf2_status quantization(const char* text, size_t len, int8_t* q, size_t cap, int32_t* n_read) const;
   tf2_status load_model(const float* model, size_t n_floats);
+  tf2_status load_model_4bit(const uint8_t* bytes, size_t n_bytes);    // straight from the 4-bit codes, no float32 copy of the weights
+  tf2_status finish_model();
   tf2_status pack(int mode);
   const PackLayer* pack_layer(int l) const;
   uint64_t tables_hash() const;
@@ -115,7 +117,28 @@ struct Net {
 
 const std::string& last_error();
 
-// model4bit.cpp: decoder of the 4-bit packed model file; returns an error text (empty = ok)
+// model4bit.cpp: one tensor of the 4-bit packed model file, in place
+struct M4Tensor {
+  int min_exp = 0, dtype = 0;
+  size_t N = 0, C = 0, H = 0, W = 0, cnt = 0, words_per_row = 0;
+  const uint8_t* payload = nullptr;
+  // 4-bit code of weight `i` of the flattened [N][C][H][W] order (dtype 0)
+  int code(size_t i) const {
+    size_t word, j;
+    if (W == 1) { word = i / 4; j = i % 4; }
+    else { const size_t r = i / W, x = i % W; word = r * words_per_row + x / 3; j = x % 3; }
+    return (int)((((unsigned)payload[2 * word] | ((unsigned)payload[2 * word + 1] << 8)) >> (4 * j)) & 15u);
+  }
+  float f32(size_t i) const { float v; std::memcpy(&v, payload + 4 * i, 4); return v; }      // dtype 1
+};
+struct M4Cursor {
+  const uint8_t* p; size_t n; size_t pos = 0; int index = 0;
+  M4Cursor(const uint8_t* bytes, size_t len) : p(bytes), n(len) {}
+  bool done() const { return pos >= n; }
+  std::string next(M4Tensor* t);          // error text, empty = ok
+};
+float m4_code_value(int code, int min_exp);
+// decoder of the whole file into a float stream; returns an error text (empty = ok)
 std::string model4bit_decode(const uint8_t* bytes, size_t n, std::vector<float>* out, size_t* n_floats);
 
 }  // namespace tf2

@@ -84,10 +84,10 @@ tf2_status Net::pack(int mode) {
   }
 
   // ---- fused pairs (conv_fused.hip): A = a conv whose ONLY consumer is B = a 1x1 / stride-1 expand with 4x its channels
-  // (branch2b -> branch2c of a ResNet bottleneck).  Both are then packed with TM = A's channel count (64 / 128 / 256), so
+  // (branch2b -> branch2c of a ResNet bottleneck).  Both are then packed with TM = A's channel count (128 / 256), so
   // that one block owns all of A's channels for its pixel tile.  Structural test here; after packing, the pair must also
   // pass the kernel's own limits (dense B, window count, LDS), else the image is repacked without it.
-  std::vector<int> fuse_next(nl, 0), fused_into(nl, -1), fuse_shapes(nl, 0);
+  std::vector<int> fuse_next(nl, 0), fused_into(nl, -1);
   std::vector<char> nofuse(nl, 0);
   const bool fusion_on = mode == 0 && getenv("TF2_AMD_NOFUSE") == nullptr;
   auto decide_fusion = [&]() {
@@ -109,7 +109,7 @@ tf2_status Net::pack(int mode) {
       if (B.src != l || B.ipool || B.pool_en || B.endpool || B.concat >= 0 || B.k != 1 || B.stride != 1 || (B.pad_h | B.pad_w)) continue;
       if (B.add_src >= l) continue;                                       // the residual must exist when A's launch runs
       if (!A.relu) continue;                                              // B reads an unsigned tensor
-      if (A.N != 64 && A.N != 128 && A.N != 256) continue;
+      if (A.N != 128 && A.N != 256) continue;                             // 64-channel pairs run faster unfused (conv_pw expand)
       if (B.N != 4 * A.N || B.C != A.N) continue;
       fuse_next[l] = b; fused_into[b] = l;
     }
@@ -414,10 +414,10 @@ tf2_status Net::pack(int mode) {
     int shapes = 0;
     if (ok) {
       const size_t h2 = (size_t)round_up((5 + pb->n_phases) * pb->TM * 4, 1024);
-      const int TNw = pa->TM == 64 ? 256 : pa->TM == 128 ? 128 : 64;
+      const int TNw = pa->TM == 128 ? 128 : 64;
       for (int sh = 0; sh < 2; sh++) {
         const int TN = sh ? TNw / 2 : TNw;
-        const int Smin = pa->TM == 256 ? 2 : 3;
+        const int Smin = (pa->TM == 256 && sh == 0) ? 2 : 3;
         if (conv_fused_lds_bytes(pa->TM, TN, Smin, pa->dual, pb->dual, (size_t)pa->hdr_bytes, h2) <= 160 * 1024) shapes |= 1 << sh;
       }
       ok = shapes == 3;
