@@ -211,26 +211,6 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
-@pytest.mark.parametrize("shape", ["0", "1"])
-def test_fused_bottleneck_pairs_both_tile_shapes(r50, monkeypatch, shape):
-    """conv_fused.hip: branch2b (3x3, stride 1 and 2) + branch2c (1x1 expand, residual, ReLU) of the thirteen stage 2-4
-    bottlenecks in one launch, wide and narrow pixel tiles forced (TM = 64 / 128 / 256; dual- and single-window pairs),
-    ragged pixel counts (batch 3 / 5): every layer with keep_all (the intermediate map is then also stored), and the
-    logits of a plain run (intermediate never leaves LDS)."""
-    monkeypatch.setenv("TF2_AMD_FUSE_SHAPE", shape)
-    rig = Rig(*r50, 0)
-    rig.check_all_layers(synth.synth_images(rig.t, 3, 61))
-    x = synth.synth_images(rig.t, 5, 62)
-    np.testing.assert_array_equal(rig.run(x, keep_all=False), rig.ref.logits(rig.ref.run(x)))
-
-
-def test_unfused_pairs_forced(r50, monkeypatch):
-    """TF2_AMD_NOFUSE=1 at pack time: every layer is its own launch again (the round-1 path)."""
-    monkeypatch.setenv("TF2_AMD_NOFUSE", "1")
-    rig = Rig(*r50, 0)
-    rig.check_all_layers(synth.synth_images(rig.t, 2, 63), layers={3, 4, 13, 14, 26, 27, 32, 33, 52, 53})
-
-
 def test_googlenet_ipool_concat_every_layer(golden_dir):
     """The reference's second shipped network (googlenet.h tables + shipped googlenet_Q): 67 table rows with independent
     pooling rows (kIpoolEnable), four-way concat slices (kNStart/kBranchTail/kConcatLayer, extra Q rows), 5x5 convs, the

@@ -207,7 +207,6 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
-  if (const char* e = getenv("TF2_AMD_FUSE_SHAPE")) o.fuse_shape = atoi(e);   // conv_fused pixel-tile shape: 0 wide, 1 narrow (default: by grid size)
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
@@ -320,34 +319,13 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
-    const PackLayer* pl = pack_layer(l);
     if (L.ipool) {
       const TensorPlan& ti = T(E.in_tensor);
       pool_step(l, ti, base + ti.offset, ti.H, ti.W);
       continue;
     }
-    if (pl->fused_into >= 0) continue;             // computed by the launch of layer pl->fused_into (conv_fused.hip)
     Launch st;
     if (!make_conv(l, st)) return nullptr;
-    if (pl->fuse_next > 0) {
-      // A (this layer) + B (its only consumer, a 1x1 expand) in one launch; B's argument block supplies the second half
-      Launch sb;
-      if (!make_conv(pl->fuse_next, sb)) return nullptr;
-      const PackLayer* pb = pack_layer(pl->fuse_next);
-      FusedArgs& f = st.fused;
-      f.a = st.conv;
-      f.w2 = sb.conv.w; f.hdr2 = sb.conv.hdr; f.hdr2_bytes = sb.conv.hdr_bytes;
-      f.hdr2_used = round_up((5 + pb->n_phases) * pb->TM * 4, 1024);
-      f.P2 = pb->n_phases; f.dual2 = pb->dual; f.fast2 = pb->fast; f.relu2 = sb.conv.g.relu;
-      f.y2 = sb.conv.y; f.y2_cp = sb.conv.g.y_cp; f.y2_off = sb.conv.g.y_off; f.y2_nvalid = sb.conv.g.y_nvalid;
-      f.res = sb.conv.res; f.res_cp = sb.conv.g.res_cp; f.res_off = sb.conv.g.res_off;
-      f.add_relu = sb.conv.g.add_relu; f.has_res = sb.conv.g.has_res;
-      f.keep_mid = wp->keep_all ? 1 : 0;
-      st.sel = Launch::SEL_FUSED;
-      // pixel-tile shape: the wide tile when it still gives every CU a block, else the narrow one
-      const int TNw = pl->TM == 128 ? 128 : 64;
-      st.shape = opts.fuse_shape >= 0 ? opts.fuse_shape : ((f.a.g.n_pix + TNw - 1) / TNw >= 256 ? 0 : 1);
-    }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en) {
@@ -431,7 +409,6 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
           case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
           case Launch::SEL_SK: rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream); break;
           case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
-          case Launch::SEL_FUSED: rc = launch_conv_fused(st.fused, st.TM, st.shape, stream); break;
           default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
         }
         break;

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 17;
+constexpr uint32_t kPackVersion = 18;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -36,9 +36,6 @@ struct PackLayer {
   int32_t fast;        // MFMA: every output row passed the range proof of the 3-instruction requantisation
   int32_t dual;        // MFMA, two-phase layers: every entry holds BOTH exponent windows' tiles ([hi TM rows][lo TM rows],
                        // one activation slab), accumulated separately and combined once: (hi << dshift[1]) + lo
-  int32_t fuse_next;   // > 0: this layer and layer `fuse_next` (its only consumer, a 1x1 expand) run as ONE conv_fused launch;
-                       // both are packed with TM = this layer's Np (64 / 128 / 256)
-  int32_t fused_into;  // >= 0: the layer whose launch computes this one (-1 otherwise)
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -113,19 +110,6 @@ struct ConvArgs {
   ConvGeom g;
 };
 
-// conv_fused.hip: layer A (any conv, ALL its output channels in one m-tile) followed by its only consumer B (1x1 expand
-// with 4x the channels, + residual): one launch, the intermediate tile stays in LDS.
-struct FusedArgs {
-  ConvArgs a;                // layer A exactly as conv_mfma2 takes it (a.y / g.y_*: A's own tensor, written only with keep_mid)
-  const int8_t* w2;          // layer B: dense weight tiles [pass][slab][(hi | lo)][TM][64]
-  const int32_t* hdr2;       // B's per-m-tile header images (stride hdr2_bytes); the first hdr2_used bytes hold rows | lo | dshift
-  int8_t* y2;
-  const int8_t* res;
-  int32_t hdr2_bytes, hdr2_used, P2, dual2, fast2, relu2;
-  int32_t y2_cp, y2_off, y2_nvalid, res_cp, res_off, add_relu, has_res;
-  int32_t keep_mid;          // also store A's output tensor (per-layer parity runs)
-};
-
 struct PoolArgs {
   const int8_t* x; int8_t* y;
   int32_t B, H, W, x_cp, x_off;
@@ -153,8 +137,6 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // 
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
-int launch_conv_fused(const FusedArgs& f, int TM, int shape, void* stream);   // 1: no instantiation fits
-size_t conv_fused_lds_bytes(int TM, int TN, int S, int dual1, int dual2, size_t hdr1_bytes, size_t hdr2_used);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);

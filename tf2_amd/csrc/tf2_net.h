@@ -37,11 +37,10 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_FUSED } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT } sel = SEL_MFMA2;
   int layer = -1;
-  int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
+  int TM = 0, signed_in = 0, mul24 = 0;
   ConvArgs conv{};
-  FusedArgs fused{};
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
@@ -58,7 +57,6 @@ struct LaunchPlan {
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
-  int fuse_shape = -1;
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };

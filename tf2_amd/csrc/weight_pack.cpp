@@ -63,7 +63,6 @@ tf2_status Net::pack(int mode) {
   packed.clear();
   Blob blob(packed);
   const size_t dir_bytes = sizeof(PackHeader) + (size_t)nl * sizeof(PackLayer);
-  const uint64_t zero_off = (dir_bytes + 255) / 256 * 256;       // right behind the directory (allocated per attempt below)
 
   // Can the tensor feeding layer l hold negative values (=> the -128 negate quirk matters)?
   std::vector<int> out_signed(nl, 0);
@@ -83,46 +82,11 @@ tf2_status Net::pack(int mode) {
     if (L.concat >= 0 && s) concat_signed[L.concat] = 1;
   }
 
-  // ---- fused pairs (conv_fused.hip): A = a conv whose ONLY consumer is B = a 1x1 / stride-1 expand with 4x its channels
-  // (branch2b -> branch2c of a ResNet bottleneck).  Both are then packed with TM = A's channel count (128 / 256), so
-  // that one block owns all of A's channels for its pixel tile.  Structural test here; after packing, the pair must also
-  // pass the kernel's own limits (dense B, window count, LDS), else the image is repacked without it.
-  std::vector<int> fuse_next(nl, 0), fused_into(nl, -1);
-  std::vector<char> nofuse(nl, 0);
-  const bool fusion_on = mode == 0 && getenv("TF2_AMD_NOFUSE") == nullptr;
-  auto decide_fusion = [&]() {
-    std::fill(fuse_next.begin(), fuse_next.end(), 0); std::fill(fused_into.begin(), fused_into.end(), -1);
-    if (!fusion_on) return;
-    std::vector<int> users(nl, 0), user_of(nl, -1);
-    for (int j = 0; j < nl; j++) {
-      if (layers[j].src >= 0) { users[layers[j].src]++; user_of[layers[j].src] = j; }
-      if (layers[j].add_src >= 0) users[layers[j].add_src] += 2;          // a residual read: never fused away
-    }
-    for (int l = 0; l + 1 < nl; l++) {
-      const tf2_layer_desc& A = layers[l];
-      if (nofuse[l] || fused_into[l] >= 0) continue;
-      if (A.ipool || A.pool_en || A.endpool || A.add_src >= 0 || A.concat >= 0 || A.src == -1) continue;
-      if (src_signed(A.src)) continue;
-      if (users[l] != 1) continue;
-      const int b = user_of[l];
-      const tf2_layer_desc& B = layers[b];
-      if (B.src != l || B.ipool || B.pool_en || B.endpool || B.concat >= 0 || B.k != 1 || B.stride != 1 || (B.pad_h | B.pad_w)) continue;
-      if (B.add_src >= l) continue;                                       // the residual must exist when A's launch runs
-      if (!A.relu) continue;                                              // B reads an unsigned tensor
-      if (A.N != 128 && A.N != 256) continue;                             // 64-channel pairs run faster unfused (conv_pw expand)
-      if (B.N != 4 * A.N || B.C != A.N) continue;
-      fuse_next[l] = b; fused_into[b] = l;
-    }
-  };
-  for (int attempt = 0; attempt < 8; attempt++) {
-  decide_fusion();
-  packed.clear();
   blob.alloc(dir_bytes);
-  if (blob.alloc(256) != zero_off) { set_error("tf2_net_pack: internal layout error"); return TF2_ERR_STATE; }
+  const uint64_t zero_off = blob.alloc(256);
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     PackLayer pl{};
-    pl.fused_into = -1;
     if (L.ipool) {
       pl.kind = KIND_NONE;
       *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
@@ -152,10 +116,7 @@ tf2_status Net::pack(int mode) {
       // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
       static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
-      int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
-      if (fuse_next[l] > 0) TM = Np;                                   // fused pair: A in one m-tile ...
-      if (fused_into[l] >= 0) TM = layers[fused_into[l]].N;            // ... and B in four of the same height
-      pl.fuse_next = fuse_next[l]; pl.fused_into = fused_into[l];
+      const int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
       const int n_mtiles = Np / TM;
       const int Ktot = taps * il.Cp_in;
       const int nslab = (Ktot + 63) / 64;
@@ -403,29 +364,6 @@ tf2_status Net::pack(int mode) {
     }
     *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
   }
-  // ---- do the fused pairs pass the kernel's limits? ----
-  bool redo = false;
-  for (int l = 0; l < nl; l++) {
-    if (fuse_next[l] <= 0) continue;
-    PackLayer* pa = blob.at<PackLayer>(sizeof(PackHeader)) + l;
-    PackLayer* pb = blob.at<PackLayer>(sizeof(PackHeader)) + fuse_next[l];
-    bool ok = pa->kind == KIND_MFMA && pb->kind == KIND_MFMA && pa->n_mtiles == 1 && pb->n_mtiles == 4 && pb->TM == pa->TM;
-    ok = ok && (pb->n_phases == 1 || pb->dual) && pb->n_entries == 4 * pb->nslab && pb->nslab == pa->TM / 64;
-    int shapes = 0;
-    if (ok) {
-      const size_t h2 = (size_t)round_up((5 + pb->n_phases) * pb->TM * 4, 1024);
-      const int TNw = pa->TM == 128 ? 128 : 64;
-      for (int sh = 0; sh < 2; sh++) {
-        const int TN = sh ? TNw / 2 : TNw;
-        const int Smin = (pa->TM == 256 && sh == 0) ? 2 : 3;
-        if (conv_fused_lds_bytes(pa->TM, TN, Smin, pa->dual, pb->dual, (size_t)pa->hdr_bytes, h2) <= 160 * 1024) shapes |= 1 << sh;
-      }
-      ok = shapes == 3;
-    }
-    if (!ok) { nofuse[l] = 1; redo = true; }
-  }
-  if (!redo) break;
-  }   // attempt
   blob.alloc(0);
   PackHeader h{};
   h.magic = kPackMagic; h.version = kPackVersion; h.n_layers = (uint32_t)nl; h.dir_bytes = (uint32_t)dir_bytes;
