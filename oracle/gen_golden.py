@@ -21,6 +21,8 @@ What it writes (all data: inputs + expected outputs, never reference source text
   ref_pyemu_block.npz      every intermediate tensor of the emulator's own Bottleneck.forward / ResNet.forward (head + tail)
                            on small seeded blocks, plus its BN on > 10^5 samples with exact rounding ties
   ref_caq.npz              outputs of the reference's calibrator functions QuantizeForShift / QuantizeChannel
+  ref_caq_squeezenet.npz   Q vectors of the reference's own calibration pass (feature_hook + QuantizeChannel) over its own
+                           SqueezeNet 1.1 forward at 1x3x227x227 with seeded parameters (BASELINE configs[0])
   ref_ssd.npz              outputs of the reference's SSD PriorBox / decode / nms (+ the L2Norm formula)
                            (TransForm_Kit/Quantization/debug/...Batch-2.py: Conv2dInt8, BN, FC),
                            AST-extracted and executed here.
@@ -385,6 +387,83 @@ def gen_caq():
     np.savez_compressed(os.path.join(OUT, "ref_caq.npz"), **out)
 
 
+def gen_caq_squeezenet():
+    """BASELINE configs[0]: the reference's OWN calibration pass on its OWN SqueezeNet 1.1 (models/SqueezeNet/
+    SqueezeNet.py imported here with torchvision stubbed; feature_hook of feature_write.py:72-87
+    and QuantizeChannel of quantization.py:48-72 executed from their AST) over three seeded 1x3x227x227 images.  The
+    model carries the seeded parameters of squeezenet_seeded_stream(); the fixture holds only the expected Q vectors
+    and a few float outputs -- tests/test_calibrate.py rebuilds weights and images from the seeds."""
+    import types
+    import torch
+    for m in ["torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.models", "cv2", "torchsummary"]:
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF + "/TransForm_Kit/Quantization")
+    from models.SqueezeNet import SqueezeNet as RS
+    net = RS.SqueezeNet("1_1").eval()
+    stream, rows = synth.squeezenet_seeded_stream()
+    fires = [net.fire2, net.fire3, net.fire4, net.fire5, net.fire6, net.fire7, net.fire8, net.fire9]
+    convs = [(net.conv1, net.bn1)]
+    for f in fires:
+        convs += [(f.squeeze, f.bn1), (f.expand1x1, f.bn2), (f.expand3x3, f.bn3)]
+    convs += [(net.final_conv, None), (net.fc, net.bn)]
+    with torch.no_grad():
+        for (cv, bn), r in zip(convs, rows):
+            w = torch.from_numpy(r["w"])
+            cv.weight.copy_(w.reshape(cv.weight.shape))
+            if "b" in r:
+                cv.bias.copy_(torch.from_numpy(r["b"]))
+            if bn is not None:
+                bn.running_mean.copy_(torch.from_numpy(r["mean"])); bn.running_var.copy_(torch.from_numpy(r["var"]))
+                bn.weight.copy_(torch.from_numpy(r["gamma"])); bn.bias.copy_(torch.from_numpy(r["beta"]))
+    # the reference's hook (feature_write.py:72-87), its globals supplied here
+    src = open(REF + "/TransForm_Kit/Quantization/feature_write.py").read()
+    tree = ast.parse(src)
+    ns = {"np": np, "torch": torch, "print": lambda *a, **k: None}
+    exec(compile(ast.Module([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "feature_hook"], []), "ref_fw", "exec"), ns)
+    qsrc = ast.parse(open(REF + "/TransForm_Kit/Quantization/quantization.py").read())
+    import math
+    qns = {"np": np, "math": math}
+    exec(compile(ast.Module([n for n in qsrc.body if isinstance(n, ast.FunctionDef) and n.name in ("QuantizeForShift", "QuantizeChannel")], []), "ref_q", "exec"), qns)
+    # module outputs in hook order (what structure_hook sizes): run once to learn the shapes
+    shapes, names = [], []
+    hs = []
+    def reg(mod):
+        def hk(m, i, o):
+            shapes.append(tuple(o.shape)); names.append(m)
+        hs.append(mod.register_forward_hook(hk))
+    net.apply(reg)
+    imgs = synth.squeezenet_calibration_images()
+    with torch.no_grad():
+        net(torch.from_numpy(imgs[0]))
+    for h in hs: h.remove()
+    Features = [np.zeros((1, 3, 227, 227))] + [np.zeros(sh) for sh in shapes]
+    ns.update(Features=Features, layer_name=["m%d" % i for i in range(len(Features))], layer_count=0, call_count=0, threshold=10 ** 9,
+              FeatureWrite=lambda *a: None)
+    with torch.no_grad():
+        for im in imgs:
+            x = torch.from_numpy(im)
+            Features[0] = np.maximum(abs(x.numpy()), Features[0])            # feature_write.py:103
+            ns["layer_count"] = 0
+            ns["feature_hook"](net, x)
+            ns["call_count"] += 1
+    # which module output is the tensor of our table row l?  (after BN / ReLU / pool, the tensor the row's Q describes)
+    mod_index = {id(m): i + 1 for i, m in enumerate(names)}
+    row_mod = [net.maxpool1]
+    for f in fires:
+        row_mod += [f.squeeze_activation, f.expand1x1_activation, f.expand3x3_activation]
+    row_mod += [net.avgpool, net.bn]
+    out = {"image_q": np.asarray(qns["QuantizeChannel"]("shift", Features[0].copy()), np.float64)}
+    for l, m in enumerate(row_mod):
+        fe = Features[mod_index[id(m)]]
+        out[f"row{l}_q"] = np.asarray(qns["QuantizeChannel"]("shift", fe.copy()), np.float64)
+        if l in (25, 26):
+            out[f"row{l}_maxabs"] = fe.astype(np.float32)
+        if l == 0:
+            out["row0_maxabs_ch0_3"] = fe[:, :4].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "ref_caq_squeezenet.npz"), **out)
+
+
 def gen_ssd():
     """Outputs of the reference's SSD post-processing functions (TransForm_Kit/Quantization/models/SSD/layers/
     functions/prior_box.py, layers/box_utils.py decode / nms, layers/modules/l2norm.py), executed from their AST."""
@@ -431,5 +510,6 @@ if __name__ == "__main__":
     gen_pyemu()
     gen_pyemu_block()
     gen_caq()
+    gen_caq_squeezenet()
     gen_ssd()
     print("golden fixtures written to", OUT)

@@ -56,9 +56,11 @@ def quantize_channels(x: np.ndarray) -> np.ndarray:
 
 
 # ---- float forward of the table program -----------------------------------------------------------------------
-def float_forward(tables: cfg.NetTables, model: np.ndarray, images, device: Optional[str] = None) -> Dict[int, "torch.Tensor"]:
+def float_forward(tables: cfg.NetTables, model: np.ndarray, images, device: Optional[str] = None, bn_eps: float = 1e-5) -> Dict[int, "torch.Tensor"]:
     """float32 forward of the k*-table program: {-1: image, l: output tensor of table row l (after pool / add /
-    global average, i.e. the tensor whose Q row is l + 1)}.  images: [B, C, H, W] float (numpy or torch)."""
+    global average, i.e. the tensor whose Q row is l + 1)}.  images: [B, C, H, W] float (numpy or torch).
+    bn_eps: 1e-5 is what the runtime folds with whatever the model says (model_loader.cpp:221, SURVEY.md App. C-11);
+    pass the framework's value (SqueezeNet.py:23 uses 1e-3) to reproduce a calibration run of the float model."""
     import torch
     import torch.nn.functional as F
     if device is None:
@@ -93,7 +95,7 @@ def float_forward(tables: cfg.NetTables, model: np.ndarray, images, device: Opti
                 sf = params[f"layer{L.index}.scale_factor"].reshape(())
                 mean = params[f"layer{L.index}.mean"].reshape(1, -1, 1, 1) / sf
                 var = params[f"layer{L.index}.var"].reshape(1, -1, 1, 1) / sf
-                y = params[f"layer{L.index}.gamma"].reshape(1, -1, 1, 1) * (y - mean) / torch.sqrt(var + 1e-5) + \
+                y = params[f"layer{L.index}.gamma"].reshape(1, -1, 1, 1) * (y - mean) / torch.sqrt(var + bn_eps) + \
                     params[f"layer{L.index}.beta"].reshape(1, -1, 1, 1)
             if L.relu:
                 y = torch.relu(y)
@@ -115,14 +117,14 @@ def float_forward(tables: cfg.NetTables, model: np.ndarray, images, device: Opti
 class Calibrator:
     """feature_write.py:73-113: running element-wise max of |feature| over calibration batches, then the Q rows."""
 
-    def __init__(self, tables: cfg.NetTables, model: np.ndarray, device: Optional[str] = None):
-        self.tables, self.model, self.device = tables, model, device
+    def __init__(self, tables: cfg.NetTables, model: np.ndarray, device: Optional[str] = None, bn_eps: float = 1e-5):
+        self.tables, self.model, self.device, self.bn_eps = tables, model, device, bn_eps
         self.plan = cfg.build_plan(tables)
         self.maxabs: Dict[int, "torch.Tensor"] = {}
 
     def observe(self, images) -> None:
         import torch
-        outs = float_forward(self.tables, self.model, images, self.device)
+        outs = float_forward(self.tables, self.model, images, self.device, self.bn_eps)
         for k, v in outs.items():
             m = v.abs().amax(dim=0, keepdim=True)                 # max over the batch: [1, C, H, W]
             self.maxabs[k] = m if k not in self.maxabs else torch.maximum(self.maxabs[k], m)

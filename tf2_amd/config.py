@@ -827,7 +827,8 @@ def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1
 def squeezenet11_tables(image_hw: int = 227) -> NetTables:
     """SqueezeNet 1.1 as in TransForm_Kit/Quantization/models/SqueezeNet/SqueezeNet.py:17-113
     (conv+BN everywhere except final_conv; fire = squeeze1x1 -> expand1x1 || expand3x3,
-    ceil-mode 3x3/s2 pools).  Concats use the reference's branch-tail encoding
+    ceil-mode 3x3/s2 pools; final_conv + global average without ReLU; fc 1000 -> 128 + BN as a 1x1 row on a
+    signed input, which the engine runs on the shift-accumulate kernel).  Concats use the reference's branch-tail encoding
     (kBranchTail/kConcatLayer/kNStart/kNEnd); a pool after a concat is
     distributed onto the branch tails as GoogLeNet's header does."""
     rows: List[dict] = []
@@ -853,7 +854,9 @@ def squeezenet11_tables(image_hw: int = 227) -> NetTables:
         add(src=("L", s), C=sq, H=H, N=ex, k=3, stride=1, pad=1, pool=pool, cat=(n_concat, ex, 2 * ex))
         cur, C, H = ("C", n_concat), 2 * ex, Ho
         n_concat += 1
-    add(src=cur, C=C, H=H, N=1000, k=1, stride=1, pad=0, pool=None, cat=None, bias=1, bn=0, endpool=H * H)
+    # final_conv (bias, no BN, NO ReLU: SqueezeNet.py:101-102) + global average, then fc 1000 -> 128 (no bias) + BN (:103-108)
+    fin = add(src=cur, C=C, H=H, N=1000, k=1, stride=1, pad=0, pool=None, cat=None, bias=1, bn=0, relu=0, endpool=H * H)
+    add(src=("L", fin), C=1000, H=1, N=128, k=1, stride=1, pad=0, pool=None, cat=None, bias=0, bn=1, relu=0)
     n = len(rows)
     t = _blank_tables(n)
     t.update(INPUT_IMAGE_C=3, INPUT_IMAGE_H=image_hw, INPUT_IMAGE_W=image_hw, FIRST_FILTER_SIZE=3,
@@ -866,7 +869,7 @@ def squeezenet11_tables(image_hw: int = 227) -> NetTables:
         t["kInputWidth"][i] = t["kInputHeight"][i] = r["H"]
         t["kOutputWidth"][i] = t["kOutputHeight"][i] = oh1
         t["kInputChannels"][i] = r["C"]; t["kOutputChannels"][i] = r["N"]; t["kConvStride"][i] = s
-        t["kBiasEnable"][i] = r.get("bias", 0); t["kBnEnable"][i] = r.get("bn", 1); t["kReluEnable"][i] = 1
+        t["kBiasEnable"][i] = r.get("bias", 0); t["kBnEnable"][i] = r.get("bn", 1); t["kReluEnable"][i] = r.get("relu", 1)
         kind, idx = r["src"]
         t["kInputLayer"][i] = (idx + 1) if kind == "L" else (n + 1 + idx)
         oh = (oh1 - 1) // s + 1

@@ -104,3 +104,34 @@ def synth_images(tables: cfg.NetTables, batch: int, seed: int = 0, kind: str = "
         return rng.integers(-128, 128, size=(batch, C, H, W)).astype(np.int8)
     x = rng.normal(0.0, 45.0, size=(batch, C, H, W))
     return np.clip(x, -126.0, 154.0).astype(np.float32)
+
+
+def squeezenet_seeded_stream(seed=5):
+    """Seeded float parameters of SqueezeNet 1.1 in table order (the float32 LoadModel stream of
+    cfg.squeezenet11_tables, NOT power-of-two weights: this is the float model the calibrator sees).  numpy only:
+    oracle/gen_golden.py loads the same numbers into the reference's PyTorch model, tests rebuild them from the seed.
+    Returns (stream, per-row dict)."""
+    t = cfg.squeezenet11_tables()
+    rng = np.random.default_rng(seed)
+    rows, parts = [], []
+    for L in cfg.build_plan(t):
+        fan = L.model_C * L.model_k * L.model_k
+        r = dict(w=(rng.standard_normal((L.N, L.model_C, L.model_k, L.model_k)) * np.sqrt(2.0 / fan)).astype(np.float32))
+        parts.append(r["w"].ravel())
+        if L.bias_en:
+            r["b"] = (rng.standard_normal(L.N) * 0.1).astype(np.float32); parts.append(r["b"])
+        if L.bn_en:
+            r["mean"] = (rng.standard_normal(L.N) * 0.2).astype(np.float32)
+            r["var"] = rng.uniform(0.5, 2.0, L.N).astype(np.float32)
+            r["gamma"] = rng.uniform(0.5, 1.5, L.N).astype(np.float32)
+            r["beta"] = (rng.standard_normal(L.N) * 0.3).astype(np.float32)
+            parts += [r["mean"], r["var"], np.ones(1, np.float32), r["gamma"], r["beta"]]
+        rows.append(r)
+    return np.concatenate(parts).astype(np.float32), rows
+
+
+
+def squeezenet_calibration_images(seed: int = 17) -> np.ndarray:
+    """Three seeded 1x3x227x227 float images (BASELINE configs[0] shape), [3, 1, 3, 227, 227]."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((3, 1, 3, 227, 227)) * 50.0).astype(np.float32)

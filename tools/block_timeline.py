@@ -18,6 +18,7 @@ for _ in range(3): r.run_batch(x)
 torch.cuda.synchronize()
 dbg = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda:0")
 os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
+net.reload_options()
 r.run_batch(x); torch.cuda.synchronize()
 from tf2_amd import _lib
 _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
@@ -37,6 +38,7 @@ print("blocks", n, "kernel span cycles", en.max(), "distinct CUs", len(set(cuid.
 life = en - st
 seg = np.stack([d[:,4]-d[:,0], d[:,5]-d[:,4], d[:,6]-d[:,5], d[:,1]-d[:,6]], 1)
 w0, w1 = d[:, 3], d[:, 7]
+print(f"RAW wall ticks: first start {w0.min()} last end {w1.max()}")
 print(f'wall clock (100 MHz): first block start -> last block end {(w1.max() - w0.min()) / 100:.2f} us; first->last block START {(w0.max() - w0.min()) / 100:.2f} us; median block {np.median(w1 - w0) / 100:.2f} us')
 print("segment medians (start->gather words, ->prologue DMAs issued, ->hdr+stage0 landed, ->end):", np.median(seg,0).astype(int).tolist())
 print("segment means:", seg.mean(0).astype(int).tolist())
@@ -56,5 +58,6 @@ for cu_ in sorted(set(cuid.tolist())):
     spans.append(ex.max()); concs.append(area / ex.max())
     if example is None: example = sorted(zip(sx.tolist(), ex.tolist()))
 spans = np.array(spans)
+if len(spans) == 0: sys.exit(0)
 print(f"per-CU: {len(spans)} CUs usable; span ticks min/median/max {spans.min()} {int(np.median(spans))} {spans.max()} ({np.median(spans)/2400:.2f} us median); mean concurrent blocks per CU {np.mean(concs):.2f}")
 print("one CU's blocks (start, end):", example)

@@ -31,6 +31,7 @@ x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
 dbg = torch.zeros(64 * 16, dtype=torch.int64, device="cuda:0")
 if a.stamps:
     os.environ["TF2_AMD_DBGPTR"] = str(dbg.data_ptr())
+    net.reload_options()
 for _ in range(3): r.run_batch(x)
 torch.cuda.synchronize()
 _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
