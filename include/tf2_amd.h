@@ -45,7 +45,9 @@ typedef struct tf2_layer_desc {
   int32_t N, k, stride; /* kOutputChannels, kFilterSize, kConvStride                     */
   int32_t pad_h, pad_w, dil; /* kPadHeight, kPadWidth, (dilation, 1 in the reference)    */
   int32_t OH, OW;       /* conv output (after conv stride)                               */
-  int32_t bias_en, bn_en, relu, ipool; /* kBiasEnable, kBnEnable, kReluEnable, kIpoolEnable */
+  int32_t bias_en, bn_en, relu, ipool; /* kBiasEnable, kBnEnable, kReluEnable, kIpoolEnable (1 = independent pooling row;
+                           2 = this build's independent L2Norm row for SSD's conv4_3 branch: N float weights in
+                           the model stream, its own Q row, no filter) */
   int32_t pool_en, pool_S, pool_st, pool_pad; /* kPoolEnable, kPoolWindow, kPoolStride2, kPoolPad */
   int32_t PH, PW;       /* kPoolOutputHeight/Width                                       */
   int32_t add_src, add_relu; /* kAdditionEnable (+ DDR page plan), kAdditionReluEnable   */

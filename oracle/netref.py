@@ -36,6 +36,8 @@ class RefNet:
                 cnt = L.N * L.model_C * L.model_k * L.model_k
                 w = model[pos:pos + cnt].reshape(L.N, L.model_C, L.model_k, L.model_k); pos += cnt
                 codes = O.encode_filters(w, q_in, q_out)
+            elif L.ipool == 2:                   # L2Norm row: N float scale weights
+                codes = model[pos:pos + L.N].copy(); pos += L.N
             else:
                 codes = None
             bias = None
@@ -83,7 +85,9 @@ class RefNet:
                 break
             t0 = time.perf_counter()
             x = outs[L.src] if L.src >= -1 else concat[-(L.src + 2)]
-            if L.ipool:
+            if L.ipool == 2:
+                y = np.stack([O.l2norm(xi, self.q[L.q_in_row], self.q[L.index + 1], self.codes[L.index]) for xi in x])
+            elif L.ipool:
                 y = np.stack([O.maxpool(xi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for xi in x])
             else:
                 res = outs[L.add_src] if L.add_src >= 0 else None

@@ -172,6 +172,17 @@ def global_avg(x, mult=669):
     return y
 
 
+def l2norm(x, qx, qy, w):
+    """x int8 [C,H,W]; qx / qy runtime q rows (int8, negated file Q); w float32 [C] -> int8 [C,H,W]."""
+    x = np.ascontiguousarray(x, np.int8)
+    Cc = x.shape[0]; HW = x.size // Cc
+    qx = np.ascontiguousarray(qx[:Cc], np.int8); qy = np.ascontiguousarray(qy[:Cc], np.int8)
+    w = np.ascontiguousarray(w, np.float32)
+    y = np.empty(x.shape, np.int8)
+    lib().tf2o_l2norm(_p(x), Cc, HW, _p(qx), _p(qy), _p(w), _p(y))
+    return y
+
+
 def topk(logits, q, k=5):
     logits = np.ascontiguousarray(logits, np.int8); q = np.ascontiguousarray(q, np.int8)
     labels = np.empty(k, np.int32); feats = np.empty(k, np.float32)

@@ -202,7 +202,7 @@ int tf2o_q_table(const int32_t* vals, int n_vals, int num_layer, int num_conv, i
     int conv_layer = layer == 0 ? 0 : layer - 1;
     int channel = layer == 0 ? 3 : kOutputChannels[conv_layer];
     for (int c = 0; c < channel; c++) {
-      if (kIpoolEnable[conv_layer]) {
+      if (kIpoolEnable[conv_layer] == 1) {           /* 2 = this build's L2Norm row: has its own Q values */
         q[offset + c] = q[kInputLayer[conv_layer] * max_c + c];                 /* :42-43 */
       } else {
         int q_value = pos < n_vals ? vals[pos] : 0; pos++;                      /* :45 */
@@ -442,4 +442,42 @@ void tf2o_layer(const tf2o_layer_t* L, int B, const int8_t* x, const uint8_t* co
     free(a); free(t);
   }
   if (pre) free(pre);
+}
+
+/* ------------------------------------------------------------------------ */
+/* SSD conv4_3 L2Norm row                      */
+/* TransForm_Kit/Quantization/models/SSD/layers/modules/l2norm.py:19-24:     */
+/*   norm = sqrt(sum_c x^2) + 1e-10 ; out = weight[c] * (x / norm)           */
+/* The reference runtime ships no SSD tables, so the INTEGER form of this    */
+/* float op is defined here (and mirrored bit for bit by l2norm_kernel):     */
+/* dequantise with the input's per-channel Q, evaluate in IEEE double in a   */
+/* fixed operation order, requantise with the output row's Q and the input   */
+/* rounding rule of runner.cpp:158-163 (half away from zero, clamp).         */
+/*   qs = max_c Qx[c];  S = sum_c (x[c] << (qs - Qx[c]))^2   (exact integer) */
+/*   norm = sqrt((double)S) * 2^-qs + 1e-10                                  */
+/*   v = ((double)x[c] * 2^-Qx[c]) / norm * ((double)w[c] * 2^Qy[c])         */
+/* x: int8 [C][HW] of one image; qx / qy: RUNTIME q rows (negated file Q).   */
+/* ------------------------------------------------------------------------ */
+void tf2o_l2norm(const int8_t* x, int C, int HW, const int8_t* qx, const int8_t* qy, const float* w, int8_t* y) {
+  int qs = -128;
+  for (int c = 0; c < C; c++) if (-(int)qx[c] > qs) qs = -(int)qx[c];
+#pragma omp parallel for
+  for (int p = 0; p < HW; p++) {
+    int64_t S = 0;
+    for (int c = 0; c < C; c++) {
+      const int64_t v = (int64_t)x[(size_t)c * HW + p] << (qs + (int)qx[c]);
+      S += v * v;
+    }
+    const double norm = sqrt((double)S) * ldexp(1.0, -qs) + 1e-10;
+    for (int c = 0; c < C; c++) {
+      const double a = ldexp(1.0, (int)qx[c]);                 /* 2^-Qx */
+      const double b = (double)w[c] * ldexp(1.0, -(int)qy[c]); /* w * 2^Qy */
+      const double t = ((double)x[(size_t)c * HW + p] * a) / norm;
+      const double v = t * b;
+      double r = v > 0 ? floor(v + 0.5) : ceil(v - 0.5);
+      if (r > 127.0) r = 127.0;
+      if (r < -128.0) r = -128.0;
+      y[(size_t)c * HW + p] = (int8_t)r;
+    }
+  }
 }

@@ -81,7 +81,10 @@ def float_forward(tables: cfg.NetTables, model: np.ndarray, images, device: Opti
 
     for L in plan:
         x = source(L)
-        if L.ipool:
+        if L.ipool == 2:            # L2Norm row (l2norm.py:19-24)
+            wl = params[f"layer{L.index}.l2w"].reshape(1, -1, 1, 1)
+            y = wl * (x / (x.pow(2).sum(dim=1, keepdim=True).sqrt() + 1e-10))
+        elif L.ipool:
             y = x
         else:
             w = params[f"layer{L.index}.filter"]
@@ -133,7 +136,7 @@ class Calibrator:
         """{-1: image row, l: row of conv l} as the reference writes them (non-negated ints)."""
         rows = {}
         for k, v in self.maxabs.items():
-            if k >= 0 and self.plan[k].ipool:
+            if k >= 0 and self.plan[k].ipool == 1:
                 continue
             rows[k] = quantize_channels(v.detach().cpu().numpy().astype(np.float64)).astype(np.int64)
         # tensors that are added together must share one Q vector (feature_writer.cl:119-122 adds raw int8 values;
@@ -150,7 +153,7 @@ class Calibrator:
         rows = self.q_rows()
         vals: List[int] = [int(v) for v in rows[-1]]
         for L in self.plan:
-            if not L.ipool:
+            if L.ipool != 1:
                 vals += [int(v) for v in rows[L.index]]
         assert len(vals) == cfg.q_value_count(self.tables)
         return "".join(f"{v}\n" for v in vals)

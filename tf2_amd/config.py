@@ -650,6 +650,8 @@ def model_float_count(t: NetTables) -> int:
     for L in build_plan(t):
         if not L.ipool:
             total += L.N * L.model_C * L.model_k * L.model_k
+        elif L.ipool == 2:
+            total += L.N                       # L2Norm row: one float scale per channel
         if L.bias_en:
             total += L.N
         if L.bn_en:
@@ -659,7 +661,7 @@ def model_float_count(t: NetTables) -> int:
 
 def q_value_count(t: NetTables) -> int:
     """Number of ints Quantization() reads from the Q file (quantization.cpp:36-53)."""
-    return 3 + sum(L.N for L in build_plan(t) if not L.ipool)
+    return 3 + sum(L.N for L in build_plan(t) if L.ipool != 1)
 
 
 # ----------------------------------------------------------------------------------
@@ -684,6 +686,14 @@ class _B:
         """An independent pooling row (kIpoolEnable, as GoogLeNet's inception pools): no filter, no Q row of its own."""
         self.rows.append(dict(src=src, C=C, H=H, W=W, N=C, k=1, stride=1, pad=0, relu=0, bn=0, bias=0, pool=pool,
                               add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=1))
+        return len(self.rows) - 1
+
+    def l2norm(self, src, C, H, W):
+        """An independent L2Norm row (kIpoolEnable = 2, this build's extension for SSD's conv4_3 branch, SSD.py:46-47 /
+        l2norm.py:19-24): per-pixel x / ||x||_2 times a per-channel float weight, requantised with its own Q row.  No
+        filter; the model stream carries its C float weights."""
+        self.rows.append(dict(src=src, C=C, H=H, W=W, N=C, k=1, stride=1, pad=0, relu=0, bn=0, bias=0, pool=None,
+                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=2))
         return len(self.rows) - 1
 
     def tables(self) -> NetTables:
@@ -771,13 +781,14 @@ def vgg16_tables(image_hw: int = 224, num_classes: int = 1000, with_fc: bool = T
     return b.tables()
 
 
-def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1) -> NetTables:
+def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1, l2norm: bool = True) -> NetTables:
     """The integer part of SSD300-VGG (TransForm_Kit/Quantization/models/SSD/SSD.py:34-77, 89-151; SURVEY.md section 8f
     rank 4) as one table program: VGG16 base with the ceil-mode third pool ('C': 75 -> 38), pool5 = 3x3 / stride 1 /
     pad 1 fused into conv5_3, conv6 = 3x3 pad 6 dilation 6, conv7 = 1x1, the four extra blocks (1x1 then 3x3 with
     stride 2 / pad 1 twice, then unpadded 3x3 twice), and the twelve multibox head convolutions (3x3 pad 1, no
-    ReLU) reading their six source maps: conv4_3 -- whose L2Norm is a float per-pixel rescale that the host applies
-    outside the integer path, SSD.py:46-47 --, conv7, conv8_2, conv9_2, conv10_2, conv11_2.  Rows are ordered trunk
+    ReLU) reading their six source maps: conv4_3 through its L2Norm row (SSD.py:46-47: per-pixel x / ||x|| times a
+    per-channel weight, requantised with its own Q row -- an "independent" row like the pooling rows, kIpoolEnable = 2),
+    conv7, conv8_2, conv9_2, conv10_2, conv11_2.  Rows are ordered trunk
     first, heads last (loc then conf per source); every head row's output is a network output
     (read with tf2_net_read_layer).  `width_div` divides all channel counts (small test nets)."""
     d = max(1, width_div)
@@ -800,8 +811,9 @@ def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1
         cur = b.conv(cur, C, H, H, N, 3, 1, 1, relu=1, bn=0, bias=1, pool=pool)
         conv_idx += 1
         if is_conv4_3:
-            # conv4_3 feeds a multibox head BEFORE pool4: the pool is its own (independent pooling) row
-            sources.append((cur, N, H))
+            # conv4_3 feeds its multibox heads BEFORE pool4 and THROUGH L2Norm (SSD.py:46-47): an L2Norm row of its own,
+            # and the pool as an independent pooling row
+            sources.append((b.l2norm(cur, N, H, H) if l2norm else cur, N, H))
             Ho = H // 2
             cur = b.pool_only(cur, N, H, H, (2, 2, 0, Ho, Ho))
             i += 1

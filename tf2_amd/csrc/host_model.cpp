@@ -84,7 +84,7 @@ tf2_status Net::quantization(const char* text, size_t len, int8_t* q, size_t cap
     const int channel = layer == 0 ? 3 : L.N;           // quantization.cpp:39 (literal 3)
     for (int c = 0; c < channel; c++) {
       int8_t* dst = q + (size_t)layer * M + c;
-      if (L.ipool) {
+      if (L.ipool == 1) {                               // (2 = L2Norm row: reads its own Q values like a conv row)
         *dst = q[(size_t)L.q_in_row * M + c];           // :42-43
       } else {
         const int v = pos < vals.size() ? vals[pos] : 0;
@@ -144,6 +144,9 @@ tf2_status Net::load_model(const float* model, size_t n_floats) {
           for (int t = 0; t < K * K; t++) m.codes[base + t] = get_real(model[pos + base + t], expand);
         }
       pos += cnt;
+    } else if (L.ipool == 2) {                      // L2Norm row: N float scale weights (l2norm.py:13)
+      if (!need(N)) { set_error("tf2_net_load_model: model stream too short (L2Norm weights of layer " + std::to_string(l) + ")"); return TF2_ERR_SIZE; }
+      m.l2w.assign(model + pos, model + pos + N); pos += N;
     }
     std::vector<float> bias_f;
     if (L.bias_en) {
@@ -245,6 +248,7 @@ tf2_status Net::load_model_4bit(const uint8_t* bytes, size_t n_bytes) {
           }
         }
     }
+    if (L.ipool == 2) { if (!next(N, "L2Norm weights", l)) return TF2_ERR_SIZE; floats(m.l2w); }
     std::vector<float> bias_f, mean, var, sf, gamma, betaf;
     if (L.bias_en) { if (!next(N, "bias", l)) return TF2_ERR_SIZE; floats(bias_f); }
     if (L.bn_en) {

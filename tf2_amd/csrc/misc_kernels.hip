@@ -223,6 +223,48 @@ __global__ __launch_bounds__(256) void global_avg_kernel(AvgArgs a) {
   }
 }
 
+// L2Norm row (l2norm.py:19-24 in the engine's integer form; the arithmetic and its order are those of tf2o_l2norm in
+// oracle/tf2_oracle.c): one wavefront per pixel, a lane owns channels 8*lane + 512*k .. +7, the exact integer sum of squares
+// meets in the wave through __shfl_xor, the rest is IEEE double (-ffp-contract=off: no fused multiply-add).
+__global__ __launch_bounds__(256) void l2norm_kernel(L2NormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= a.n_pix) return;                               // wave-uniform
+  const int8_t* xp = a.x + (size_t)pix * a.x_cp;
+  long long S = 0;
+  for (int c0 = lane * 8; c0 < a.C; c0 += 512) {
+    const unsigned long long v8 = *reinterpret_cast<const unsigned long long*>(xp + c0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const long long v = (long long)(signed char)((v8 >> (8 * i)) & 0xff) << a.e[c0 + i];
+      S += v * v;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) S += __shfl_xor(S, m, 64);
+  const double norm = __builtin_sqrt((double)S) * __builtin_ldexp(1.0, -a.qs) + 1e-10;
+  int8_t* yp = a.y + (size_t)pix * a.y_cp;
+  for (int c0 = lane * 8; c0 < a.C; c0 += 512) {
+    const unsigned long long v8 = *reinterpret_cast<const unsigned long long*>(xp + c0);
+    unsigned long long o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const double x = (double)(int)(signed char)((v8 >> (8 * i)) & 0xff);
+      const double t = (x * a.a[c0 + i]) / norm;
+      const double v = t * a.b[c0 + i];
+      double r = v > 0 ? __builtin_floor(v + 0.5) : __builtin_ceil(v - 0.5);
+      r = r > 127.0 ? 127.0 : (r < -128.0 ? -128.0 : r);
+      o |= (unsigned long long)((int)r & 0xff) << (8 * i);
+    }
+    *reinterpret_cast<unsigned long long*>(yp + c0) = o;
+  }
+}
+
+int launch_l2norm(const L2NormArgs& a, void* stream) {
+  hipLaunchKernelGGL(l2norm_kernel, dim3((a.n_pix + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 static inline int grid_for(long long total, int block = 256) {
   long long g = (total + block - 1) / block;
   long long cap = 256LL * 16;

@@ -77,6 +77,9 @@ tf2_status Net::init(const tf2_net_desc* d, const tf2_layer_desc* ls) {
       for (int j = 0; j < l; j++)
         if (layers[j].concat == cid) { srcH = layers[j].endpool ? 1 : layers[j].PH; srcW = layers[j].endpool ? 1 : layers[j].PW; }
     }
+    if (L.ipool == 2 && (srcC != L.C || L.N != L.C || L.pool_en || L.endpool || L.add_src >= 0 || L.concat >= 0 || L.src < 0)) {
+      set_error("layer " + std::to_string(l) + ": an L2Norm row maps C channels of a layer output onto C channels, nothing else"); return TF2_ERR_ARG;
+    }
     if (!L.ipool && (srcC != L.C || srcH != L.H || srcW != L.W)) {
       set_error("layer " + std::to_string(l) + ": input " + std::to_string(L.C) + "x" + std::to_string(L.H) + "x" + std::to_string(L.W) +
                 " does not match its producer's " + std::to_string(srcC) + "x" + std::to_string(srcH) + "x" + std::to_string(srcW));
@@ -319,6 +322,17 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
+    if (L.ipool == 2) {                  // L2Norm row
+      const PackLayer* pl2 = pack_layer(l);
+      const TensorPlan& ti = T(E.in_tensor); const TensorPlan& to = T(E.out_tensor);
+      Launch st; st.kind = Launch::L2N; st.layer = l;
+      L2NormArgs& a = st.l2n;
+      a.x = base + ti.offset; a.y = base + to.offset + E.out_off;
+      a.a = (const double*)(pk + pl2->off_w); a.b = (const double*)(pk + pl2->off_w2); a.e = (const int32_t*)(pk + pl2->off_bias);
+      a.n_pix = batch * ti.H * ti.W; a.C = round_up(L.N, 16); a.x_cp = ti.Cp; a.y_cp = to.Cp; a.qs = pl2->max_shift;
+      lp.steps.push_back(st);
+      continue;
+    }
     if (L.ipool) {
       const TensorPlan& ti = T(E.in_tensor);
       pool_step(l, ti, base + ti.offset, ti.H, ti.W);
@@ -404,6 +418,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       }
       case Launch::POOL: rc = launch_maxpool(st.pool, stream); break;
       case Launch::AVG: rc = launch_global_avg(st.avg, stream); break;
+      case Launch::L2N: rc = launch_l2norm(st.l2n, stream); break;
       case Launch::CONV:
         switch (st.sel) {
           case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;

@@ -16,7 +16,7 @@ constexpr uint32_t kPackVersion = 18;
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ---- conv kernel kinds -----------------------------------------------------------
-enum ConvKind : int32_t { KIND_NONE = 0, KIND_MFMA = 1, KIND_SHIFT = 2 };
+enum ConvKind : int32_t { KIND_NONE = 0, KIND_MFMA = 1, KIND_SHIFT = 2, KIND_L2NORM = 3 };
 
 // Directory entry of the packed weight image, one per layer.  All offsets are relative
 // to the start of the image so that it can be broadcast and bound on any rank.
@@ -122,6 +122,15 @@ struct AvgArgs {
   int32_t B, HW, x_cp, x_off, y_cp, y_off, C, mult;
 };
 
+// L2Norm row (SSD conv4_3 branch, l2norm.py:19-24) in the engine's integer form -- see oracle/tf2_oracle.c tf2o_l2norm
+struct L2NormArgs {
+  const int8_t* x; int8_t* y;
+  const double* a;            // 2^-Qx[c]
+  const double* b;            // w[c] * 2^Qy[c]
+  const int32_t* e;           // qs - Qx[c] >= 0
+  int32_t n_pix, C, x_cp, y_cp, qs;
+};
+
 struct PrepArgs {
   const void* img; int8_t* y;
   int32_t B, C, H, W;         // source image dims
@@ -140,12 +149,14 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream)
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);
+int launch_l2norm(const L2NormArgs& a, void* stream);
 const char* device_last_error();
 
 // ---- host model -------------------------------------------------------------------
 struct LayerModel {
   std::vector<uint8_t> codes;               // [N][C][k][k] (layer 0 rewritten when conv1_rewrite)
   std::vector<int32_t> bias, alpha, beta;   // BiasBnParam, types.h:39-43
+  std::vector<float> l2w;                   // L2Norm rows: per-channel scale weights
 };
 
 struct Tensor {           // a device activation tensor [B][H][W][Cp]

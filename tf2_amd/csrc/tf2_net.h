@@ -36,7 +36,7 @@ struct WorkPlan {
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
-  enum Kind { PREP, CONV, POOL, AVG } kind = CONV;
+  enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
   enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0;
@@ -44,6 +44,7 @@ struct Launch {
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
+  L2NormArgs l2n{};
 };
 
 struct LaunchPlan {

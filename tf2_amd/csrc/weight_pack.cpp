@@ -17,6 +17,7 @@
 // The image is position independent (offsets relative to its start) so that rank 0 can
 // broadcast it once over RCCL and every rank bind it at its own address.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "tf2_net.h"
@@ -75,7 +76,11 @@ tf2_status Net::pack(int mode) {
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     int s;
-    if (L.ipool) s = src_signed(L.src);
+    if (L.ipool == 2) {                     // L2Norm: sign(w) * sign(x)
+      s = src_signed(L.src);
+      for (float wv : models[l].l2w) if (wv < 0) s = 1;
+    }
+    else if (L.ipool) s = src_signed(L.src);
     else if (L.add_src >= 0) s = L.add_relu ? 0 : 1;
     else s = L.relu ? 0 : 1;
     out_signed[l] = s;
@@ -87,6 +92,30 @@ tf2_status Net::pack(int mode) {
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     PackLayer pl{};
+    if (L.ipool == 2) {
+      // L2Norm row: per channel a = 2^-Qx, b = w * 2^Qy (doubles), e = qs - Qx (left shifts of the exact integer sum of
+      // squares), qs = max Qx -- the constants of tf2o_l2norm / l2norm_kernel
+      const int M = nd.max_out_channel;
+      const int8_t* qx = q.data() + (size_t)L.q_in_row * M;
+      const int8_t* qy = q.data() + (size_t)(l + 1) * M;
+      const int C = L.N, Cp = round_up(C, 16);
+      int qs = -128;
+      for (int c = 0; c < C; c++) qs = std::max(qs, -(int)qx[c]);
+      std::vector<double> a(Cp, 0.0), b(Cp, 0.0);
+      std::vector<int32_t> e(Cp, 0);
+      for (int c = 0; c < C; c++) {
+        a[c] = std::ldexp(1.0, (int)qx[c]);
+        b[c] = (double)models[l].l2w[c] * std::ldexp(1.0, -(int)qy[c]);
+        e[c] = qs + (int)qx[c];
+        if (e[c] > 12) { set_error("layer " + std::to_string(l) + ": L2Norm input Q spread too wide"); return TF2_ERR_UNSUPPORTED; }
+      }
+      pl.kind = KIND_L2NORM; pl.Np = Cp; pl.max_shift = qs;
+      pl.off_w = blob.alloc((size_t)Cp * 8); std::memcpy(blob.at<uint8_t>(pl.off_w), a.data(), (size_t)Cp * 8);
+      pl.off_w2 = blob.alloc((size_t)Cp * 8); std::memcpy(blob.at<uint8_t>(pl.off_w2), b.data(), (size_t)Cp * 8);
+      pl.off_bias = blob.alloc((size_t)Cp * 4); std::memcpy(blob.at<uint8_t>(pl.off_bias), e.data(), (size_t)Cp * 4);
+      *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
+      continue;
+    }
     if (L.ipool) {
       pl.kind = KIND_NONE;
       *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;

@@ -34,6 +34,8 @@ def split_model(tables: cfg.NetTables, model: np.ndarray) -> List[Tuple[str, np.
     for L in cfg.build_plan(tables):
         if not L.ipool:
             take(f"layer{L.index}.filter", (L.N, L.model_C, L.model_k, L.model_k), True)
+        elif L.ipool == 2:
+            take(f"layer{L.index}.l2w", (L.N, 1, 1, 1))
         if L.bias_en:
             take(f"layer{L.index}.bias", (L.N, 1, 1, 1))
         if L.bn_en:

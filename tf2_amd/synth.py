@@ -30,7 +30,10 @@ def synth_q_values(tables: cfg.NetTables, seed: int = 0, lo: int = 2, hi: int = 
     rows: Dict[int, np.ndarray] = {}
     vals: List[int] = [2, 2, 2][:3]
     for L in plan:
-        if L.ipool:
+        if L.ipool == 1:
+            continue
+        if L.ipool == 2:                     # L2Norm output: weight ~ 20 times a unit vector -> Q = 2 keeps it in int8
+            rows[L.index] = np.full(L.N, 2) - rng.integers(0, 2, size=L.N)
             continue
         if L.add_src >= 0 and L.add_src in rows and rows[L.add_src].size == L.N:
             r = rows[L.add_src]
@@ -45,7 +48,7 @@ def synth_q_values(tables: cfg.NetTables, seed: int = 0, lo: int = 2, hi: int = 
         if L.add_src >= 0 and not plan[L.add_src].ipool:
             rows[L.add_src] = rows[L.index]
     for L in plan:
-        if not L.ipool:
+        if L.ipool != 1:
             vals.extend(int(v) for v in rows[L.index])
     return np.asarray(vals, np.int32)
 
@@ -77,6 +80,8 @@ def synth_model(tables: cfg.NetTables, q_vals, seed: int = 0, zero_frac: float =
             row_energy = (w.astype(np.float64) ** 2).sum(axis=1)
         else:
             row_energy = np.ones(L.N)
+            if L.ipool == 2:                 # L2Norm scale weights (SSD.py:24 initialises them to 20)
+                out.append(rng.uniform(12.0, 24.0, size=L.N).astype(np.float32))
         if L.bias_en:
             out.append(rng.uniform(-0.5, 0.5, size=L.N).astype(np.float32))
         if L.bn_en:
