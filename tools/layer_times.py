@@ -59,6 +59,8 @@ if a.stamps:
     print("cycle stamps of block 0 (deltas, 100 MHz ticks?): start->e_start, ->header+A landed+barrier, ->prologue B issued, ->loop end, ->epilogue end")
     for i in range(n):
         r = d[i]
-        print(i, [int(r[1] - r[0]), int(r[2] - r[1]), int(r[3] - r[2]), int(r[5] - r[3]), int(r[6] - r[5])])
+        print(i, [int(r[1] - r[0]), int(r[2] - r[1]), int(r[3] - r[2]), int(r[5] - r[3]), int(r[6] - r[5])],
+              "K loop of block 0 / wave 0 (cycles per step): vmcnt wait %.0f  barrier %.0f  body(reads, DMA issue, MFMA issue) %.0f  over %d steps" %
+              (r[8] / max(1, r[11]), r[9] / max(1, r[11]), r[10] / max(1, r[11]), r[11]) if r[11] else "")
 if a.out:
     json.dump(rows, open(a.out, "w"), indent=0, default=float)
