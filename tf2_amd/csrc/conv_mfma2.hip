@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // its per-wave instruction count: many light waves (32x32 or 32x64 tiles) beat four waves with 64x64 tiles.
 // DUAL: two-phase layers packed with both exponent windows per entry (weight_pack.cpp): [hi TM rows][lo TM rows] of
 // weights and ONE activation slab per K step, two accumulators, combined once as (hi << dshift[1]) + lo.
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool PF, int ORD = 0>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   constexpr int AG = A_BYTES / 1024, BG = TN / 16, NG = AG + BG;
   constexpr int NI_LO = NG / NW, REM = NG % NW, NI_HI = NI_LO + (REM ? 1 : 0);
   static_assert((S - 2) * NI_HI <= 15, "vmcnt immediate range");
-  static_assert(!PF || S >= 4, "the prefetching loop keeps one more stage resident");
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [ring S*STAGE][header: rows {bias, alpha, beta64.lo, beta64.hi} (4*TM) | lo (TM) | dshift (P*TM) | steps[max_ent] |
   //           goff[max_ent*4] | ghw[max_ent*4]]   (gather words resolved per (entry, chunk) at pack time;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
           const int row = wn * WTN + j * 32 + (lane & 31);
           bf[j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
         }
-        if (ORD == 0 && ks == 0) issue_next();
+        if (ks == 0) issue_next();
 #pragma unroll
         for (int i = 0; i < NTM; i++)
 #pragma unroll
@@ -309,9 +308,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
             acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af2[i], bf[j], acc2[i][j], 0, 0, 0);
           }
-        // ORD 1: the next stage's DMAs go out behind the first half's MFMAs (the matrix pipe has work queued while the
-        // wave waits for the texture-address unit to take its requests); ORD 2: behind all of the step's MFMAs
-        if ((ORD == 1 && ks == 0) || (ORD == 2 && ks == 1)) { __builtin_amdgcn_sched_barrier(0); issue_next(); __builtin_amdgcn_sched_barrier(0); }
       }
     } else {
       i32x4 af[2][NTM], bf[2][NTN];
@@ -329,122 +325,41 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
           bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
         }
       }
-      if (ORD == 0) issue_next();
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-        for (int i = 0; i < NTM; i++)
-#pragma unroll
-          for (int j = 0; j < NTN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
-        if ((ORD == 1 && ks == 0) || (ORD == 2 && ks == 1)) { __builtin_amdgcn_sched_barrier(0); issue_next(); __builtin_amdgcn_sched_barrier(0); }
-      }
-    }
-    cslot = cslot + 1 == S ? 0 : cslot + 1;
-  };
-
-  if constexpr (PF) {
-    // ---- prefetching loop: the fragments of step it+1 are read from LDS while the MFMAs of step it run -------------
-    // conv_mfma2's plain loop is barrier -> ds_read -> MFMA per step: with every wave of the block released by the same
-    // barrier, the matrix pipe sits idle through each step's LDS read phase (measured 45 % MFMA-busy inside the K loop
-    // of the two-window 3x3 layers, tools/block_timeline.py).  Here step it's operands were read during step it-1 into
-    // a second register set, so its MFMAs issue right after the barrier; the price is one more resident ring stage
-    // (stage it+1 must have landed before step it starts) and twice the fragment registers.
-    struct Frags { i32x4 af[2][NTM]; i32x4 af2[DUAL ? 2 : 1][DUAL ? NTM : 1]; i32x4 bf[2][NTN]; };
-    auto read_frags = [&](int slot_idx, Frags& f) {
-      const int8_t* A = lds + slot_idx * STAGE;
-      const int8_t* B = A + A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < NTM; i++) {
-          const int row = wm * WTM + i * 32 + (lane & 31);
-          const int o = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-          f.af[ks][i] = *reinterpret_cast<const i32x4*>(A + o);
-          if (DUAL) f.af2[ks][i] = *reinterpret_cast<const i32x4*>(A + TM * 64 + o);
-        }
-#pragma unroll
-        for (int j = 0; j < NTN; j++) {
-          const int row = wn * WTN + j * 32 + (lane & 31);
-          f.bf[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-        }
-      }
-    };
-    auto mfma_frags = [&](const Frags& f) {
+      issue_next();
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
         for (int i = 0; i < NTM; i++)
 #pragma unroll
-          for (int j = 0; j < NTN; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.af[ks][i], f.bf[ks][j], acc[i][j], 0, 0, 0);
-            if (DUAL) acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.af2[ks][i], f.bf[ks][j], acc2[i][j], 0, 0, 0);
-          }
-    };
-    // one step: MFMAs of `it` from `cur`; meanwhile stage it+1 (landed, barrier) is read into `nxt` and stage it+S-1 issued
-    auto step = [&](int it, const Frags& cur, Frags& nxt) {
-      const bool has_next = it + 1 < n_ent;
-      if (has_next) {
-        // stage it+1 landed?  Younger in the queue: stages it+2 .. it+S-2 (all issued when it+S-2 < n_ent)
-        if (it + S - 2 < n_ent) { if (ni_hi) wait_vmcnt<(S - 3) * NI_HI>(); else wait_vmcnt<(S - 3) * NI_LO>(); }
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();          // ... in every wave; and every wave is done reading stage it-1
-        asm volatile("" ::: "memory");
-      }
-      if (it + S - 1 < n_ent) {
-        issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot);      // into the slot of stage it-1
-        islot = islot + 1 == S ? 0 : islot + 1;
-        off_nx = goff[(it + S) * 4 + chunk];
-        if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
-      }
-      if (has_next) {
-        const int nslot = cslot + 1 == S ? 0 : cslot + 1;
-        read_frags(nslot, nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);       // the reads above are issued before the matrix work below
-      if (!DUAL)
-        while (it == next_b) {
-          phase++; phase_shift(phase);
-          next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
-        }
-      mfma_frags(cur);
-      cslot = cslot + 1 == S ? 0 : cslot + 1;
-    };
-    Frags f0, f1;
-    read_frags(0, f0);                         // stage 0 landed (wait + barrier above)
-    int it = 0;
-    while (it < n_ent) {
-      step(it, f0, f1);
-      if (++it >= n_ent) break;
-      step(it, f1, f0);
-      ++it;
+          for (int j = 0; j < NTN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
     }
-  } else {
-    int it = 0;
-    long long t_wait = 0, t_bar = 0, t_body = 0;     // dbg: cycles of block 0 / wave 0 in vmcnt wait, barrier, step body
-    for (; it < n_main; it++) {
-      if (it) {
-        const long long c0 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
-        wait_main();
-        const long long c1 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
-        __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
-        asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
-        if (dbg_on) { const long long c2 = (long long)__builtin_readcyclecounter(); t_wait += c1 - c0; t_bar += c2 - c1; }
-      }
-      const long long c3 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
-      body(it, true);
-      if (dbg_on) t_body += (long long)__builtin_readcyclecounter() - c3;
+    cslot = cslot + 1 == S ? 0 : cslot + 1;
+  };
+
+  int it = 0;
+  long long t_wait = 0, t_bar = 0, t_body = 0;     // dbg (tools/layer_times.py --stamps): cycles of block 0 / wave 0 in the vmcnt wait, the barrier, the step body
+  for (; it < n_main; it++) {
+    if (it) {
+      const long long c0 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
+      wait_main();
+      const long long c1 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
+      __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
+      asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
+      if (dbg_on) { const long long c2 = (long long)__builtin_readcyclecounter(); t_wait += c1 - c0; t_bar += c2 - c1; }
     }
-    if (dbg_on) { adbg[8] = t_wait; adbg[9] = t_bar; adbg[10] = t_body; adbg[11] = n_main; }
-    for (; it < n_ent; it++) {               // tail: nothing left to issue, wait for everything
-      if (it) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      body(it, false);
+    const long long c3 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
+    body(it, true);
+    if (dbg_on) t_body += (long long)__builtin_readcyclecounter() - c3;
+  }
+  if (dbg_on) { adbg[8] = t_wait; adbg[9] = t_bar; adbg[10] = t_body; adbg[11] = n_main; }
+  for (; it < n_ent; it++) {               // tail: nothing left to issue, wait for everything
+    if (it) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    body(it, false);
   }
   if (DUAL) {
     // combine the two windows: (hi << dshift[1][row]) + lo   (Z/2^32, as the Horner form)
@@ -507,12 +422,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool PF = false, int ORD = 0>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
 static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, PF, ORD>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
@@ -520,30 +435,15 @@ static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool DUAL>
-static int launch_ord(const ConvArgs& a, hipStream_t s) {
-  const int ord = (a.g.flags >> 5) & 3;      // A/B switch: where in the step the next stage's DMAs are issued
-  const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
-  if (ord == 1) return pad ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, DUAL, false, 1>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, DUAL, false, 1>(a, s);
-  if (ord == 2) return pad ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, DUAL, false, 2>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, DUAL, false, 2>(a, s);
-  return pad ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, DUAL, false, 0>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, DUAL, false, 0>(a, s);
-}
-
 template <int WM, int WN, int WTM, int WTN, int S, int OCC>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   // bounds checks on the gathered taps are only needed for padded convolutions
-  return launch_ord<WM, WN, WTM, WTN, S, OCC, false>(a, s);
-}
-
-// prefetching loop (PF): one more ring stage, one block per CU for the two-window tiles
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool DUAL>
-static int launch_pf(const ConvArgs& a, hipStream_t s) {
-  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, DUAL, true>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, DUAL, true>(a, s);
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, false>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, false>(a, s);
 }
 
 template <int WM, int WN, int WTM, int WTN, int S, int OCC>
 static int launch_dual(const ConvArgs& a, hipStream_t s) {
-  return launch_ord<WM, WN, WTM, WTN, S, OCC, true>(a, s);
+  return (a.g.pad_h | a.g.pad_w) ? launch_cfg2<WM, WN, WTM, WTN, S, OCC, true, true>(a, s) : launch_cfg2<WM, WN, WTM, WTN, S, OCC, false, true>(a, s);
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so
@@ -555,18 +455,6 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   const bool w16 = (a.g.flags & 4) != 0;
   static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
   const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
-  // long K walks take the prefetching loop (a.g.flags bit 3 = off, bit 4 = also for short walks: A/B switches)
-  static const int pf_min = getenv("TF2_AMD_PF_MIN") ? atoi(getenv("TF2_AMD_PF_MIN")) : 8;
-  const bool pf = (a.g.flags & 16) && a.ent0 >= pf_min && !w4 && !w16;      // measured slower (profiles/r02_prefetch_loop_layer_times.txt): opt-in
-  if (pf) {
-    if (a.dual) {
-      if (TM == 128) return launch_pf<4, 2, 32, 64, 4, 1, true>(a, s);
-      if (TM == 64 && blocks256 >= t256) return launch_pf<2, 4, 32, 64, 4, 1, true>(a, s);
-    } else {
-      if (TM == 128) return launch_pf<4, 2, 32, 64, 4, 1, false>(a, s);        // (two register sets of fragments: 128 VGPRs spill)
-      if (TM == 64 && blocks256 >= t256) return launch_pf<2, 4, 32, 64, 4, 1, false>(a, s);
-    }
-  }
   if (a.dual) {
     if (TM == 128) return launch_dual<4, 2, 32, 64, 3, 2>(a, s);
     if (TM == 64) return blocks256 >= t256 ? launch_dual<2, 4, 32, 64, 3, 2>(a, s) : launch_dual<2, 2, 32, 32, 4, 4>(a, s);

@@ -206,7 +206,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
 // ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
 void Net::load_options() {
   RunOpts o;
-  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 126;   // conv_mfma2 A/B switches: 2 = 4-wave, 4 = 16-wave blocks, 8 = no prefetching loop, 16 = prefetching loop for short K walks too
+  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 6;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);

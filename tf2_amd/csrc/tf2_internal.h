@@ -71,7 +71,7 @@ struct ConvGeom {
   int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
   int32_t relu, add_relu, has_res;
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
-  int32_t flags;             // conv_mfma2 A/B switches (TF2_AMD_EXP): bits 1,2 block shapes, bit 3 no prefetching loop, bit 4 always
+  int32_t flags;             // bits 1,2: conv_mfma2 block-shape A/B switches (TF2_AMD_EXP)
 };
 
 // n / d for 0 <= n < 2^31 as one 32x32->hi multiply and a shift: L = ceil(log2 d), m = floor(2^(31+L) / d) + 1,
