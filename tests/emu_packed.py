@@ -8,7 +8,7 @@ import numpy as np
 HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir_bytes", "<u4"),
                 ("total_bytes", "<u8"), ("tables_hash", "<u8"), ("zero_off", "<u8")])
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
-                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual")] +
+                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
                                     "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes")])
 

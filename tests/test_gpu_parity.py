@@ -211,6 +211,22 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
+def test_fused_bottleneck_pairs(r50, monkeypatch):
+    """conv_bneck.hip: branch2b (3x3 / stride 1) + branch2c (1x1 expand, residual, ReLU) of the stride-1 bottlenecks in one
+    launch (C = 64 / 128 / 256; halo tile and intermediate tile in LDS, weights from registers): every layer with keep_all
+    (the intermediate map is then also stored) at ragged batches, the logits of plain runs, and the unfused path
+    (TF2_AMD_NOFUSE=1 at pack time) on the same inputs."""
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(synth.synth_images(rig.t, 3, 61))
+    x = synth.synth_images(rig.t, 5, 62)
+    want = rig.ref.logits(rig.ref.run(x))
+    np.testing.assert_array_equal(rig.run(x, keep_all=False), want)
+    monkeypatch.setenv("TF2_AMD_NOFUSE", "1")
+    rig2 = Rig(*r50, 0)
+    np.testing.assert_array_equal(rig2.run(x, keep_all=False), want)
+    rig2.check_all_layers(synth.synth_images(rig.t, 2, 63), layers={3, 4, 16, 17, 32, 33, 52, 53})
+
+
 def test_googlenet_ipool_concat_every_layer(golden_dir):
     """The reference's second shipped network (googlenet.h tables + shipped googlenet_Q): 67 table rows with independent
     pooling rows (kIpoolEnable), four-way concat slices (kNStart/kBranchTail/kConcatLayer, extra Q rows), 5x5 convs, the

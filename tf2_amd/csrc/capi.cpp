@@ -104,7 +104,7 @@ tf2_status tf2_net_get_bias_bn(const tf2_net* net, int layer, int32_t* bias, int
   return TF2_OK;
 }
 
-tf2_status tf2_net_pack(tf2_net* net, int mode) { CHECK_NET(net); net->impl.launch_plans.clear(); return net->impl.pack(mode); }
+tf2_status tf2_net_pack(tf2_net* net, int mode) { CHECK_NET(net); net->impl.launch_plans.clear(); net->impl.plans.clear(); return net->impl.pack(mode); }
 
 size_t tf2_net_packed_size(const tf2_net* net) { return net && net->impl.packed_valid ? net->impl.packed.size() : 0; }
 
@@ -128,7 +128,7 @@ tf2_status tf2_net_packed_adopt(tf2_net* net, const void* host_src, size_t n_byt
   N.packed.assign((const uint8_t*)host_src, (const uint8_t*)host_src + n_bytes);
   N.packed_valid = true;
   N.packed_dev = nullptr; N.packed_dev_bytes = 0;
-  N.launch_plans.clear();
+  N.launch_plans.clear(); N.plans.clear();
   return TF2_OK;
 }
 

@@ -153,6 +153,19 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   }
   wp.final_tensor = layer_out[nl - 1];
   wp.tensors[wp.final_tensor].last_use = nl;
+  // Fused pairs (conv_bneck.hip: layer l computes layer fuse_next as well, block by block): everything the launch reads
+  // stays live until the LATER layer's index, and everything it writes exists from the EARLIER one -- otherwise the
+  // first-fit planner hands the expand's output the memory of the 3x3's input, which other blocks are still reading.
+  if (packed_valid)
+    for (int l = 0; l < nl; l++) {
+      const PackLayer* pl = pack_layer(l);
+      if (!pl || pl->fuse_next <= 0) continue;
+      const int b = pl->fuse_next;
+      TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
+      tin.last_use = std::max(tin.last_use, b);
+      for (size_t t = 0; t < wp.tensors.size(); t++)
+        if (born[t] == b) born[t] = l;
+    }
   // ---- offsets ----
   struct Seg { size_t off, len; };
   std::vector<Seg> free_list;           // sorted by offset
@@ -338,8 +351,31 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       pool_step(l, ti, base + ti.offset, ti.H, ti.W);
       continue;
     }
+    const PackLayer* pl = pack_layer(l);
+    if (pl->fused_into >= 0) continue;             // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     Launch st;
     if (!make_conv(l, st)) return nullptr;
+    if (pl->fuse_next > 0) {
+      // this 3x3 + its only consumer (the 1x1 expand) in one launch; the expand's argument block supplies the second half
+      Launch sb;
+      if (!make_conv(pl->fuse_next, sb)) return nullptr;
+      const PackLayer* pb = pack_layer(pl->fuse_next);
+      BneckArgs& f = st.bneck;
+      const ConvArgs& ca = st.conv; const ConvArgs& cb = sb.conv;
+      f.x = ca.x; f.y_mid = ca.y; f.ymid_cp = ca.g.y_cp;
+      f.w1 = ca.w; f.hdr1 = ca.hdr; f.hdr1_used = round_up((5 + pl->n_phases) * pl->TM * 4, 1024);
+      f.dual1 = pl->dual; f.fast1 = pl->fast; f.relu1 = ca.g.relu;
+      f.w2 = cb.w; f.hdr2 = cb.hdr; f.hdr2_bytes = cb.hdr_bytes; f.hdr2_used = round_up((5 + pb->n_phases) * pb->TM * 4, 1024);
+      f.dual2 = pb->dual; f.fast2 = pb->fast; f.relu2 = cb.g.relu;
+      f.y = cb.y; f.y_cp = cb.g.y_cp; f.y_off = cb.g.y_off; f.y_nvalid = cb.g.y_nvalid;
+      f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
+      f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0;
+      f.B = batch; f.H = L.H; f.W = L.W;
+      const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
+      f.R = std::min(TN / L.W, L.H);
+      f.tiles_per_img = (L.H + f.R - 1) / f.R;
+      st.sel = Launch::SEL_BNECK; st.shape = TN;
+    }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en) {
@@ -424,6 +460,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
           case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
           case Launch::SEL_SK: rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream); break;
           case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
+          case Launch::SEL_BNECK: rc = launch_conv_bneck(st.bneck, st.TM, st.shape, stream); break;
           default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
         }
         break;

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 18;
+constexpr uint32_t kPackVersion = 19;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -36,6 +36,9 @@ struct PackLayer {
   int32_t fast;        // MFMA: every output row passed the range proof of the 3-instruction requantisation
   int32_t dual;        // MFMA, two-phase layers: every entry holds BOTH exponent windows' tiles ([hi TM rows][lo TM rows],
                        // one activation slab), accumulated separately and combined once: (hi << dshift[1]) + lo
+  int32_t fuse_next;   // > 0: this 3x3 layer and layer `fuse_next` (its only consumer, the 1x1 expand) run as ONE conv_bneck launch;
+                       // both are packed with TM = this layer's channel count (64 / 128 / 256)
+  int32_t fused_into;  // >= 0: the layer whose launch computes this one (-1 otherwise)
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -110,6 +113,24 @@ struct ConvArgs {
   ConvGeom g;
 };
 
+// conv_bneck.hip: layer C (3x3 / stride 1 / pad 1, C -> C channels, C = 64 / 128 / 256) followed by its only consumer E
+// (1x1, C -> 4C, + residual): one launch per R x W pixel band of an image.
+struct BneckArgs {
+  const int8_t* x;           // C's input, NHWC with exactly C bytes per pixel
+  int8_t* y_mid;             // C's own output tensor (written only with keep_mid)
+  int8_t* y;                 // E's output tensor
+  const int8_t* res;
+  const int8_t* w1;          // C: dense weight tiles [tap * slabs + slab][(hi | lo)][TM][64]
+  const int8_t* w2;          // E: dense weight tiles [pass * slabs + slab][(hi | lo)][TM][64]
+  const int32_t* hdr1;       // header image of C's single m-tile; the first hdr1_used bytes hold rows | lo | dshift
+  const int32_t* hdr2;       // E's four header images (stride hdr2_bytes)
+  const int8_t* zero;
+  int32_t hdr1_used, hdr2_bytes, hdr2_used;
+  int32_t B, H, W, R, tiles_per_img;     // R output rows per block, ceil(H / R) blocks per image
+  int32_t dual1, fast1, relu1, dual2, fast2, relu2, add_relu, has_res, keep_mid;
+  int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
+};
+
 struct PoolArgs {
   const int8_t* x; int8_t* y;
   int32_t B, H, W, x_cp, x_off;
@@ -146,6 +167,8 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // 
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
+int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
+size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);

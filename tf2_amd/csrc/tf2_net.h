@@ -37,10 +37,11 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK } sel = SEL_MFMA2;
   int layer = -1;
-  int TM = 0, signed_in = 0, mul24 = 0;
+  int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   ConvArgs conv{};
+  BneckArgs bneck{};
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};

@@ -87,11 +87,49 @@ tf2_status Net::pack(int mode) {
     if (L.concat >= 0 && s) concat_signed[L.concat] = 1;
   }
 
+  const uint64_t zero_off = (dir_bytes + 255) / 256 * 256;       // right behind the directory (allocated per attempt below)
+  // ---- fused pairs (conv_bneck.hip): A = a 3x3 / stride 1 / pad 1 conv with C -> C channels (C = 64 / 128 / 256) whose
+  // ONLY consumer is B = a 1x1 / stride-1 expand to 4C channels (branch2b -> branch2c of a ResNet bottleneck).  Both are
+  // then packed with TM = C rows per m-tile (A: one m-tile, B: four).  Structural test here; after packing, the pair must
+  // also pass the kernel's limits (dense weights, at most two exponent windows, LDS), else the image is repacked without it.
+  std::vector<int> fuse_next(nl, 0), fused_into(nl, -1);
+  std::vector<char> nofuse(nl, 0);
+  const bool fusion_on = mode == 0 && getenv("TF2_AMD_NOFUSE") == nullptr;
+  auto decide_fusion = [&]() {
+    std::fill(fuse_next.begin(), fuse_next.end(), 0); std::fill(fused_into.begin(), fused_into.end(), -1);
+    if (!fusion_on) return;
+    std::vector<int> users(nl, 0), user_of(nl, -1);
+    for (int j = 0; j < nl; j++) {
+      if (layers[j].src >= 0) { users[layers[j].src]++; user_of[layers[j].src] = j; }
+      if (layers[j].add_src >= 0) users[layers[j].add_src] += 2;          // a residual read: never fused away
+    }
+    for (int l = 0; l + 1 < nl; l++) {
+      const tf2_layer_desc& A = layers[l];
+      if (nofuse[l] || fused_into[l] >= 0) continue;
+      if (A.ipool || A.pool_en || A.endpool || A.add_src >= 0 || A.concat >= 0 || A.src < 0) continue;
+      if (A.k != 3 || A.stride != 1 || A.pad_h != 1 || A.pad_w != 1 || A.dil != 1 || A.C != A.N || !A.relu) continue;
+      if (A.N != 64 && A.N != 128) continue;            // (256-channel pairs on 14x14 maps: too few blocks per launch, measured no faster)
+      if (src_signed(A.src) || layers[A.src].concat >= 0) continue;       // unsigned input tensor with exactly C bytes per pixel
+      if (users[l] != 1) continue;
+      const int b = user_of[l];
+      const tf2_layer_desc& B = layers[b];
+      if (B.src != l || B.ipool || B.pool_en || B.endpool || B.concat >= 0 || B.k != 1 || B.stride != 1 || (B.pad_h | B.pad_w)) continue;
+      if (B.add_src >= l) continue;                                       // the residual must exist when A's launch runs
+      if (B.N != 4 * A.N || B.C != A.N) continue;
+      const int TN = A.N == 64 ? 256 : 128;
+      if (A.W > TN) continue;                                             // at least one full-width row per block
+      fuse_next[l] = b; fused_into[b] = l;
+    }
+  };
+  for (int attempt = 0; attempt < 8; attempt++) {
+  decide_fusion();
+  packed.clear();
   blob.alloc(dir_bytes);
-  const uint64_t zero_off = blob.alloc(256);
+  if (blob.alloc(256) != zero_off) { set_error("tf2_net_pack: internal layout error"); return TF2_ERR_STATE; }
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     PackLayer pl{};
+    pl.fused_into = -1;
     if (L.ipool == 2) {
       // L2Norm row: per channel a = 2^-Qx, b = w * 2^Qy (doubles), e = qs - Qx (left shifts of the exact integer sum of
       // squares), qs = max Qx -- the constants of tf2o_l2norm / l2norm_kernel
@@ -145,7 +183,10 @@ tf2_status Net::pack(int mode) {
       // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
       static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
-      const int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
+      int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
+      if (fuse_next[l] > 0) TM = Np;                                   // fused pair: the 3x3 in one m-tile ...
+      if (fused_into[l] >= 0) TM = layers[fused_into[l]].N;            // ... and the expand in four of the same height
+      pl.fuse_next = fuse_next[l]; pl.fused_into = fused_into[l];
       const int n_mtiles = Np / TM;
       const int Ktot = taps * il.Cp_in;
       const int nslab = (Ktot + 63) / 64;
@@ -393,6 +434,25 @@ tf2_status Net::pack(int mode) {
     }
     *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
   }
+  // ---- do the fused pairs pass the kernel's limits? ----
+  bool redo = false;
+  for (int l = 0; l < nl; l++) {
+    if (fuse_next[l] <= 0) continue;
+    const tf2_layer_desc& A = layers[l];
+    PackLayer* pa = blob.at<PackLayer>(sizeof(PackHeader)) + l;
+    PackLayer* pb = blob.at<PackLayer>(sizeof(PackHeader)) + fuse_next[l];
+    bool ok = pa->kind == KIND_MFMA && pb->kind == KIND_MFMA && pa->n_mtiles == 1 && pb->n_mtiles == 4 && pb->TM == pa->TM;
+    ok = ok && (pa->n_phases == 1 || pa->dual) && (pb->n_phases == 1 || pb->dual);
+    ok = ok && pa->nslab == 9 * (pa->TM / 64) && pa->n_entries == pa->nslab && pb->nslab == pa->TM / 64 && pb->n_entries == 4 * pb->nslab;
+    if (ok) {
+      const int TN = pa->TM == 64 ? 256 : 128;
+      const size_t h1 = (size_t)round_up((5 + pa->n_phases) * pa->TM * 4, 1024), h2 = (size_t)round_up((5 + pb->n_phases) * pb->TM * 4, 1024);
+      ok = conv_bneck_lds_bytes(pa->TM, TN, TN / A.W, A.W, h1, h2) <= 160 * 1024;
+    }
+    if (!ok) { nofuse[l] = 1; redo = true; }
+  }
+  if (!redo) break;
+  }   // attempt
   blob.alloc(0);
   PackHeader h{};
   h.magic = kPackMagic; h.version = kPackVersion; h.n_layers = (uint32_t)nl; h.dir_bytes = (uint32_t)dir_bytes;
