@@ -353,6 +353,22 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     }
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0) continue;             // computed by the launch of layer pl->fused_into (conv_bneck.hip)
+    if (pl->kind == KIND_HEAD) {
+      // global average of layer l-1's map + this FC + the dense logits in one launch (the AVG step of l-1 was not emitted)
+      const tf2_layer_desc& S = layers[l - 1];
+      const LayerExec& ES = wp->exec[l - 1];
+      const TensorPlan& tcs = T(ES.conv_tensor); const TensorPlan& tavg = T(ES.out_tensor); const TensorPlan& ty = T(E.out_tensor);
+      Launch st; st.kind = Launch::HEAD; st.layer = l;
+      HeadArgs& h = st.head;
+      h.x = base + tcs.offset; h.avg_out = base + tavg.offset; h.y = base + ty.offset; h.logits = nullptr;
+      h.w = (const int32_t*)(pk + pl->off_w); h.bias = (const int32_t*)(pk + pl->off_bias);
+      h.alpha = (const int32_t*)(pk + pl->off_alpha); h.beta = (const int32_t*)(pk + pl->off_beta);
+      h.B = batch; h.HW = S.PH * S.PW; h.x_cp = tcs.Cp; h.C = round_up(S.N, 8); h.N = L.N; h.Np = pl->Np;
+      h.mult = S.endpool_mult; h.avg_cp = tavg.Cp; h.y_cp = ty.Cp; h.relu = L.relu;
+      lp.steps.push_back(st);
+      lp.logits_by_head = true;
+      continue;
+    }
     Launch st;
     if (!make_conv(l, st)) return nullptr;
     if (pl->fuse_next > 0) {
@@ -380,7 +396,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en) {
       pool_step(l, tc, base + tc.offset, L.OH, L.OW);
-    } else if (L.endpool) {
+    } else if (L.endpool && !(l + 1 < nl && pack_layer(l + 1)->kind == KIND_HEAD)) {
       Launch sa; sa.kind = Launch::AVG; sa.layer = l;
       AvgArgs& aa = sa.avg;
       const TensorPlan& to = T(E.out_tensor);
@@ -455,6 +471,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       case Launch::POOL: rc = launch_maxpool(st.pool, stream); break;
       case Launch::AVG: rc = launch_global_avg(st.avg, stream); break;
       case Launch::L2N: rc = launch_l2norm(st.l2n, stream); break;
+      case Launch::HEAD: { HeadArgs h = st.head; h.logits = logits; rc = launch_head(h, stream); break; }
       case Launch::CONV:
         switch (st.sel) {
           case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
@@ -474,7 +491,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     prof_event_layer.push_back(-1);
   }
   // dense logits [batch][H_last * W_last][N_last]  (H = W = 1 for the classification networks)
-  if (logits) {
+  if (logits && !lp->logits_by_head) {
     const TensorPlan& tf = wp->tensors[wp->final_tensor];
     const tf2_layer_desc& LL = layers[nl - 1];
     const size_t rows = (size_t)batch * tf.H * tf.W;

@@ -36,7 +36,7 @@ struct WorkPlan {
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
-  enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
+  enum Kind { PREP, CONV, POOL, AVG, L2N, HEAD } kind = CONV;
   enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
@@ -46,6 +46,7 @@ struct Launch {
   AvgArgs avg{};
   PrepArgs prep{};
   L2NormArgs l2n{};
+  HeadArgs head{};
 };
 
 struct LaunchPlan {
@@ -54,6 +55,7 @@ struct LaunchPlan {
   void* ws = nullptr;
   const uint8_t* packed_dev = nullptr;
   std::vector<Launch> steps;
+  bool logits_by_head = false;      // the last launch writes the dense logits itself (head_kernel): no copy
 };
 
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)

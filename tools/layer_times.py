@@ -48,8 +48,9 @@ for i, L in enumerate(plan):
     byts = (L.C * L.H * L.W + L.N * L.PH * L.PW * (2 if L.add_src >= 0 else 1)) * a.batch
     TM = int(pl["TM"]); npix = a.batch * L.OH * L.OW
     blocks = int(pl["n_mtiles"]) * (-(-npix // (128 if TM == 128 else 256))) if int(pl["kind"]) == 1 else 0
+    if us <= 0: us = 1e-9
     ent = int(pl["n_entries"]) / max(1, int(pl["n_mtiles"]))
-    us = ms[i] * 1e3
+    us = max(ms[i] * 1e3, 1e-9)
     rows.append(dict(layer=i, k=L.k, C=L.C, N=L.N, HW=L.OH, stride=L.stride, phases=int(pl["n_phases"]), entries_per_mtile=ent,
                      blocks=blocks, us=float(us), tops=ops / us / 1e6, gbps=byts / us / 1e3))
     print(f"{i:>2} {L.k} {L.C:>4} {L.N:>4} {L.OH:>3} {L.stride} {int(pl['n_phases'])} {ent:6.1f} {blocks:>6} {us:7.1f} {ops/us/1e6:7.1f} {byts/us/1e3:7.1f}")
