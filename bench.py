@@ -297,7 +297,7 @@ def main():
     for i, L in enumerate(plan):
         c = classes.setdefault(lo[i]["cls"], dict(ops=0, bytes=0, ms=0.0, kernel=set()))
         c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
-        c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift", 3: "l2norm", 4: "head"}.get(int(kinds[i]), "?"))
+        c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift", 3: "l2norm"}.get(int(kinds[i]), "?"))
     PEAK_I8 = 5000.0    # TOP/s dense int8 MFMA (MI355X_MICROARCH.md: ~2x the 2.5 PF bf16 dense peak)
     PEAK_HBM = 8000.0   # GB/s
     per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), ms=round(v["ms"], 4),
@@ -308,7 +308,7 @@ def main():
                  for k, v in classes.items()}
     # dominant kernel family = the convolution kernels: all their launches of one step.  SURVEY.md 8(d): the binding
     # roofline of the layer-by-layer int8 streaming is HBM; the int8 MFMA fraction is reported beside it.
-    cv = [i for i in range(len(plan)) if kinds[i] in (1, 2, 4)]
+    cv = [i for i in range(len(plan)) if kinds[i] in (1, 2)]
     dom_ops = sum(lo[i]["ops"] for i in cv) * args.batch
     alg_bytes = sum(lo[i]["bytes"] for i in cv) * args.batch
     dom_ms = float(sum(per_layer_ms[i] for i in cv))

@@ -51,7 +51,7 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
     """L: LayerSpec.  x_t: input tensor [B,H,W,Cp_in] int8.  Returns conv-stage output NCHW
     [B,N,OH,OW] after requant/relu/residual (before pool / global average)."""
     B, H, W, Cp = x_t.shape
-    assert Cp == int(pl["Cp_in"]) or int(pl["kind"]) in (2, 4)
+    assert Cp == int(pl["Cp_in"]) or int(pl["kind"]) == 2
     N, OH, OW = L.N, L.OH, L.OW
     Np = int(pl["Np"])
     bias = i32(blob, int(pl["off_bias"]), Np).astype(np.int64)
@@ -111,12 +111,6 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
                         a = (a + (wt[e, 0].astype(np.float64) @ slab(int(entries[e])).astype(np.float64).T).astype(np.int64)) % 2 ** 32
             acc[mt * TM:(mt + 1) * TM] = a
         acc = (bias[:, None] + (acc << lo[:, None])) % 2 ** 32
-    elif int(pl["kind"]) == 4:
-        # head_kernel: +-2^s as int32, transposed [C][Np]; the input is the averaged 1x1 map
-        Cc = L.C
-        w = i32(blob, int(pl["off_w"]), Cc * Np).reshape(Cc, Np).astype(np.int64)
-        xv = x_t.reshape(npix, -1)[:, :Cc].astype(np.int64)                  # [B, C]
-        acc = (bias[:, None] + (xv @ w).T) % 2 ** 32
     else:
         k, taps, ncc = L.k, L.k * L.k, int(pl["n_cchunk"])
         cnt = (Np // 8) * ncc * taps * 128

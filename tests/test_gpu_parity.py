@@ -215,7 +215,9 @@ def test_fused_bottleneck_pairs(r50, monkeypatch):
     """conv_bneck.hip: branch2b (3x3 / stride 1) + branch2c (1x1 expand, residual, ReLU) of the stride-1 bottlenecks in one
     launch (C = 64 / 128 / 256; halo tile and intermediate tile in LDS, weights from registers): every layer with keep_all
     (the intermediate map is then also stored) at ragged batches, the logits of plain runs, and the unfused path
-    (TF2_AMD_NOFUSE=1 at pack time) on the same inputs."""
+    (TF2_AMD_NOFUSE=1 at pack time) on the same inputs.  TF2_AMD_BNECK_MIN=1: the fused launch also for the small grids of
+    these batches (by default a pair runs fused only when it has at least 256 row bands, i.e. blocks)."""
+    monkeypatch.setenv("TF2_AMD_BNECK_MIN", "1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 3, 61))
     x = synth.synth_images(rig.t, 5, 62)

@@ -74,7 +74,7 @@ def test_tiny_all_modes(mode, kind):
         x[0, :, :2, :] = -128                     # force the negate quirk
     kinds, _ = check_net(t, q, model, x, mode)
     if mode == 0:
-        assert set(kinds) <= {1, 2, 4} and 1 in kinds        # 4: the avg + FC head (head_kernel)
+        assert set(kinds) <= {1, 2} and 1 in kinds
     if mode == 2:
         assert set(kinds) == {2}
 
@@ -93,7 +93,7 @@ def test_resnet50_selected_layers(golden_dir):
     model = synth.synth_model(t, q, 0)
     x = synth.synth_images(t, 1, 0)
     kinds, pls = check_net(t, q, model, x, 0, layers={0, 1, 3, 4, 11, 13, 14, 46, 52, 53})
-    assert set(kinds) == {1, 4} and kinds[-1] == 4      # MFMA everywhere, the FC behind the global average as head_kernel
+    assert set(kinds) == {1}
     # the shipped resnet50_Q has per-input-channel Q spreads up to 2 in the early layers: those
     # need a second exponent window; the uniform-Q late layers need exactly one phase
     assert int(pls[3]["n_phases"]) == 2 and int(pls[46]["n_phases"]) == 1

@@ -304,6 +304,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   const int chl = tile_ch + 16 * half;
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
     *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
+  else if (px < g.n_pix && g.y_tail == 8 && chl == g.y_nvalid) {
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<i32x2_t*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = i32x2_t{out[0], out[1]};
+  }
 }
 
 template <int S, bool PADCHK, bool DUAL, int NWV>

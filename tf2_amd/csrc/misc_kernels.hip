@@ -265,63 +265,6 @@ int launch_l2norm(const L2NormArgs& a, void* stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Network head: global average (full_size_pool.cl:104-119: int16 accumulator, (S * mult >> 14) + 1 >> 1, clamp) of image
-// b's last feature map into LDS, then 128 outputs of the FC behind it as shift-accumulate with int32 weights +-2^s (pe.cl:27-49
-// on a 1x1 map; the averaged values are non-negative, so the -128 negate quirk cannot occur -- checked at pack time), the
-// requantisation of pe.cl:185-203, and the dense int8 logits.  Block = (image, 128 output channels); thread = (output, K half).
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  extern __shared__ int head_lds[];
-  int* const xs = head_lds;                               // [C] averaged activations
-  int* const part = head_lds + a.C;                       // [128] partial sums of the second K half
-  const int b = blockIdx.x, n0 = blockIdx.y * 128, tid = threadIdx.x;
-  const int8_t* xb = a.x + (size_t)b * a.HW * a.x_cp;
-  for (int c0 = tid * 8; c0 < a.C; c0 += 2048) {
-    int sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = 0; p < a.HW; p++) {
-      const unsigned long long v = *reinterpret_cast<const unsigned long long*>(xb + (size_t)p * a.x_cp + c0);
-#pragma unroll
-      for (int i = 0; i < 8; i++) sum[i] += (int)(signed char)((v >> (8 * i)) & 0xff);
-    }
-    unsigned long long o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int sv = (int)(short)sum[i];                   // int16 accumulator wrap (types.h:30)
-      int m = (((sv * a.mult) >> 14) + 1) >> 1;            // full_size_pool.cl:118
-      m = m > 127 ? 127 : (m < -128 ? -128 : m);
-      xs[c0 + i] = m;
-      o |= (unsigned long long)(m & 0xff) << (8 * i);
-    }
-    if (blockIdx.y == 0) *reinterpret_cast<unsigned long long*>(a.avg_out + (size_t)b * a.avg_cp + c0) = o;
-  }
-  __syncthreads();
-  const int o = tid & 127, kq = tid >> 7;
-  const int n = n0 + o;
-  const int kh = (a.C + 1) / 2;
-  const int c_lo = kq * kh, c_hi = (c_lo + kh) < a.C ? (c_lo + kh) : a.C;
-  unsigned acc = 0;
-  const int32_t* wp = a.w + n;
-#pragma unroll 8
-  for (int c = c_lo; c < c_hi; c++) acc += (unsigned)wp[(size_t)c * a.Np] * (unsigned)xs[c];      // Z/2^32, as pe.cl:43
-  if (kq == 1) part[o] = (int)acc;
-  __syncthreads();
-  if (kq == 0 && n < a.N) {
-    const int v = (int)(acc + (unsigned)part[o] + (unsigned)a.bias[n]);
-    long long pr = (long long)v * (long long)a.alpha[n];
-    int t = (int)(pr >> kAlphaInflat);
-    t = (int)((unsigned)t + (unsigned)a.beta[n]);
-    int r = ((t >> (kInflat - 1)) + 1) >> 1;
-    r = r > 127 ? 127 : (r < -128 ? -128 : r);
-    if (a.relu) r = r > 0 ? r : 0;
-    a.y[(size_t)b * a.y_cp + n] = (int8_t)r;
-    if (a.logits) a.logits[(size_t)b * a.N + n] = (int8_t)r;
-  }
-}
-
-int launch_head(const HeadArgs& a, void* stream) {
-  hipLaunchKernelGGL(head_kernel, dim3(a.B, (a.N + 127) / 128), dim3(256), (size_t)(a.C + 128) * 4, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 static inline int grid_for(long long total, int block = 256) {
   long long g = (total + block - 1) / block;
   long long cap = 256LL * 16;

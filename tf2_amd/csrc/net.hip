@@ -223,6 +223,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
+  if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 256)
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
@@ -332,6 +333,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     }
     return true;
   };
+  std::vector<char> fused_done(nl, 0);
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
@@ -352,26 +354,14 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       continue;
     }
     const PackLayer* pl = pack_layer(l);
-    if (pl->fused_into >= 0) continue;             // computed by the launch of layer pl->fused_into (conv_bneck.hip)
-    if (pl->kind == KIND_HEAD) {
-      // global average of layer l-1's map + this FC + the dense logits in one launch (the AVG step of l-1 was not emitted)
-      const tf2_layer_desc& S = layers[l - 1];
-      const LayerExec& ES = wp->exec[l - 1];
-      const TensorPlan& tcs = T(ES.conv_tensor); const TensorPlan& tavg = T(ES.out_tensor); const TensorPlan& ty = T(E.out_tensor);
-      Launch st; st.kind = Launch::HEAD; st.layer = l;
-      HeadArgs& h = st.head;
-      h.x = base + tcs.offset; h.avg_out = base + tavg.offset; h.y = base + ty.offset; h.logits = nullptr;
-      h.w = (const int32_t*)(pk + pl->off_w); h.bias = (const int32_t*)(pk + pl->off_bias);
-      h.alpha = (const int32_t*)(pk + pl->off_alpha); h.beta = (const int32_t*)(pk + pl->off_beta);
-      h.B = batch; h.HW = S.PH * S.PW; h.x_cp = tcs.Cp; h.C = round_up(S.N, 8); h.N = L.N; h.Np = pl->Np;
-      h.mult = S.endpool_mult; h.avg_cp = tavg.Cp; h.y_cp = ty.Cp; h.relu = L.relu;
-      lp.steps.push_back(st);
-      lp.logits_by_head = true;
-      continue;
-    }
+    if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     Launch st;
     if (!make_conv(l, st)) return nullptr;
-    if (pl->fuse_next > 0) {
+    // a fused launch needs enough row bands to fill the chip (one block per band): small batches run the two layers on their own
+    const int bn_TN = pl->TM == 64 ? 256 : 128;
+    const int bn_R = pl->fuse_next > 0 ? std::min(bn_TN / L.W, L.H) : 1;
+    if (pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks) {
+      fused_done[pl->fuse_next] = 1;
       // this 3x3 + its only consumer (the 1x1 expand) in one launch; the expand's argument block supplies the second half
       Launch sb;
       if (!make_conv(pl->fuse_next, sb)) return nullptr;
@@ -392,11 +382,19 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       f.tiles_per_img = (L.H + f.R - 1) / f.R;
       st.sel = Launch::SEL_BNECK; st.shape = TN;
     }
+    // the last layer of a classifier (1x1 map, split-K kernel) stores the dense logits [batch][N] itself: no copy kernel
+    if (l == nl - 1 && !wp->keep_all && st.sel == Launch::SEL_SK && !L.pool_en && !L.endpool && L.concat < 0 &&
+        L.PH * L.PW == 1 && (L.N % 16 == 0 || L.N % 16 == 8)) {
+      st.conv_direct = st.conv;
+      ConvGeom& gd = st.conv_direct.g;
+      gd.y_cp = L.N; gd.y_off = 0; gd.y_nvalid = L.N / 16 * 16; gd.y_tail = L.N % 16;
+      lp.logits_direct = (int)lp.steps.size();
+    }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en) {
       pool_step(l, tc, base + tc.offset, L.OH, L.OW);
-    } else if (L.endpool && !(l + 1 < nl && pack_layer(l + 1)->kind == KIND_HEAD)) {
+    } else if (L.endpool) {
       Launch sa; sa.kind = Launch::AVG; sa.layer = l;
       AvgArgs& aa = sa.avg;
       const TensorPlan& to = T(E.out_tensor);
@@ -471,11 +469,15 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       case Launch::POOL: rc = launch_maxpool(st.pool, stream); break;
       case Launch::AVG: rc = launch_global_avg(st.avg, stream); break;
       case Launch::L2N: rc = launch_l2norm(st.l2n, stream); break;
-      case Launch::HEAD: { HeadArgs h = st.head; h.logits = logits; rc = launch_head(h, stream); break; }
       case Launch::CONV:
         switch (st.sel) {
           case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
-          case Launch::SEL_SK: rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream); break;
+          case Launch::SEL_SK:
+            if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
+              ConvArgs cd = st.conv_direct; cd.y = logits;
+              rc = launch_conv_mfma_sk(cd, opts.sk8_blocks, stream);
+            } else rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream);
+            break;
           case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
           case Launch::SEL_BNECK: rc = launch_conv_bneck(st.bneck, st.TM, st.shape, stream); break;
           default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
@@ -491,7 +493,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     prof_event_layer.push_back(-1);
   }
   // dense logits [batch][H_last * W_last][N_last]  (H = W = 1 for the classification networks)
-  if (logits && !lp->logits_by_head) {
+  if (logits && lp->logits_direct < 0) {
     const TensorPlan& tf = wp->tensors[wp->final_tensor];
     const tf2_layer_desc& LL = layers[nl - 1];
     const size_t rows = (size_t)batch * tf.H * tf.W;

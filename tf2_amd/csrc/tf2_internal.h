@@ -16,7 +16,7 @@ constexpr uint32_t kPackVersion = 19;
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ---- conv kernel kinds -----------------------------------------------------------
-enum ConvKind : int32_t { KIND_NONE = 0, KIND_MFMA = 1, KIND_SHIFT = 2, KIND_L2NORM = 3, KIND_HEAD = 4 };
+enum ConvKind : int32_t { KIND_NONE = 0, KIND_MFMA = 1, KIND_SHIFT = 2, KIND_L2NORM = 3 };
 
 // Directory entry of the packed weight image, one per layer.  All offsets are relative
 // to the start of the image so that it can be broadcast and bound on any rank.
@@ -71,6 +71,8 @@ struct ConvGeom {
   int32_t n_pix;             // batch * OH * OW
   int32_t y_cp, y_off;       // output bytes per pixel, channel offset of this layer's slice
   int32_t y_nvalid;          // valid output channels rounded up to the store granule
+  int32_t y_tail;            // conv_mfma_sk only: 8 = the 16-channel group starting at y_nvalid holds 8 more valid channels (dense
+                             // logits rows of N = 8 mod 16 channels, e.g. 1000: the padding must not run into the next row)
   int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
   int32_t relu, add_relu, has_res;
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
@@ -152,18 +154,6 @@ struct L2NormArgs {
   int32_t n_pix, C, x_cp, y_cp, qs;
 };
 
-// head_kernel (misc_kernels.hip): global average of the last feature map + the FC layer behind it + the dense logits, one
-// launch instead of three (full_size_pool.cl:95-125, then the FC as the 1x1 convolution of pe.cl on a 1x1 map)
-struct HeadArgs {
-  const int8_t* x;            // the conv output before the average: [B][HW][x_cp]
-  int8_t* avg_out;            // the averaged tensor [B][avg_cp] (read back by per-layer tests; consumed from LDS here)
-  int8_t* y;                  // the FC's own tensor [B][y_cp]
-  int8_t* logits;             // dense [B][N] (may be null)
-  const int32_t* w;           // +-2^s as int32, transposed: [C][Np]
-  const int32_t* bias; const int32_t* alpha; const int32_t* beta;
-  int32_t B, HW, x_cp, C, N, Np, mult, avg_cp, y_cp, relu;
-};
-
 struct PrepArgs {
   const void* img; int8_t* y;
   int32_t B, C, H, W;         // source image dims
@@ -185,7 +175,6 @@ int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);
 int launch_l2norm(const L2NormArgs& a, void* stream);
-int launch_head(const HeadArgs& a, void* stream);
 const char* device_last_error();
 
 // ---- host model -------------------------------------------------------------------

@@ -36,17 +36,17 @@ struct WorkPlan {
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
-  enum Kind { PREP, CONV, POOL, AVG, L2N, HEAD } kind = CONV;
+  enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
   enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   ConvArgs conv{};
+  ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
   BneckArgs bneck{};
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
   L2NormArgs l2n{};
-  HeadArgs head{};
 };
 
 struct LaunchPlan {
@@ -55,12 +55,13 @@ struct LaunchPlan {
   void* ws = nullptr;
   const uint8_t* packed_dev = nullptr;
   std::vector<Launch> steps;
-  bool logits_by_head = false;      // the last launch writes the dense logits itself (head_kernel): no copy
+  int logits_direct = -1;           // index of the conv step that writes the dense logits itself (its y is patched per call), else -1
 };
 
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
+  long bneck_min_blocks = 256;
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };

@@ -92,19 +92,6 @@ tf2_status Net::pack(int mode) {
   // ONLY consumer is B = a 1x1 / stride-1 expand to 4C channels (branch2b -> branch2c of a ResNet bottleneck).  Both are
   // then packed with TM = C rows per m-tile (A: one m-tile, B: four).  Structural test here; after packing, the pair must
   // also pass the kernel's limits (dense weights, at most two exponent windows, LDS), else the image is repacked without it.
-  // ---- network head (head_kernel): the last layer is an FC on the 1x1 map that the layer before it produces by its global
-  // average; nobody else reads that map, and it cannot hold negatives (the int32 weights +-2^s multiply the value itself,
-  // which equals pe.cl's negate-then-shift except for x = -128)
-  int head_layer = -1;
-  if (mode == 0 && nl >= 2 && getenv("TF2_AMD_NOHEAD") == nullptr) {
-    const tf2_layer_desc& F = layers[nl - 1];
-    if (!F.ipool && F.k == 1 && F.H == 1 && F.W == 1 && F.src == nl - 2 && !F.pool_en && !F.endpool && F.add_src < 0 && F.concat < 0) {
-      const tf2_layer_desc& S = layers[nl - 2];
-      bool ok = S.endpool && !S.ipool && S.concat < 0 && !src_signed(nl - 2) && S.N % 8 == 0;
-      for (int j = 0; j < nl - 1 && ok; j++) ok = layers[j].src != nl - 2 && layers[j].add_src != nl - 2;
-      if (ok) head_layer = nl - 1;
-    }
-  }
   std::vector<int> fuse_next(nl, 0), fused_into(nl, -1);
   std::vector<char> nofuse(nl, 0);
   const bool fusion_on = mode == 0 && getenv("TF2_AMD_NOFUSE") == nullptr;
@@ -190,21 +177,7 @@ tf2_status Net::pack(int mode) {
     pl.signed_in = in_signed ? 1 : 0;
     pl.Cp_in = il.Cp_in;
 
-    if (l == head_layer) {
-      pl.kind = KIND_HEAD;
-      const int Np = round_up(N, 128);
-      std::vector<int32_t> w((size_t)C * Np, 0);
-      for (int n = 0; n < N; n++)
-        for (int c = 0; c < C; c++) {
-          const uint8_t code = m.codes[(size_t)n * C + c];
-          if (code_zero(code)) continue;
-          const uint32_t mag = 1u << code_shift(code);
-          w[(size_t)c * Np + n] = (int32_t)(code_neg(code) ? 0u - mag : mag);
-        }
-      pl.Np = Np; pl.n_phases = 1; pl.TM = 128; pl.n_mtiles = Np / 128;
-      pl.off_w = blob.alloc(w.size() * 4);
-      std::memcpy(blob.at<uint8_t>(pl.off_w), w.data(), w.size() * 4);
-    } else if (use_mfma) {
+    if (use_mfma) {
       pl.kind = KIND_MFMA;
       const int Np = round_up(N, 64);
       // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output

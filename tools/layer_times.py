@@ -48,7 +48,6 @@ for i, L in enumerate(plan):
     byts = (L.C * L.H * L.W + L.N * L.PH * L.PW * (2 if L.add_src >= 0 else 1)) * a.batch
     TM = int(pl["TM"]); npix = a.batch * L.OH * L.OW
     blocks = int(pl["n_mtiles"]) * (-(-npix // (128 if TM == 128 else 256))) if int(pl["kind"]) == 1 else 0
-    if us <= 0: us = 1e-9
     ent = int(pl["n_entries"]) / max(1, int(pl["n_mtiles"]))
     us = max(ms[i] * 1e3, 1e-9)
     rows.append(dict(layer=i, k=L.k, C=L.C, N=L.N, HW=L.OH, stride=L.stride, phases=int(pl["n_phases"]), entries_per_mtile=ent,
