@@ -165,7 +165,13 @@ def main():
             i = step_no[0] % n_inflight
             step_no[0] += 1
             with torch.cuda.stream(fl_streams[i]):
-                one(fl_runners[i], x)
+                if args.graph:
+                    key = (i, x.data_ptr(), x.shape[0])
+                    if key not in graphs:
+                        graphs[key] = fl_runners[i].capture(x, split=args.split)
+                    graphs[key]()
+                else:
+                    one(fl_runners[i], x)
             return
         if args.graph:
             key = (x.data_ptr(), x.shape[0])

@@ -6,7 +6,7 @@ gfx950 -- validated here against layers whose byte count is known), wave cycles 
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r01_pmc_conv_b32.json")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_pmc_conv_b32.json")
 
 def table(d):
     f = glob.glob(f"{src}/{d}/runc/*_counter_collection.csv")[0]
@@ -16,19 +16,43 @@ def table(d):
         e[x["Counter_Name"]] = float(x["Counter_Value"])
     return [v for v in disp.values() if "tf2::conv_" in v["kernel"]]
 
-n = 54
+# conv launches of ONE step in launch order -> table rows (layers); a conv_bneck launch computes two layers (the 3x3 and the
+# 1x1 expand behind it): its counters go to the first, the second gets an all-zero row with fused_into set
+sys.path.insert(0, ROOT)
+import numpy as np
+from tf2_amd import config as cfg, network, synth
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import emu_packed as emu
+_t = cfg.resnet50_tables()
+_q = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
+_net = network.NetWork(_t); _net.Quantization(synth.q_text(_q)); _net.LoadModel(synth.synth_model(_t, _q, 0)); _net.Pack(0)
+_, _pls = emu.parse(_net.packed_host())
+B = int(os.environ.get("PMC_BATCH", "32"))
+_plan = cfg.build_plan(_t)
+fused_into = {}
+for i, (L, pl) in enumerate(zip(_plan, _pls)):
+    fn = int(pl["fuse_next"])
+    TN = 256 if int(pl["TM"]) == 64 else 128
+    if fn > 0 and B * -(-L.H // max(1, min(TN // L.W, L.H))) >= 256:
+        fused_into[fn] = i
+launch_layers = [i for i in range(len(_plan)) if i not in fused_into]
+n = len(launch_layers)
 sq1, sq2, t1, t2 = (table(d)[-n:] for d in ("sq1", "sq2", "tcc1", "tcc2"))
-rows = []
-for i in range(n):
-    a, b, c, d = sq1[i], sq2[i], t1[i], t2[i]
-    rows.append(dict(layer=i, kernel=a["kernel"].split("(")[0][:60], grid_threads=a["grid"], vgpr=a["vgpr"],
+rows = [None] * len(_plan)
+for i in fused_into:
+    rows[i] = dict(layer=i, kernel="(computed by the conv_bneck launch of layer %d)" % fused_into[i], fused_into=fused_into[i], grid_threads=0, vgpr=0,
+                   fetch_bytes=0.0, fetch_bytes_raw_counter=0.0, write_bytes=0.0, waves=0.0, wave_cycles_quad=0.0, wait_any=0.0, wait_inst_any=0.0,
+                   active_inst_any=0.0, insts_valu=0.0, insts_salu=0.0, insts_lds=0.0, insts_vmem=0.0, insts_mfma=0.0, mfma_busy_cycles=0.0, lds_bank_conflict=0.0)
+for k, i in enumerate(launch_layers):
+    a, b, c, d = sq1[k], sq2[k], t1[k], t2[k]
+    rows[i] = dict(layer=i, kernel=a["kernel"].split("(")[0][:60], grid_threads=a["grid"], vgpr=a["vgpr"],
                      fetch_bytes=2 * c["FETCH_SIZE"] * 1024, fetch_bytes_raw_counter=c["FETCH_SIZE"] * 1024,
                      write_bytes=d["WRITE_SIZE"] * 1024, waves=a["SQ_WAVES"], wave_cycles_quad=a["SQ_WAVE_CYCLES"],
                      wait_any=a["SQ_WAIT_ANY"], wait_inst_any=a["SQ_WAIT_INST_ANY"], active_inst_any=a["SQ_ACTIVE_INST_ANY"],
                      insts_valu=a["SQ_INSTS_VALU"], insts_salu=b["SQ_INSTS_SALU"], insts_lds=b["SQ_INSTS_LDS"],
                      insts_vmem=b["SQ_INSTS_VMEM"], insts_mfma=b["SQ_INSTS_MFMA"], mfma_busy_cycles=b["SQ_VALU_MFMA_BUSY_CYCLES"],
-                     lds_bank_conflict=b["SQ_LDS_BANK_CONFLICT"]))
+                     lds_bank_conflict=b["SQ_LDS_BANK_CONFLICT"])
 tot = dict(fetch_bytes=sum(r["fetch_bytes"] for r in rows), write_bytes=sum(r["write_bytes"] for r in rows))
-json.dump(dict(note="rocprofv3 --pmc passes (separate runs: SQ x2, FETCH_SIZE+GRBM, WRITE_SIZE), ResNet50 batch 32, one step; "
+json.dump(dict(note="rocprofv3 --pmc passes (separate runs: SQ x2, FETCH_SIZE+GRBM, WRITE_SIZE), ResNet50 batch 32, one step (a conv_bneck launch covers two table rows: counters on the first); "
                     "fetch_bytes = 2 x FETCH_SIZE KiB (gfx950 correction)", total=tot, layers=rows), open(out, "w"), indent=1)
 print("wrote", out, {k: round(v / 1e6, 1) for k, v in tot.items()}, "MB per step")
