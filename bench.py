@@ -325,20 +325,21 @@ def main():
             pm = json.load(open(pj))
             if len(pm.get("layers", [])) == len(plan):
                 tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in cv)
-                traffic = round(tb / len(cv))
-                traffic_note = (f"mean HBM bytes per launch over the step's {len(cv)} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)"
+                traffic = round(tb / max(1, sum(1 for i in cv if nl[i] > 0)))
+                traffic_note = (f"mean HBM bytes per launch over the step's {sum(1 for i in cv if nl[i] > 0)} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)"
                                 f"+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
                 break
+    n_launch = max(1, sum(1 for i in cv if nl[i] > 0))      # a conv_bneck launch computes two table rows
     gbps = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tops = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
+    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw / conv_bneck: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
              2: "conv_shift_kernel"}[args.mode]
     roofline = dict(bound="hbm", kernel=kname, achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
                     traffic=traffic, traffic_note=traffic_note,
-                    algorithmic_bytes_per_launch=round(alg_bytes / max(1, len(cv))), launches_per_step=len(cv),
-                    avg_launch_us=round(dom_ms / max(1, len(cv)) * 1e3, 2), event_pair_scale=round(event_scale, 4),
+                    algorithmic_bytes_per_launch=round(alg_bytes / n_launch), launches_per_step=n_launch,
+                    avg_launch_us=round(dom_ms / n_launch * 1e3, 2), event_pair_scale=round(event_scale, 4),
                     mfma_side=dict(achieved_tops=round(tops, 1), peak_tops=PEAK_I8, frac=round(tops / PEAK_I8, 4),
-                                   algorithmic_ops_per_launch=round(dom_ops / max(1, len(cv)))),
+                                   algorithmic_ops_per_launch=round(dom_ops / n_launch)),
                     note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d): 26.9 MB per image) of "
                          "the step's conv launches / sum of their HIP-event durations on the launch stream, one batch at a time; "
                          "per-layer event times rescaled by event_pair_scale = (one event pair around the whole layer loop) / (their sum)")
