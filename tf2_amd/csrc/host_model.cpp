@@ -4,7 +4,7 @@
 // :129-258, filter_trans :25-96) and quantization.cpp (:25-55): float32 power-of-two
 // weights -> one-byte codes (zero | sign | shift), bias/BN -> BiasBnParam fixed point,
 // ASCII Q file -> runtime q table.  Results are bit-identical to the reference's own
-// compiled functions (tests/test_host_vs_ref.py); the FPGA re-layout (FilterConvert
+// compiled functions (tests/test_golden_host.py); the FPGA re-layout (FilterConvert
 // :263-322) is not reproduced -- weight_pack.cpp builds the GPU layouts instead.
 #include <cmath>
 #include <cstdlib>
