@@ -108,3 +108,38 @@ def test_pack_modes_and_phase_structure():
         net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(mode)
         sizes.append(net.packed_host().size)
     assert len(set(sizes)) == 3
+
+
+def test_logits_size_and_third_party_table_checks():
+    """tf2_net_logits_size = the dense output [batch][H_last * W_last][N_last]; descs that would index outside the q table
+    or a channel row (a hand-edited <net>.h, a third-party caller) are refused at create time with the layer named."""
+    t = cfg.tiny_tables()
+    net = network.NetWork(t)
+    N = net.plan[-1].N
+    assert _lib.lib().tf2_net_logits_size(net._h, 5) == 5 * N
+    v = cfg.vgg16_tables(64, 10, with_fc=False)           # ends on a 2x2 feature map, not on a 1x1 classifier
+    nv = network.NetWork(v)
+    L = nv.plan[-1]
+    assert _lib.lib().tf2_net_logits_size(nv._h, 3) == 3 * L.PH * L.PW * L.N and L.PH * L.PW > 1
+    lib = _lib.lib()
+
+    def create(mut):
+        plan, nd, arr = network._layer_descs(t)
+        mut(nd, arr)
+        h = C.c_void_p()
+        st = lib.tf2_net_create(C.byref(nd), arr, C.byref(h))
+        msg = lib.tf2_last_error().decode()
+        if st == 0:
+            lib.tf2_net_destroy(h)
+        return st, msg
+
+    st, msg = create(lambda nd, a: setattr(a[1], "q_in_row", 99))
+    assert st == -1 and "layer 1" in msg and "q_in_row" in msg
+    st, msg = create(lambda nd, a: setattr(a[2], "n_start", nd.max_out_channel))
+    assert st == -1 and "layer 2" in msg
+    st, msg = create(lambda nd, a: setattr(nd, "max_out_channel", 4))
+    assert st == -1
+    st, msg = create(lambda nd, a: None)
+    assert st == 0
+    # options are re-read on request (kernel A/B switches for tests and tools); harmless on the CPU
+    assert lib.tf2_net_reload_options(net._h) == 0
