@@ -116,7 +116,9 @@ tf2_status tf2_net_packed_adopt(tf2_net* net, const void* host_src, size_t n_byt
 tf2_status tf2_net_bind_device(tf2_net* net, const void* packed_dev, size_t n_bytes);
 
 /* ---- running (replaces Runner::Run, runner.cpp:54-198, and the OpenCL device pipeline) */
-/* keep_all != 0: every layer output gets its own buffer (per-layer parity tests).       */
+/* keep_all != 0: every layer output gets its own buffer (per-layer parity tests).  Ask AFTER tf2_net_pack /
+ * tf2_net_packed_adopt: the plan depends on which layer pairs the packed image runs as one launch (their inputs
+ * stay live longer); a buffer sized before packing may be refused by tf2_net_run with TF2_ERR_SIZE.               */
 size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all);
 /* Bytes of the dense int8 output of a run: [batch][H_last * W_last][N_last] (NHWC; H_last = W_last = 1 for the
  * classification networks, i.e. [batch][N_last] -- the buffer Runner::Run reads back, runner.cpp:176-186).      */
