@@ -142,3 +142,46 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
             s = np.maximum(s, 0)
         y = s.astype(np.int8)
     return np.ascontiguousarray(y)
+
+
+def conv_stem_from_packed(blob, pl, L, x_nchw):
+    """conv_stem.hip's data flow for the executed first layer: ONE copy of x per pixel (32 bytes), signed window values
+    [window][tap][64 rows][32] at off_w2 (16-byte chunk c of row r at slot c ^ ((r >> 3) & 1)), and the x = -128
+    correction -2 * w * x128 for the negative weights derived from the same tiles (|w| of the negative bytes, twice)."""
+    assert int(pl["kind"]) == 1 and int(pl["off_w2"]) != 0 and int(pl["Np"]) == 64 and L.k == 3
+    P = int(pl["n_phases"])
+    B, C, H, W = x_nchw.shape
+    N, OH, OW = L.N, L.OH, L.OW
+    assert OH == H - 2 and OW == W - 2 and C <= 32
+    st = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + P * 9 * 64 * 32].tobytes(), np.int8).reshape(P, 9, 64, 2, 16)
+    w = np.zeros((P, 9, 64, 32), np.int64)
+    for r in range(64):
+        sw = (r >> 3) & 1
+        w[:, :, r, 0:16] = st[:, :, r, 0 ^ sw]
+        w[:, :, r, 16:32] = st[:, :, r, 1 ^ sw]
+    negmag = np.where(w < 0, -w, 0)
+    x_t = np.zeros((B, H, W, 32), np.int64)
+    x_t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))
+    x128 = np.where(x_t == -128, -128, 0)
+    npix = B * OH * OW
+    win = []
+    for p in range(P):
+        a = np.zeros((64, npix), np.int64)
+        for t in range(9):
+            dh, dw = divmod(t, 3)
+            xs = x_t[:, dh:dh + OH, dw:dw + OW, :].reshape(npix, 32)
+            qs = x128[:, dh:dh + OH, dw:dw + OW, :].reshape(npix, 32)
+            a += w[p, t] @ xs.T + 2 * (negmag[p, t] @ qs.T)
+        win.append(a % 2 ** 32)
+    bias = i32(blob, int(pl["off_bias"]), 64).astype(np.int64)
+    alpha = i32(blob, int(pl["off_alpha"]), 64)
+    beta = i32(blob, int(pl["off_beta"]), 64)
+    lo = i32(blob, int(pl["off_lo"]), 64).astype(np.int64)
+    dsh = i32(blob, int(pl["off_dshift"]), P * 64).reshape(P, 64).astype(np.int64)
+    acc = win[0]
+    for p in range(1, P):
+        acc = ((acc << dsh[p][:, None]) + win[p]) % 2 ** 32
+    acc = (bias[:, None] + (acc << lo[:, None])) % 2 ** 32
+    acc = ((acc + 2 ** 31) % 2 ** 32 - 2 ** 31)
+    y = requant(acc[:N], alpha[:N, None], beta[:N, None], L.relu)
+    return np.ascontiguousarray(y.reshape(N, B, OH, OW).transpose(1, 0, 2, 3))

@@ -128,6 +128,18 @@ def test_resnet50_int8_input_with_minus128(r50_rig):
     r50_rig.check_all_layers(x, layers={0, 1, 4, 53})
 
 
+def test_resnet50_stem_blocks_with_and_without_minus128(r50_rig):
+    """conv_stem.hip decides per block (7 output rows of one image) whether the x = -128 correction runs: a batch in
+    which one image has a small saturated patch, one is saturated everywhere and two have no -128 at all."""
+    x = synth.synth_images(r50_rig.t, 4, 21)
+    x[1, :, 60:64, 150:170] = -1000.0            # clamps to -128 in a few row bands of image 1
+    x[2] = -1000.0
+    outs = r50_rig.ref.run(x)
+    q_in = outs[-1]
+    assert (q_in[1] == -128).any() and not (q_in[0] == -128).any() and not (q_in[3] == -128).any()
+    r50_rig.check_all_layers(x, layers={0, 53})
+
+
 def test_resnet50_full_batch32_logits_and_properties(r50_rig):
     """BASELINE batch: all 32 logits rows against the oracle; batch invariance (row i of the
     batch run == the same image run alone); determinism."""

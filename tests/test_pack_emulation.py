@@ -118,3 +118,27 @@ def test_wide_shift_range_needs_more_windows():
     x = synth.synth_images(t, 2, 9)
     kinds, pls = check_net(t, q, model, x, 0)
     assert int(pls[1]["n_phases"]) >= 2
+
+
+@pytest.mark.parametrize("kind", ["float", "int8"])
+def test_resnet50_first_layer_stem_image(golden_dir, kind):
+    """The x-only weight tiles of conv_stem.hip: signed window values on one copy of x, plus the x = -128 correction
+    derived from them, give the oracle's first layer -- with images that hold -128 (uniform int8) and without."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    x = synth.synth_images(t, 1, 3, kind=kind)
+    if kind == "int8":
+        x[0, :, 5:9, :] = -128
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+    blob = net.packed_host()
+    _, pls = emu.parse(blob)
+    assert int(pls[0]["off_w2"]) != 0
+    R = netref.RefNet(t, q, model)
+    outs = R.run(x)
+    L = R.plan[0]
+    assert (outs[-1] == -128).any() == (kind == "int8")
+    y = emu.conv_stem_from_packed(blob, pls[0], L, outs[-1])
+    y = np.stack([O.maxpool(yi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for yi in y])
+    np.testing.assert_array_equal(y, outs[0])

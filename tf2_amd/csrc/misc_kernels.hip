@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
 // k2(0,1) k3(1,1) k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2) (feature_trans, input_loader.cpp:27-73): a 3x3 window at
 // stride 2 per channel, 27 loads that neighbouring lanes share in L1, 32-bit index arithmetic.  The 64 bytes of
 // [x | xneg] per pixel go through LDS so that every wave store is 1 KiB of contiguous NHWC bytes.
-template <bool SRC_Q>
+// XONLY: 32 bytes of x per pixel and no xneg half -- the input of conv_stem.hip, which handles x = -128 itself.
+template <bool SRC_Q, bool XONLY>
 __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
   __shared__ __attribute__((aligned(16))) int tile[256][17];        // 64 B per pixel (+1 word: bank spread)
   const int total = a.B * a.OH * a.OW;
@@ -136,18 +137,20 @@ __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
         p |= (q & 0xff) << (8 * j);
         n |= ((-q) & 0xff) << (8 * j);        // (int8)(-x): -128 stays -128 (pe.cl:32-37)
       }
-      tile[threadIdx.x][w] = p; tile[threadIdx.x][8 + w] = n;
+      tile[threadIdx.x][w] = p; if (!XONLY) tile[threadIdx.x][8 + w] = n;
     }
   }
   __syncthreads();
   // 256 pixels x 64 B = 16 KiB, written as 4 x (256 lanes x 16 B): consecutive lanes -> consecutive 16-byte chunks
+  // (XONLY: 2 x 16 B per pixel)
+  constexpr int CPP = XONLY ? 2 : 4;                   // 16-byte chunks per pixel
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int c = r * 256 + (int)threadIdx.x;          // chunk index inside the block's 16 KiB
-    const int pl = c >> 2, ch = c & 3;
+  for (int r = 0; r < CPP; r++) {
+    const int c = r * 256 + (int)threadIdx.x;          // chunk index inside the block's output
+    const int pl = c / CPP, ch = c % CPP;
     if (pix0 + pl < total) {
       i32x4 o = {tile[pl][ch * 4], tile[pl][ch * 4 + 1], tile[pl][ch * 4 + 2], tile[pl][ch * 4 + 3]};
-      *reinterpret_cast<i32x4*>(a.y + (size_t)(pix0 + pl) * 64 + ch * 16) = o;
+      *reinterpret_cast<i32x4*>(a.y + (size_t)(pix0 + pl) * (CPP * 16) + ch * 16) = o;
     }
   }
 }
@@ -275,10 +278,16 @@ int launch_prep_input(const PrepArgs& a, void* stream) {
   const long long pixels = (long long)a.B * a.OH * a.OW;
   if (a.rewrite && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
-    if (a.src_is_q) hipLaunchKernelGGL(prep_rewrite3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(prep_rewrite3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.xonly) {
+      if (a.src_is_q) hipLaunchKernelGGL((prep_rewrite3_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((prep_rewrite3_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+      if (a.src_is_q) hipLaunchKernelGGL((prep_rewrite3_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((prep_rewrite3_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
+  if (a.xonly) return -1;                       // only the space-to-depth form has an x-only variant (net.hip checks the same limits)
   long long total = (long long)a.B * a.OH * a.OW * (a.half / 16);
   hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -216,6 +216,17 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   return &res.first->second;
 }
 
+// conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
+// space-to-depth prep applies; the input tensor then carries 32 bytes per pixel in the same allocation.
+bool Net::stem_selected(int batch) const {
+  const tf2_layer_desc& L0 = layers[0];
+  const PackLayer* p0 = pack_layer(0);
+  const long long pixels = (long long)batch * L0.H * L0.W;
+  return opts.stem_mode != 0 && p0 && p0->kind == KIND_MFMA && p0->off_w2 != 0 && nd.conv1_rewrite && nd.image_c == 3 &&
+         in_layout[0].Cp_in == 64 && in_layout[0].half == 32 && L0.OH == L0.H - 2 && L0.OW == L0.W - 2 &&
+         pixels * 64 < (1ll << 31) && (long long)batch * 3 * nd.image_h * nd.image_w < (1ll << 31);
+}
+
 // ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
 void Net::load_options() {
   RunOpts o;
@@ -224,6 +235,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 256)
+  if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
@@ -248,6 +260,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
   const uint64_t zero_off = reinterpret_cast<const PackHeader*>(packed.data())->zero_off;
   auto fail = [&](const std::string& m) -> const LaunchPlan* { set_error(m); return nullptr; };
 
+  const bool stem = stem_selected(batch);
   // input: quantise + (space-to-depth) + [x | xneg]
   {
     const tf2_layer_desc& L0 = layers[0];
@@ -256,7 +269,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     pa.img = nullptr; pa.y = base + T(wp->input_tensor).offset;
     pa.B = batch; pa.C = nd.image_c; pa.H = nd.image_h; pa.W = nd.image_w;
     pa.OH = L0.H; pa.OW = L0.W; pa.y_cp = in_layout[0].Cp_in; pa.half = in_layout[0].half;
-    pa.rewrite = nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = 0;
+    pa.rewrite = nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = 0; pa.xonly = stem ? 1 : 0;
     if (!nd.conv1_rewrite && (L0.H != nd.image_h || L0.W != nd.image_w || L0.C != nd.image_c)) return fail("layer 0 input does not match the image");
     lp.steps.push_back(st);
   }
@@ -382,6 +395,28 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       f.tiles_per_img = (L.H + f.R - 1) / f.R;
       st.sel = Launch::SEL_BNECK; st.shape = TN;
     }
+    if (l == 0 && stem) {
+      const ConvArgs& ca = st.conv;
+      StemArgs& f = st.stem;
+      f.x = ca.x; f.y = ca.y; f.w = (const int8_t*)(pk + pl->off_w2); f.hdr = ca.hdr; f.zero = ca.zero;
+      f.hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
+      f.B = batch; f.H = L.H; f.W = L.W; f.OH = L.OH; f.OW = L.OW;
+      f.relu = ca.g.relu; f.fast = ca.g.fast; f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid;
+      // rows per block: the fewest rounds of (two blocks per CU) x rows; two blocks must share a CU's 160 KiB
+      long best = -1;
+      for (int R = 2; R <= 8; R++) {
+        if (2 * conv_stem_lds_bytes(pl->n_phases, R, L.W, (size_t)f.hdr_used) > 160 * 1024) break;
+        const long blocks = (long)batch * ((L.OH + R - 1) / R);
+        const long cost = ((blocks + 511) / 512) * R;
+        if (best < 0 || cost < best || (cost == best && R == 7)) { best = cost; f.R = R; }
+      }
+      if (best >= 0) {
+        f.bands_per_img = (L.OH + f.R - 1) / f.R;
+        st.sel = Launch::SEL_STEM; st.shape = pl->n_phases;
+      } else {
+        return fail("conv_stem does not fit this first layer; run with TF2_AMD_STEM=0");
+      }
+    }
     // the last layer of a classifier (1x1 map, split-K kernel) stores the dense logits [batch][N] itself: no copy kernel
     if (l == nl - 1 && !wp->keep_all && st.sel == Launch::SEL_SK && !L.pool_en && !L.endpool && L.concat < 0 &&
         L.PH * L.PW == 1 && (L.N % 16 == 0 || L.N % 16 == 8)) {
@@ -480,6 +515,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
             break;
           case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
           case Launch::SEL_BNECK: rc = launch_conv_bneck(st.bneck, st.TM, st.shape, stream); break;
+          case Launch::SEL_STEM: rc = launch_conv_stem(st.stem, st.shape, stream); break;
           default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
         }
         break;
@@ -531,14 +567,15 @@ tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, si
   const TensorPlan& t = wp.tensors[tid];
   const size_t npix = (size_t)batch * t.H * t.W;
   if (cap < npix * C) { set_error("tf2_net_read_layer: destination too small"); return TF2_ERR_SIZE; }
-  std::vector<int8_t> tmp(npix * t.Cp);
+  const size_t Cp = (layer == -1 && packed_valid && stem_selected(batch)) ? 32 : (size_t)t.Cp;     // x-only image tensor (conv_stem.hip)
+  std::vector<int8_t> tmp(npix * Cp);
   HIP_OK(hipMemcpyAsync(tmp.data(), (const int8_t*)ws + t.offset, tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_OK(hipStreamSynchronize((hipStream_t)stream));
   const size_t HW = (size_t)t.H * t.W;
   for (int b = 0; b < batch; b++)
     for (int c = 0; c < C; c++)
       for (size_t p = 0; p < HW; p++)
-        dst[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * t.Cp + off + c];
+        dst[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * Cp + off + c];
   return TF2_OK;
 }
 

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 19;
+constexpr uint32_t kPackVersion = 20;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -133,6 +133,20 @@ struct BneckArgs {
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
 };
 
+// conv_stem.hip: layer 0 in its executed 3x3 / stride 1 / pad 0 form on the x-only image tensor (32 bytes per pixel)
+struct StemArgs {
+  const int8_t* x;           // [B][H][W][32]: 27 (or fewer) channels of x, zero padded
+  int8_t* y;
+  const int8_t* w;           // [window][tap][64 rows][32] signed window values, rows swizzled (weight_pack.cpp)
+  const int32_t* hdr;        // the layer's header image; the first hdr_used bytes hold rows | lo | dshift
+  const int8_t* zero;
+  int32_t hdr_used;
+  int32_t B, H, W, OH, OW;   // input and output maps (OH = H - 2, OW = W - 2)
+  int32_t R, bands_per_img;  // output rows per block, ceil(OH / R) blocks per image
+  int32_t relu, fast;
+  int32_t y_cp, y_off, y_nvalid;
+};
+
 struct PoolArgs {
   const int8_t* x; int8_t* y;
   int32_t B, H, W, x_cp, x_off;
@@ -161,6 +175,7 @@ struct PrepArgs {
   int32_t rewrite;            // 1: 7x7/s2 space-to-depth form (27 channels on 114x114)
   int32_t q0;                 // runtime (negated) Q of image channel 0
   int32_t src_is_q;           // 1: source already int8
+  int32_t xonly;              // 1 (rewrite form only): 32 bytes of x per pixel, no xneg half (conv_stem.hip)
 };
 
 // kernel launchers (tf2_kernels.hip)
@@ -171,6 +186,8 @@ int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
+int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit
+size_t conv_stem_lds_bytes(int nwin, int R, int W, size_t hdr_used);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);

@@ -37,12 +37,13 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   ConvArgs conv{};
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
   BneckArgs bneck{};
+  StemArgs stem{};
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
@@ -62,6 +63,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 256;
+  int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };
@@ -106,6 +108,7 @@ struct Net {
   tf2_status load_model_4bit(const uint8_t* bytes, size_t n_bytes);    // straight from the 4-bit codes, no float32 copy of the weights
   tf2_status finish_model();
   tf2_status pack(int mode);
+  bool stem_selected(int batch) const;     // layer 0 runs on conv_stem.hip (x-only image tensor)
   const PackLayer* pack_layer(int l) const;
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
