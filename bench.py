@@ -332,7 +332,7 @@ def main():
     n_launch = max(1, sum(1 for i in cv if nl[i] > 0))      # a conv_bneck launch computes two table rows
     gbps = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tops = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw / conv_bneck: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
+    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw / conv_bneck / conv_stem: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
              2: "conv_shift_kernel"}[args.mode]
     roofline = dict(bound="hbm", kernel=kname, achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
                     traffic=traffic, traffic_note=traffic_note,

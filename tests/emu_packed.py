@@ -146,19 +146,15 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
 
 def conv_stem_from_packed(blob, pl, L, x_nchw):
     """conv_stem.hip's data flow for the executed first layer: ONE copy of x per pixel (32 bytes), signed window values
-    [window][tap][64 rows][32] at off_w2 (16-byte chunk c of row r at slot c ^ ((r >> 3) & 1)), and the x = -128
+    [window][tap][K half][64 rows][16] at off_w2, and the x = -128
     correction -2 * w * x128 for the negative weights derived from the same tiles (|w| of the negative bytes, twice)."""
     assert int(pl["kind"]) == 1 and int(pl["off_w2"]) != 0 and int(pl["Np"]) == 64 and L.k == 3
     P = int(pl["n_phases"])
     B, C, H, W = x_nchw.shape
     N, OH, OW = L.N, L.OH, L.OW
     assert OH == H - 2 and OW == W - 2 and C <= 32
-    st = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + P * 9 * 64 * 32].tobytes(), np.int8).reshape(P, 9, 64, 2, 16)
-    w = np.zeros((P, 9, 64, 32), np.int64)
-    for r in range(64):
-        sw = (r >> 3) & 1
-        w[:, :, r, 0:16] = st[:, :, r, 0 ^ sw]
-        w[:, :, r, 16:32] = st[:, :, r, 1 ^ sw]
+    st = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + P * 9 * 64 * 32].tobytes(), np.int8).reshape(P, 9, 2, 64, 16)
+    w = np.ascontiguousarray(st.transpose(0, 1, 3, 2, 4)).reshape(P, 9, 64, 32).astype(np.int64)
     negmag = np.where(w < 0, -w, 0)
     x_t = np.zeros((B, H, W, 32), np.int64)
     x_t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))

@@ -18,8 +18,9 @@
 // rows are one contiguous NHWC range that goes global -> LDS once; all 9 x (1 or 2 windows) weight tiles (36 KiB) sit in
 // LDS next to it; waves take 64-pixel tiles round-robin and sweep window by window into one accumulator set of
 // 64 channels x 64 pixels; no barrier and no memory instruction but ds_read in the K loop.
-// Both LDS operands are 32 bytes per row: slot c' of row r holds chunk c' ^ ((r >> 3) & 1), so the sixteen lanes a
-// ds_read_b128 services together (8 consecutive rows + the 8 rows 24 further, MI355X_MICROARCH.md LDS table) cover all 64 banks.
+// Both LDS operands are 32 bytes per row, stored as two planes of 16 bytes per row (K bytes 0-15 | 16-31): a lane's MFMA
+// fragment is 16 bytes at plane[lane >> 5] + 16 * row, so the sixteen lanes a ds_read_b128 services together read 256
+// contiguous bytes whatever the tap offset -- no bank conflict, no swizzle arithmetic, and a tap is an immediate offset.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <type_traits>
@@ -50,6 +51,11 @@ __device__ __forceinline__ unsigned stem_negmag(unsigned w) {
   return (~w & mask) + s;                                      // (~b) + 1 per byte; b != 0 there, so no carry out
 }
 
+template <int T, int N, class F>
+__device__ __forceinline__ void stem_static_for(F& fn) {
+  if constexpr (T < N) { fn(std::integral_constant<int, T>{}); stem_static_for<T + 1, N>(fn); }
+}
+
 template <int NWIN>
 __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
   const int half = lane >> 5;
   const int W = a.W, OW = a.OW, R = a.R;
   const int n_h = (R + 2) * W;                              // input pixels of a full band
-  const int halo_bytes = ((n_h + 31) & ~31) * 32;
+  const int plane = ((n_h + 63) & ~63) * 16;                  // bytes of one 16-byte plane of the input tile
+  const int halo_bytes = 2 * plane;
   int8_t* const wts = lds;
   int8_t* const halo = lds + NWIN * 9 * kStemTile;
   int* const prm = reinterpret_cast<int*>(halo + halo_bytes);
@@ -87,14 +94,14 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hs + i * 1024), TF2_LDS_PTR(reinterpret_cast<int8_t*>(prm) + i * 1024), 16, 0, 0);
     for (int i = wave; i < NWIN * 9 * (kStemTile / 1024); i += 8)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(a.w + i * 1024 + lane * 16), TF2_LDS_PTR(wts + i * 1024), 16, 0, 0);
-    // lane l of an instruction fills 16-byte slot l of a 32-pixel group: pixel (l >> 1), slot (l & 1)
+    // plane k of the input tile = 16-byte chunk k of every pixel: lane l of an instruction fetches pixel 64 * g + l
     const int8_t* xb = a.x + ((long long)img * a.H + r0) * W * 32;
-    const int n_grp = halo_bytes >> 10;
-    for (int gi = wave; gi < n_grp; gi += 8) {
-      const int h = gi * 32 + (lane >> 1);
-      const int c = (lane & 1) ^ ((h >> 3) & 1);
-      const int8_t* src = h < n_valid ? xb + h * 32 + c * 16 : a.zero;
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + gi * 1024), 16, 0, 0);
+    const int n_grp = plane >> 10;
+    for (int gi = wave; gi < 2 * n_grp; gi += 8) {
+      const int k = gi >= n_grp, g = gi - k * n_grp;
+      const int h = g * 64 + lane;
+      const int8_t* src = h < n_valid ? xb + h * 32 + k * 16 : a.zero;
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + k * plane + g * 1024), 16, 0, 0);
     }
     if (tid == 0) *flag = 0;
   }
@@ -119,13 +126,9 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
   asm volatile("" ::: "memory");
   const bool quirk = __builtin_amdgcn_readfirstlane(*flag) != 0;
 
-  // lane-constant operand offsets
-  int a_off[2];
-#pragma unroll
-  for (int rt = 0; rt < 2; rt++) {
-    const int row = rt * 32 + (lane & 31);
-    a_off[rt] = row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
-  }
+  // lane-constant operand addresses: weights [window][tap][K half][64 rows][16]
+  const int8_t* const a_base = wts + half * (kStemTile / 2) + (lane & 31) * 16;
+  const int8_t* const b_plane = halo + half * plane;
   const int lo_bound = a.relu ? 0 : -128;
   const int n_tiles = (n_px + 63) >> 6;
   const int* const dsh = prm + kPrmWordsPerRow * 64;
@@ -133,24 +136,34 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
   auto run = [&](auto quirk_c) {
     constexpr bool QUIRK = decltype(quirk_c)::value;
     for (int tile = wave; tile < n_tiles; tile += 8) {
-      int h0[2];
+      const int8_t* b0[2];
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         int p = tile * 64 + j * 32 + (lane & 31);
         if (p >= n_px) p = 0;                                // computed on pixel 0, never stored
         const int r = p / OW;
-        h0[j] = r * W + (p - r * OW);
+        b0[j] = b_plane + (r * W + (p - r * OW)) * 16;
       }
       i32x16 acc[2][2];
+      const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      // virtual step v = (window, tap), window-major; the operands of step v + 1 are read while step v's MFMAs run
+      struct Fr { i32x4 a[2], b[2]; };
+      Fr f0, f1;
+      auto load_fr = [&](Fr& f, int v) {
+        const int t = v % 9;
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++)
+        for (int rt = 0; rt < 2; rt++) f.a[rt] = *reinterpret_cast<const i32x4*>(a_base + v * kStemTile + rt * 512);
+        const int tap_off = ((t / 3) * W + t % 3) * 16;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[rt][j][r] = 0;
-#pragma unroll
-      for (int win = 0; win < NWIN; win++) {
-        if (win == 1) {
+        for (int j = 0; j < 2; j++) f.b[j] = *reinterpret_cast<const i32x4*>(b0[j] + tap_off);
+      };
+      load_fr(f0, 0);
+      auto step = [&](auto v_c) {
+        constexpr int v = decltype(v_c)::value;
+        Fr& cur = (v & 1) ? f1 : f0;
+        Fr& nxt = (v & 1) ? f0 : f1;
+        if (v + 1 < NWIN * 9) load_fr(nxt, v + 1);
+        if (v == 9) {
           // Horner step between the windows: acc <<= dshift[1][row]  (weight_pack.cpp: high window first)
 #pragma unroll
           for (int rt = 0; rt < 2; rt++) {
@@ -166,38 +179,29 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
           }
         }
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-          i32x4 af[2], bf[2];
+        for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-          for (int rt = 0; rt < 2; rt++) af[rt] = *reinterpret_cast<const i32x4*>(wts + (win * 9 + t) * kStemTile + a_off[rt]);
+          for (int j = 0; j < 2; j++)
+            acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.a[rt], cur.b[j], v == 0 ? zero16 : acc[rt][j], 0, 0, 0);
+        if (QUIRK) {
+          i32x4 an[2], bq[2];
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const int h = h0[j] + (t / 3) * W + t % 3;
-            bf[j] = *reinterpret_cast<const i32x4*>(halo + h * 32 + ((half ^ ((h >> 3) & 1)) << 4));
+          for (int i = 0; i < 4; i++) {
+            an[0][i] = (int)stem_negmag((unsigned)cur.a[0][i]); an[1][i] = (int)stem_negmag((unsigned)cur.a[1][i]);
+            bq[0][i] = (int)stem_x128((unsigned)cur.b[0][i]); bq[1][i] = (int)stem_x128((unsigned)cur.b[1][i]);
           }
 #pragma unroll
           for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[rt], bf[j], acc[rt][j], 0, 0, 0);
-          if (QUIRK) {
-            i32x4 an[2], bq[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              an[0][i] = (int)stem_negmag((unsigned)af[0][i]); an[1][i] = (int)stem_negmag((unsigned)af[1][i]);
-              bq[0][i] = (int)stem_x128((unsigned)bf[0][i]); bq[1][i] = (int)stem_x128((unsigned)bf[1][i]);
+            for (int j = 0; j < 2; j++) {
+              // |w| * x128 twice = -2 * w * x128 for the negative weights
+              acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(an[rt], bq[j], acc[rt][j], 0, 0, 0);
+              acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(an[rt], bq[j], acc[rt][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-              for (int j = 0; j < 2; j++) {
-                // |w| * x128 twice = -2 * w * x128 for the negative weights
-                acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(an[rt], bq[j], acc[rt][j], 0, 0, 0);
-                acc[rt][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(an[rt], bq[j], acc[rt][j], 0, 0, 0);
-              }
-          }
-          __builtin_amdgcn_sched_barrier(0);                 // steps stay in order: the unrolled sweep must not pile up its reads
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);                   // steps stay in order: the unrolled sweep must not pile up its reads
+      };
+      stem_static_for<0, NWIN * 9>(step);
       // ---- epilogue: pe.cl:185-203, relu.cl:54; 16 contiguous NHWC bytes per lane and 32x32 tile -----------------------------
       const i32x4 nores = {0, 0, 0, 0};
       auto epilogue = [&](auto fast_c) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
 
 size_t conv_stem_lds_bytes(int nwin, int R, int W, size_t hdr_used) {
   const int n_h = (R + 2) * W;
-  return (size_t)nwin * 9 * kStemTile + (size_t)((n_h + 31) & ~31) * 32 + hdr_used + 64;
+  return (size_t)nwin * 9 * kStemTile + (size_t)((n_h + 63) & ~63) * 32 + hdr_used + 64;
 }
 
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream) {

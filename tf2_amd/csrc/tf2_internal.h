@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 20;
+constexpr uint32_t kPackVersion = 21;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -137,7 +137,7 @@ struct BneckArgs {
 struct StemArgs {
   const int8_t* x;           // [B][H][W][32]: 27 (or fewer) channels of x, zero padded
   int8_t* y;
-  const int8_t* w;           // [window][tap][64 rows][32] signed window values, rows swizzled (weight_pack.cpp)
+  const int8_t* w;           // [window][tap][K half][64 rows][16] signed window values (weight_pack.cpp)
   const int32_t* hdr;        // the layer's header image; the first hdr_used bytes hold rows | lo | dshift
   const int8_t* zero;
   int32_t hdr_used;

@@ -298,8 +298,8 @@ tf2_status Net::pack(int mode) {
       pl.TM = TM; pl.n_mtiles = n_mtiles; pl.n_phases = P; pl.nslab = nslab; pl.Np = Np;
       pl.n_entries = (int32_t)entries.size();
       // ---- conv_stem.hip image (off_w2 != 0 on an MFMA layer): the executed first layer on ONE copy of x per pixel ----
-      // [window][tap][64 rows][32 bytes] of SIGNED window values (x half minus the magnitudes of the xneg half), 16-byte
-      // chunk c of row r at slot c ^ ((r >> 3) & 1).  The x = -128 correction is derived from these in the kernel.
+      // [window][tap][K half][64 rows][16 bytes] of SIGNED window values (x half minus the magnitudes of the xneg half).
+      // The x = -128 correction is derived from these in the kernel.
       if (is_image && in_signed && il.Cp_in == 64 && il.half == 32 && k == 3 && L.stride == 1 && L.dil == 1 && (L.pad_h | L.pad_w) == 0 &&
           Np == 64 && TM == 64 && P <= 2 && C <= 32 && !L.endpool && getenv("TF2_AMD_NOSTEM") == nullptr) {
         std::vector<int8_t> st((size_t)P * 9 * 64 * 32, 0);
@@ -307,8 +307,8 @@ tf2_status Net::pack(int mode) {
           for (int t = 0; t < 9; t++)
             for (int r = 0; r < 64; r++) {
               const int8_t* src = &W[((size_t)p * Np + r) * Kp + (size_t)t * 64];
-              int8_t* dst = &st[(((size_t)p * 9 + t) * 64 + r) * 32];
-              for (int c = 0; c < 32; c++) dst[(((c >> 4) ^ ((r >> 3) & 1)) << 4) + (c & 15)] = (int8_t)(src[c] - src[32 + c]);
+              int8_t* tile = &st[((size_t)p * 9 + t) * 64 * 32];
+              for (int c = 0; c < 32; c++) tile[(c >> 4) * 1024 + r * 16 + (c & 15)] = (int8_t)(src[c] - src[32 + c]);
             }
         pl.off_w2 = blob.alloc(st.size());
         std::memcpy(blob.at<uint8_t>(pl.off_w2), st.data(), st.size());
