@@ -5,8 +5,9 @@ One process per GPU (torchrun contract), batches sharded with no data-path colle
 scaling: every rank runs `--batch` images per step); the packed weights are broadcast once
 over RCCL before timing.  A "step" = one pass of the whole hot path over one batch already
 resident in HBM: input quantisation + space-to-depth, all 54 layers, logits copy.  Consecutive
-steps are independent batches: by default three are in flight (`--inflight`, step i on HIP stream
-i % 3 with its own workspace) so that the latency-bound small layers of one batch overlap with
+steps are independent batches: by default four are in flight (`--inflight`, step i on HIP stream
+i % 4 with its own workspace; the HIP runtime's hardware-queue count is raised so that each of these streams has
+its own queue, see GPU_MAX_HW_QUEUES below) so that the latency-bound small layers of one batch overlap with
 another batch's kernels; all K timed steps complete inside the timed region, and the
 one-batch-at-a-time rate is reported beside it (`images_per_s_one_batch_at_a_time`).
 
@@ -27,6 +28,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes streams onto 4 hardware queues by default, one of them held by the null stream: a fourth
+# in-flight stream would share a queue and serialise behind another batch (measured: 62.8 k img/s with 4 streams on the
+# default against 74.5 k with >= 5 queues, profiles/r02_inflight_hwqueues.txt).  Read by the runtime at initialisation,
+# so it is set before torch loads it; a deployment that keeps several batches in flight sets the same variable.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def layer_ops(plan):
@@ -94,7 +100,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra-batches", type=str, default="1,64", help="also time these per-GPU batch sizes")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
