@@ -79,6 +79,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   // the counted waits are per class (wave-uniform branch).
   constexpr int AG = A_BYTES / 1024, BG = TN / 16, NG = AG + BG;
   constexpr int NI_LO = NG / NW, REM = NG % NW, NI_HI = NI_LO + (REM ? 1 : 0);
+  // AG a multiple of NW (every shape but the single-window 64 x 256 one): a wave's j-th group is a weight group for
+  // j < NA and an activation group after that, for every wave -- decided at compile time, no per-lane select
+  constexpr bool STATIC_GRP = (AG % NW) == 0;
+  constexpr int NA = AG / NW;
   static_assert((S - 2) * NI_HI <= 15, "vmcnt immediate range");
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   // LDS map: [ring S*STAGE][header: rows {bias, alpha, beta64.lo, beta64.hi} (4*TM) | lo (TM) | dshift (P*TM) | steps[max_ent] |
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   for (int j = 0; j < NI_HI; j++) {
     const int gi = wave + NW * j;            // group index: < AG weights, else activations
     brow_h[j] = -(1 << 20); brow_w[j] = 0; brow_ptr[j] = azero; brow_ok[j] = false;
+    if (STATIC_GRP && j < NA) continue;
     if (gi >= AG && gi < NG) {
       const int p = px0 + (gi - AG) * 16 + (lane >> 2);
       if (p < g.n_pix) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #pragma unroll
     for (int j = 0; j < NI_HI; j++) {
       const int gi = wave + NW * j;
-      if (gi < AG) {
+      if (STATIC_GRP ? j < NA : gi < AG) {
         __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + gi * 1024), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
       } else if (j < NI_LO || ni_hi) {
         bool ok = off >= 0 && brow_ok[j];
