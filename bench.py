@@ -351,6 +351,9 @@ def main():
                          "per-layer event times rescaled by event_pair_scale = (one event pair around the whole layer loop) / (their sum)")
     total_bytes = sum(r["bytes"] for r in lo) * args.batch
     hbm_gbps = total_bytes / (ms_per_step * 1e-3) / 1e9
+    # the same algorithmic bytes against the TIMED region (batches in flight): the rate the whole pipeline sustains
+    roofline["in_flight"] = dict(achieved=round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1), frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM, 4),
+                                 note="conv launches' algorithmic bytes per step / ms_per_step of the timed region")
 
     # ---- CPU baseline: the oracle (restated reference CPU path) on the host cores, rank 0, N=1 ----
     cpu = None
