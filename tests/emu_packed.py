@@ -17,8 +17,15 @@ def parse(blob: np.ndarray):
     h = np.frombuffer(blob[:HDR.itemsize].tobytes(), HDR)[0]
     n = int(h["n_layers"])
     pls = np.frombuffer(blob[HDR.itemsize:HDR.itemsize + n * PL.itemsize].tobytes(), PL)
-    assert int(h["dir_bytes"]) == HDR.itemsize + n * PL.itemsize
+    # the directory holds n more entries: the layers' wide-tile alternatives (kind 0 where there is none), see parse_alt
+    assert int(h["dir_bytes"]) == HDR.itemsize + 2 * n * PL.itemsize
     return h, pls
+
+
+def parse_alt(blob: np.ndarray):
+    h = np.frombuffer(blob[:HDR.itemsize].tobytes(), HDR)[0]
+    n = int(h["n_layers"])
+    return np.frombuffer(blob[HDR.itemsize + n * PL.itemsize:HDR.itemsize + 2 * n * PL.itemsize].tobytes(), PL)
 
 
 def i32(blob, off, n):

@@ -142,3 +142,28 @@ def test_resnet50_first_layer_stem_image(golden_dir, kind):
     y = emu.conv_stem_from_packed(blob, pls[0], L, outs[-1])
     y = np.stack([O.maxpool(yi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for yi in y])
     np.testing.assert_array_equal(y, outs[0])
+
+
+def test_resnet50_wide_tile_alternatives(golden_dir):
+    """Layers with >= 1024 output channels on small maps are packed twice: 64-row tiles (small batches, split-K) and 128-row
+    tiles (net.hip picks them when their grid fills the chip).  The alternative entry must compute the same layer."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    x = synth.synth_images(t, 1, 0)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+    blob = net.packed_host()
+    _, pls = emu.parse(blob)
+    alts = emu.parse_alt(blob)
+    have = [i for i in range(len(alts)) if int(alts[i]["kind"]) == 1]
+    assert have and all(int(alts[i]["TM"]) == 128 and int(pls[i]["TM"]) == 64 and int(pls[i]["Np"]) >= 1024 for i in have)
+    R = netref.RefNet(t, q, model)
+    outs = R.run(x)
+    for i in (have[0], have[-1]):
+        L = R.plan[i]
+        S = R.plan[L.src]
+        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
+        res = outs[L.add_src] if L.add_src >= 0 else None
+        y = emu.conv_from_packed(blob, alts[i], L, x_t, res)
+        np.testing.assert_array_equal(y, outs[i], err_msg=f"layer {i} wide-tile alternative")

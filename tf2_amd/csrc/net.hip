@@ -236,6 +236,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 256)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
@@ -290,6 +291,12 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
     const PackLayer* pl = pack_layer(l);
+    // the wide-tile alternative (128-row tiles, weight_pack.cpp) where its grid still fills the chip: fewer operand bytes and
+    // instructions per MAC; small batches keep the 64-row tiles (more blocks, split-K)
+    if (const PackLayer* pa = pack_layer_alt(l)) {
+      const long blocks128 = ((long)batch * L.OH * L.OW + 127) / 128 * (pa->Np / 128);
+      if (blocks128 >= opts.alt_min_blocks) pl = pa;
+    }
     st.kind = Launch::CONV; st.layer = l;
     ConvArgs& ca = st.conv;
     const TensorPlan& ti = T(E.in_tensor); const TensorPlan& tc = T(E.conv_tensor);

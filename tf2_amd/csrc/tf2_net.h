@@ -63,6 +63,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 256;
+  long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
@@ -110,6 +111,7 @@ struct Net {
   tf2_status pack(int mode);
   bool stem_selected(int batch) const;     // layer 0 runs on conv_stem.hip (x-only image tensor)
   const PackLayer* pack_layer(int l) const;
+  const PackLayer* pack_layer_alt(int l) const;
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws);

@@ -57,13 +57,22 @@ const PackLayer* Net::pack_layer(int l) const {
   return reinterpret_cast<const PackLayer*>(packed.data() + sizeof(PackHeader)) + l;
 }
 
+// the layer's wide-tile alternative (128-row tiles), or null
+const PackLayer* Net::pack_layer_alt(int l) const {
+  if (!packed_valid || l < 0 || l >= nd.n_layers) return nullptr;
+  const PackLayer* p = reinterpret_cast<const PackLayer*>(packed.data() + sizeof(PackHeader)) + nd.n_layers + l;
+  return p->kind == KIND_MFMA ? p : nullptr;
+}
+
 tf2_status Net::pack(int mode) {
   if (!model_loaded) { set_error("tf2_net_pack: load a model first"); return TF2_ERR_STATE; }
   if (mode < 0 || mode > 2) { set_error("tf2_net_pack: mode must be 0, 1 or 2"); return TF2_ERR_ARG; }
   const int nl = nd.n_layers;
   packed.clear();
   Blob blob(packed);
-  const size_t dir_bytes = sizeof(PackHeader) + (size_t)nl * sizeof(PackLayer);
+  // directory: nl entries, then nl ALTERNATIVE entries (kind 0 where there is none): the same layer packed with 128-row
+  // tiles for launches whose grid fills the chip with them (net.hip launch_plan picks per batch size)
+  const size_t dir_bytes = sizeof(PackHeader) + (size_t)2 * nl * sizeof(PackLayer);
 
   // Can the tensor feeding layer l hold negative values (=> the -128 negate quirk matters)?
   std::vector<int> out_signed(nl, 0);
@@ -159,6 +168,14 @@ tf2_status Net::pack(int mode) {
       *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
       continue;
     }
+    for (int variant = 0; variant < 2; variant++) {        // 0: the layer's own entry, 1: its wide-tile alternative (if any)
+    if (variant == 1) {
+      const PackLayer& p0 = *(blob.at<PackLayer>(sizeof(PackHeader)) + l);
+      const bool want = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 1024 && p0.fuse_next <= 0 && p0.fused_into < 0 &&
+                        getenv("TF2_AMD_NOALT") == nullptr;
+      if (!want) break;
+      pl = PackLayer{}; pl.fused_into = -1;
+    }
     const LayerModel& m = models[l];
     const int N = L.N, C = L.C, k = L.k, taps = k * k;
     const InLayout& il = in_layout[l];
@@ -184,6 +201,7 @@ tf2_status Net::pack(int mode) {
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
       static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
       int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
+      if (variant == 1) TM = 128;
       if (fuse_next[l] > 0) TM = Np;                                   // fused pair: the 3x3 in one m-tile ...
       if (fused_into[l] >= 0) TM = layers[fused_into[l]].N;            // ... and the expand in four of the same height
       pl.fuse_next = fuse_next[l]; pl.fused_into = fused_into[l];
@@ -448,7 +466,8 @@ tf2_status Net::pack(int mode) {
       pl.off_alpha = blob.alloc((size_t)Np * 4); std::memcpy(blob.at<uint8_t>(pl.off_alpha), al.data(), (size_t)Np * 4);
       pl.off_beta = blob.alloc((size_t)Np * 4); std::memcpy(blob.at<uint8_t>(pl.off_beta), be.data(), (size_t)Np * 4);
     }
-    *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
+    *(blob.at<PackLayer>(sizeof(PackHeader)) + l + (size_t)variant * nl) = pl;
+    }   // variant
   }
   // ---- do the fused pairs pass the kernel's limits? ----
   bool redo = false;
