@@ -223,6 +223,22 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
+def test_first_layer_generic_path_and_wide_tile_alternatives(r50, monkeypatch):
+    """Two run-time choices against the oracle, every layer: (1) TF2_AMD_STEM=0 -- the first layer on the generic ring kernel
+    over [x | xneg] instead of conv_stem.hip on x alone; (2) TF2_AMD_ALT_MIN=0 -- the 128-row alternatives of the layers with
+    >= 1024 output channels (normally taken only when their grid fills the chip, i.e. from batch 32 on) at a ragged batch of 3."""
+    monkeypatch.setenv("TF2_AMD_STEM", "0")
+    monkeypatch.setenv("TF2_AMD_ALT_MIN", "0")
+    rig = Rig(*r50, 0)
+    x = synth.synth_images(rig.t, 3, 71)
+    x[1, :, 10:14, :] = -1000.0                      # clamps to -128: the negate quirk through the xneg half
+    rig.check_all_layers(x)
+    monkeypatch.delenv("TF2_AMD_STEM")
+    monkeypatch.setenv("TF2_AMD_ALT_MIN", "1000000")  # never: the 64-row tiles / split-K kernel for every small-map layer
+    rig.net.reload_options()
+    rig.check_all_layers(x, layers={0, 24, 27, 43, 46, 52, 53})
+
+
 def test_fused_bottleneck_pairs(r50, monkeypatch):
     """conv_bneck.hip: branch2b (3x3 / stride 1) + branch2c (1x1 expand, residual, ReLU) of the stride-1 bottlenecks in one
     launch (C = 64 / 128 / 256; halo tile and intermediate tile in LDS, weights from registers): every layer with keep_all
