@@ -160,7 +160,8 @@ def test_resnet50_wide_tile_alternatives(golden_dir):
     assert have and all(int(alts[i]["TM"]) == 128 and int(pls[i]["TM"]) == 64 and int(pls[i]["Np"]) >= 1024 for i in have)
     R = netref.RefNet(t, q, model)
     outs = R.run(x)
-    for i in (have[0], have[-1]):
+    assert all(R.plan[i].OH * R.plan[i].OW >= 16 for i in have)          # the 1x1-map FC row has none
+    for i in (have[0], [j for j in have if not R.plan[j].endpool][-1]):
         L = R.plan[i]
         S = R.plan[L.src]
         x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
