@@ -121,8 +121,23 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
     else:
         k, taps, ncc = L.k, L.k * L.k, int(pl["n_cchunk"])
         cnt = (Np // 8) * ncc * taps * 128
-        w = i32(blob, int(pl["off_w"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64)
-        w2 = i32(blob, int(pl["off_w2"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64) if int(pl["signed_in"]) else None
+        if int(pl["fast"]):
+            # packed 4-bit filters (weight_pack.cpp): nibble {sign << 3 | e}, e = 7 zero, shift = A[n] + B[c] - e
+            nb = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + cnt // 2].tobytes(), np.uint8)
+            v = np.stack([nb & 15, nb >> 4], axis=1).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64)
+            ab = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + Np + ncc * 16].tobytes(), np.int8).astype(np.int64)
+            A = ab[:Np].reshape(Np // 8, 1, 1, 1, 8, 1)
+            Bc = ab[Np:].reshape(1, ncc, 1, 2, 1, 8)
+            e = v & 7
+            mag = np.where(e == 7, 0, np.left_shift(np.int64(1), np.clip(A + Bc - e, 0, 31)))
+            neg = (v & 8) != 0
+            if int(pl["signed_in"]):
+                w, w2 = np.where(neg, 0, mag), np.where(neg, mag, 0)
+            else:
+                w, w2 = np.where(neg, -mag, mag), None
+        else:
+            w = i32(blob, int(pl["off_w"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64)
+            w2 = i32(blob, int(pl["off_w2"]), cnt).reshape(Np // 8, ncc, taps, 2, 8, 8).astype(np.int64) if int(pl["signed_in"]) else None
         pb, poh, pow_ = np.unravel_index(np.arange(npix), (B, OH, OW))
         acc = np.zeros((Np, npix), np.int64)
         for cc in range(ncc):

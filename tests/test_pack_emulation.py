@@ -77,6 +77,8 @@ def test_tiny_all_modes(mode, kind):
         assert set(kinds) <= {1, 2} and 1 in kinds
     if mode == 2:
         assert set(kinds) == {2}
+        # INQ weights (7 exponents + per-channel Q): every shift layer keeps its filters as packed 4-bit codes
+        assert all(int(p["fast"]) == 1 for p in _ if int(p["kind"]) == 2)
 
 
 def test_squeezenet_small_image():
@@ -118,6 +120,9 @@ def test_wide_shift_range_needs_more_windows():
     x = synth.synth_images(t, 2, 9)
     kinds, pls = check_net(t, q, model, x, 0)
     assert int(pls[1]["n_phases"]) >= 2
+    # the shift kernel: 15 exponents do not fit the 4-bit form (7 per (row, channel)), that layer keeps int32 weights
+    kinds, pls = check_net(t, q, model, x, 2)
+    assert int(pls[1]["kind"]) == 2 and int(pls[1]["fast"]) == 0 and int(pls[0]["fast"]) == 1
 
 
 @pytest.mark.parametrize("kind", ["float", "int8"])

@@ -19,6 +19,12 @@
 // lane then reads its own 16 bytes per tap (ds_read_b128, lane-linear = conflict-free)
 // and unpacks them once for the 8 output channels of its wave.
 // Epilogue identical to conv_mfma.hip (bias, BN requant, ReLU, residual, 8-byte store).
+//
+// PACKED4 (PackLayer::fast on a shift layer, weight_pack.cpp): the filters stay packed in HBM as 4-bit codes {sign, e} with
+// s = A[n] + B[c] - e -- the INQ form of 4bit_data_format.txt, 8x fewer weight bytes than the int32 form -- and every wave
+// expands the codes of its 8 output channels for the current 16-channel chunk to +-2^s in LDS (two codes per lane and tap),
+// next to the staged input tile; the multiply-accumulate then takes its weight from a broadcast ds_read instead of a
+// scalar load.
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
 #include "tf2_device.h"
@@ -39,9 +45,9 @@ __device__ __forceinline__ int requant_i8s(int acc, int alpha, int beta, int rel
 
 constexpr int kMaxTaps = 49;   // up to 7x7 filters
 
-template <bool SIGNED_IN, bool MUL24>
+template <bool SIGNED_IN, bool MUL24, bool PACKED4>
 __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
-  // LDS: [tap][64 pixels][16 bytes]
+  // LDS: [tap][64 pixels][16 bytes] | PACKED4: [wave][tap][half][8 n][8 c] int32 (+ the same again for the negative magnitudes)
   extern __shared__ __attribute__((aligned(16))) int8_t lds_raw[];
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x;
@@ -81,6 +87,21 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
       }
       *reinterpret_cast<i32x4*>(lds_raw + (size_t)it * 16) = v;
     }
+    int* const wl = reinterpret_cast<int*>(lds_raw + (size_t)taps * 64 * 16) + (size_t)wave * taps * 128 * (SIGNED_IN ? 2 : 1);
+    if (PACKED4 && wave_active) {
+      // expand this wave's codes of chunk cc: weight idx = tap * 128 + half * 64 + r * 8 + c (the int32 layout's order)
+      const uint8_t* nb = reinterpret_cast<const uint8_t*>(a.w) + (((size_t)(n0 >> 3) * a.n_cchunk + cc) * taps * 128) / 2;
+      const int8_t* ab = a.w2;                                   // A[Np] | B[n_cchunk * 16]
+      for (int i = lane; i < taps * 128; i += 64) {
+        const int within = i & 127, h = within >> 6, r = (within >> 3) & 7, c = within & 7;
+        const unsigned v = (nb[i >> 1] >> (4 * (i & 1))) & 15u;
+        const int e = (int)(v & 7u);
+        const int sft = (int)ab[n0 + r] + (int)ab[a.Np + cc * 16 + h * 8 + c] - e;
+        const int mag = e == 7 ? 0 : (int)(1u << (sft & 31));
+        if (SIGNED_IN) { wl[i] = (v & 8u) ? 0 : mag; wl[taps * 128 + i] = (v & 8u) ? mag : 0; }
+        else wl[i] = (v & 8u) ? (int)(0u - (unsigned)mag) : mag;
+      }
+    }
     __syncthreads();
     if (!wave_active) continue;
     // ---- shift-accumulate ----
@@ -101,8 +122,8 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
           xs[c] = (int)(signed char)((word >> (8 * (c & 3))) & 0xff);
           if (SIGNED_IN) xn[c] = (int)(signed char)(-xs[c]);   // int8 negate: -(-128) == -128 (pe.cl:32-37)
         }
-        const int* wp = wbase + (tap * 2 + h) * 64;      // wave-uniform -> scalar loads
-        const int* wq = SIGNED_IN ? w2base + (tap * 2 + h) * 64 : nullptr;
+        const int* wp = PACKED4 ? wl + (tap * 2 + h) * 64 : wbase + (tap * 2 + h) * 64;      // wave-uniform: scalar loads (LDS broadcast reads with PACKED4)
+        const int* wq = SIGNED_IN ? (PACKED4 ? wl + taps * 128 + (tap * 2 + h) * 64 : w2base + (tap * 2 + h) * 64) : nullptr;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
 #pragma unroll
@@ -149,19 +170,27 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
   *reinterpret_cast<int2*>(a.y + (size_t)px * g.y_cp + g.y_off + n0) = out;
 }
 
-int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream) {
+size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4) {
+  return (size_t)taps * 64 * 16 + (packed4 ? (size_t)4 * taps * 128 * 4 * (signed_in ? 2 : 1) : 0);
+}
+
+int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int taps = a.k * a.k;
   if (taps > kMaxTaps) return -2;
   dim3 grid((a.g.n_pix + 63) / 64, (a.Np / 8 + 3) / 4);
-  size_t lds = (size_t)taps * 64 * 16;
-  if (signed_in) {
-    if (mul24) hipLaunchKernelGGL((conv_shift_kernel<true, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_shift_kernel<true, false>), grid, dim3(256), lds, s, a);
+  const size_t lds = conv_shift_lds_bytes(taps, signed_in, packed4);
+  if (lds > 160 * 1024) return -3;
+#define TF2_SH(S, M, P) do { auto fn = conv_shift_kernel<S, M, P>; if (lds > 64 * 1024 && !lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
+                             hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, a); } while (0)
+  if (packed4) {
+    if (signed_in) { if (mul24) TF2_SH(true, true, true); else TF2_SH(true, false, true); }
+    else { if (mul24) TF2_SH(false, true, true); else TF2_SH(false, false, true); }
   } else {
-    if (mul24) hipLaunchKernelGGL((conv_shift_kernel<false, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_shift_kernel<false, false>), grid, dim3(256), lds, s, a);
+    if (signed_in) { if (mul24) TF2_SH(true, true, false); else TF2_SH(true, false, false); }
+    else { if (mul24) TF2_SH(false, true, false); else TF2_SH(false, false, false); }
   }
+#undef TF2_SH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

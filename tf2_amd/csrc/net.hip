@@ -347,7 +347,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
       if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
     } else if (pl->kind == KIND_SHIFT) {
-      st.sel = Launch::SEL_SHIFT;
+      st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {
       set_error("layer " + std::to_string(l) + " has no packed kernel"); return false;
     }
@@ -523,7 +523,7 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
           case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
           case Launch::SEL_BNECK: rc = launch_conv_bneck(st.bneck, st.TM, st.shape, stream); break;
           case Launch::SEL_STEM: rc = launch_conv_stem(st.stem, st.shape, stream); break;
-          default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, stream); break;
+          default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream); break;
         }
         break;
     }

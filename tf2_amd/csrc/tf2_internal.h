@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 22;
+constexpr uint32_t kPackVersion = 23;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -183,7 +183,8 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
-int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, void* stream);
+int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
+size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit

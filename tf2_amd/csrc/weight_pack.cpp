@@ -432,6 +432,68 @@ tf2_status Net::pack(int mode) {
       }
       pl.Np = Np; pl.n_cchunk = n_cchunk; pl.nslab = 0; pl.n_phases = 1; pl.TM = 8; pl.n_mtiles = Np / 8;
       const size_t cnt = (size_t)(Np / 8) * n_cchunk * taps * 128;
+      // ---- packed 4-bit filters (PackLayer::fast = 1 on a shift layer): INQ weights are sign + one of 7 exponents, and the
+      // shift of a code is kInflat + Q_in[c] - Q_out[n] - i (model_loader.cpp:159-162), i.e. s = A[n] + B[c] - e with e in
+      // 0..6.  Stored: one nibble per weight {sign << 3 | e, e = 7: zero weight} in the order of the int32 layout below, then
+      // A[Np] and B[n_cchunk * 16] as int8; conv_shift.hip expands a block's nibbles to +-2^s in LDS.  A layer whose codes do
+      // not fit that form (arbitrary shifts: tests/test_gpu_parity.py::test_wide_shift_range_phases) or whose expanded tile
+      // does not fit LDS keeps the int32 form.
+      {
+        const int M = nd.max_out_channel;
+        std::vector<int> Bc(n_cchunk * 16, 0), An(Np, -1000);
+        bool ok4 = getenv("TF2_AMD_NO4BIT") == nullptr && taps <= (in_signed ? 25 : 49);
+        for (int pass = 0; pass < 2 && ok4; pass++) {          // pass 0: B from the input's Q row; pass 1: B = 0
+          std::fill(Bc.begin(), Bc.end(), 0); std::fill(An.begin(), An.end(), -1000);
+          if (pass == 0) {
+            if (L.src == -1 || L.q_in_row < 0 || C > M) continue;
+            const int8_t* q_in = q.data() + (size_t)L.q_in_row * M;
+            for (int c = 0; c < C; c++) Bc[c] = (int)q_in[c];
+          }
+          bool fits = true;
+          for (int n = 0; n < N; n++)
+            for (int c = 0; c < C; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (!code_zero(code)) An[n] = std::max(An[n], code_shift(code) - Bc[c]);
+              }
+          for (int n = 0; n < N && fits; n++)
+            for (int c = 0; c < C && fits; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (code_zero(code)) continue;
+                const int e = An[n] + Bc[c] - code_shift(code);
+                if (e < 0 || e > 6) { fits = false; break; }
+              }
+          for (int n = 0; n < Np; n++) if (An[n] == -1000) An[n] = 0;
+          for (int n = 0; n < Np && fits; n++) if (An[n] < -128 || An[n] > 127) fits = false;
+          if (fits) { ok4 = true; goto have4; }
+        }
+        ok4 = false;
+      have4:
+        if (ok4) {
+          std::vector<uint8_t> nib(cnt / 2, 0x77);              // every weight zero
+          for (int n = 0; n < N; n++)
+            for (int c = 0; c < C; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (code_zero(code)) continue;
+                const size_t idx = (((size_t)(n >> 3) * n_cchunk + (c >> 4)) * taps + t) * 128 +
+                                   (size_t)((c >> 3) & 1) * 64 + (size_t)(n & 7) * 8 + (c & 7);
+                const unsigned v = (unsigned)(An[n] + Bc[c] - code_shift(code)) | (code_neg(code) ? 8u : 0u);
+                uint8_t& b = nib[idx >> 1];
+                b = (idx & 1) ? (uint8_t)((b & 0x0f) | (v << 4)) : (uint8_t)((b & 0xf0) | v);
+              }
+          std::vector<int8_t> ab(Np + n_cchunk * 16, 0);
+          for (int n = 0; n < Np; n++) ab[n] = (int8_t)An[n];
+          for (int c = 0; c < n_cchunk * 16; c++) ab[Np + c] = (int8_t)Bc[c];
+          pl.fast = 1;
+          pl.off_w = blob.alloc(nib.size());
+          std::memcpy(blob.at<uint8_t>(pl.off_w), nib.data(), nib.size());
+          pl.off_w2 = blob.alloc(ab.size());
+          std::memcpy(blob.at<uint8_t>(pl.off_w2), ab.data(), ab.size());
+        }
+      }
+      if (!pl.fast) {
       std::vector<int32_t> w(cnt, 0), w2(in_signed ? cnt : 0, 0);
       for (int n = 0; n < N; n++)
         for (int c = 0; c < C; c++)
@@ -454,6 +516,7 @@ tf2_status Net::pack(int mode) {
         pl.off_w2 = blob.alloc(cnt * 4);
         std::memcpy(blob.at<uint8_t>(pl.off_w2), w2.data(), cnt * 4);
       }
+      }   // int32 form
     }
     // ---- per-channel epilogue parameters (padded rows: all zero => output 0) ----
     {
