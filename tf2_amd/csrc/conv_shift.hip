@@ -89,17 +89,34 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
     }
     int* const wl = reinterpret_cast<int*>(lds_raw + (size_t)taps * 64 * 16) + (size_t)wave * taps * 128 * (SIGNED_IN ? 2 : 1);
     if (PACKED4 && wave_active) {
-      // expand this wave's codes of chunk cc: weight idx = tap * 128 + half * 64 + r * 8 + c (the int32 layout's order)
-      const uint8_t* nb = reinterpret_cast<const uint8_t*>(a.w) + (((size_t)(n0 >> 3) * a.n_cchunk + cc) * taps * 128) / 2;
+      // expand this wave's codes of chunk cc: weight idx = tap * 128 + half * 64 + r * 8 + c (the int32 layout's order).
+      // One dword = 8 codes = the 8 channels c of one (tap, half, r): lane l takes dwords l, l + 64, ... -> its (half, r) never
+      // change, so its eight shifts S[c] = A[n0 + r] + B[chunk, half, c] are computed once per chunk.
+      const unsigned* nb = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(a.w) + (((size_t)(n0 >> 3) * a.n_cchunk + cc) * taps * 128) / 2);
       const int8_t* ab = a.w2;                                   // A[Np] | B[n_cchunk * 16]
-      for (int i = lane; i < taps * 128; i += 64) {
-        const int within = i & 127, h = within >> 6, r = (within >> 3) & 7, c = within & 7;
-        const unsigned v = (nb[i >> 1] >> (4 * (i & 1))) & 15u;
-        const int e = (int)(v & 7u);
-        const int sft = (int)ab[n0 + r] + (int)ab[a.Np + cc * 16 + h * 8 + c] - e;
-        const int mag = e == 7 ? 0 : (int)(1u << (sft & 31));
-        if (SIGNED_IN) { wl[i] = (v & 8u) ? 0 : mag; wl[taps * 128 + i] = (v & 8u) ? mag : 0; }
-        else wl[i] = (v & 8u) ? (int)(0u - (unsigned)mag) : mag;
+      const int r = lane & 7, h = (lane >> 3) & 1;
+      const int An = (int)ab[n0 + r];
+      const int2 bw = *reinterpret_cast<const int2*>(ab + a.Np + cc * 16 + h * 8);
+      int S[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) S[c] = An + (int)(signed char)(((c < 4 ? bw.x : bw.y) >> (8 * (c & 3))) & 0xff);
+      for (int j = lane; j < taps * 16; j += 64) {
+        const unsigned word = nb[j];
+        int wv[8], wn[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const unsigned v = (word >> (4 * c)) & 15u;
+          const int e = (int)(v & 7u);
+          const int mag = e == 7 ? 0 : (int)(1u << ((S[c] - e) & 31));
+          if (SIGNED_IN) { wv[c] = (v & 8u) ? 0 : mag; wn[c] = (v & 8u) ? mag : 0; }
+          else wv[c] = (v & 8u) ? (int)(0u - (unsigned)mag) : mag;
+        }
+        i32x4* d = reinterpret_cast<i32x4*>(wl + j * 8);
+        d[0] = i32x4{wv[0], wv[1], wv[2], wv[3]}; d[1] = i32x4{wv[4], wv[5], wv[6], wv[7]};
+        if (SIGNED_IN) {
+          i32x4* d2 = reinterpret_cast<i32x4*>(wl + taps * 128 + j * 8);
+          d2[0] = i32x4{wn[0], wn[1], wn[2], wn[3]}; d2[1] = i32x4{wn[4], wn[5], wn[6], wn[7]};
+        }
       }
     }
     __syncthreads();
