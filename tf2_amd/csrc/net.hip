@@ -236,7 +236,9 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 256)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
+  if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
+  if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
+  if (const char* e = getenv("TF2_AMD_ALT_CONC")) o.alt_conc_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
@@ -248,12 +250,12 @@ void Net::load_options() {
 // Net::run used to rebuild ~60 argument structs, scan the packed directory and read a dozen environment variables
 // per call; at batch 1 (57 launches of a few microseconds) that host work was the step.  Now a step is a loop over
 // prepared launches; only the image and logits pointers change between calls.
-const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
+const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent) {
   for (const LaunchPlan& lp : launch_plans)
-    if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev) return &lp;
+    if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0)) return &lp;
   if (launch_plans.size() >= 16) launch_plans.erase(launch_plans.begin());
   LaunchPlan lp;
-  lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev;
+  lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0;
   int8_t* base = (int8_t*)ws;
   const int nl = nd.n_layers;
   auto T = [&](int id) -> const TensorPlan& { return wp->tensors[id]; };
@@ -292,10 +294,11 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws) {
     const LayerExec& E = wp->exec[l];
     const PackLayer* pl = pack_layer(l);
     // the wide-tile alternative (128-row tiles, weight_pack.cpp) where its grid still fills the chip: fewer operand bytes and
-    // instructions per MAC; small batches keep the 64-row tiles (more blocks, split-K)
+    // instructions per MAC; small batches keep the 64-row tiles (more blocks, split-K).  With several batches in flight the
+    // other batches' kernels fill the chip, so the wide form pays from a much smaller grid on.
     if (const PackLayer* pa = pack_layer_alt(l)) {
       const long blocks128 = ((long)batch * L.OH * L.OW + 127) / 128 * (pa->Np / 128);
-      if (blocks128 >= opts.alt_min_blocks) pl = pa;
+      if (blocks128 >= (concurrent ? opts.alt_min_blocks_conc : opts.alt_min_blocks)) pl = pa;
     }
     st.kind = Launch::CONV; st.layer = l;
     ConvArgs& ca = st.conv;
@@ -471,7 +474,13 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     else wp = a;
   }
   if (ws_bytes < wp->total_bytes) { set_error("tf2_net_run: workspace too small"); return TF2_ERR_SIZE; }
-  const LaunchPlan* lp = launch_plan(batch, wp, ws);
+  // batches in flight?  (calls on at least two different streams among the last eight)
+  void* const tag = (void*)((uintptr_t)stream + 1);          // the null stream is a stream too; 0 = empty slot
+  recent_streams[recent_pos] = tag; recent_pos = (recent_pos + 1) & 7;
+  bool concurrent = opts.alt_conc_mode == 1;
+  if (opts.alt_conc_mode == 2)
+    for (int i = 0; i < 8 && !concurrent; i++) concurrent = recent_streams[i] != nullptr && recent_streams[i] != tag;
+  const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent);
   if (!lp) return TF2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nl = nd.n_layers;

@@ -55,6 +55,7 @@ struct LaunchPlan {
   const WorkPlan* wp = nullptr;
   void* ws = nullptr;
   const uint8_t* packed_dev = nullptr;
+  int concurrent = 0;               // built for several batches in flight (wide-tile alternatives from a smaller grid on)
   std::vector<Launch> steps;
   int logits_direct = -1;           // index of the conv step that writes the dense logits itself (its y is patched per call), else -1
 };
@@ -63,7 +64,9 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 256;
-  long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN
+  long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
+  long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
+  int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
@@ -114,7 +117,9 @@ struct Net {
   const PackLayer* pack_layer_alt(int l) const;
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
-  const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws);
+  const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
+  int recent_pos = 0;
   void load_options();
   size_t logits_bytes(int batch) const;
   tf2_status run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,

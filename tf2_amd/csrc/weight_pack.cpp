@@ -171,7 +171,7 @@ tf2_status Net::pack(int mode) {
     for (int variant = 0; variant < 2; variant++) {        // 0: the layer's own entry, 1: its wide-tile alternative (if any)
     if (variant == 1) {
       const PackLayer& p0 = *(blob.at<PackLayer>(sizeof(PackHeader)) + l);
-      const bool want = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 1024 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0 &&
+      const bool want = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 256 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0 &&
                         getenv("TF2_AMD_NOALT") == nullptr;
       if (!want) break;
       pl = PackLayer{}; pl.fused_into = -1;
