@@ -208,6 +208,7 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     default for dense 1x1 stride-1 layers with K <= 128; TF2_AMD_PW=0 sends them back to conv_mfma2.  Ragged pixel
     counts (batch 3 and 5), with / without residual, one and two K slabs, single- and dual-window packing."""
     monkeypatch.setenv("TF2_AMD_PW_SLABS", "2")      # also the two-slab instantiations (default: one slab only)
+    monkeypatch.setenv("TF2_AMD_PW_MINPIX", "0")     # ... and at these small pixel counts (default: from 8192 pixels on)
     rig = Rig(*r50, 0)
     pw_layers = {1, 2, 4, 7, 10, 14, 17, 20, 23}
     for b, seed in ((3, 51), (5, 52)):
