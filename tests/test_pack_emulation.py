@@ -163,12 +163,17 @@ def test_resnet50_wide_tile_alternatives(golden_dir):
     _, pls = emu.parse(blob)
     alts = emu.parse_alt(blob)
     have = [i for i in range(len(alts)) if int(alts[i]["kind"]) == 1]
-    assert have and all(int(alts[i]["TM"]) == 128 and int(pls[i]["TM"]) == 64 and int(pls[i]["Np"]) >= 256 for i in have)
+    wide = [i for i in have if int(alts[i]["TM"]) == 128]
+    narrow = [i for i in have if int(alts[i]["TM"]) == 64]         # 28x28 layers: 64-row tiles for the grids of batch 1-2
+    assert wide and narrow and len(wide) + len(narrow) == len(have)
+    assert all(int(pls[i]["TM"]) == 64 and int(pls[i]["Np"]) >= 256 for i in wide)
+    assert all(int(pls[i]["TM"]) == 128 for i in narrow)
     R = netref.RefNet(t, q, model)
     outs = R.run(x)
-    assert all(R.plan[i].OH * R.plan[i].OW >= 16 for i in have)          # the 1x1-map FC row has none
-    k3 = [j for j in have if R.plan[j].k == 3]
-    for i in (have[0], k3[0], k3[-1], [j for j in have if not R.plan[j].endpool][-1]):
+    assert all(R.plan[i].OH * R.plan[i].OW >= 16 for i in wide) and all(R.plan[i].OH == 28 for i in narrow)
+    k3 = [j for j in wide if R.plan[j].k == 3]
+    n3 = [j for j in narrow if R.plan[j].k == 3]
+    for i in (wide[0], k3[0], k3[-1], [j for j in wide if not R.plan[j].endpool][-1], narrow[0], n3[0], n3[-1], narrow[-1]):
         L = R.plan[i]
         S = R.plan[L.src]
         x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))

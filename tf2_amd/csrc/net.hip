@@ -238,6 +238,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
+  if (const char* e = getenv("TF2_AMD_ALT_NARROW")) o.alt_narrow_blocks = atol(e);   // a 128-row layer takes its 64-row alternative below this many 128 x 128 blocks
   if (const char* e = getenv("TF2_AMD_ALT_CONC")) o.alt_conc_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
@@ -289,16 +290,20 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     lp.steps.push_back(st);
   };
   // argument block + kernel selection of one conv layer
-  auto make_conv = [&](int l, Launch& st) -> bool {
+  auto make_conv = [&](int l, Launch& st, bool allow_alt) -> bool {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
     const PackLayer* pl = pack_layer(l);
     // the wide-tile alternative (128-row tiles, weight_pack.cpp) where its grid still fills the chip: fewer operand bytes and
     // instructions per MAC; small batches keep the 64-row tiles (more blocks, split-K).  With several batches in flight the
     // other batches' kernels fill the chip, so the wide form pays from a much smaller grid on.
-    if (const PackLayer* pa = pack_layer_alt(l)) {
+    // The reverse on the 28x28 maps: their 128-row layers have a 64-row alternative (more blocks, split-K) for grids of a few
+    // blocks (batch 1-2).
+    const PackLayer* pa = allow_alt ? pack_layer_alt(l) : nullptr;
+    if (pa) {
       const long blocks128 = ((long)batch * L.OH * L.OW + 127) / 128 * (pa->Np / 128);
-      if (blocks128 >= (concurrent ? opts.alt_min_blocks_conc : opts.alt_min_blocks)) pl = pa;
+      if (pa->TM == 128) { if (blocks128 >= (concurrent ? opts.alt_min_blocks_conc : opts.alt_min_blocks)) pl = pa; }
+      else if (blocks128 < opts.alt_narrow_blocks) pl = pa;
     }
     st.kind = Launch::CONV; st.layer = l;
     ConvArgs& ca = st.conv;
@@ -379,15 +384,16 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     Launch st;
-    if (!make_conv(l, st)) return nullptr;
     // a fused launch needs enough row bands to fill the chip (one block per band): small batches run the two layers on their own
     const int bn_TN = pl->TM == 64 ? 256 : 128;
     const int bn_R = pl->fuse_next > 0 ? std::min(bn_TN / L.W, L.H) : 1;
-    if (pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks) {
+    const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks;
+    if (!make_conv(l, st, !fuse_now)) return nullptr;     // the fused launch needs the pair's own (one m-tile) entries
+    if (fuse_now) {
       fused_done[pl->fuse_next] = 1;
       // this 3x3 + its only consumer (the 1x1 expand) in one launch; the expand's argument block supplies the second half
       Launch sb;
-      if (!make_conv(pl->fuse_next, sb)) return nullptr;
+      if (!make_conv(pl->fuse_next, sb, false)) return nullptr;
       const PackLayer* pb = pack_layer(pl->fuse_next);
       BneckArgs& f = st.bneck;
       const ConvArgs& ca = st.conv; const ConvArgs& cb = sb.conv;

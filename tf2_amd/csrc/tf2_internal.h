@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 24;
+constexpr uint32_t kPackVersion = 25;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

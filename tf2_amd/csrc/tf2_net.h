@@ -65,6 +65,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 256;
   long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
+  long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)

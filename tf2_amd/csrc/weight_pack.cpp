@@ -168,12 +168,17 @@ tf2_status Net::pack(int mode) {
       *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
       continue;
     }
-    for (int variant = 0; variant < 2; variant++) {        // 0: the layer's own entry, 1: its wide-tile alternative (if any)
+    int alt_TM = 0;
+    for (int variant = 0; variant < 2; variant++) {        // 0: the layer's own entry, 1: its alternative tile height (if any)
     if (variant == 1) {
       const PackLayer& p0 = *(blob.at<PackLayer>(sizeof(PackHeader)) + l);
-      const bool want = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 256 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0 &&
-                        getenv("TF2_AMD_NOALT") == nullptr;
-      if (!want) break;
+      // wide alternative (128-row tiles) of a 64-row layer on a small map; NARROW alternative (64-row tiles, split-K) of a
+      // 128-row layer on a 28x28 map, for the tiny grids of batch 1-2 (never for the second half of a fused pair; the first
+      // half keeps its one-m-tile entry for the fused launch and gets the narrow one for its own)
+      const bool wide = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 256 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0;
+      const bool narrow = p0.kind == KIND_MFMA && p0.TM == 128 && p0.fused_into < 0 && L.OH * L.OW <= 784;
+      if (!(wide || narrow) || getenv("TF2_AMD_NOALT") != nullptr) break;
+      alt_TM = wide ? 128 : 64;
       pl = PackLayer{}; pl.fused_into = -1;
     }
     const LayerModel& m = models[l];
@@ -201,10 +206,10 @@ tf2_status Net::pack(int mode) {
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
       static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
       int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
-      if (variant == 1) TM = 128;
       if (fuse_next[l] > 0) TM = Np;                                   // fused pair: the 3x3 in one m-tile ...
       if (fused_into[l] >= 0) TM = layers[fused_into[l]].N;            // ... and the expand in four of the same height
       pl.fuse_next = fuse_next[l]; pl.fused_into = fused_into[l];
+      if (variant == 1) { TM = alt_TM; pl.fuse_next = 0; pl.fused_into = -1; }      // an alternative is never launched fused
       const int n_mtiles = Np / TM;
       const int Ktot = taps * il.Cp_in;
       const int nslab = (Ktot + 63) / 64;
