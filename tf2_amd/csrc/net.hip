@@ -387,7 +387,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     // a fused launch needs enough row bands to fill the chip (one block per band): small batches run the two layers on their own
     const int bn_TN = pl->TM == 64 ? 256 : 128;
     const int bn_R = pl->fuse_next > 0 ? std::min(bn_TN / L.W, L.H) : 1;
-    const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks;
+    // (128-channel pairs: 42.6 against 46.8 us at batch 64 one batch at a time, but 0.62 against 0.51 us per further image --
+    //  with batches in flight the two separate launches win)
+    const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks &&
+                          !(concurrent && pl->TM == 128 && opts.bneck_min_blocks > 1);
     if (!make_conv(l, st, !fuse_now)) return nullptr;     // the fused launch needs the pair's own (one m-tile) entries
     if (fuse_now) {
       fused_done[pl->fuse_next] = 1;
