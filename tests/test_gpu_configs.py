@@ -149,3 +149,24 @@ def test_run_split_and_its_graph_equal_run_batch(r50_rig):
     buf.copy_(torch.from_numpy(x2))
     replay(); torch.cuda.synchronize()
     np.testing.assert_array_equal(r._logits.cpu().numpy(), rig.run(x2, keep_all=False))
+
+
+@pytest.mark.parametrize("conc", ["0", "1"])
+def test_resnet50_batch_sizes_and_tile_choices(r50, monkeypatch, conc):
+    """The launch plan picks tile heights by batch size and by whether batches are in flight (wide / narrow alternatives,
+    fused or separate bottleneck pairs, conv_pw or the ring kernel): batch sizes on both sides of every threshold, with the
+    one-stream and the several-streams choice forced, against the oracle (three images each) and against themselves (an image
+    run alone gives its row of the batch)."""
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    rig = Rig(*r50, 0)
+    x = synth.synth_images(rig.t, 64, 91)
+    want = rig.ref.logits(rig.ref.run(x[:3]))
+    rows = {}
+    for b in (1, 2, 3, 4, 9, 17, 33, 64):
+        got = rig.run(x[:b], keep_all=False)
+        np.testing.assert_array_equal(got[:min(b, 3)], want[:min(b, 3)], err_msg=f"batch {b}")
+        for i in range(b):
+            if i in rows:
+                np.testing.assert_array_equal(got[i], rows[i], err_msg=f"batch {b}, image {i}")
+            else:
+                rows[i] = got[i].copy()
