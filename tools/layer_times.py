@@ -16,13 +16,16 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--out", default=None)
 ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--uniform-q", action="store_true", help="one Q value per tensor (every layer single-window): the bound for grouped packing")
+ap.add_argument("--uniform-q2", action="store_true", help="the same, only for tensors that carry exactly two Q values")
 a = ap.parse_args()
 t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
-if a.uniform_q:
+if a.uniform_q or a.uniform_q2:
     pos = 3
     for L in plan:
-        qv[pos:pos + L.N] = int(np.round(qv[pos:pos + L.N].mean())); pos += L.N
+        if a.uniform_q or len(np.unique(qv[pos:pos + L.N])) == 2:
+            qv[pos:pos + L.N] = int(np.round(qv[pos:pos + L.N].mean()))
+        pos += L.N
 model = synth.synth_model(t, qv, 0)
 net = network.NetWork(t); net.Init(model, synth.q_text(qv), device="cuda:0", pack_mode=a.mode)
 _, pls = emu.parse(net.packed_host())
