@@ -10,7 +10,7 @@ HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
                                      "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
-                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes")])
+                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad")])
 
 
 def parse(blob: np.ndarray):
@@ -59,6 +59,14 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
     [B,N,OH,OW] after requant/relu/residual (before pool / global average)."""
     B, H, W, Cp = x_t.shape
     assert Cp == int(pl["Cp_in"]) or int(pl["kind"]) == 2
+    # doubled input channels (weight_pack.cpp): stored as 2x - 128, an out-of-range tap reads the pad row (-128 there)
+    pad = None
+    if int(pl["off_pad"]):
+        pad = np.frombuffer(blob[int(pl["off_pad"]):int(pl["off_pad"]) + Cp].tobytes(), np.int8)
+        x_t = x_t.copy()
+        d = pad == -128
+        assert (x_t[..., d] >= 0).all()
+        x_t[..., d] = (2 * x_t[..., d].astype(np.int16) - 128).astype(np.int8)
     N, OH, OW = L.N, L.OH, L.OW
     Np = int(pl["Np"])
     bias = i32(blob, int(pl["off_bias"]), Np).astype(np.int64)
@@ -93,6 +101,8 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
                 ih = poh * L.stride - L.pad_h + int(dh); iw = pow_ * L.stride - L.pad_w + dw
                 ok = (ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)
                 v = np.zeros((npix, 16), np.int8)
+                if pad is not None:
+                    v[:] = pad[coff:coff + 16]
                 v[ok] = x_t[pb[ok], ih[ok], iw[ok], coff:coff + 16]
                 m[:, sg * 16:(sg + 1) * 16] = v
             slabs[sl] = m

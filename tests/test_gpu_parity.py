@@ -240,6 +240,20 @@ def test_first_layer_generic_path_and_wide_tile_alternatives(r50, monkeypatch):
     rig.check_all_layers(x, layers={0, 24, 27, 43, 46, 52, 53})
 
 
+def test_doubled_channels_on_and_off(r50, monkeypatch):
+    """Internal two-Q tensors store their higher-Q channels as 2x - 128 (one exponent window for the consumers,
+    weight_pack.cpp): the default run reads them back through read_layer's inverse in every other test; here the plain form
+    (TF2_AMD_NODBL=1 at pack time) on the same images, every layer, and both against the oracle.  The images saturate some
+    3x3 borders' neighbourhoods so that padded taps (pad value -128 on doubled channels) matter."""
+    x = synth.synth_images(r50[0], 3, 81)
+    x[1, :, :8, :] = 150.0
+    x[2, :, :, -6:] = -120.0
+    Rig(*r50, 0).check_all_layers(x)
+    monkeypatch.setenv("TF2_AMD_NODBL", "1")
+    rig = Rig(*r50, 0)
+    rig.check_all_layers(x, layers={2, 3, 4, 6, 7, 12, 13, 14, 16, 17, 26, 27, 53})
+
+
 def test_fused_bottleneck_pairs(r50, monkeypatch):
     """conv_bneck.hip: branch2b (3x3 / stride 1) + branch2c (1x1 expand, residual, ReLU) of the stride-1 bottlenecks in one
     launch (C = 64 / 128 / 256; halo tile and intermediate tile in LDS, weights from registers): every layer with keep_all

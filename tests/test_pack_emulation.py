@@ -98,7 +98,9 @@ def test_resnet50_selected_layers(golden_dir):
     assert set(kinds) == {1}
     # the shipped resnet50_Q has per-input-channel Q spreads up to 2 in the early layers: those
     # need a second exponent window; the uniform-Q late layers need exactly one phase
-    assert int(pls[3]["n_phases"]) == 2 and int(pls[46]["n_phases"]) == 1
+    # (layer 3 reads a two-Q tensor: one window thanks to the doubled channels, test_resnet50_doubled_channels; layer 1's input
+    # carries three Q values)
+    assert int(pls[1]["n_phases"]) == 2 and int(pls[3]["n_phases"]) == 1 and int(pls[46]["n_phases"]) == 1
 
 
 def test_wide_shift_range_needs_more_windows():
@@ -180,3 +182,21 @@ def test_resnet50_wide_tile_alternatives(golden_dir):
         res = outs[L.add_src] if L.add_src >= 0 else None
         y = emu.conv_from_packed(blob, alts[i], L, x_t, res)
         np.testing.assert_array_equal(y, outs[i], err_msg=f"layer {i} wide-tile alternative")
+
+
+def test_resnet50_doubled_channels(golden_dir):
+    """Tensors inside the bottlenecks whose channels carry exactly two Q values store the higher-Q channels as 2x - 128; their
+    consumers are packed with those channels' weights one exponent lower, 64 * sum(w) in the bias and -128 as the pad value --
+    and need ONE exponent window where they needed two.  The packed consumer must still compute the oracle's layer."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    x = synth.synth_images(t, 1, 0)
+    kinds, pls = check_net(t, q, model, x, 0, layers={3, 4, 6, 7, 13, 14, 16, 17, 26, 27, 29, 30})
+    producers = [i for i in range(len(pls)) if int(pls[i]["off_dbl"])]
+    consumers = [i for i in range(len(pls)) if int(pls[i]["off_pad"])]
+    assert set(producers) == {2, 5, 6, 8, 12, 13, 15, 16, 18, 19, 22, 25, 26, 29}, producers
+    assert set(consumers) == {3, 6, 7, 9, 13, 14, 16, 17, 19, 20, 23, 26, 27, 30}, consumers
+    assert all(int(pls[i]["n_phases"]) == 1 for i in consumers)
+    # layer 28 has no range-proven requantisation (no free header word): its output stays plain and layer 29 keeps two windows
+    assert int(pls[28]["fast"]) == 0 and int(pls[29]["n_phases"]) == 2

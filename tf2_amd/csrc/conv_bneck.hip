@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
       const int hr = h / Wp, hc = h - hr * Wp;
       const int row = r0 - 1 + hr, col = hc - 1;
       const bool ok = h < n_h && (unsigned)row < (unsigned)a.H && (unsigned)col < (unsigned)W;
-      const int8_t* src = ok ? a.x + (((long long)img * a.H + row) * W + col) * TM + s * 64 + chunk * 16 : a.zero;
+      const int8_t* src = ok ? a.x + (((long long)img * a.H + row) * W + col) * TM + s * 64 + chunk * 16
+                             : a.zero + s * 64 + chunk * 16;       // the stored form of x = 0: the zero page, or the 3x3's pad row
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(mid1 + s * slabb + grp * 1024), 16, 0, 0);
     }
   }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-        const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores);
+        const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores, a.dbl_mid != 0);
         const int row = wn * WTN + j * 32 + (lane & 31);
         const int c = (chl & 63) >> 4;
         *reinterpret_cast<i32x4*>(mid2 + (chl >> 6) * (TN * 64) + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;

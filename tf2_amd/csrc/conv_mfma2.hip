@@ -196,8 +196,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   auto issue_stage = [&](int e, int off, int hw, int slot_idx) {
     int8_t* const slot = lds + slot_idx * STAGE;
     const int8_t* wsrc = aw + (size_t)e * A_BYTES + a_lane_off;
-    int dh = 0, dw = 0;
-    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
+    int dh = 0, dw = 0, pc = 0;              // pc: the segment's channel offset = its place in the layer's pad row
+    if (PADCHK) { dh = hw & 0xff; dw = (hw >> 8) & 0xff; pc = (int)((unsigned)hw >> 16); }
 #pragma unroll
     for (int j = 0; j < NI_HI; j++) {
       const int gi = wave + NW * j;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
           const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
           ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         }
-        const int8_t* src = ok ? brow_ptr[j] + off : azero;
+        const int8_t* src = ok ? brow_ptr[j] + off : azero + pc;      // out of range: the stored form of x = 0 (weight_pack.cpp off_pad)
         __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
       }
     }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j]);
+        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j], g.dbl_out != 0);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl);
           *dst = out;

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 
   auto issue_B = [&](int off, int hw, int slot_idx) {
     int8_t* const slot = ring + slot_idx * STAGE + A_BYTES;
-    int dh = 0, dw = 0;
-    if (PADCHK) { dh = hw & 0xffff; dw = hw >> 16; }
+    int dh = 0, dw = 0, pc = 0;              // pc: the segment's channel offset = its place in the layer's pad row
+    if (PADCHK) { dh = hw & 0xff; dw = (hw >> 8) & 0xff; pc = (int)((unsigned)hw >> 16); }
 #pragma unroll
     for (int j = 0; j < BI; j++) {
       bool ok = off >= 0 && brow_ok[j];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
         const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
         ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
       }
-      const int8_t* src = ok ? brow_ptr[j] + off : azero;
+      const int8_t* src = ok ? brow_ptr[j] + off : azero + pc;      // out of range: the stored form of x = 0 (off_pad)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
     }
   };
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     for (int r = 0; r < 4; r++) a16[G * 4 + r] = sum[G][r];
   i32x4 out;
   if (g.fast) out = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
-                              : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
+                              : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
   else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
                        : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
   const int chl = tile_ch + 16 * half;

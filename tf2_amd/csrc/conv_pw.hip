@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     i32x4 out;
     const int row0 = wr * 32 + 4 * half;
     if (g.fast) out = g.has_res ? requant_tile16<true, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res)
-                                : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res);
+                                : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
     else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res)
                          : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res);
     const int px = t * 32 + (lane & 31);

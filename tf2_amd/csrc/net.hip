@@ -312,7 +312,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     ca.w = (const int8_t*)(pk + pl->off_w); ca.w2 = (const int8_t*)(pk + pl->off_w2);
     ca.bias = (const int32_t*)(pk + pl->off_bias); ca.alpha = (const int32_t*)(pk + pl->off_alpha);
     ca.beta = (const int32_t*)(pk + pl->off_beta);
-    ca.zero = (const int8_t*)(pk + zero_off); ca.max_ent = pl->max_ent;
+    ca.zero = (const int8_t*)(pk + (pl->off_pad ? pl->off_pad : zero_off)); ca.max_ent = pl->max_ent;
     ca.dual = pl->dual;
     set_fast_div((uint32_t)pl->n_mtiles, &ca.mt_m, &ca.mt_s);
     bool dense = false;
@@ -340,6 +340,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     g.y_nvalid = round_up(L.N, 16);
     g.relu = L.relu; g.add_relu = L.add_relu; g.has_res = L.add_src >= 0;
     g.fast = pl->fast;
+    g.dbl_out = pl->off_dbl != 0;
     if (g.has_res) {
       const TensorPlan& tr = T(E.res_tensor);
       ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;
@@ -407,7 +408,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.dual2 = pb->dual; f.fast2 = pb->fast; f.relu2 = cb.g.relu;
       f.y = cb.y; f.y_cp = cb.g.y_cp; f.y_off = cb.g.y_off; f.y_nvalid = cb.g.y_nvalid;
       f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
-      f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0;
+      f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0;
       f.B = batch; f.H = L.H; f.W = L.W;
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
       f.R = std::min(TN / L.W, L.H);
@@ -597,10 +598,16 @@ tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, si
   HIP_OK(hipMemcpyAsync(tmp.data(), (const int8_t*)ws + t.offset, tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_OK(hipStreamSynchronize((hipStream_t)stream));
   const size_t HW = (size_t)t.H * t.W;
+  // doubled channels are stored as 2y - 128 (weight_pack.cpp): hand back y
+  const PackLayer* pl = layer >= 0 ? pack_layer(layer) : nullptr;
+  const uint8_t* dblf = (pl && pl->off_dbl) ? packed.data() + pl->off_dbl : nullptr;
   for (int b = 0; b < batch; b++)
     for (int c = 0; c < C; c++)
-      for (size_t p = 0; p < HW; p++)
-        dst[((size_t)b * C + c) * HW + p] = tmp[((size_t)b * HW + p) * Cp + off + c];
+      for (size_t p = 0; p < HW; p++) {
+        int8_t v = tmp[((size_t)b * HW + p) * Cp + off + c];
+        if (dblf && dblf[c]) v = (int8_t)(((int)v + 128) >> 1);
+        dst[((size_t)b * C + c) * HW + p] = v;
+      }
   return TF2_OK;
 }
 

@@ -33,9 +33,11 @@ constexpr int kPrmWordsPerRow = 5;
 // Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
 // LEAN (1 or 2): for kernels compiled for 8 waves/SIMD (64 registers); the number of rows read ahead.
 // resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
-template <bool HAS_RES, int LEAN = 0, bool FAST = false>
-__device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
-                                                   int lo_bound, int rlo, const rq_i32x4& resv) {
+// DBL (FAST layers without a residual whose output tensor has "doubled" channels, weight_pack.cpp): header word 0 of a row is
+// -128 for a doubled channel, 0 otherwise, and the stored value is (c << 1) - 128 resp. c.
+template <bool HAS_RES, int LEAN, bool FAST, bool DBL>
+__device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
+                                                        int lo_bound, int rlo, const rq_i32x4& resv) {
   unsigned rd[4] = {0, 0, 0, 0};
   if (HAS_RES) {
     // the prefetched 16 contiguous bytes back into the C/D layout (the store swaps are involutions)
@@ -81,6 +83,7 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
       }
       int c;
       asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+      if (DBL) c = (int)(((unsigned)c << ((unsigned)pr[0] >> 31)) + (unsigned)pr[0]);
       if (HAS_RES) {
         const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
         const int sres = c + rr;
@@ -97,6 +100,15 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
   auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
   auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
   return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+}
+
+template <bool HAS_RES, int LEAN = 0, bool FAST = false>
+__device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0, int lo_bound, int rlo, const rq_i32x4& resv,
+                                                   bool dbl = false /* wave-uniform */) {
+  if constexpr (!HAS_RES && FAST) {
+    if (dbl) return requant_tile16_impl<false, LEAN, true, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
+  }
+  return requant_tile16_impl<HAS_RES, LEAN, FAST, false>(a16, prm, TM, row0, lo_bound, rlo, resv);
 }
 
 }  // namespace tf2

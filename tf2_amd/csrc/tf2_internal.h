@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 25;
+constexpr uint32_t kPackVersion = 26;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -51,6 +51,11 @@ struct PackLayer {
   uint64_t off_dshift;   // int32[n_phases][Np]  Horner shift applied when entering phase p>=1
   uint64_t off_hdr;      // MFMA: n_mtiles headers of hdr_bytes each (the LDS image conv_mfma2 copies per block)
   uint64_t hdr_bytes;    // multiple of 1024
+  // "Doubled" channels (weight_pack.cpp): an internal post-ReLU tensor whose channels carry exactly two Q values stores the
+  // channels with the higher one as 2x - 128, so that its consumers need ONE exponent window instead of two.
+  uint64_t off_dbl;      // uint8[Np]: 1 = this layer stores output channel n as 2y - 128 (0: no such channel)
+  uint64_t off_pad;      // uint8[Cp_in + 16]: what an out-of-range tap reads (the stored form of x = 0: -128 on doubled input
+                         // channels), 0: the zero page
 };
 
 struct PackHeader {
@@ -58,7 +63,7 @@ struct PackHeader {
   uint32_t n_layers, dir_bytes;
   uint64_t total_bytes;
   uint64_t tables_hash;     // hash of the layer descs the image was packed for
-  uint64_t zero_off;        // offset of a 256-byte all-zero block (source of padded taps for LDS-DMA)
+  uint64_t zero_off;        // offset of an all-zero block of >= max Cp_in + 16 bytes (source of padded taps for LDS-DMA)
 };
 
 // ---- device-side parameter blocks -------------------------------------------------
@@ -77,6 +82,7 @@ struct ConvGeom {
   int32_t relu, add_relu, has_res;
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
   int32_t flags;             // bits 1,2: conv_mfma2 block-shape A/B switches (TF2_AMD_EXP)
+  int32_t dbl_out;           // the output tensor has doubled channels (PackLayer::off_dbl): header word 0 of a row = -128 or 0
 };
 
 // n / d for 0 <= n < 2^31 as one 32x32->hi multiply and a shift: L = ceil(log2 d), m = floor(2^(31+L) / d) + 1,
@@ -130,6 +136,7 @@ struct BneckArgs {
   int32_t hdr1_used, hdr2_bytes, hdr2_used;
   int32_t B, H, W, R, tiles_per_img;     // R output rows per block, ceil(H / R) blocks per image
   int32_t dual1, fast1, relu1, dual2, fast2, relu2, add_relu, has_res, keep_mid;
+  int32_t dbl_mid;           // the 3x3's output (the intermediate tile) has doubled channels
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
 };
 

@@ -130,11 +130,62 @@ tf2_status Net::pack(int mode) {
       fuse_next[l] = b; fused_into[b] = l;
     }
   };
+  // ---- doubled channels.  The shift of a code is 15 + Q_in[c] - Q_out[n] - i (model_loader.cpp:159-162): a tensor whose
+  // channels carry two Q values costs its consumers a ninth exponent level, i.e. a second 7-exponent window.  x is 7-bit after
+  // ReLU, so the channels with the HIGHER Q can be stored as x' = 2x - 128 (int8) instead: w * x = (w/2) * x' + 64 * w -- the
+  // consumer packs those channels' weights one exponent lower (all of them must be even) and adds 64 * sum(w) to its bias;
+  // an out-of-range tap (x = 0) reads -128.  Only tensors nothing but MFMA convolutions read (no residual, pool, average,
+  // concat, L2Norm, final output), written by a layer with ReLU and the range-proven requantisation (its header row has a
+  // free word for the -128), qualify: in ResNet-50 the 64/128/256-channel tensors inside the bottlenecks.
+  std::vector<std::vector<uint8_t>> dbl(nl);
+  if (mode == 0 && getenv("TF2_AMD_NODBL") == nullptr) {
+    const int M = nd.max_out_channel;
+    for (int p = 0; p + 1 < nl; p++) {
+      const tf2_layer_desc& P_ = layers[p];
+      if (P_.ipool || !P_.relu || P_.pool_en || P_.endpool || P_.concat >= 0 || P_.add_src >= 0 || out_signed[p]) continue;
+      bool ok = true; int n_cons = 0;
+      for (int j = 0; j < nl && ok; j++) {
+        if (layers[j].add_src == p) ok = false;
+        if (layers[j].src != p) continue;
+        n_cons++;
+        if (layers[j].ipool || layers[j].C != P_.N) ok = false;
+      }
+      if (!ok || n_cons == 0) continue;
+      const int8_t* qo = q.data() + (size_t)(p + 1) * M;
+      int v0 = qo[0], v1 = qo[0]; bool two = true;
+      for (int n = 0; n < P_.N && two; n++) {
+        if (qo[n] == v0 || qo[n] == v1) continue;
+        if (v0 == v1) { if (qo[n] < v0) v0 = qo[n]; else v1 = qo[n]; }
+        else two = false;
+      }
+      if (!two || v0 == v1) continue;
+      std::vector<uint8_t> f(P_.N, 0);
+      for (int n = 0; n < P_.N; n++) f[n] = qo[n] == v1;
+      // every consumer weight on a doubled channel must be even (shift >= 1)
+      for (int j = 0; j < nl && ok; j++) {
+        if (layers[j].src != p) continue;
+        const tf2_layer_desc& J = layers[j];
+        const int taps = J.k * J.k;
+        for (int n = 0; n < J.N && ok; n++)
+          for (int c = 0; c < J.C && ok; c++) {
+            if (!f[c]) continue;
+            for (int t = 0; t < taps; t++) {
+              const uint8_t code = models[j].codes[((size_t)n * J.C + c) * taps + t];
+              if (!code_zero(code) && code_shift(code) < 1) { ok = false; break; }
+            }
+          }
+      }
+      if (ok) dbl[p] = f;
+    }
+  }
   for (int attempt = 0; attempt < 8; attempt++) {
   decide_fusion();
   packed.clear();
   blob.alloc(dir_bytes);
-  if (blob.alloc(256) != zero_off) { set_error("tf2_net_pack: internal layout error"); return TF2_ERR_STATE; }
+  // the zero block: what an out-of-range tap reads (16 bytes at the segment's channel offset), for every layer without its own pad row
+  size_t zero_bytes = 256;
+  for (int l = 0; l < nl; l++) zero_bytes = std::max(zero_bytes, (size_t)round_up(in_layout[l].Cp_in + 16, 256));
+  if (blob.alloc(zero_bytes) != zero_off) { set_error("tf2_net_pack: internal layout error"); return TF2_ERR_STATE; }
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     PackLayer pl{};
@@ -181,7 +232,26 @@ tf2_status Net::pack(int mode) {
       alt_TM = wide ? 128 : 64;
       pl = PackLayer{}; pl.fused_into = -1;
     }
-    const LayerModel& m = models[l];
+    // doubled input channels: weights one exponent lower, 64 * sum(w) into the bias (Z/2^32 like the accumulator)
+    const std::vector<uint8_t>* in_dbl = (L.src >= 0 && !dbl[L.src].empty()) ? &dbl[L.src] : nullptr;
+    LayerModel mm;
+    if (in_dbl) {
+      mm = models[l];
+      const int tp = L.k * L.k;
+      for (int n = 0; n < L.N; n++)
+        for (int c = 0; c < L.C; c++) {
+          if (!(*in_dbl)[c]) continue;
+          for (int t = 0; t < tp; t++) {
+            uint8_t& code = mm.codes[((size_t)n * L.C + c) * tp + t];
+            if (code_zero(code)) continue;
+            const int sft = code_shift(code);
+            const uint32_t half_w = 1u << (sft - 1);
+            mm.bias[n] = (int32_t)((uint32_t)mm.bias[n] + (code_neg(code) ? 0u - half_w * 128u : half_w * 128u));
+            code = (uint8_t)((code & 0xe0) | (sft - 1));
+          }
+        }
+    }
+    const LayerModel& m = in_dbl ? mm : models[l];
     const int N = L.N, C = L.C, k = L.k, taps = k * k;
     const InLayout& il = in_layout[l];
     const bool in_signed = src_signed(L.src) != 0;
@@ -357,7 +427,7 @@ tf2_status Net::pack(int mode) {
       // words: per row {bias, alpha, beta64.lo, beta64.hi} (4*TM; beta64 = (int64)beta << 20, the addend of the
       //        64-bit multiply-add; one 16-byte read per output row) | lo[TM] | dshift[P][TM] | steps[max_ent] (Horner phase steps to take before
       //        the entry) | goff[max_ent][4] (per 16-byte segment: byte offset from the pixel's tap origin,
-      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 16 for the zero-padding test);
+      //        -1 = K padding) | ghw[max_ent][4] (dh | dw << 8 for the zero-padding test, channel offset << 16);
       //        steps[max_ent-2], steps[max_ent-1] = the m-tile's first and end entry (scalar-loaded by every block)
       // ---- range proof for the fast requantisation (requant_epilogue.h) ----
       // With |x| <= 128, |sum| <= amax[n] = 128 * sum |w|.  If for every row  amax + |bias| < 2^31  (no int32 wrap
@@ -379,6 +449,19 @@ tf2_status Net::pack(int mode) {
         else if ((amax + ab) * aa + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) fast = false;
       }
       pl.fast = fast ? 1 : 0;
+      if (!fast) dbl[l].clear();          // no free header word for the -128: this layer's output stays plain (its consumers come later)
+      if (!dbl[l].empty()) {
+        std::vector<uint8_t> f(Np, 0);
+        std::copy(dbl[l].begin(), dbl[l].end(), f.begin());
+        pl.off_dbl = blob.alloc(Np);
+        std::memcpy(blob.at<uint8_t>(pl.off_dbl), f.data(), Np);
+      }
+      if (in_dbl) {
+        std::vector<int8_t> pad(il.Cp_in + 16, 0);
+        for (int c = 0; c < C; c++) if ((*in_dbl)[c]) pad[c] = -128;
+        pl.off_pad = blob.alloc(pad.size());
+        std::memcpy(blob.at<uint8_t>(pl.off_pad), pad.data(), pad.size());
+      }
       {
         const size_t words = (size_t)5 * TM + (size_t)P * TM + (size_t)9 * pl.max_ent;
         const size_t hb = (words * 4 + 1023) / 1024 * 1024;
@@ -393,7 +476,8 @@ tf2_status Net::pack(int mode) {
             if (fast) {
               const int64_t al = n < N ? (int64_t)m.alpha[n] : 0;
               const int64_t bp = (n < N ? (int64_t)m.bias[n] * al : 0) + b64 + ((int64_t)1 << 34);
-              pr[0] = 0; pr[1] = (int32_t)(al << lo_last[n]);
+              pr[0] = (n < N && !dbl[l].empty() && dbl[l][n]) ? -128 : 0;      // doubled channel: stored as 2y - 128 (requant_epilogue.h)
+              pr[1] = (int32_t)(al << lo_last[n]);
               pr[2] = (int32_t)(uint32_t)((uint64_t)bp & 0xffffffffu);
               pr[3] = (int32_t)(uint32_t)((uint64_t)bp >> 32);
             } else {
@@ -423,13 +507,15 @@ tf2_status Net::pack(int mode) {
               if (t >= taps) { o = -1; hw = 0; continue; }
               const int dh = (t / k) * L.dil, dw = (t % k) * L.dil;
               o = (dh * L.W + dw) * il.Cp_in + pc;
-              hw = dh | (dw << 16);
+              hw = dh | (dw << 8) | (pc << 16);      // pc: where an out-of-range tap reads inside the layer's pad row
             }
           }
         }
       }
     } else {
       pl.kind = KIND_SHIFT;
+      dbl[l].clear();                     // the shift kernel writes plain outputs
+      if (in_dbl) { set_error("layer " + std::to_string(l) + ": internal error, doubled input on a shift-kernel layer"); return TF2_ERR_STATE; }
       const int Np = round_up(N, 8);
       const int n_cchunk = (C + 15) / 16;
       if (n_cchunk * 16 > (in_signed && is_image ? il.half : il.Cp_in)) {
