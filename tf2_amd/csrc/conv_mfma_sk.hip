@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   if (g.fast) out = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
                               : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
   else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
-                       : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv);
+                       : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
   const int chl = tile_ch + 16 * half;
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
     *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;

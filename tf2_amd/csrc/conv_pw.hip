@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     if (g.fast) out = g.has_res ? requant_tile16<true, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res)
                                 : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
     else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res)
-                         : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res);
+                         : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
     const int px = t * 32 + (lane & 31);
     if (px <= last_px && ch_ok)
       *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;

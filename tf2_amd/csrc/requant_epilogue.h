@@ -33,8 +33,9 @@ constexpr int kPrmWordsPerRow = 5;
 // Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
 // LEAN (1 or 2): for kernels compiled for 8 waves/SIMD (64 registers); the number of rows read ahead.
 // resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
-// DBL (FAST layers without a residual whose output tensor has "doubled" channels, weight_pack.cpp): header word 0 of a row is
-// -128 for a doubled channel, 0 otherwise, and the stored value is (c << 1) - 128 resp. c.
+// DBL (layers without a residual whose output tensor has "doubled" channels, weight_pack.cpp): header word 0 of a row (FAST;
+// generic rows: bits 8.. of the row's shift word) is -128 for a doubled channel, 0 otherwise, and the stored value is
+// (c << 1) - 128 resp. c.
 template <bool HAS_RES, int LEAN, bool FAST, bool DBL>
 __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
                                                         int lo_bound, int rlo, const rq_i32x4& resv) {
@@ -83,7 +84,10 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
       }
       int c;
       asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
-      if (DBL) c = (int)(((unsigned)c << ((unsigned)pr[0] >> 31)) + (unsigned)pr[0]);
+      if (DBL) {
+        const int kd = FAST ? pr[0] : (lo4[r] >> 8);          // -128 or 0 (generic rows keep it above the shift amount)
+        c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
+      }
       if (HAS_RES) {
         const int rr = (int)(signed char)((rd[G] >> (8 * r)) & 0xff);
         const int sres = c + rr;
@@ -105,8 +109,8 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
 template <bool HAS_RES, int LEAN = 0, bool FAST = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0, int lo_bound, int rlo, const rq_i32x4& resv,
                                                    bool dbl = false /* wave-uniform */) {
-  if constexpr (!HAS_RES && FAST) {
-    if (dbl) return requant_tile16_impl<false, LEAN, true, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
+  if constexpr (!HAS_RES) {
+    if (dbl) return requant_tile16_impl<false, LEAN, FAST, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
   }
   return requant_tile16_impl<HAS_RES, LEAN, FAST, false>(a16, prm, TM, row0, lo_bound, rlo, resv);
 }

@@ -135,8 +135,8 @@ tf2_status Net::pack(int mode) {
   // ReLU, so the channels with the HIGHER Q can be stored as x' = 2x - 128 (int8) instead: w * x = (w/2) * x' + 64 * w -- the
   // consumer packs those channels' weights one exponent lower (all of them must be even) and adds 64 * sum(w) to its bias;
   // an out-of-range tap (x = 0) reads -128.  Only tensors nothing but MFMA convolutions read (no residual, pool, average,
-  // concat, L2Norm, final output), written by a layer with ReLU and the range-proven requantisation (its header row has a
-  // free word for the -128), qualify: in ResNet-50 the 64/128/256-channel tensors inside the bottlenecks.
+  // concat, L2Norm, final output), written by a layer with ReLU, qualify: in ResNet-50 the 64/128/256-channel tensors inside
+  // the bottlenecks.  The producer's header rows carry the -128 (requant_epilogue.h).
   std::vector<std::vector<uint8_t>> dbl(nl);
   if (mode == 0 && getenv("TF2_AMD_NODBL") == nullptr) {
     const int M = nd.max_out_channel;
@@ -449,7 +449,6 @@ tf2_status Net::pack(int mode) {
         else if ((amax + ab) * aa + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) fast = false;
       }
       pl.fast = fast ? 1 : 0;
-      if (!fast) dbl[l].clear();          // no free header word for the -128: this layer's output stays plain (its consumers come later)
       if (!dbl[l].empty()) {
         std::vector<uint8_t> f(Np, 0);
         std::copy(dbl[l].begin(), dbl[l].end(), f.begin());
@@ -485,7 +484,8 @@ tf2_status Net::pack(int mode) {
               pr[2] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
               pr[3] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
             }
-            h[4 * TM + r] = lo_last[n];
+            // the final shift; generic rows of a doubled channel carry the -128 above it (FAST rows: word 0)
+            h[4 * TM + r] = lo_last[n] | ((!fast && n < N && !dbl[l].empty() && dbl[l][n]) ? (int32_t)0xffff8000 : 0);
             for (int p = 0; p < P; p++) h[5 * TM + p * TM + r] = dshift[(size_t)p * Np + n];
           }
           int32_t* hs = h + 5 * TM + P * TM;
