@@ -254,7 +254,7 @@ void Net::load_options() {
 const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent) {
   for (const LaunchPlan& lp : launch_plans)
     if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0)) return &lp;
-  if (launch_plans.size() >= 16) launch_plans.erase(launch_plans.begin());
+  if (launch_plans.size() >= 64) launch_plans.erase(launch_plans.begin());
   LaunchPlan lp;
   lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0;
   int8_t* base = (int8_t*)ws;
