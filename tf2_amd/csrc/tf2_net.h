@@ -63,7 +63,7 @@ struct LaunchPlan {
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
-  long bneck_min_blocks = 256;
+  long bneck_min_blocks = 200;
   long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
   long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
