@@ -104,6 +104,10 @@ def main():
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
+    ap.add_argument("--stagger-layer", type=int, default=-1,
+                    help=">= 0: stage-interlocked pipelining of the batches in flight -- step k+1's stream waits (hipStreamWaitEvent) for an "
+                         "event that step k's run records once its layers 0..L are enqueued (tf2_net_run_ex mark_event), so a batch "
+                         "enters the chip-filling first stages when its predecessor has left them; -1: off")
     ap.add_argument("--split", type=int, default=1, help="run every batch as this many sub-batches on concurrent streams (Runner.run_split)")
     ap.add_argument("--spawn-check", action="store_true", help="only launch N ranks, pin, broadcast a small network, report")
     ap.add_argument("--master-port", type=int, default=0)
@@ -163,8 +167,12 @@ def main():
     graphs = {}
     serial = [False]      # True: one batch at a time on the default stream (reported next to the pipelined figure)
 
-    def one(rn, x):
-        return rn.run_split(x, args.split) if args.split > 1 else rn.run_batch(x)
+    def one(rn, x, **kw):
+        return rn.run_split(x, args.split) if args.split > 1 else rn.run_batch(x, **kw)
+
+    stagger = args.stagger_layer >= 0 and n_inflight > 1 and not args.graph and args.split == 1
+    mark_ring = [torch.cuda.Event() for _ in range(2 * n_inflight)] if stagger else []
+    prev_mark = [None]
 
     def step(x):
         if n_inflight > 1 and not serial[0]:
@@ -176,6 +184,12 @@ def main():
                     if key not in graphs:
                         graphs[key] = fl_runners[i].capture(x, split=args.split)
                     graphs[key]()
+                elif stagger:
+                    if prev_mark[0] is not None:
+                        fl_streams[i].wait_event(prev_mark[0])
+                    ev = mark_ring[step_no[0] % len(mark_ring)]
+                    one(fl_runners[i], x, concurrency=1, mark=(ev, args.stagger_layer))
+                    prev_mark[0] = ev
                 else:
                     one(fl_runners[i], x)
             return
@@ -198,6 +212,7 @@ def main():
         for _ in range(warmup):
             step(x)
         barrier()
+        prev_mark[0] = None                 # the timed region starts with an empty pipeline: the first step waits for nobody
         t0 = time.perf_counter()
         for _ in range(steps):
             step(x)
@@ -389,7 +404,8 @@ def main():
                     config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
                                          f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
-                                sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph)),
+                                sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph),
+                                stage_interlock_layer=(args.stagger_layer if stagger else None)),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

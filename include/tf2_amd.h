@@ -94,7 +94,9 @@ tf2_status tf2_net_load_model(tf2_net* net, const float* model, size_t n_floats)
 /* The 4-bit packed model file of TransForm_Kit (Compression/compress_net/4bit_data_format.txt:1-44: per tensor
  * {int8 min_exp, int8 dtype, int16 N,C,H,W}, then 4-bit power-of-two codes in 16-bit words or float32).  The
  * reference documents the format and ships no reader; these are the canonical ones.  _decode: float32 LoadModel
- * stream into `floats` (capacity in floats; pass NULL/0 to get the count only).  _load_model_4bit = decode + LoadModel. */
+ * stream into `floats` (capacity in floats; pass NULL/0 to get the count only).  _load_model_4bit walks the file in place:
+ * every 4-bit code goes straight to the reference's byte code (Get_real of the code's value through a 16-entry table per
+ * (tensor, expand)) -- no float32 copy of the weights is made; bit-identical to decode + LoadModel.                       */
 tf2_status tf2_model4bit_decode(const void* bytes, size_t n_bytes, float* floats, size_t capacity, size_t* n_floats);
 tf2_status tf2_net_load_model_4bit(tf2_net* net, const void* bytes, size_t n_bytes);
 /* Introspection for per-function parity tests: byte codes [N][C][k][k] of a layer
@@ -136,6 +138,39 @@ tf2_status tf2_net_run(tf2_net* net, const float* images_dev, int batch, void* w
 /* Same, from already-quantised int8 images [batch][image_c][image_h][image_w].          */
 tf2_status tf2_net_run_q(tf2_net* net, const int8_t* images_q_dev, int batch, void* workspace_dev,
                          size_t workspace_bytes, int8_t* logits_dev, void* hip_stream);
+/* The same step with per-call options (the reference has one frame loop on one command queue, runner.cpp:140-175; a
+ * GPU server keeps several independent batches in flight on several streams):
+ *  - images_are_q   1: int8 images (tf2_net_run_q), 0: float32.
+ *  - concurrency    how the launch plan picks its tile shapes: 0 = this batch runs alone on the GPU, 1 = other batches are
+ *                   in flight on other streams (their kernels fill the chip: wider tiles, unfused pairs), -1 = decide from
+ *                   the streams of the last eight calls on this handle (what tf2_net_run does).  Results are bit-identical
+ *                   whichever is chosen.
+ *  - mark_event / mark_after_layer   a hipEvent_t recorded on hip_stream once every launch of layers 0..mark_after_layer
+ *                   has been enqueued (ignored when mark_event is NULL).  A caller that pipelines batches lets the next
+ *                   batch's stream wait for it (hipStreamWaitEvent), so that batch k+1 enters the chip-filling first
+ *                   stage when batch k has left it instead of competing with it; bench.py does.
+ * Threading: a handle may be used from several host threads, one stream per thread; the calls serialise on an internal
+ * mutex while they look up / build the launch plan and enqueue (kernel execution is asynchronous as always).  Everything
+ * else on a handle (create / set_q / load / pack / bind / reload_options / profile / destroy) must not run concurrently
+ * with a run on the same handle.  tf2_last_error is per thread.                                                          */
+typedef struct tf2_run_opts {
+  uint32_t size;              /* sizeof(tf2_run_opts), for forward compatibility */
+  int32_t images_are_q;
+  int32_t concurrency;
+  int32_t mark_after_layer;
+  void* mark_event;
+} tf2_run_opts;
+tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void* workspace_dev, size_t workspace_bytes,
+                          int8_t* logits_dev, void* hip_stream, const tf2_run_opts* opts);
+/* Introspection: the kernel launches one step of `batch` images consists of, in issue order, as the library's own launch
+ * plan selects them (concurrency as in tf2_run_opts: 0 or 1).  Needs a packed image, no device.  rows[i].layer = the table
+ * row the launch belongs to (-1: input preparation; a fused launch carries its first row).  Returns the number of launches
+ * in *n (also when capacity is too small: TF2_ERR_SIZE).  tools/pmc_summary.py attaches rocprofv3 rows to layers with it. */
+typedef struct tf2_launch_info {
+  int32_t layer, grid, block, lds_bytes, vgprs;
+  char kernel[96];
+} tf2_launch_info;
+tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, tf2_launch_info* rows, int capacity, int* n);
 /* After a keep_all run: copy layer `layer`'s output to the host as dense NCHW int8
  * [batch][N][PH][PW] (or [batch][N] after an end pool).  layer == -1: the quantised,
  * transformed network input [batch][C0][H0][W0].  Synchronises the stream.

@@ -170,3 +170,43 @@ def test_resnet50_batch_sizes_and_tile_choices(r50, monkeypatch, conc):
                 np.testing.assert_array_equal(got[i], rows[i], err_msg=f"batch {b}, image {i}")
             else:
                 rows[i] = got[i].copy()
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_four_batches_in_flight_as_bench_times_them(r50, graph):
+    """The configuration bench.py's headline is timed in, checked as executed: ONE Net, four Runners (own workspaces) on four
+    HIP streams (GPU_MAX_HW_QUEUES=8 from conftest), the library's stream-history heuristic left on auto, eight different
+    batch-32 inputs issued round-robin for 16 steps with no synchronisation in between -- launched, and replayed from captured
+    HIP graphs.  Every logits row of the last four steps: three rows per batch against the oracle, all 32 against a serial
+    run_batch of the same input (feature_writer.cl:88-151 is the output contract of each step)."""
+    torch = _torch()
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "8"
+    rig = Rig(*r50, 0)
+    n_fl, n_in, n_steps = 4, 8, 16
+    xs = [synth.synth_images(rig.t, 32, 300 + i) for i in range(n_in)]
+    xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
+    serial = [rig.run(x, keep_all=False).copy() for x in xs]          # one stream, one batch at a time
+    for i in range(n_in - n_fl, n_in):
+        np.testing.assert_array_equal(serial[i][:3], rig.ref.logits(rig.ref.run(xs[i][:3])), err_msg=f"serial run, input {i}")
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_fl)]
+    runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
+    bufs = [xd[i].clone() for i in range(n_fl)]                        # static input buffers of the captured graphs
+    for st, rn, b in zip(streams, runners, bufs):                      # bench.py timed(): set-up call per stream
+        with torch.cuda.stream(st):
+            rn.run_batch(b)
+    torch.cuda.synchronize()
+    replays = [None] * n_fl
+    for k in range(n_steps):                                           # no synchronisation inside this loop
+        i = k % n_fl
+        with torch.cuda.stream(streams[i]):
+            if graph:
+                if replays[i] is None:
+                    replays[i] = runners[i].capture(bufs[i])
+                bufs[i].copy_(xd[k % n_in], non_blocking=True)
+                replays[i]()
+            else:
+                runners[i].run_batch(xd[k % n_in])
+    torch.cuda.synchronize()
+    for k in range(n_steps - n_fl, n_steps):
+        got = runners[k % n_fl]._logits.cpu().numpy()
+        np.testing.assert_array_equal(got, serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl} (graph={graph})")

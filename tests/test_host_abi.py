@@ -143,3 +143,45 @@ def test_logits_size_and_third_party_table_checks():
     assert st == 0
     # options are re-read on request (kernel A/B switches for tests and tools); harmless on the CPU
     assert lib.tf2_net_reload_options(net._h) == 0
+
+
+def test_describe_launches_is_the_librarys_own_selection(golden_dir):
+    """tf2_net_describe_launches: the launch list of a step as Net::launch_plan and the launchers select it -- what
+    tools/pmc_summary.py uses to attach rocprofv3 rows to layers.  No device needed."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
+    one = net.describe_launches(32, 0)
+    many = net.describe_launches(32, 1)
+    assert one[0]["layer"] == -1 and "prep" in one[0]["kernel"]
+    assert one[1]["layer"] == 0 and "conv_stem" in one[1]["kernel"] and one[2]["kernel"] == "maxpool_kernel"
+    assert [r["layer"] for r in one] == sorted(r["layer"] for r in one)
+    # fused pairs (conv_bneck) carry their first row; with batches in flight the 128-channel pairs run unfused
+    fused_one = {r["layer"] for r in one if "conv_bneck" in r["kernel"]}
+    fused_many = {r["layer"] for r in many if "conv_bneck" in r["kernel"]}
+    assert fused_one == {3, 6, 9, 16, 19, 22} and fused_many == {3, 6, 9}
+    assert len(many) == len(one) + 3
+    # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation
+    ring = [r for r in one if "conv_mfma" in r["kernel"]]
+    assert ring and all(r["kernel"].endswith("dense>") for r in ring)
+    assert all(0 < r["grid"] and r["block"] in (256, 512) and 0 <= r["lds_bytes"] <= 160 * 1024 for r in one)
+    # batch 1: small grids, the split-K kernel on the 64-row layers
+    assert any("conv_mfma_sk" in r["kernel"] for r in net.describe_launches(1, 0))
+    with pytest.raises(_lib.Tf2Error):
+        net.describe_launches(0, 0)
+
+
+def test_run_ex_rejects_bad_options_without_touching_the_device():
+    t = cfg.tiny_tables()
+    q = synth.synth_q_values(t, 0)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
+    L = _lib.lib()
+    buf = (C.c_char * 64)()
+    assert C.sizeof(_lib.RunOpts) == 24
+    for o in (_lib.RunOpts(8, 0, -1, -1, None),                      # older / truncated struct
+              _lib.RunOpts(24, 0, 2, -1, None),                      # concurrency out of range
+              _lib.RunOpts(24, 0, 0, 999, C.cast(buf, C.c_void_p))):  # mark layer outside the table
+        assert L.tf2_net_run_ex(net._h, buf, 1, buf, 64, buf, None, C.byref(o)) == -1, L.tf2_last_error()
+    assert L.tf2_net_run_ex(net._h, buf, 1, buf, 64, buf, None, None) == -1

@@ -11,7 +11,13 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtf2amd.so")
+# One hardware queue per in-flight stream: the HIP runtime multiplexes streams onto 4 hardware queues by default (one of them the
+# null stream's), so a fourth in-flight batch would queue behind another (-15 %, profiles/r02_inflight_hwqueues.txt).  The runtime
+# reads the variable when it initialises, i.e. it only takes effect if tf2_amd is imported before the first HIP call of the
+# process; a deployment that embeds the C library directly exports it itself (INTEGRATION.md "Deployment preconditions").
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# TF2_AMD_LIB: another build of the same sources (tools/probe_run.py loads the -DTF2_PROBES library); never a fallback
+LIB_PATH = os.environ.get("TF2_AMD_LIB") or os.path.join(_HERE, "libtf2amd.so")
 
 
 class Tf2Error(RuntimeError):
@@ -25,6 +31,18 @@ class LayerDesc(C.Structure):
         "src", "q_in_row", "C", "H", "W", "N", "k", "stride", "pad_h", "pad_w", "dil", "OH", "OW",
         "bias_en", "bn_en", "relu", "ipool", "pool_en", "pool_S", "pool_st", "pool_pad", "PH", "PW",
         "add_src", "add_relu", "endpool", "endpool_mult", "concat", "n_start", "model_C", "model_k")]
+
+
+class RunOpts(C.Structure):
+    """tf2_run_opts (include/tf2_amd.h)."""
+    _fields_ = [("size", C.c_uint32), ("images_are_q", C.c_int32), ("concurrency", C.c_int32), ("mark_after_layer", C.c_int32),
+                ("mark_event", C.c_void_p)]
+
+
+class LaunchInfo(C.Structure):
+    """tf2_launch_info (include/tf2_amd.h)."""
+    _fields_ = [("layer", C.c_int32), ("grid", C.c_int32), ("block", C.c_int32), ("lds_bytes", C.c_int32), ("vgprs", C.c_int32),
+                ("kernel", C.c_char * 96)]
 
 
 class NetDesc(C.Structure):
@@ -85,6 +103,8 @@ def lib() -> C.CDLL:
     L.tf2_net_reload_options.argtypes = [vp]
     L.tf2_net_run.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
+    L.tf2_net_run_ex.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp, C.POINTER(RunOpts)]
+    L.tf2_net_describe_launches.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LaunchInfo), C.c_int, C.POINTER(C.c_int)]
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
     L.tf2_net_profile.argtypes = [vp, C.c_int]
     L.tf2_net_profile_read.argtypes = [vp, vp, vp, vp, C.c_int]
@@ -99,7 +119,7 @@ EXPORTED = [
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
-    "tf2_net_run_q", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
+    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_describe_launches", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
 def check(status: int) -> None:

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 #include "tf2_net.h"
+#include "tf2_device.h"
 
 using namespace tf2;
 
@@ -168,6 +169,35 @@ tf2_status tf2_net_run_q(tf2_net* net, const int8_t* images_q_dev, int batch, vo
   CHECK_NET(net);
   if (!images_q_dev || !ws) { set_error("tf2_net_run_q: null device pointer"); return TF2_ERR_ARG; }
   return net->impl.run(images_q_dev, true, batch, ws, ws_bytes, logits_dev, hip_stream);
+}
+
+tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void* ws, size_t ws_bytes, int8_t* logits_dev,
+                          void* hip_stream, const tf2_run_opts* o) {
+  CHECK_NET(net);
+  if (!images_dev || !ws) { set_error("tf2_net_run_ex: null device pointer"); return TF2_ERR_ARG; }
+  if (!o || o->size < sizeof(tf2_run_opts)) { set_error("tf2_net_run_ex: opts missing or older than this library's tf2_run_opts"); return TF2_ERR_ARG; }
+  if (o->concurrency < -1 || o->concurrency > 1) { set_error("tf2_net_run_ex: concurrency must be -1, 0 or 1"); return TF2_ERR_ARG; }
+  if (o->mark_event && (o->mark_after_layer < 0 || o->mark_after_layer >= net->impl.nd.n_layers)) {
+    set_error("tf2_net_run_ex: mark_after_layer outside the layer table"); return TF2_ERR_ARG;
+  }
+  return net->impl.run(images_dev, o->images_are_q != 0, batch, ws, ws_bytes, logits_dev, hip_stream, o->concurrency, o->mark_event, o->mark_after_layer);
+}
+
+tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, tf2_launch_info* rows, int capacity, int* n) {
+  CHECK_NET(net);
+  if (!n || (capacity > 0 && !rows)) { set_error("tf2_net_describe_launches: null argument"); return TF2_ERR_ARG; }
+  std::vector<std::pair<int, LaunchRecord>> v;
+  tf2_status st = net->impl.describe_launches(batch, concurrency != 0, &v);
+  if (st != TF2_OK) return st;
+  *n = (int)v.size();
+  if ((int)v.size() > capacity) { set_error("tf2_net_describe_launches: " + std::to_string(v.size()) + " launches, capacity " + std::to_string(capacity)); return TF2_ERR_SIZE; }
+  for (size_t i = 0; i < v.size(); i++) {
+    tf2_launch_info& r = rows[i];
+    r.layer = v[i].first; r.grid = (int32_t)v[i].second.grid; r.block = (int32_t)v[i].second.block;
+    r.lds_bytes = (int32_t)v[i].second.lds; r.vgprs = v[i].second.vgprs;
+    std::memcpy(r.kernel, v[i].second.kernel, sizeof r.kernel);
+  }
+  return TF2_OK;
 }
 
 tf2_status tf2_net_read_layer(tf2_net* net, int layer, int batch, const void* ws, int8_t* host_dst,

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   constexpr int NE1 = 9 * NSL;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
 
+  TF2_PROBE_WORD(a.probe);           // timing probes (tf2_device.h; constant 0 in the product build)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     constexpr int win = v / NE1, e = v % NE1, t = e / NSL, s = e % NSL;
     Afr& cur = (v & 1) ? f1 : f0;
     Afr& nxt = (v & 1) ? f0 : f1;
-    if (v + 1 < NW1 * NE1) load_a1(nxt, v + 1);
+    if (v + 1 < NW1 * NE1 && !(prb & kProbeNoA)) load_a1(nxt, v + 1);
     if (win == 1 && e == 0) window_shift(prm1 + kPrmWordsPerRow * TM);
     const int8_t* B = mid1 + s * slabb;
     int ba[NTN];
@@ -193,7 +194,10 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
       for (int j = 0; j < NTN; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (ba[j] ^ (ks << 5)));
 #pragma unroll
-      for (int j = 0; j < NTN; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NTN; j++) {
+        if (prb & kProbeNoMfma) { asm volatile("" :: "v"(cur.k[ks]), "v"(bf[j])); continue; }
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);                   // steps stay in order: the unrolled loop must not pile up loads
   };
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     constexpr int mt = u / NV2, v = u % NV2, win = v / NSL, s = v % NSL;
     Afr& cur = (u & 1) ? g1 : g0;
     Afr& nxt = (u & 1) ? g0 : g1;
-    if (u + 1 < kBneckPasses * NV2) load_a2(nxt, (u + 1) / NV2, (u + 1) % NV2);
+    if (u + 1 < kBneckPasses * NV2 && !(prb & kProbeNoA)) load_a2(nxt, (u + 1) / NV2, (u + 1) % NV2);
     if (v == 0 && mt + 1 < kBneckPasses) { if (mt & 1) load_res(res0, mt + 1); else load_res(res1, mt + 1); }
     if (win == 1 && s == 0) window_shift(reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(prm2) + (size_t)mt * a.hdr2_used) + kPrmWordsPerRow * TM);
     const int8_t* B = mid2 + s * (TN * 64);
@@ -260,9 +264,12 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
       for (int j = 0; j < NTN; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm[j] ^ (ks << 5)));
 #pragma unroll
-      for (int j = 0; j < NTN; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NTN; j++) {
+        if (prb & kProbeNoMfma) { asm volatile("" :: "v"(cur.k[ks]), "v"(bf[j])); continue; }
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
+      }
     }
-    if (v == NV2 - 1) {
+    if (v == NV2 - 1 && !(prb & kProbeNoEpi)) {
       int* const pm = reinterpret_cast<int*>(reinterpret_cast<int8_t*>(prm2) + (size_t)mt * a.hdr2_used);
       const int chl = mt * TM + wm * 32 + 16 * half;
       i32x4 (&rv)[NTN] = (mt & 1) ? res1 : res0;
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
           for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
           const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j]);
           const int p = wn * WTN + j * 32 + (lane & 31);
+          if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
           if (p < n_px && chl + 16 <= a.y_nvalid)
             *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
         }
@@ -304,11 +312,12 @@ static int launch_bneck_shape(const BneckArgs& a, hipStream_t s) {
   if (lds > 160 * 1024 || a.R * a.W > TN) return 1;
   const int grid = a.B * a.tiles_per_img;
 #define TF2_BN(D1, D2) do { auto fn = conv_bneck_kernel<WM, WN, NTN, D1, D2>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
-                           hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a); } while (0)
+                           TF2_LAUNCH_NAME("conv_bneck_kernel<TM%d,TN%d,%s,%s>", TM, TN, D1 ? "dual" : "single", D2 ? "dual" : "single"); \
+                           TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, a); } while (0)
   if (a.dual1) { if (a.dual2) TF2_BN(true, true); else TF2_BN(true, false); }
   else { if (a.dual2) TF2_BN(false, true); else TF2_BN(false, false); }
 #undef TF2_BN
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return launch_ok() ? 0 : -1;
 }
 
 // TM = channels of the 3x3, TN = pixel capacity of a block (a.R * a.W <= TN).  Instantiated: 64 x 256 and 128 x 128 (wave

@@ -68,7 +68,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // its per-wave instruction count: many light waves (32x32 or 32x64 tiles) beat four waves with 64x64 tiles.
 // DUAL: two-phase layers packed with both exponent windows per entry (weight_pack.cpp): [hi TM rows][lo TM rows] of
 // weights and ONE activation slab per K step, two accumulators, combined once as (hi << dshift[1]) + lo.
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
+// DENSE (ConvArgs::dense): the gather words of a step come from its index (tf2_device.h dense_gather) instead of the header's
+// goff / ghw tables and the m-tile's entry range is mtile * nslab .. + nslab: nothing in front of the first DMAs but the
+// kernel arguments (one dependent scalar-load round trip and the LDS table reads of every step less).
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
@@ -91,6 +94,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   int* const prm = reinterpret_cast<int*>(lds + S * STAGE);
 
   TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
+  TF2_PROBE_WORD(g.flags);           // prb: timing probes (tools/probe_run.py, -DTF2_PROBES builds only; constant 0 in the product)
+  if (prb & kProbeExit0) return;
   long long* const adbg = a.dbg; long long* const adbg2 = a.dbg2;
   asm volatile("" :: "s"(adbg), "s"(adbg2));
   const int tid = threadIdx.x;
@@ -134,21 +139,36 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   cvec_p const hg = (cvec_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent);
   // this m-tile's {first, end} entry: the last two words of steps[] (weight_pack.cpp), same scalar round trip
   typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
-  const auto ee = *(cvec2_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
-  const int e_begin = ee[0];
-  const int n_ent = ee[1] - ee[0];
+  int e_begin, n_ent;
   int pro_off[S - 1], pro_hw[S - 1];
+  const DenseGeom dg = {a_cslabs, a_cs_m, a_cs_s, a_k, a_kk_m, a_kk_s, a_dil, g.W, g.Cp_in};
+  const int lane_c16 = chunk * 16;
+  auto gather_of = [&](int sl, int& off, int& hw) {      // DENSE: this lane's gather words of slab sl
+    int o, h;
+    dense_gather(dg, sl, o, h);
+    off = o + lane_c16; hw = h + (lane_c16 << 16);
+  };
+  if (DENSE) {
+    n_ent = a_nslab; e_begin = mtile * n_ent;
 #pragma unroll
-  for (int s = 0; s < S - 1; s++) {
-    const i32x4 o = hg[s];                               // s_load_dwordx4, unconditional
-    pro_off[s] = chunk == 0 ? o[0] : chunk == 1 ? o[1] : chunk == 2 ? o[2] : o[3];
-    pro_hw[s] = 0;
-    if (PADCHK) {
-      const i32x4 h = hg[a_max_ent + s];
-      pro_hw[s] = chunk == 0 ? h[0] : chunk == 1 ? h[1] : chunk == 2 ? h[2] : h[3];
+    for (int s = 0; s < S - 1; s++) gather_of(s, pro_off[s], pro_hw[s]);
+  } else {
+    const auto ee = *(cvec2_p)(unsigned long long)(ahdr + hdr_words + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
+    e_begin = ee[0];
+    n_ent = ee[1] - ee[0];
+#pragma unroll
+    for (int s = 0; s < S - 1; s++) {
+      const i32x4 o = hg[s];                               // s_load_dwordx4, unconditional
+      pro_off[s] = chunk == 0 ? o[0] : chunk == 1 ? o[1] : chunk == 2 ? o[2] : o[3];
+      pro_hw[s] = 0;
+      if (PADCHK) {
+        const i32x4 h = hg[a_max_ent + s];
+        pro_hw[s] = chunk == 0 ? h[0] : chunk == 1 ? h[1] : chunk == 2 ? h[2] : h[3];
+      }
     }
   }
   TF2_STAMP(1);
+  if (prb & kProbeExit1) { if (pro_off[0] == 0x7eadbeef) ay[0] = 1; return; }
 
   // residual tile prefetch FIRST (ordinary loads, the oldest entries of this wave's VMEM queue: every counted
   // wait below covers them; first use is in the epilogue)
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   }
 
   // one stage = entry e (weights) + this lane's gather words off/hw (activations) into ring slot slot_idx
-  auto issue_stage = [&](int e, int off, int hw, int slot_idx) {
+  auto issue_stage = [&](int e, int off, int hw, int slot_idx, bool in_loop = false) {
     int8_t* const slot = lds + slot_idx * STAGE;
     const int8_t* wsrc = aw + (size_t)e * A_BYTES + a_lane_off;
     int dh = 0, dw = 0, pc = 0;              // pc: the segment's channel offset = its place in the layer's pad row
@@ -202,10 +222,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     for (int j = 0; j < NI_HI; j++) {
       const int gi = wave + NW * j;
       if (STATIC_GRP ? j < NA : gi < AG) {
+        if (!((prb & kProbeNoA) && in_loop))
         __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + gi * 1024), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
-      } else if (j < NI_LO || ni_hi) {
+      } else if ((j < NI_LO || ni_hi) && !((prb & kProbeNoB) && in_loop)) {
         bool ok = off >= 0 && brow_ok[j];
-        if (PADCHK) {
+        if (PADCHK && !(prb & kProbeNoPad)) {
           const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
           ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         }
@@ -266,13 +287,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   int cslot = 0;                           // ring slot of the stage being computed
   int islot = S - 1;                       // ring slot the next issued stage goes to
   // gather words of the next stage to issue, read one iteration ahead (tables are padded by S entries)
-  int off_nx = goff[(S - 1) * 4 + chunk];
-  int hw_nx = PADCHK ? ghw[(S - 1) * 4 + chunk] : 0;
+  int off_nx, hw_nx = 0;
+  if (DENSE) gather_of(S - 1, off_nx, hw_nx);
+  else { off_nx = goff[(S - 1) * 4 + chunk]; if (PADCHK) hw_nx = ghw[(S - 1) * 4 + chunk]; }
   // iteration at which the next Horner phase starts (steps[] holds the P-1 boundaries, then INT_MAX)
-  int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
+  int next_b = DENSE ? 0x7fffffff : __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int it, bool issue) {
-    if (!DUAL)
+    if (!DUAL && !DENSE)
       while (it == next_b) {               // rare: phase boundary
         phase++; phase_shift(phase);
         next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
@@ -281,10 +303,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     const int8_t* B = A + A_BYTES;
     auto issue_next = [&]() {
       if (issue) {
-        issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot);
+        issue_stage(e_begin + it + S - 1, off_nx, hw_nx, islot, true);
         islot = islot + 1 == S ? 0 : islot + 1;
-        off_nx = goff[(it + S) * 4 + chunk];
-        if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk];
+        if (DENSE) gather_of(it + S, off_nx, hw_nx);
+        else { off_nx = goff[(it + S) * 4 + chunk]; if (PADCHK) hw_nx = ghw[(it + S) * 4 + chunk]; }
       }
     };
     if (DUAL) {
@@ -310,6 +332,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         for (int i = 0; i < NTM; i++)
 #pragma unroll
           for (int j = 0; j < NTN; j++) {
+            if (prb & kProbeNoMfma) { asm volatile("" :: "v"(af[i]), "v"(af2[i]), "v"(bf[j])); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
             acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af2[i], bf[j], acc2[i][j], 0, 0, 0);
           }
@@ -336,8 +359,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #pragma unroll
         for (int i = 0; i < NTM; i++)
 #pragma unroll
-          for (int j = 0; j < NTN; j++)
+          for (int j = 0; j < NTN; j++) {
+            if (prb & kProbeNoMfma) { asm volatile("" :: "v"(af[ks][i]), "v"(bf[ks][j])); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+          }
     }
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
@@ -349,6 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
       const long long c0 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
       wait_main();
       const long long c1 = dbg_on ? (long long)__builtin_readcyclecounter() : 0;
+      if (!(prb & kProbeNoBar))
       __builtin_amdgcn_s_barrier();          // every wave's part of stage `it` landed; slot (it-1)%S is free
       asm volatile("" ::: "memory");         // compile-time fence: no LDS access may be hoisted above the barrier
       if (dbg_on) { const long long c2 = (long long)__builtin_readcyclecounter(); t_wait += c1 - c0; t_bar += c2 - c1; }
@@ -381,11 +407,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
             acc[i][j][G * 4 + r] = (int)(((unsigned)acc[i][j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[i][j][G * 4 + r]);
       }
     }
-  } else {
+  } else if (!DENSE) {
     while (phase + 1 < P) { phase++; phase_shift(phase); }      // phases that start after the last entry
   }
   TF2_STAMP(5);
 
+  if (prb & kProbeNoEpi) return;
   // ---- epilogue --------------------------------------------------------------------------------
   // per output: v = bias + (sum << lo);  x = low32((v*alpha + (beta << 20)) >> 20)   (pe.cl:191-193, the
   // 32-bit truncation and wrap-around of the reference kept);  y = sat(x + 2^14) >> 15, which equals
@@ -427,17 +454,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
-static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
+static int launch_cfg3(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
-  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("conv_mfma2_kernel<%dx%d waves of %dx%d,S%d,%s%s%s>", WM, WN, WTM, WTN, S, PADCHK ? "pad," : "", DUAL ? "dual," : "", DENSE ? "dense" : "tables");
+  TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL>
+static int launch_cfg2(const ConvArgs& a, hipStream_t s) {
+  return a.dense ? launch_cfg3<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, true>(a, s) : launch_cfg3<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, false>(a, s);
 }
 
 template <int WM, int WN, int WTM, int WTN, int S, int OCC>

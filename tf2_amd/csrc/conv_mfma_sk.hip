@@ -40,7 +40,9 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 
 // NWV = 4 or 8 waves split the slab list; with 8 the grid of a 7x7 / 14x14 layer at batch 32 (56..392 blocks) puts
 // twice as many waves on the chip and every wave walks half as many K steps; waves 0-3 run the epilogue.
-template <int S, bool PADCHK, bool DUAL, int NWV>
+// DENSE (ConvArgs::dense, see conv_mfma2.hip): gather words from the slab index, entry range from the kernel arguments -- the
+// activation DMAs of the first stages go out together with the weight DMAs instead of behind the header's landing.
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
@@ -52,6 +54,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   int* const prm = reinterpret_cast<int*>(lds + RING_ALL);
 
   TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
+  TF2_PROBE_WORD(g.flags);
+  if (prb & kProbeExit0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,9 +76,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   const int px0 = ntile * TN;
   // this m-tile's {first, end} entry: the last two words of steps[] in its header image (weight_pack.cpp)
   typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
-  const auto ee = *(cvec2_p)(unsigned long long)(ahdr + (size_t)mtile * (size_t)(a_hdr_bytes >> 2) + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
-  const int e_begin = ee[0];
-  const int n_ent = ee[1] - ee[0];
+  int e_begin, n_ent;
+  if (DENSE) { n_ent = a_nslab; e_begin = mtile * n_ent; }
+  else {
+    const auto ee = *(cvec2_p)(unsigned long long)(ahdr + (size_t)mtile * (size_t)(a_hdr_bytes >> 2) + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
+    e_begin = ee[0];
+    n_ent = ee[1] - ee[0];
+  }
+  if (prb & kProbeExit1) { if (n_ent == 0x7eadbeef) ay[0] = 1; return; }
   const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
   const int n_mine = n_virt > wave ? (n_virt - wave + NWV - 1) / NWV : 0;     // (virtual) entries wave, wave+NWV, ...
   // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
@@ -82,12 +91,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // see conv_mfma2.hip
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;
+  const DenseGeom dg = {a_cslabs, a_cs_m, a_cs_s, a_k, a_kk_m, a_kk_s, a_dil, g.W, g.Cp_in};
+  const int lane_c16 = chunk * 16;
+  auto gather_of = [&](int sl, int& off, int& hw) {             // DENSE: this lane's gather words of slab sl (entry index == slab)
+    int o, h;
+    dense_gather(dg, sl, o, h);
+    off = o + lane_c16; hw = h + (lane_c16 << 16);
+  };
 
   auto issue_A = [&](int k, int slot_idx) {                     // k-th entry of this wave
     int8_t* const slot = ring + slot_idx * STAGE;
     const int8_t* wsrc = aw + (size_t)(e_begin + ent_of(k)) * ((DUAL ? 2 : 1) * A_BYTES) + (DUAL ? (wave & 1) * A_BYTES : 0) + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++)
+      if (!(prb & kProbeNoA) || k < S - 1)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + j * 1024), TF2_LDS_PTR(slot + j * 1024), 16, 0, 0);
   };
 
@@ -144,18 +161,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
 
-  if (g.has_res && wave < 4) sk_wait_vmcnt<1>(); else sk_wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();            // header complete (all four waves' parts)
-  asm volatile("" ::: "memory");
+  if (!DENSE) {
+    if (g.has_res && wave < 4) sk_wait_vmcnt<1>(); else sk_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();            // header complete (all four waves' parts): the gather tables are read from it
+    asm volatile("" ::: "memory");
+  }
 
-  auto issue_B = [&](int off, int hw, int slot_idx) {
+  auto issue_B = [&](int off, int hw, int slot_idx, bool in_loop = false) {
     int8_t* const slot = ring + slot_idx * STAGE + A_BYTES;
     int dh = 0, dw = 0, pc = 0;              // pc: the segment's channel offset = its place in the layer's pad row
     if (PADCHK) { dh = hw & 0xff; dw = (hw >> 8) & 0xff; pc = (int)((unsigned)hw >> 16); }
 #pragma unroll
     for (int j = 0; j < BI; j++) {
+      if ((prb & kProbeNoB) && in_loop) continue;
       bool ok = off >= 0 && brow_ok[j];
-      if (PADCHK) {
+      if (PADCHK && !(prb & kProbeNoPad)) {
         const int ih = brow_h[j] + dh, iw = brow_w[j] + dw;
         ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
       }
@@ -186,18 +206,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   for (int s = 0; s < S - 1; s++)
     if (s < n_mine) {
       const int e = ent_of(s);
-      issue_B(goff[e * 4 + chunk], PADCHK ? ghw[e * 4 + chunk] : 0, s);
+      int o, h = 0;
+      if (DENSE) gather_of(e, o, h); else { o = goff[e * 4 + chunk]; if (PADCHK) h = ghw[e * 4 + chunk]; }
+      issue_B(o, h, s);
     }
   int phase = 0;
   int cslot = 0, islot = S - 1;
   const int n_main = n_mine - (S - 1);
-  int off_nx = goff[ent_of(S - 1) * 4 + chunk];
-  int hw_nx = PADCHK ? ghw[ent_of(S - 1) * 4 + chunk] : 0;
-  int next_b = __builtin_amdgcn_readfirstlane(steps[0]);
+  int off_nx, hw_nx = 0;
+  if (DENSE) gather_of(ent_of(S - 1), off_nx, hw_nx);
+  else { off_nx = goff[ent_of(S - 1) * 4 + chunk]; if (PADCHK) hw_nx = ghw[ent_of(S - 1) * 4 + chunk]; }
+  int next_b = DENSE ? 0x7fffffff : __builtin_amdgcn_readfirstlane(steps[0]);
 
   auto body = [&](int k, bool issue) {
     const int e = wave + NWV * k;          // index in the m-tile's entry list
-    if (!DUAL)
+    if (!DUAL && !DENSE)
       while (e >= next_b) {                // this wave has crossed into the next phase(s)
         phase++; phase_shift(phase);
         next_b = __builtin_amdgcn_readfirstlane(steps[phase]);
@@ -217,18 +240,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     }
     if (issue) {
       issue_A(k + S - 1, islot);
-      issue_B(off_nx, hw_nx, islot);
+      issue_B(off_nx, hw_nx, islot, true);
       islot = islot + 1 == S ? 0 : islot + 1;
-      off_nx = goff[ent_of(k + S) * 4 + chunk];
-      if (PADCHK) hw_nx = ghw[ent_of(k + S) * 4 + chunk];
+      if (DENSE) gather_of(ent_of(k + S), off_nx, hw_nx);
+      else { off_nx = goff[ent_of(k + S) * 4 + chunk]; if (PADCHK) hw_nx = ghw[ent_of(k + S) * 4 + chunk]; }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 2; j++) {
+          if (prb & kProbeNoMfma) { asm volatile("" :: "v"(af[ks][i]), "v"(bf[ks][j])); continue; }
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+        }
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
 
@@ -244,8 +269,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     asm volatile("" ::: "memory");
     body(k, false);
   }
-  if (!DUAL) while (phase + 1 < P) { phase++; phase_shift(phase); }
+  if (!DUAL && !DENSE) while (phase + 1 < P) { phase++; phase_shift(phase); }
 
+  if (prb & kProbeNoEpi) return;
   // ---- reduce the four partial tiles through LDS (the rings are dead now) ---------------------
   sk_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -310,16 +336,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   }
 }
 
-template <int S, bool PADCHK, bool DUAL, int NWV>
-static int launch_sk2(const ConvArgs& a, hipStream_t s) {
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
+static int launch_sk3(const ConvArgs& a, hipStream_t s) {
   constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV>;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV, DENSE>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + 63) / 64;
-  hipLaunchKernelGGL(fn, dim3(ntiles * a.n_mtiles), dim3(NWV * 64), lds, s, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("conv_mfma_sk_kernel<S%d,%s%s%d waves,%s>", S, PADCHK ? "pad," : "", DUAL ? "dual," : "", NWV, DENSE ? "dense" : "tables");
+  TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles), dim3(NWV * 64), lds, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
+template <int S, bool PADCHK, bool DUAL, int NWV>
+static int launch_sk2(const ConvArgs& a, hipStream_t s) {
+  return a.dense ? launch_sk3<S, PADCHK, DUAL, NWV, true>(a, s) : launch_sk3<S, PADCHK, DUAL, NWV, false>(a, s);
 }
 
 // For 64-row packed layers with a long slab list and a grid that would not fill the chip.
@@ -331,15 +363,18 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
   const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);
   const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
+  // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU); TF2_AMD_SK_S3 overrides
+  static const long s3_blocks_env = getenv("TF2_AMD_SK_S3") ? atol(getenv("TF2_AMD_SK_S3")) : -1;
+  const long s3_blocks = s3_blocks_env >= 0 ? s3_blocks_env : 256;
   if (w8) {
     if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
     return pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);
   }
   if (a.dual) {
-    if (blocks <= 256) return pad ? launch_sk2<3, true, true, 4>(a, s) : launch_sk2<3, false, true, 4>(a, s);
+    if (blocks <= s3_blocks) return pad ? launch_sk2<3, true, true, 4>(a, s) : launch_sk2<3, false, true, 4>(a, s);
     return pad ? launch_sk2<2, true, true, 4>(a, s) : launch_sk2<2, false, true, 4>(a, s);
   }
-  if (blocks <= 256) return pad ? launch_sk2<3, true, false, 4>(a, s) : launch_sk2<3, false, false, 4>(a, s);
+  if (blocks <= s3_blocks) return pad ? launch_sk2<3, true, false, 4>(a, s) : launch_sk2<3, false, false, 4>(a, s);
   return pad ? launch_sk2<2, true, false, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
 }
 

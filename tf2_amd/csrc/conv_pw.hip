@@ -41,6 +41,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
 
   TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
   (void)a_max_ent; (void)P; (void)mt_m; (void)mt_s;
+  TF2_PROBE_WORD(g.flags);           // timing probes (tf2_device.h; constant 0 in the product build)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     for (int s = 0; s < NSLAB; s++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
+        if (prb & kProbeNoMfma) { asm volatile("" :: "v"(T.bf[s][ks])); continue; }
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s][0][ks], T.bf[s][ks], acc, 0, 0, 0);
         if (DUAL) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s][1][ks], T.bf[s][ks], acc2, 0, 0, 0);
       }
@@ -125,11 +127,14 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     }
     i32x4 out;
     const int row0 = wr * 32 + 4 * half;
+    if (prb & kProbeNoEpi) out = i32x4{a16[0] + a16[4], a16[1] + a16[5], a16[2] + a16[6] + a16[8] + a16[12], a16[3] + a16[7] + T.res[0]};
+    else
     if (g.fast) out = g.has_res ? requant_tile16<true, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res)
                                 : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
     else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res)
                          : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
     const int px = t * 32 + (lane & 31);
+    if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); return; }
     if (px <= last_px && ch_ok)
       *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
   };
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     for (int j = 0; j < D; j++) {
       if (more) {
         const int tn = t + (D - 1) * NPW;
-        load_tile(tn < t_end ? tn : t_last, T[(j + D - 1) % D]);
+        if (!(prb & kProbeNoB)) load_tile(tn < t_end ? tn : t_last, T[(j + D - 1) % D]);
         compute_tile(t, T[j]);
         t += NPW;
         more = t < t_end;
@@ -178,8 +183,9 @@ static int launch_pw2(const ConvArgs& a, hipStream_t s) {
   const int chunks = 8 * k;
   int tpc = (n_t32 + chunks - 1) / chunks;
   tpc = (tpc + NPW - 1) / NPW * NPW;               // equal work for the pixel streams of a block
-  hipLaunchKernelGGL(fn, dim3(8 * M * k), dim3(512), lds, s, a, n_t32, tpc);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("conv_pw_kernel<TM%d,%d slabs,%s>", TM, NSLAB, DUAL ? "dual" : "single");
+  TF2_LAUNCH(fn, dim3(8 * M * k), dim3(512), lds, s, a, n_t32, tpc);
+  return launch_ok() ? 0 : -1;
 }
 
 // Does the layer qualify?  `dense` = every m-tile's entry list is exactly slabs 0..nslab-1 (checked by the caller on

@@ -199,7 +199,7 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, 
   const size_t lds = conv_shift_lds_bytes(taps, signed_in, packed4);
   if (lds > 160 * 1024) return -3;
 #define TF2_SH(S, M, P) do { auto fn = conv_shift_kernel<S, M, P>; if (lds > 64 * 1024 && !lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
-                             hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, a); } while (0)
+                             TF2_LAUNCH_NAME("conv_shift_kernel"); TF2_LAUNCH(fn, grid, dim3(256), lds, s, a); } while (0)
   if (packed4) {
     if (signed_in) { if (mul24) TF2_SH(true, true, true); else TF2_SH(true, false, true); }
     else { if (mul24) TF2_SH(false, true, true); else TF2_SH(false, false, true); }
@@ -208,7 +208,7 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, 
     else { if (mul24) TF2_SH(false, true, false); else TF2_SH(false, false, false); }
   }
 #undef TF2_SH
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return launch_ok() ? 0 : -1;
 }
 
 }  // namespace tf2

@@ -240,13 +240,13 @@ int launch_conv_stem(const StemArgs& a, int nwin, void* stream) {
   if (nwin == 2) {
     auto fn = conv_stem_kernel<2>;
     if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
+    TF2_LAUNCH_NAME("conv_stem_kernel<%d windows>", nwin); TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, a);
   } else {
     auto fn = conv_stem_kernel<1>;
     if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
+    TF2_LAUNCH_NAME("conv_stem_kernel<%d windows>", nwin); TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, a);
   }
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return launch_ok() ? 0 : -1;
 }
 
 }  // namespace tf2

@@ -7,6 +7,7 @@
 // All are one pass over their tensors with 16-byte (pool) or coalesced accesses.
 #include <hip/hip_runtime.h>
 #include "tf2_internal.h"
+#include "tf2_device.h"
 
 namespace tf2 {
 
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void l2norm_kernel(L2NormArgs a) {
 }
 
 int launch_l2norm(const L2NormArgs& a, void* stream) {
-  hipLaunchKernelGGL(l2norm_kernel, dim3((a.n_pix + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("l2norm_kernel"); TF2_LAUNCH(l2norm_kernel, dim3((a.n_pix + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_ok() ? 0 : -1;
 }
 
 static inline int grid_for(long long total, int block = 256) {
@@ -279,29 +280,29 @@ int launch_prep_input(const PrepArgs& a, void* stream) {
   if (a.rewrite && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
     if (a.xonly) {
-      if (a.src_is_q) hipLaunchKernelGGL((prep_rewrite3_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((prep_rewrite3_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      if (a.src_is_q) { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+      else { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
     } else {
-      if (a.src_is_q) hipLaunchKernelGGL((prep_rewrite3_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((prep_rewrite3_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+      if (a.src_is_q) { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+      else { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_ok() ? 0 : -1;
   }
   if (a.xonly) return -1;                       // only the space-to-depth form has an x-only variant (net.hip checks the same limits)
   long long total = (long long)a.B * a.OH * a.OW * (a.half / 16);
-  hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("prep_input_kernel"); TF2_LAUNCH(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_ok() ? 0 : -1;
 }
 
 int launch_maxpool(const PoolArgs& a, void* stream) {
   long long total = (long long)a.B * a.PH * a.PW * a.C16;
-  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("maxpool_kernel"); TF2_LAUNCH(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_ok() ? 0 : -1;
 }
 
 int launch_global_avg(const AvgArgs& a, void* stream) {
-  hipLaunchKernelGGL(global_avg_kernel, dim3(a.B * ((a.C / 16 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  TF2_LAUNCH_NAME("global_avg_kernel"); TF2_LAUNCH(global_avg_kernel, dim3(a.B * ((a.C / 16 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_ok() ? 0 : -1;
 }
 
 const char* device_last_error() { return hipGetErrorString(hipGetLastError()); }

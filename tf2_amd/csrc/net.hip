@@ -7,9 +7,11 @@
 // stream over NHWC int8 activation tensors that live in a caller-owned workspace.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "tf2_net.h"
+#include "tf2_device.h"
 
 namespace tf2 {
 
@@ -230,12 +232,13 @@ bool Net::stem_selected(int batch) const {
 // ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
 void Net::load_options() {
   RunOpts o;
-  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 6;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
+  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 0xffe;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
   if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
   if (const char* e = getenv("TF2_AMD_ALT_NARROW")) o.alt_narrow_blocks = atol(e);   // a 128-row layer takes its 64-row alternative below this many 128 x 128 blocks
@@ -254,7 +257,7 @@ void Net::load_options() {
 const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent) {
   for (const LaunchPlan& lp : launch_plans)
     if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0)) return &lp;
-  if (launch_plans.size() >= 64) launch_plans.erase(launch_plans.begin());
+  if (launch_plans.size() >= 64) launch_plans.pop_front();
   LaunchPlan lp;
   lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0;
   int8_t* base = (int8_t*)ws;
@@ -324,6 +327,13 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       for (int mt = 0; mt < pl->n_mtiles && dense; mt++)
         dense = hd[(size_t)mt * (pl->n_phases + 1) + pl->n_phases] - hd[(size_t)mt * (pl->n_phases + 1)] == pl->nslab;
       ca.ent0 = hd[pl->n_phases] - hd[0];
+      // arithmetic gather (tf2_internal.h ConvArgs::dense): no header read in front of the first activation DMAs
+      const int taps_l = L.k * L.k;
+      ca.cslabs = pl->Cp_in / 64;
+      if (opts.dense_mode && dense && (pl->n_phases == 1 || pl->dual) && pl->Cp_in % 64 == 0 && pl->nslab == taps_l * ca.cslabs && L.k <= 15) {
+        ca.dense = 1;
+        set_fast_div((uint32_t)ca.cslabs, &ca.cs_m, &ca.cs_s); set_fast_div((uint32_t)L.k, &ca.kk_m, &ca.kk_s);
+      }
     }
     if (opts.dbg2 && opts.dbg_layer == l) ca.dbg2 = opts.dbg2;
     if (opts.dbg) ca.dbg = opts.dbg + (size_t)l * 16;
@@ -409,7 +419,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.y = cb.y; f.y_cp = cb.g.y_cp; f.y_off = cb.g.y_off; f.y_nvalid = cb.g.y_nvalid;
       f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
       f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0;
-      f.B = batch; f.H = L.H; f.W = L.W;
+      f.B = batch; f.H = L.H; f.W = L.W; f.probe = opts.flags;
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
       f.R = std::min(TN / L.W, L.H);
       f.tiles_per_img = (L.H + f.R - 1) / f.R;
@@ -463,6 +473,66 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   return &launch_plans.back();
 }
 
+static thread_local LaunchRecorder* g_recorder = nullptr;
+LaunchRecorder*& launch_recorder() { return g_recorder; }
+
+// one prepared launch of a step -> its kernel (or, with a recorder installed, its description)
+int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool images_are_q, int8_t* logits, void* stream) {
+  switch (st.kind) {
+    case Launch::PREP: {
+      PrepArgs pa = st.prep; pa.img = images; pa.src_is_q = images_are_q ? 1 : 0;
+      return launch_prep_input(pa, stream);
+    }
+    case Launch::POOL: return launch_maxpool(st.pool, stream);
+    case Launch::AVG: return launch_global_avg(st.avg, stream);
+    case Launch::L2N: return launch_l2norm(st.l2n, stream);
+    case Launch::CONV:
+      switch (st.sel) {
+        case Launch::SEL_PW: return launch_conv_pw(st.conv, st.TM, stream);
+        case Launch::SEL_SK:
+          if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
+            ConvArgs cd = st.conv_direct; cd.y = logits;
+            return launch_conv_mfma_sk(cd, opts.sk8_blocks, stream);
+          }
+          return launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream);
+        case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
+        case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
+        case Launch::SEL_STEM: return launch_conv_stem(st.stem, st.shape, stream);
+        default: return launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream);
+      }
+  }
+  return -1;
+}
+
+// The launches one step of `batch` images consists of, as the library itself would issue them (kernel, grid, LDS, registers):
+// tile shapes, fused pairs and split-K variants are decided in launch_plan / the launchers, nowhere else.  No device needed.
+tf2_status Net::describe_launches(int batch, bool concurrent, std::vector<std::pair<int, LaunchRecord>>* out) {
+  std::lock_guard<std::mutex> lock(run_mutex);
+  if (!packed_valid) { set_error("tf2_net_describe_launches: no packed image"); return TF2_ERR_STATE; }
+  if (batch <= 0) { set_error("tf2_net_describe_launches: batch must be positive"); return TF2_ERR_ARG; }
+  const WorkPlan* wp = plan(batch, false);
+  const uint8_t* saved = packed_dev;
+  if (!packed_dev) packed_dev = packed.data();               // addresses are only formatted into argument blocks nobody launches
+  static char fake_ws[16];
+  const LaunchPlan* lp = launch_plan(batch, wp, fake_ws, concurrent);
+  packed_dev = saved;
+  if (!lp) return TF2_ERR_ARG;
+  LaunchRecorder rec; rec.name[0] = 0;
+  g_recorder = &rec;
+  int rc = 0;
+  for (const Launch& st : lp->steps) {
+    const size_t before = rec.rows.size();
+    rc = issue(st, lp, fake_ws, false, nullptr, nullptr);
+    if (rc) break;
+    for (size_t i = before; i < rec.rows.size(); i++) out->emplace_back(st.layer, rec.rows[i]);
+  }
+  g_recorder = nullptr;
+  for (auto it = launch_plans.begin(); it != launch_plans.end(); ++it)       // the description's plan is not a run plan
+    if (&*it == lp) { launch_plans.erase(it); break; }
+  if (rc) { set_error("tf2_net_describe_launches: " + std::string(device_last_error())); return TF2_ERR_HIP; }
+  return TF2_OK;
+}
+
 size_t Net::logits_bytes(int batch) const {
   const tf2_layer_desc& LL = layers[nd.n_layers - 1];
   const size_t hw = LL.endpool ? 1 : (size_t)LL.PH * LL.PW;
@@ -470,7 +540,8 @@ size_t Net::logits_bytes(int batch) const {
 }
 
 tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
-                    int8_t* logits, void* stream) {
+                    int8_t* logits, void* stream, int concurrency, void* mark_event, int mark_after_layer) {
+  std::lock_guard<std::mutex> lock(run_mutex);
   if (!packed_valid) { set_error("tf2_net_run: no packed image (tf2_net_pack / tf2_net_packed_adopt)"); return TF2_ERR_STATE; }
   if (!packed_dev) { set_error("tf2_net_run: packed image not bound to the device (tf2_net_bind_device)"); return TF2_ERR_STATE; }
   if (q.empty()) { set_error("tf2_net_run: q table not set"); return TF2_ERR_STATE; }
@@ -488,7 +559,8 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   void* const tag = (void*)((uintptr_t)stream + 1);          // the null stream is a stream too; 0 = empty slot
   recent_streams[recent_pos] = tag; recent_pos = (recent_pos + 1) & 7;
   bool concurrent = opts.alt_conc_mode == 1;
-  if (opts.alt_conc_mode == 2)
+  if (concurrency >= 0 && opts.alt_conc_mode == 2) concurrent = concurrency != 0;        // the caller's own statement (tf2_net_run_ex)
+  else if (opts.alt_conc_mode == 2)
     for (int i = 0; i < 8 && !concurrent; i++) concurrent = recent_streams[i] != nullptr && recent_streams[i] != tag;
   const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent);
   if (!lp) return TF2_ERR_ARG;
@@ -507,7 +579,21 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     }
     return TF2_OK;
   };
+  bool mark_pending = mark_event != nullptr;
+#ifdef TF2_PROBES
+  // tools/probe_run.py: leave out the launches of a layer range (results are then wrong; only durations are read)
+  static const char* skip_env = getenv("TF2_AMD_SKIP_LAYERS");
+  int skip_lo = 1 << 30, skip_hi = -1 << 30;
+  if (const char* e = getenv("TF2_AMD_SKIP_LAYERS")) { (void)skip_env; if (sscanf(e, "%d-%d", &skip_lo, &skip_hi) != 2) { skip_lo = 1 << 30; skip_hi = -1 << 30; } }
+#endif
   for (const Launch& st : lp->steps) {
+#ifdef TF2_PROBES
+    if (st.layer >= skip_lo && st.layer <= skip_hi) continue;
+#endif
+    if (mark_pending && st.layer > mark_after_layer) {       // every launch of layers 0..mark_after_layer is enqueued
+      HIP_OK(hipEventRecord((hipEvent_t)mark_event, s));
+      mark_pending = false;
+    }
     if (profiling && st.layer != ev_layer) {            // one event pair per layer (conv + its pool / average)
       if (tf2_status e = close_layer_event()) return e;
       if (st.layer >= 0) {
@@ -520,34 +606,10 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
       HIP_OK(hipEventCreate(&loop0)); HIP_OK(hipEventCreate(&loop1));
       HIP_OK(hipEventRecord(loop0, s));
     }
-    int rc = 0;
-    switch (st.kind) {
-      case Launch::PREP: {
-        PrepArgs pa = st.prep; pa.img = images; pa.src_is_q = images_are_q ? 1 : 0;
-        rc = launch_prep_input(pa, stream);
-        break;
-      }
-      case Launch::POOL: rc = launch_maxpool(st.pool, stream); break;
-      case Launch::AVG: rc = launch_global_avg(st.avg, stream); break;
-      case Launch::L2N: rc = launch_l2norm(st.l2n, stream); break;
-      case Launch::CONV:
-        switch (st.sel) {
-          case Launch::SEL_PW: rc = launch_conv_pw(st.conv, st.TM, stream); break;
-          case Launch::SEL_SK:
-            if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
-              ConvArgs cd = st.conv_direct; cd.y = logits;
-              rc = launch_conv_mfma_sk(cd, opts.sk8_blocks, stream);
-            } else rc = launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream);
-            break;
-          case Launch::SEL_MFMA2: rc = launch_conv_mfma2(st.conv, st.TM, stream); break;
-          case Launch::SEL_BNECK: rc = launch_conv_bneck(st.bneck, st.TM, st.shape, stream); break;
-          case Launch::SEL_STEM: rc = launch_conv_stem(st.stem, st.shape, stream); break;
-          default: rc = launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream); break;
-        }
-        break;
-    }
+    const int rc = issue(st, lp, images, images_are_q, logits, stream);
     if (rc) { set_error("kernel launch failed at layer " + std::to_string(st.layer) + ": " + device_last_error()); return TF2_ERR_HIP; }
   }
+  if (mark_pending) HIP_OK(hipEventRecord((hipEvent_t)mark_event, s));
   if (profiling) { if (tf2_status e = close_layer_event()) return e; }
   if (profiling_loop && loop0) {
     HIP_OK(hipEventRecord(loop1, s));

@@ -118,6 +118,13 @@ struct ConvArgs {
   int32_t max_ent;
   int32_t n_phases, n_mtiles, Np, nslab;
   int32_t k, dil, n_cchunk, Cp_half;   // shift kernel: filter size, dilation, chunks, x|xneg split
+  // "Dense" layers (net.hip make_conv: every m-tile holds all nslab slabs in order, one window or dual, Cp_in a multiple of 64):
+  // the ring kernels then derive a step's gather words from its index -- slab sl = (tap t, channel slab cs), t = sl / cslabs --
+  // instead of reading them from the header image, so the first activation DMAs need nothing but the kernel arguments.
+  int32_t dense;             // 1: arithmetic gather (conv_mfma2 / conv_mfma_sk DENSE instantiations)
+  int32_t cslabs;            // Cp_in / 64
+  uint32_t cs_m; int32_t cs_s; // set_fast_div(cslabs)
+  uint32_t kk_m; int32_t kk_s; // set_fast_div(k)
   ConvGeom g;
 };
 
@@ -137,6 +144,7 @@ struct BneckArgs {
   int32_t B, H, W, R, tiles_per_img;     // R output rows per block, ceil(H / R) blocks per image
   int32_t dual1, fast1, relu1, dual2, fast2, relu2, add_relu, has_res, keep_mid;
   int32_t dbl_mid;           // the 3x3's output (the intermediate tile) has doubled channels
+  int32_t probe;             // timing probes (ConvGeom::flags of the pair; read by -DTF2_PROBES builds only)
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
 };
 

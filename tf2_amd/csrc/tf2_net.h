@@ -1,12 +1,16 @@
 // tf2_net.h -- the network handle behind the C ABI (host side).
 #pragma once
 #include <cstring>
+#include <list>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "tf2_internal.h"
 
 namespace tf2 {
+
+struct LaunchRecord;
 
 struct TensorPlan {
   int H = 0, W = 0, C = 0, Cp = 0;
@@ -68,6 +72,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
+  int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
@@ -94,7 +99,9 @@ struct Net {
   std::vector<int> concat_C;             // channels of each concat tensor
 
   std::map<std::pair<int, int>, WorkPlan> plans;   // (batch, keep_all) -> plan
-  std::vector<LaunchPlan> launch_plans;            // prepared steps, keyed by (batch, plan, workspace, packed image)
+  std::list<LaunchPlan> launch_plans;              // prepared steps, keyed by (batch, plan, workspace, packed image); a list: growth and
+                                                   // eviction never move a plan another thread is walking (oldest evicted at 64, under run_mutex)
+  std::mutex run_mutex;                            // serialises run(): plan lookup / build, stream history, enqueue (tf2_amd.h threading note)
   RunOpts opts;
 
   // profiling
@@ -124,7 +131,9 @@ struct Net {
   void load_options();
   size_t logits_bytes(int batch) const;
   tf2_status run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
-                 int8_t* logits, void* stream);
+                 int8_t* logits, void* stream, int concurrency = -1, void* mark_event = nullptr, int mark_after_layer = -1);
+  int issue(const Launch& st, const LaunchPlan* lp, const void* images, bool images_are_q, int8_t* logits, void* stream);
+  tf2_status describe_launches(int batch, bool concurrent, std::vector<std::pair<int, struct LaunchRecord>>* out);
   tf2_status read_layer(int layer, int batch, const void* ws, int8_t* dst, size_t cap, void* stream);
   void drain_profile();
 };

@@ -171,6 +171,16 @@ class NetWork:
         """Re-read the TF2_AMD_* run-time switches from the environment (sampled at creation otherwise)."""
         _lib.check(_lib.lib().tf2_net_reload_options(self._h))
 
+    def describe_launches(self, batch: int, concurrency: int = 0):
+        """The kernel launches of one step, as the library's launch plan selects them: list of dicts
+        {layer, kernel, grid, block, lds_bytes, vgprs} (tf2_net_describe_launches; no device needed)."""
+        import ctypes as C
+        rows = (_lib.LaunchInfo * 512)()
+        n = C.c_int(0)
+        _lib.check(_lib.lib().tf2_net_describe_launches(self._h, batch, concurrency, rows, 512, C.byref(n)))
+        return [dict(layer=r.layer, kernel=r.kernel.decode(), grid=r.grid, block=r.block, lds_bytes=r.lds_bytes, vgprs=r.vgprs)
+                for r in rows[:n.value]]
+
     def workspace_size(self, batch: int, keep_all: bool = False) -> int:
         return int(_lib.lib().tf2_net_workspace_size(self._h, batch, int(keep_all)))
 
@@ -204,20 +214,34 @@ class Runner:
             self._logits = torch.empty((batch, N) if nbytes == batch * N else (batch, nbytes // (batch * N), N),
                                        dtype=torch.int8, device=net.device)
 
-    def run_batch(self, images, keep_all: bool = False):
+    def run_batch(self, images, keep_all: bool = False, concurrency: int = -1, mark=None):
         """images: torch tensor on the network's device, float32 [B,C,H,W] (preprocessed
         floats as in the image .bin files) or int8 (already quantised).  Returns the int8
-        logits tensor [B, N_last] (device).  Enqueued on the current HIP stream."""
+        logits tensor [B, N_last] (device).  Enqueued on the current HIP stream.
+        concurrency: -1 let the library decide from its stream history, 0 this batch runs alone, 1 other batches are in
+        flight on other streams (tile-shape choice only; same results).  mark = (torch.cuda.Event, layer): the event is
+        recorded on the stream once the launches of layers 0..layer are enqueued (tf2_net_run_ex)."""
         import torch
+        import ctypes as C
         net = self.network
         assert images.is_contiguous() and images.device == net.device
         B = images.shape[0]
         self._ensure(B, keep_all)
         stream = torch.cuda.current_stream(net.device).cuda_stream
-        fn = _lib.lib().tf2_net_run if images.dtype == torch.float32 else _lib.lib().tf2_net_run_q
         assert images.dtype in (torch.float32, torch.int8)
-        _lib.check(fn(net._h, images.data_ptr(), B, self._ws.data_ptr(), self._ws.numel(),
-                      self._logits.data_ptr(), stream))
+        if concurrency == -1 and mark is None:
+            fn = _lib.lib().tf2_net_run if images.dtype == torch.float32 else _lib.lib().tf2_net_run_q
+            _lib.check(fn(net._h, images.data_ptr(), B, self._ws.data_ptr(), self._ws.numel(),
+                          self._logits.data_ptr(), stream))
+            return self._logits
+        o = _lib.RunOpts(C.sizeof(_lib.RunOpts), int(images.dtype == torch.int8), int(concurrency), -1, None)
+        if mark is not None:
+            ev, layer = mark
+            ev.record(torch.cuda.current_stream(net.device))       # creates the underlying hipEvent_t; re-recorded by the library
+            o.mark_event = ev.cuda_event
+            o.mark_after_layer = int(layer)
+        _lib.check(_lib.lib().tf2_net_run_ex(net._h, images.data_ptr(), B, self._ws.data_ptr(), self._ws.numel(),
+                                             self._logits.data_ptr(), stream, C.byref(o)))
         return self._logits
 
     def run_split(self, images, parts: int = 2):
