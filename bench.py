@@ -344,7 +344,7 @@ def main():
     alg_bytes = sum(lo[i]["bytes"] for i in cv) * args.batch
     dom_ms = float(sum(per_layer_ms[i] for i in cv))
     traffic, traffic_note = None, "no PMC pass committed for this batch size and kernel mode"
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         pj = os.path.join(ROOT, "profiles", f"{rnd}_pmc_conv_b{args.batch}.json")
         if os.path.exists(pj) and args.mode == 0:
             pm = json.load(open(pj))
@@ -354,6 +354,14 @@ def main():
                 traffic_note = (f"mean HBM bytes per launch over the step's {sum(1 for i in cv if nl[i] > 0)} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)"
                                 f"+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
                 break
+    # the committed rocprofv3 --kernel-trace --stats summary of the same workload (tools/round_evidence.sh: ONLY batch-N steps one at
+    # a time in the profiled process): the conv kernels' time per step as the profiler sees it, next to the live HIP-event figure
+    rocprof_us, rocprof_src = None, None
+    for rnd in ("r03",):
+        pj = os.path.join(ROOT, "profiles", f"{rnd}_rocprof_b{args.batch}_summary.json")
+        if os.path.exists(pj) and args.mode == 0:
+            rs = json.load(open(pj))
+            rocprof_us, rocprof_src = round(rs["conv_us_per_step"], 1), os.path.basename(pj)
     n_launch = max(1, sum(1 for i in cv if nl[i] > 0))      # a conv_bneck launch computes two table rows
     gbps = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tops = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -363,6 +371,7 @@ def main():
                     traffic=traffic, traffic_note=traffic_note,
                     algorithmic_bytes_per_launch=round(alg_bytes / n_launch), launches_per_step=n_launch,
                     avg_launch_us=round(dom_ms / n_launch * 1e3, 2), event_pair_scale=round(event_scale, 4),
+                    kernel_us_per_step=round(dom_ms * 1e3, 1), kernel_us_per_step_rocprof=rocprof_us, rocprof_summary=rocprof_src,
                     mfma_side=dict(achieved_tops=round(tops, 1), peak_tops=PEAK_I8, frac=round(tops / PEAK_I8, 4),
                                    algorithmic_ops_per_launch=round(dom_ops / n_launch)),
                     note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d): 26.9 MB per image) of "
@@ -381,7 +390,7 @@ def main():
         ref = netref.RefNet(tables, qv, model)
         n_done, t_cpu = 0, 0.0
         imgs = synth.synth_images(tables, 64, seed=100)
-        chunk = max(1, min(8, O.num_threads()))
+        chunk = max(1, min(16, O.num_threads()))          # tf2o_layer parallelises over (image, output channel): every thread busy
         first_logits = None
         while t_cpu < args.cpu_seconds and n_done + chunk <= 64:
             t0 = time.perf_counter()
@@ -394,7 +403,9 @@ def main():
         got = runner.run_batch(torch.from_numpy(imgs[:first_logits.shape[0]]).to(device)).cpu().numpy()
         parity = bool((got == first_logits).all())
         cpu = dict(value=round(n_done / t_cpu, 3), unit="images/s", cores=O.num_threads(), kind="port",
-                   sample=f"{n_done} synthetic 224x224 images, same ResNet50 weights/Q, oracle/tf2_oracle.c (OpenMP) in {t_cpu:.1f} s",
+                   sample=f"{n_done} synthetic 224x224 images, same ResNet50 weights/Q, oracle/tf2_oracle.c (OpenMP over image x output "
+                          f"channel, {O.num_threads()} threads = the CPUs this process may use: affinity {len(os.sched_getaffinity(0))}, "
+                          f"cgroup quota applied; {os.cpu_count()} logical CPUs visible) in {t_cpu:.1f} s",
                    parity_with_gpu_logits=parity)
 
     if rank == 0:

@@ -40,6 +40,9 @@ def lib():
         L.tf2o_mul.restype = C.c_int32
         L.tf2o_mul.argtypes = [C.c_int8, C.c_uint8]
         L.tf2o_num_threads.restype = C.c_int
+        L.tf2o_set_num_threads.argtypes = [C.c_int]
+        if "OMP_NUM_THREADS" not in os.environ:       # not more threads than CPUs this process may really use (cgroup quota)
+            L.tf2o_set_num_threads(min(L.tf2o_num_threads(), effective_cpus()))
         _LIB = L
     return _LIB
 
@@ -48,7 +51,29 @@ def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t) if a is not None else None
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256 logical
+    CPUs with cpu.max = 16 cores runs 256 OpenMP threads on 16 cores' worth of time)."""
+    import math, os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, math.ceil(q / p_)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def num_threads():
+    """OpenMP threads the oracle runs on: the process's effective CPUs (set once), unless OMP_NUM_THREADS says otherwise."""
     return lib().tf2o_num_threads()
 
 

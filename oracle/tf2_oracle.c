@@ -57,6 +57,9 @@
 int tf2o_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
+}
+void tf2o_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
 #else
   return 1;
 #endif
@@ -374,6 +377,9 @@ typedef struct {
   int add_en, add_relu, endpool, endpool_mult;
 } tf2o_layer_t;
 
+/* Built for a baseline ISA (the library travels to the GPU box); the hot loop nest is cloned for wider SIMD and picked at load
+ * time, so that the CPU baseline bench.py reports is the host's honest vector speed. */
+__attribute__((target_clones("avx512f", "avx2", "default")))
 static void conv_one(const tf2o_layer_t* L, const int8_t* x, const uint8_t* codes, const int32_t* bias,
                      int n, uint32_t* a) {
   const int OH = L->OH, OW = L->OW, H = L->H, W = L->W, C = L->C;

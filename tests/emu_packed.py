@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: a numpy model of what the HIP conv kernels compute FROM THE PACKED
 IMAGE (tf2_amd/csrc/weight_pack.cpp layouts), used on the CPU to check the packing logic
 (exponent windows, Horner shifts, slab lists, kinfo gather, [x|xneg] image layout) against
-the oracle before anything runs on a GPU.  It mirrors conv_mfma.hip / conv_shift.hip's
+the oracle before anything runs on a GPU.  It mirrors conv_mfma2.hip / conv_shift.hip's
 data flow, not their scheduling."""
 import numpy as np
 
@@ -10,7 +10,7 @@ HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
                                      "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
-                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad")])
+                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_unit")])
 
 
 def parse(blob: np.ndarray):

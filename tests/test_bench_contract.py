@@ -32,3 +32,8 @@ def test_bench_line_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["parity_with_gpu_logits"] is True
+    # the committed rocprofv3 summary of the same workload (profiles/rNN_rocprof_b32_summary.json, tools/round_evidence.sh) agrees
+    # with the live HIP-event figure behind `roofline.frac`
+    assert r["kernel_us_per_step"] > 0
+    if r.get("kernel_us_per_step_rocprof"):
+        assert abs(r["kernel_us_per_step_rocprof"] - r["kernel_us_per_step"]) / r["kernel_us_per_step"] < 0.10, (r["kernel_us_per_step_rocprof"], r["kernel_us_per_step"])

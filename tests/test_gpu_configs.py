@@ -210,3 +210,29 @@ def test_four_batches_in_flight_as_bench_times_them(r50, graph):
     for k in range(n_steps - n_fl, n_steps):
         got = runners[k % n_fl]._logits.cpu().numpy()
         np.testing.assert_array_equal(got, serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl} (graph={graph})")
+
+
+def test_cli_on_the_shipped_image(r50, golden_dir, tmp_path, capsys):
+    """The reference's host CLI (main.cpp:19-61: model_file q_file image_file verify_file num_images) through tf2_amd.cli: the
+    shipped test image and Q file, a model file in the float32 LoadModel stream format, the shipped golden logits as the verify
+    file.  Prints what main() prints (arguments, latency / throughput, the compare line, top-5 per image) and its top-5 equals
+    the oracle's for the same model."""
+    from tf2_amd import cli
+    t, q, model = r50
+    mf = tmp_path / "param.bin"
+    np.asarray(model, np.float32).tofile(mf)
+    img = os.path.join(golden_dir, "resnet50_data_label_100.bin")
+    rc = cli.main([str(mf), os.path.join(golden_dir, "resnet50_Q"), img, os.path.join(golden_dir, "resnet50_fc1000_label_100.bin"), "2"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "num_images = 2" in out and "Latency = " in out and "Throughput = " in out
+    assert out.count("compare finished, error=") == 2 and out.count("rank=0") == 2
+    labels = [int(l.split("label=")[1].split()[0]) for l in out.splitlines() if l.startswith("rank=")]
+    assert len(labels) == 10 and labels[:5] == labels[5:]
+    rig = Rig(t, q, model, 0)
+    x = np.fromfile(img, np.float32).reshape(1, 3, 224, 224)
+    want = rig.ref.logits(rig.ref.run(x))
+    assert labels[:5] == rig.ref.top5(want[0])[0].tolist()
+    # a missing verify file is reported, not fatal (the reference prints the open error and goes on, network_helper.cpp:77-83)
+    assert cli.main([str(mf), os.path.join(golden_dir, "resnet50_Q"), img, str(tmp_path / "nope.bin"), "1"]) == 0
+    assert "verify file not readable" in capsys.readouterr().out

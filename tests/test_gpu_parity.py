@@ -355,3 +355,44 @@ def test_runner_run_mirrors_reference_flow(r50_rig, golden_dir):
     assert out.shape == (2, 1000) and (out[0] == out[1]).all() and r.throughput_fps > 0
     err = network.Verify(0, os.path.join(golden_dir, "resnet50_fc1000_label_100.bin"), net.q, out, num_layer=net.num_layer)
     assert np.isfinite(err)        # synthetic weights: the number is meaningless, the plumbing is what is checked
+
+
+def _stem_nopool_tables():
+    b = cfg._B("stem_nopool", image=(3, 224, 224), first_filter=7, rewrite=1)
+    a = b.conv(-1, 27, 114, 114, 64, 3, 1, 0, relu=1)                       # conv1 in its executed form, NO pool
+    x = b.conv(a, 64, 112, 112, 64, 3, 2, 1, relu=1)                          # reads the (doubled) stem output
+    y = b.conv(x, 64, 56, 56, 32, 1, 1, 0, relu=1, endpool=1, endpool_hw=56 * 56)
+    b.conv(y, 32, 1, 1, 10, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+def _expand_nores_tables():
+    b = cfg._B("expand_nores", image=(3, 32, 32), first_filter=3)
+    a = b.conv(-1, 3, 32, 32, 64, 3, 1, 1, relu=1)
+    x = b.conv(a, 64, 32, 32, 64, 3, 1, 1, relu=1)                            # 3x3 C -> C ...
+    e = b.conv(x, 64, 32, 32, 256, 1, 1, 0, relu=1)                           # ... and its 1x1 expand WITHOUT a shortcut
+    r = b.conv(e, 256, 32, 32, 64, 1, 1, 0, relu=1)                           # reads the (doubled) expand output
+    y = b.conv(r, 64, 32, 32, 32, 3, 2, 1, relu=1, endpool=1, endpool_hw=16 * 16)
+    b.conv(y, 32, 1, 1, 10, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+@pytest.mark.parametrize("which", ["stem_without_pool", "fused_expand_without_residual"])
+def test_doubled_channels_written_by_conv_stem_and_by_a_fused_expand(which, monkeypatch):
+    """The two producers of a "doubled" tensor (weight_pack.cpp: channels stored as 2y - 128) that ResNet-50 never exercises:
+    conv_stem (a first layer without a pool) and conv_bneck's expand epilogue (an expand without a shortcut).  Their header rows
+    carry the -128 and their consumers' weights are halved, so the kernels must apply the doubling -- every layer vs the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_packed as emu
+    monkeypatch.setenv("TF2_AMD_BNECK_MIN", "1")
+    t = _stem_nopool_tables() if which == "stem_without_pool" else _expand_nores_tables()
+    q = synth.synth_q_values(t, 1, spread=1)
+    rig = Rig(t, q, synth.synth_model(t, q, 1), 0)
+    _, pls = emu.parse(rig.net.packed_host())
+    launches = rig.net.describe_launches(4, 0)
+    if which == "stem_without_pool":
+        assert int(pls[0]["off_dbl"]) != 0 and any("conv_stem" in l["kernel"] for l in launches)
+    else:
+        assert int(pls[2]["off_dbl"]) != 0 and int(pls[2]["fused_into"]) == 1 and any("conv_bneck" in l["kernel"] for l in launches)
+    rig.check_all_layers(synth.synth_images(t, 4, 3))

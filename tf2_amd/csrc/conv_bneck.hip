@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
           int a16[16];
 #pragma unroll
           for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-          const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j]);
+          const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j], a.dbl_out != 0);
           const int p = wn * WTN + j * 32 + (lane & 31);
           if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
           if (p < n_px && chl + 16 <= a.y_nvalid)

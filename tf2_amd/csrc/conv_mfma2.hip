@@ -1,9 +1,11 @@
 // conv_mfma2.hip -- implicit-GEMM INT8 convolution, LDS-DMA pipelined (gfx950).
 //
-// Same arithmetic, operand orientation, LDS swizzle and epilogue semantics as conv_mfma.hip
-// (see the header there for the Z/2^32 exponent-window / Horner argument and the reference
-// citations); what changes is how operands reach the matrix cores and how much latency a
-// block exposes:
+// Arithmetic: the reference's PE adds x * (+-2^s) into an int32 that wraps (pe.cl:27-49); here every weight row is split
+// into 7-exponent windows of int8 values that the matrix cores multiply, and the windows are recombined by left shifts --
+// the same value in Z/2^32 (proof and packed layout: weight_pack.cpp header).  Operand orientation: A = weights (rows =
+// output channels), B = gathered NHWC activations (columns = pixels); both tiles sit in LDS as 64-byte rows whose four
+// 16-byte chunks are XOR-swizzled with (row >> 2) & 3; the epilogue is requant_epilogue.h (pe.cl:185-203, relu.cl:54,
+// feature_writer.cl:88-122).  How operands reach the matrix cores and how little latency a block exposes:
 //
 //  * everything the K loop and the epilogue need per m-tile (bias / final shift / alpha /
 //    beta, Horner shifts, this m-tile's slab list with the phase boundaries encoded, and the

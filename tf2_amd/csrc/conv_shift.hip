@@ -18,7 +18,7 @@
 // coalesced 16-byte loads into LDS (zero padding applied there, sequencer.cl:287); each
 // lane then reads its own 16 bytes per tap (ds_read_b128, lane-linear = conflict-free)
 // and unpacks them once for the 8 output channels of its wave.
-// Epilogue identical to conv_mfma.hip (bias, BN requant, ReLU, residual, 8-byte store).
+// Epilogue: the arithmetic of requant_epilogue.h's generic path (bias, BN requant, ReLU, residual), 8-byte stores.
 //
 // PACKED4 (PackLayer::fast on a shift layer, weight_pack.cpp): the filters stay packed in HBM as 4-bit codes {sign, e} with
 // s = A[n] + B[c] - e -- the INQ form of 4bit_data_format.txt, 8x fewer weight bytes than the int32 form -- and every wave

@@ -238,6 +238,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
   if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
   if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
@@ -373,6 +374,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     return true;
   };
   std::vector<char> fused_done(nl, 0);
+  bool stem_pool_fused = false;
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
@@ -418,7 +420,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.dual2 = pb->dual; f.fast2 = pb->fast; f.relu2 = cb.g.relu;
       f.y = cb.y; f.y_cp = cb.g.y_cp; f.y_off = cb.g.y_off; f.y_nvalid = cb.g.y_nvalid;
       f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
-      f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0;
+      f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0; f.dbl_out = pb->off_dbl != 0;
       f.B = batch; f.H = L.H; f.W = L.W; f.probe = opts.flags;
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
       f.R = std::min(TN / L.W, L.H);
@@ -429,18 +431,36 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const ConvArgs& ca = st.conv;
       StemArgs& f = st.stem;
       f.x = ca.x; f.y = ca.y; f.w = (const int8_t*)(pk + pl->off_w2); f.hdr = ca.hdr; f.zero = ca.zero;
+      f.unit = pl->off_unit ? (const int8_t*)(pk + pl->off_unit) : nullptr;
       f.hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
       f.B = batch; f.H = L.H; f.W = L.W; f.OH = L.OH; f.OW = L.OW;
-      f.relu = ca.g.relu; f.fast = ca.g.fast; f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid;
+      f.relu = ca.g.relu; f.fast = ca.g.fast; f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid; f.dbl_out = ca.g.dbl_out; f.probe = opts.flags; f.dbg2 = (opts.dbg2 && opts.dbg_layer == 0) ? opts.dbg2 : nullptr;
       // rows per block: the fewest rounds of (two blocks per CU) x rows; two blocks must share a CU's 160 KiB
       long best = -1;
       for (int R = 2; R <= 8; R++) {
-        if (2 * conv_stem_lds_bytes(pl->n_phases, R, L.W, (size_t)f.hdr_used) > 160 * 1024) break;
+        if (2 * conv_stem_lds_bytes(pl->off_unit ? 1 : pl->n_phases, R, L.W, (size_t)f.hdr_used) > 160 * 1024) break;
         const long blocks = (long)batch * ((L.OH + R - 1) / R);
         const long cost = ((blocks + 511) / 512) * R;
         if (best < 0 || cost < best || (cost == best && R == 7)) { best = cost; f.R = R; }
       }
-      if (best >= 0) {
+      // the layer's 3x3 / stride 2 / pad 1 max pool in the same launch (conv_stem_pool_kernel): pooled rows per block = the most
+      // that lets two blocks share a CU
+      stem_pool_fused = false;
+      if (opts.stem_pool && L.pool_en && L.pool_S == 3 && L.pool_st == 2 && L.pool_pad == 1 && pl->off_unit && 
+          L.PH == (L.OH + 1) / 2 && L.PW == (L.OW + 1) / 2 && L.N == 64 && E.conv_tensor != E.out_tensor) {
+        int pk = 0;
+        for (int k = 1; k <= 8; k++)
+          if (2 * conv_stem_pool_lds_bytes(k, L.W, L.OW, (size_t)f.hdr_used) <= 160 * 1024) pk = k;
+        if (pk >= 2) {
+          const TensorPlan& to = T(E.out_tensor);
+          f.yp = base + to.offset; f.PH = L.PH; f.PW = L.PW; f.yp_cp = to.Cp; f.yp_off = E.out_off; f.pk = pk;
+          f.bands_per_img = (L.PH + pk - 1) / pk; f.R = 2 * pk + 1;
+          st.sel = Launch::SEL_STEM; st.shape = pl->n_phases;
+          stem_pool_fused = true; best = -2;
+        }
+      }
+      if (best == -2) {
+      } else if (best >= 0) {
         f.bands_per_img = (L.OH + f.R - 1) / f.R;
         st.sel = Launch::SEL_STEM; st.shape = pl->n_phases;
       } else {
@@ -457,7 +477,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
-    if (L.pool_en) {
+    if (L.pool_en && !(l == 0 && stem_pool_fused)) {
       pool_step(l, tc, base + tc.offset, L.OH, L.OW);
     } else if (L.endpool) {
       Launch sa; sa.kind = Launch::AVG; sa.layer = l;

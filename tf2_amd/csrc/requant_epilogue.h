@@ -1,4 +1,4 @@
-// Shared epilogue arithmetic of the MFMA convolution kernels (conv_mfma2 / conv_mfma_sk / conv_mfma_ws).
+// Shared epilogue arithmetic of the MFMA convolution kernels (conv_mfma2 / conv_mfma_sk / conv_pw / conv_bneck / conv_stem).
 //
 // Reference semantics (device/src/pe.cl:191-194, relu.cl:54, feature_writer.cl:119-122), 32-bit truncation
 // and wrap-around kept:

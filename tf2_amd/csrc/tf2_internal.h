@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 26;
+constexpr uint32_t kPackVersion = 27;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -56,6 +56,10 @@ struct PackLayer {
   uint64_t off_dbl;      // uint8[Np]: 1 = this layer stores output channel n as 2y - 128 (0: no such channel)
   uint64_t off_pad;      // uint8[Cp_in + 16]: what an out-of-range tap reads (the stored form of x = 0: -128 on doubled input
                          // channels), 0: the zero page
+  uint64_t off_unit;     // conv_stem only, != 0: the layer's LOW exponent window is nothing but unit taps (+x << 0, the conv1
+                         // rewrite's memset rows, model_loader.cpp:244-257), the same (tap, channel) set in every output row:
+                         // int8[9][32] 0/1 mask; off_w2 then holds the HIGH window alone and the kernel adds the per-pixel sum
+                         // of the masked inputs to every channel's accumulator instead of sweeping a second window
 };
 
 struct PackHeader {
@@ -144,6 +148,7 @@ struct BneckArgs {
   int32_t B, H, W, R, tiles_per_img;     // R output rows per block, ceil(H / R) blocks per image
   int32_t dual1, fast1, relu1, dual2, fast2, relu2, add_relu, has_res, keep_mid;
   int32_t dbl_mid;           // the 3x3's output (the intermediate tile) has doubled channels
+  int32_t dbl_out;           // the expand's output has doubled channels (only without a residual: weight_pack.cpp)
   int32_t probe;             // timing probes (ConvGeom::flags of the pair; read by -DTF2_PROBES builds only)
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
 };
@@ -155,11 +160,19 @@ struct StemArgs {
   const int8_t* w;           // [window][tap][K half][64 rows][16] signed window values (weight_pack.cpp)
   const int32_t* hdr;        // the layer's header image; the first hdr_used bytes hold rows | lo | dshift
   const int8_t* zero;
+  const int8_t* unit;        // PackLayer::off_unit: int8[9][32] unit-tap mask (w then holds the high window alone), or null
   int32_t hdr_used;
   int32_t B, H, W, OH, OW;   // input and output maps (OH = H - 2, OW = W - 2)
   int32_t R, bands_per_img;  // output rows per block, ceil(OH / R) blocks per image
   int32_t relu, fast;
   int32_t y_cp, y_off, y_nvalid;
+  int32_t dbl_out;           // the output tensor has doubled channels (PackLayer::off_dbl; header rows carry the -128)
+  int32_t probe;             // timing probes (-DTF2_PROBES builds only)
+  long long* dbg2;           // optional: per-block {start, end, hw id, ...} stamps (tools/block_timeline.py), else null
+  // fused 3x3 / stride 2 / pad 1 max pool (conv_stem_pool_kernel; pool.cl:152-260 + pool_tail.cl:91-216 in the reference's pipeline):
+  int8_t* yp;                // pooled output tensor [B][PH][PW][yp_cp], or null (y then gets the conv map)
+  int32_t PH, PW, yp_cp, yp_off;
+  int32_t pk;                // pooled rows per block (2 * pk + 1 conv rows)
 };
 
 struct PoolArgs {
@@ -204,6 +217,7 @@ int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      //
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit
 size_t conv_stem_lds_bytes(int nwin, int R, int W, size_t hdr_used);
+size_t conv_stem_pool_lds_bytes(int pk, int W, int OW, size_t hdr_used);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
 int launch_prep_input(const PrepArgs& a, void* stream);

@@ -3,11 +3,21 @@
 // The reference re-lays filters for its PE array in FilterConvert
 // (host/src/model_loader.cpp:263-322); this is the MI355X counterpart.  Two layouts:
 //
-//  MFMA  (conv_mfma.hip)  A weight code is the integer +-2^s.  Per output channel n the
-//        shifts that occur are covered, from the largest down, by windows of 7 exponents
-//        [lo_p[n], lo_p[n]+6]; window p becomes an int8 matrix W_p[n][k] = +-2^(s-lo_p[n])
-//        (zero elsewhere).  sum_k x*2^s == sum_p (sum_k x*W_p) << lo_p[n] in Z/2^32, which
-//        the kernel evaluates Horner-style.  K is ordered (tap, physical channel) and cut
+//  MFMA  (conv_mfma2 / conv_mfma_sk / conv_pw / conv_bneck / conv_stem .hip)  A weight code is the integer +-2^s.  Per
+//        output channel n the shifts that occur are covered, from the largest down, by windows of 7 exponents
+//        [lo_p[n], lo_p[n]+6]; window p becomes an int8 matrix W_p[n][k] = +-2^(s-lo_p[n]) (zero elsewhere; |value| <= 64).
+//        WHY THIS IS EXACT.  The reference accumulates acc = bias + sum_k MUL(x_k, code_k) in a 32-bit int that wraps
+//        (pe.cl:43 "change from long int to int"), i.e. in the ring Z/2^32, where MUL is x * (+-2^s) with the shift done on
+//        32 bits (pe.cl:36-37).  In that ring multiplication by 2^a is a homomorphism of addition, so for any partition of
+//        the taps of row n into windows p with bases lo_p:
+//            sum_k x_k * (+-2^{s_k})  ==  sum_p ( sum_{k in p} x_k * (+-2^{s_k - lo_p}) ) << lo_p       (mod 2^32).
+//        The inner sums are what the int8 MFMA computes -- exactly, as integers: |x| <= 128, |W| <= 64, K <= 2^16 terms keep
+//        every partial sum below 2^31 in magnitude only when the true sum is; when it is not, the MFMA's int32 accumulator
+//        wraps mod 2^32 as well, and a wrapped inner sum shifted left by lo_p is still the right residue because
+//        (a mod 2^32) << lo == (a << lo) mod 2^32.  Evaluating the outer sum Horner-style, acc = (acc << (lo_{p-1} - lo_p))
+//        + inner_p, or keeping one accumulator per window and combining once ((hi << d) + lo, "dual" below) gives the same
+//        residue for the same reason.  The -128 negate quirk (pe.cl:32-37: (int8)(-x)) is not a ring identity and is handled
+//        separately: [x | xneg] input halves for image layers, the conv_stem correction term, the shift kernel elsewhere.  K is ordered (tap, physical channel) and cut
 //        into 64-byte slabs; only slabs with a non-zero weight inside an (m-tile, phase)
 //        are stored ("entries").  For image layers the input tensor is [x | xneg] and
 //        negative weights become positive magnitudes on the xneg half (pe.cl:32-37 quirk).
@@ -395,8 +405,24 @@ tf2_status Net::pack(int mode) {
       // The x = -128 correction is derived from these in the kernel.
       if (is_image && in_signed && il.Cp_in == 64 && il.half == 32 && k == 3 && L.stride == 1 && L.dil == 1 && (L.pad_h | L.pad_w) == 0 &&
           Np == 64 && TM == 64 && P <= 2 && C <= 32 && !L.endpool && getenv("TF2_AMD_NOSTEM") == nullptr) {
-        std::vector<int8_t> st((size_t)P * 9 * 64 * 32, 0);
-        for (int p = 0; p < P; p++)
+        // Is the low window nothing but the rewrite's unit taps?  (+x << 0 on the x half, identical positions in every row, window
+        // base 0.)  Then it contributes the SAME per-pixel sum to every output channel: conv_stem adds that sum instead of sweeping
+        // a second window (half the MFMAs and half the weight tile).  TF2_AMD_NOUNIT keeps the two-window form.
+        std::vector<int8_t> unit(9 * 32, 0);
+        bool unit_ok = P == 2 && getenv("TF2_AMD_NOUNIT") == nullptr;
+        for (int t = 0; t < 9 && unit_ok; t++)
+          for (int c = 0; c < 32 && unit_ok; c++) {
+            const int8_t v0 = W[((size_t)1 * Np + 0) * Kp + (size_t)t * 64 + c];
+            if (v0 != 0 && v0 != 1) unit_ok = false;
+            unit[t * 32 + c] = v0;
+            for (int r = 0; r < N && unit_ok; r++) {
+              if (W[((size_t)1 * Np + r) * Kp + (size_t)t * 64 + c] != v0 || W[((size_t)1 * Np + r) * Kp + (size_t)t * 64 + 32 + c] != 0) unit_ok = false;
+              if (lo[(size_t)1 * Np + r] != 0) unit_ok = false;
+            }
+          }
+        const int PS = unit_ok ? 1 : P;                      // windows in the stem image
+        std::vector<int8_t> st((size_t)PS * 9 * 64 * 32, 0);
+        for (int p = 0; p < PS; p++)
           for (int t = 0; t < 9; t++)
             for (int r = 0; r < 64; r++) {
               const int8_t* src = &W[((size_t)p * Np + r) * Kp + (size_t)t * 64];
@@ -405,6 +431,10 @@ tf2_status Net::pack(int mode) {
             }
         pl.off_w2 = blob.alloc(st.size());
         std::memcpy(blob.at<uint8_t>(pl.off_w2), st.data(), st.size());
+        if (unit_ok) {
+          pl.off_unit = blob.alloc(unit.size());
+          std::memcpy(blob.at<uint8_t>(pl.off_unit), unit.data(), unit.size());
+        }
       }
       pl.off_w = blob.alloc(std::max<size_t>(tiles.size(), 64));
       std::memcpy(blob.at<uint8_t>(pl.off_w), tiles.data(), tiles.size());

@@ -57,38 +57,49 @@ def prior_boxes(cfg: dict = VOC):
 
 
 def decode(loc, priors, variances: Sequence[float]):
-    """box_utils.py:140-158: offsets + centre-form priors -> corner-form boxes."""
+    """Regression offsets -> boxes (semantics of box_utils.py:140-158).  A prior is (cx, cy, w, h); the network predicts the
+    centre shift in units of variance[0] * prior size and the log of the size ratio in units of variance[1]:
+        centre = prior_centre + t_xy * v0 * prior_wh,   size = prior_wh * exp(t_wh * v1),
+    returned in corner form (centre -+ size / 2)."""
     import torch
-    boxes = torch.cat((priors[:, :2] + loc[:, :2] * variances[0] * priors[:, 2:],
-                       priors[:, 2:] * torch.exp(loc[:, 2:] * variances[1])), 1)
-    boxes[:, :2] -= boxes[:, 2:] / 2
-    boxes[:, 2:] += boxes[:, :2]
-    return boxes
+    v_centre, v_size = float(variances[0]), float(variances[1])
+    p_centre, p_size = priors[:, :2], priors[:, 2:]
+    centre = p_centre + loc[:, :2] * v_centre * p_size
+    size = p_size * torch.exp(loc[:, 2:] * v_size)
+    top_left = centre - size / 2
+    return torch.cat((top_left, top_left + size), 1)      # x2 = x1 + w: the reference's own rounding of the far corner
+
+
+def _iou_one_to_many(box, area_box, others, area_others):
+    """IoU of one corner-form box with each row of `others`."""
+    import torch
+    lo = torch.maximum(others[:, :2], box[:2])
+    hi = torch.minimum(others[:, 2:], box[2:])
+    wh = (hi - lo).clamp(min=0.0)
+    inter = wh[:, 0] * wh[:, 1]
+    return inter / ((area_others - inter) + area_box)
 
 
 def nms(boxes, scores, overlap: float = 0.5, top_k: int = 200):
-    """box_utils.py:175-239: indices of the kept boxes, best first; only the top_k scores are considered; a box
-    survives a kept one when IoU <= overlap."""
+    """Greedy non-maximum suppression (semantics of box_utils.py:175-239): among the top_k highest scores, repeatedly keep the best
+    remaining box and drop every remaining box whose IoU with it exceeds `overlap` (IoU <= overlap survives).  Returns the kept
+    indices, best first.  Candidates are walked in ascending-score order from the back, as the reference's sort leaves them,
+    so ties resolve the same way."""
     import torch
     if boxes.numel() == 0:
         return torch.zeros(0, dtype=torch.long, device=boxes.device)
-    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
-    area = (x2 - x1) * (y2 - y1)
-    _, idx = scores.sort(0)
-    idx = idx[-top_k:]
-    keep: List[int] = []
-    while idx.numel() > 0:
-        i = idx[-1]
-        keep.append(int(i))
-        if idx.numel() == 1:
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    order = scores.sort(0).indices[-top_k:]                # ascending; the best candidate is the last element
+    kept: List[int] = []
+    while order.numel() > 0:
+        best = order[-1]
+        kept.append(int(best))
+        order = order[:-1]
+        if order.numel() == 0:
             break
-        idx = idx[:-1]
-        xx1 = torch.clamp(x1[idx], min=float(x1[i])); yy1 = torch.clamp(y1[idx], min=float(y1[i]))
-        xx2 = torch.clamp(x2[idx], max=float(x2[i])); yy2 = torch.clamp(y2[idx], max=float(y2[i]))
-        inter = torch.clamp(xx2 - xx1, min=0.0) * torch.clamp(yy2 - yy1, min=0.0)
-        union = (area[idx] - inter) + area[i]
-        idx = idx[(inter / union).le(overlap)]
-    return torch.tensor(keep, dtype=torch.long, device=boxes.device)
+        iou = _iou_one_to_many(boxes[best], area[best], boxes[order], area[order])
+        order = order[iou <= overlap]
+    return torch.tensor(kept, dtype=torch.long, device=boxes.device)
 
 
 def l2norm(x, weight, eps: float = 1e-10):
@@ -99,23 +110,24 @@ def l2norm(x, weight, eps: float = 1e-10):
 
 def detect(loc, conf, priors, num_classes: int, top_k: int = 200, conf_thresh: float = 0.01, nms_thresh: float = 0.45,
            variance: Sequence[float] = (0.1, 0.2)):
-    """detection.py:27-62: loc [B, P, 4], conf [B, P, num_classes] (already softmaxed) -> [B, num_classes, top_k, 5]
-    rows (score, x1, y1, x2, y2), class 0 = background left empty."""
+    """Per-image, per-class detection list (semantics of detection.py:27-62).  loc [B, P, 4] offsets, conf [B, P, classes]
+    class probabilities -> [B, classes, top_k, 5] rows (score, x1, y1, x2, y2); class 0 is background and stays empty; unused
+    rows are zero.  For every foreground class: candidates above conf_thresh, decoded boxes, NMS, best first."""
     import torch
-    num = loc.size(0)
-    output = torch.zeros(num, num_classes, top_k, 5, device=loc.device)
-    conf_preds = conf.transpose(2, 1)
-    for i in range(num):
-        decoded = decode(loc[i], priors, variance)
-        for cl in range(1, num_classes):
-            c_mask = conf_preds[i, cl].gt(conf_thresh)
-            scores = conf_preds[i, cl][c_mask]
-            if scores.numel() == 0:
+    n_img = loc.size(0)
+    result = torch.zeros(n_img, num_classes, top_k, 5, device=loc.device)
+    for b in range(n_img):
+        boxes_b = decode(loc[b], priors, variance)
+        for cls in range(1, num_classes):
+            p = conf[b, :, cls]
+            sel = p > conf_thresh
+            if not bool(sel.any()):
                 continue
-            boxes = decoded[c_mask]
-            ids = nms(boxes, scores, nms_thresh, top_k)
-            output[i, cl, :ids.numel()] = torch.cat((scores[ids].unsqueeze(1), boxes[ids]), 1)
-    return output
+            cand_scores, cand_boxes = p[sel], boxes_b[sel]
+            keep = nms(cand_boxes, cand_scores, nms_thresh, top_k)
+            result[b, cls, :keep.numel(), 0] = cand_scores[keep]
+            result[b, cls, :keep.numel(), 1:] = cand_boxes[keep]
+    return result
 
 
 def head_rows(plan) -> List[Tuple[int, int]]:

@@ -44,13 +44,29 @@ n = len(plan); ms = np.zeros(n, np.float32); nl = np.zeros(n, np.int32); kd = np
 _lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kd.ctypes.data, n))
 ms /= np.maximum(nl, 1)
 rows = []
+# table rows computed by another row's launch (conv_bneck pairs), from the library's own launch list
+launches = net.describe_launches(a.batch, 0)
+own = {l["layer"] for l in launches}
+grid_of = {}
+for l in launches:
+    if "conv_" in l["kernel"]: grid_of.setdefault(l["layer"], l["grid"])
+fused_into = {i: max(j for j in own if j < i) for i in range(n) if i not in own}
 print(f"{'l':>2} {'k':>1} {'C':>4} {'N':>4} {'HW':>3} s P  ent/mt blocks   us     TOPS   GB/s")
 for i, L in enumerate(plan):
     pl = pls[i]
+    if i in fused_into:
+        rows.append(dict(layer=i, k=L.k, C=L.C, N=L.N, HW=L.OH, stride=L.stride, fused_into=fused_into[i], us=0.0))
+        print(f"{i:>2} {L.k} {L.C:>4} {L.N:>4} {L.OH:>3} {L.stride}  (computed by the launch of layer {fused_into[i]}: its time, ops and bytes are on that row)")
+        continue
+    fused = [j for j, f in fused_into.items() if f == i]
     ops = 2 * L.N * L.C * L.k * L.k * L.OH * L.OW * a.batch
     byts = (L.C * L.H * L.W + L.N * L.PH * L.PW * (2 if L.add_src >= 0 else 1)) * a.batch
+    for j in fused:                      # a fused launch: both rows' ops; the intermediate tensor never reaches HBM
+        F = plan[j]
+        ops += 2 * F.N * F.C * F.k * F.k * F.OH * F.OW * a.batch
+        byts += (F.N * F.PH * F.PW * (2 if F.add_src >= 0 else 1) - L.N * L.PH * L.PW) * a.batch
     TM = int(pl["TM"]); npix = a.batch * L.OH * L.OW
-    blocks = int(pl["n_mtiles"]) * (-(-npix // (128 if TM == 128 else 256))) if int(pl["kind"]) == 1 else 0
+    blocks = grid_of.get(i, 0)          # the launch's actual grid
     ent = int(pl["n_entries"]) / max(1, int(pl["n_mtiles"]))
     us = max(ms[i] * 1e3, 1e-9)
     rows.append(dict(layer=i, k=L.k, C=L.C, N=L.N, HW=L.OH, stride=L.stride, phases=int(pl["n_phases"]), entries_per_mtile=ent,

@@ -6,7 +6,7 @@ gfx950 -- validated here against layers whose byte count is known), wave cycles 
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_pmc_conv_b32.json")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_pmc_conv_b32.json")
 
 def table(d):
     f = glob.glob(f"{src}/{d}/runc/*_counter_collection.csv")[0]
@@ -16,28 +16,32 @@ def table(d):
         e[x["Counter_Name"]] = float(x["Counter_Value"])
     return [v for v in disp.values() if "tf2::conv_" in v["kernel"]]
 
-# conv launches of ONE step in launch order -> table rows (layers); a conv_bneck launch computes two layers (the 3x3 and the
-# 1x1 expand behind it): its counters go to the first, the second gets an all-zero row with fused_into set
+# conv launches of ONE step in launch order -> table rows (layers).  The launch list is the library's own
+# (tf2_net_describe_launches: tile shapes, fused pairs, split-K variants are decided in one place); a conv_bneck launch computes
+# two layers (the 3x3 and the 1x1 expand behind it): its counters go to the first, the second gets an all-zero row.
 sys.path.insert(0, ROOT)
 import numpy as np
 from tf2_amd import config as cfg, network, synth
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import emu_packed as emu
 _t = cfg.resnet50_tables()
 _q = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 _net = network.NetWork(_t); _net.Quantization(synth.q_text(_q)); _net.LoadModel(synth.synth_model(_t, _q, 0)); _net.Pack(0)
-_, _pls = emu.parse(_net.packed_host())
 B = int(os.environ.get("PMC_BATCH", "32"))
 _plan = cfg.build_plan(_t)
+_launches = [l for l in _net.describe_launches(B, 0) if "conv_" in l["kernel"]]
+launch_layers = [l["layer"] for l in _launches]
 fused_into = {}
-for i, (L, pl) in enumerate(zip(_plan, _pls)):
-    fn = int(pl["fuse_next"])
-    TN = 256 if int(pl["TM"]) == 64 else 128
-    if fn > 0 and B * -(-L.H // max(1, min(TN // L.W, L.H))) >= 256:
-        fused_into[fn] = i
-launch_layers = [i for i in range(len(_plan)) if i not in fused_into]
+for k, l in enumerate(_launches):
+    if "conv_bneck" in l["kernel"]:
+        nxt = launch_layers[k + 1] if k + 1 < len(launch_layers) else len(_plan)
+        for j in range(l["layer"] + 1, nxt):
+            fused_into[j] = l["layer"]
 n = len(launch_layers)
 sq1, sq2, t1, t2 = (table(d)[-n:] for d in ("sq1", "sq2", "tcc1", "tcc2"))
+for k, l in enumerate(_launches):          # the profiler's rows are the launch plan's rows, kernel by kernel
+    base = l["kernel"].split("<")[0]
+    for tb in (sq1, sq2, t1, t2):
+        assert base in tb[k]["kernel"], (k, l, tb[k]["kernel"])
+assert "conv_stem" in sq1[0]["kernel"]
 rows = [None] * len(_plan)
 for i in fused_into:
     rows[i] = dict(layer=i, kernel="(computed by the conv_bneck launch of layer %d)" % fused_into[i], fused_into=fused_into[i], grid_threads=0, vgpr=0,

@@ -18,6 +18,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--inflight-steps", type=int, default=60)
 ap.add_argument("--out", default=None)
+ap.add_argument("--last-layer", type=int, default=53, help="print per-layer rows up to this layer")
 a = ap.parse_args()
 
 PROBES = [("base", 0), ("noB", 8), ("noA", 16), ("noAB", 24), ("noMFMA", 32), ("noEpi", 64), ("noBar", 256),
@@ -87,9 +88,11 @@ for name, bits in PROBES:
 
 print("\nper layer, one batch at a time (us): " + " ".join(f"{p[0]:>9}" for p in PROBES))
 for i, L in enumerate(plan):
+    if i > a.last_layer: break
     print(f"{i:>2} k{L.k} C{L.C:<4} N{L.N:<4} {L.OH:>3}^2 s{L.stride} " + " ".join(f"{res[p[0]]['serial_us'][i]:9.1f}" for p in PROBES))
 print("\nper layer, the several-streams launch plan on one stream (us): " + " ".join(f"{p[0]:>9}" for p in PROBES))
 for i, L in enumerate(plan):
+    if i > a.last_layer: break
     print(f"{i:>2} k{L.k} C{L.C:<4} N{L.N:<4} {L.OH:>3}^2 s{L.stride} " + " ".join(f"{res[p[0]]['conc_plan_us'][i]:9.1f}" for p in PROBES))
 if a.out:
     json.dump(res, open(a.out, "w"))

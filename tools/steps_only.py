@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""N steps of ResNet50 at one batch size, one batch at a time on one stream, and nothing else (no latency leg, no sweep, no
+event records): the workload rocprofv3 --kernel-trace --stats and the --pmc passes are run on (tools/round_evidence.sh), so
+that every row of their per-kernel tables is this configuration only."""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from tf2_amd import config as cfg, network, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--warmup", type=int, default=0, help="untimed steps are kernels too: keep 0 for profiles, the summary divides by --steps")
+ap.add_argument("--conc", type=int, default=0, help="launch plan: 0 one batch at a time, 1 the several-batches-in-flight choice")
+ap.add_argument("--meta", default=None, help="write {batch, steps, launches} here")
+a = ap.parse_args()
+t = cfg.resnet50_tables()
+qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
+net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device="cuda:0")
+r = network.Runner(None, net)
+x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
+for _ in range(a.warmup + a.steps):
+    r.run_batch(x, concurrency=a.conc)
+torch.cuda.synchronize()
+if a.meta:
+    json.dump(dict(batch=a.batch, steps=a.warmup + a.steps, conc=a.conc, launches=net.describe_launches(a.batch, a.conc)), open(a.meta, "w"), indent=0)
