@@ -182,18 +182,26 @@ def conv_stem_from_packed(blob, pl, L, x_nchw):
     correction -2 * w * x128 for the negative weights derived from the same tiles (|w| of the negative bytes, twice)."""
     assert int(pl["kind"]) == 1 and int(pl["off_w2"]) != 0 and int(pl["Np"]) == 64 and L.k == 3
     P = int(pl["n_phases"])
+    unit = None
+    PS = P
+    if int(pl["off_unit"]):
+        # the low window is the unit-tap mask: the stem image holds the high window alone (weight_pack.cpp off_unit)
+        assert P == 2
+        unit = np.frombuffer(blob[int(pl["off_unit"]):int(pl["off_unit"]) + 9 * 32].tobytes(), np.int8).reshape(9, 32).astype(np.int64)
+        assert set(np.unique(unit).tolist()) <= {0, 1}
+        PS = 1
     B, C, H, W = x_nchw.shape
     N, OH, OW = L.N, L.OH, L.OW
     assert OH == H - 2 and OW == W - 2 and C <= 32
-    st = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + P * 9 * 64 * 32].tobytes(), np.int8).reshape(P, 9, 2, 64, 16)
-    w = np.ascontiguousarray(st.transpose(0, 1, 3, 2, 4)).reshape(P, 9, 64, 32).astype(np.int64)
+    st = np.frombuffer(blob[int(pl["off_w2"]):int(pl["off_w2"]) + PS * 9 * 64 * 32].tobytes(), np.int8).reshape(PS, 9, 2, 64, 16)
+    w = np.ascontiguousarray(st.transpose(0, 1, 3, 2, 4)).reshape(PS, 9, 64, 32).astype(np.int64)
     negmag = np.where(w < 0, -w, 0)
     x_t = np.zeros((B, H, W, 32), np.int64)
     x_t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))
     x128 = np.where(x_t == -128, -128, 0)
     npix = B * OH * OW
     win = []
-    for p in range(P):
+    for p in range(PS):
         a = np.zeros((64, npix), np.int64)
         for t in range(9):
             dh, dw = divmod(t, 3)
@@ -201,6 +209,12 @@ def conv_stem_from_packed(blob, pl, L, x_nchw):
             qs = x128[:, dh:dh + OH, dw:dw + OW, :].reshape(npix, 32)
             a += w[p, t] @ xs.T + 2 * (negmag[p, t] @ qs.T)
         win.append(a % 2 ** 32)
+    if unit is not None:                 # S(pixel): the masked inputs' sum, the same for every output row (conv_stem.hip UNIT)
+        s_px = np.zeros(npix, np.int64)
+        for t in range(9):
+            dh, dw = divmod(t, 3)
+            s_px += x_t[:, dh:dh + OH, dw:dw + OW, :].reshape(npix, 32) @ unit[t]
+        win.append(np.broadcast_to(s_px[None, :] % 2 ** 32, (64, npix)))
     bias = i32(blob, int(pl["off_bias"]), 64).astype(np.int64)
     alpha = i32(blob, int(pl["off_alpha"]), 64)
     beta = i32(blob, int(pl["off_beta"]), 64)
