@@ -42,8 +42,14 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 // twice as many waves on the chip and every wave walks half as many K steps; waves 0-3 run the epilogue.
 // DENSE (ConvArgs::dense, see conv_mfma2.hip): gather words from the slab index, entry range from the kernel arguments -- the
 // activation DMAs of the first stages go out together with the weight DMAs instead of behind the header's landing.
-template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
+// AVG (ConvGeom::avg_mult != 0, four waves): the layer ends in the reference's full_size_pool stage (full_size_pool.cl:95-125:
+// int16 sum over the map, x 669 >> 14, round, clamp).  A pixel tile is then ONE image's OHW <= 64 pixels (columns beyond
+// OHW are dead), the requantised + residual-added outputs are summed over the valid pixels in the wave (__shfl_xor over the 32
+// lanes of a half), the two pixel halves meet in LDS, and the block stores its 64 averaged channels of that image -- the conv
+// map itself never reaches memory and the global_avg_kernel launch disappears.
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
+  static_assert(!AVG || NWV == 4, "the fused global average runs with four waves");
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
   constexpr int AI = 4, BI = 4, NI = 8;        // LDS-DMA instructions per wave per stage
@@ -73,7 +79,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   }
   const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
   const int mtile = bid - ntile * a_n_mtiles;
-  const int px0 = ntile * TN;
+  const int px0 = AVG ? ntile * g.OHW : ntile * TN;           // AVG: tile = image `ntile`, local pixels 0 .. OHW - 1
+  const int px_end = AVG ? px0 + g.OHW : g.n_pix;             // first pixel this tile must not touch
   // this m-tile's {first, end} entry: the last two words of steps[] in its header image (weight_pack.cpp)
   typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
   int e_begin, n_ent;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 #pragma unroll
   for (int j = 0; j < BI; j++) {
     const int p = px0 + j * 16 + (lane >> 2);
-    if (p < g.n_pix) {
+    if (p < px_end) {
       const int b = fast_div(p, g.ohw_m, g.ohw_s);
       const int rem = p - b * g.OHW;
       const int oh = fast_div(rem, g.ow_m, g.ow_s);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   if (g.has_res && wave < 4) {
     const int px = px0 + tj * 32 + (lane & 31);
     const int chl = mtile * TM + ti * 32 + 16 * half;
-    const bool ok = px < g.n_pix && chl + 16 <= g.y_nvalid;
+    const bool ok = px < px_end && chl + 16 <= g.y_nvalid;
     const int8_t* rp = ok ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
     resv = *reinterpret_cast<const i32x4*>(rp);
   }
@@ -328,6 +335,37 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
                        : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
   const int chl = tile_ch + 16 * half;
+  if (AVG) {
+    // per-channel sum of this wave's 32 pixel columns (dead columns count 0), then over the two pixel halves of the tile
+    int sum16[16];
+    const bool live = px < px_end;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      int v = live ? (int)(signed char)(((unsigned)out[q >> 2] >> (8 * (q & 3))) & 0xff) : 0;
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);      // lanes 0-31 and 32-63 reduce separately (m < 32)
+      sum16[q] = v;
+    }
+    int* const xch = reinterpret_cast<int*>(lds);              // [ti][half][16] partial sums of the tj = 1 waves (rings are dead)
+    __syncthreads();                                           // every wave has read its reduction operands
+    if (tj == 1 && (lane & 31) == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) xch[(ti * 2 + half) * 16 + q] = sum16[q];
+    }
+    __syncthreads();
+    if (tj == 0 && (lane & 31) == 0 && chl + 16 <= g.y_nvalid) {
+      unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int sv = (int)(short)(sum16[q] + xch[(ti * 2 + half) * 16 + q]);     // Sreal: int16 accumulator wrap (types.h:30)
+        int m = (((sv * g.avg_mult) >> 14) + 1) >> 1;                                // full_size_pool.cl:115-118
+        m = m > 127 ? 127 : (m < -128 ? -128 : m);
+        o[q >> 2] |= (unsigned)(m & 0xff) << (8 * (q & 3));
+      }
+      *reinterpret_cast<i32x4*>(ay + (size_t)ntile * g.y_cp + g.y_off + chl) = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    }
+    return;
+  }
   if (px < g.n_pix && chl + 16 <= g.y_nvalid)
     *reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl) = out;
   else if (px < g.n_pix && g.y_tail == 8 && chl == g.y_nvalid) {
@@ -336,17 +374,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   }
 }
 
-template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
-static int launch_sk3(const ConvArgs& a, hipStream_t s) {
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
+static int launch_sk4(const ConvArgs& a, hipStream_t s) {
   constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV, DENSE>;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV, DENSE, AVG>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
-  const int ntiles = (a.g.n_pix + 63) / 64;
-  TF2_LAUNCH_NAME("conv_mfma_sk_kernel<S%d,%s%s%d waves,%s>", S, PADCHK ? "pad," : "", DUAL ? "dual," : "", NWV, DENSE ? "dense" : "tables");
+  const int ntiles = AVG ? a.g.n_pix / a.g.OHW : (a.g.n_pix + 63) / 64;
+  TF2_LAUNCH_NAME("conv_mfma_sk_kernel<S%d,%s%s%d waves,%s%s>", S, PADCHK ? "pad," : "", DUAL ? "dual," : "", NWV, AVG ? "global average," : "", DENSE ? "dense" : "tables");
   TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles), dim3(NWV * 64), lds, s, a);
   return launch_ok() ? 0 : -1;
+}
+
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
+static int launch_sk3(const ConvArgs& a, hipStream_t s) {
+  if constexpr (NWV == 4 && S == 2 && !PADCHK) { if (a.g.avg_mult) return launch_sk4<S, PADCHK, DUAL, NWV, DENSE, true>(a, s); }
+  if (a.g.avg_mult) return -1;                       // the fused average exists for the unpadded two-stage four-wave shape only
+  return launch_sk4<S, PADCHK, DUAL, NWV, DENSE, false>(a, s);
 }
 
 template <int S, bool PADCHK, bool DUAL, int NWV>
@@ -359,6 +404,10 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
   const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
+  if (a.g.avg_mult) {                                 // global average fused (net.hip checked: 1x1-style unpadded layer, OHW <= 64)
+    if (pad) return -1;
+    return a.dual ? launch_sk2<2, false, true, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
+  }
   // 8-way split only for grids far below one block per CU (7x7 maps at batch 32: measured 16.0 -> 14.7 us) -- at 392
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
   const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);

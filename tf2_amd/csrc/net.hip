@@ -238,7 +238,8 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
+  if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
+  if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
   if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
   if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
@@ -303,7 +304,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     // other batches' kernels fill the chip, so the wide form pays from a much smaller grid on.
     // The reverse on the 28x28 maps: their 128-row layers have a 64-row alternative (more blocks, split-K) for grids of a few
     // blocks (batch 1-2).
-    const PackLayer* pa = allow_alt ? pack_layer_alt(l) : nullptr;
+    const PackLayer* pa = (allow_alt && !(L.endpool && opts.avg_fuse && pl->TM == 64)) ? pack_layer_alt(l) : nullptr;   // (the fused global average runs on the 64-row tiles)
     if (pa) {
       const long blocks128 = ((long)batch * L.OH * L.OW + 127) / 128 * (pa->Np / 128);
       if (pa->TM == 128) { if (blocks128 >= (concurrent ? opts.alt_min_blocks_conc : opts.alt_min_blocks)) pl = pa; }
@@ -364,6 +365,13 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const bool sk = pl->TM == 64 && opts.sk_mode != 2 &&
                       (opts.sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
       st.sel = sk ? Launch::SEL_SK : Launch::SEL_MFMA2;
+      // the layer's global average inside the launch (conv_mfma_sk AVG): 64-row tiles, one image per pixel tile
+      if (opts.avg_fuse && L.endpool && !L.pool_en && pl->TM == 64 && g.OHW <= 64 && (g.pad_h | g.pad_w) == 0 && L.concat < 0 &&
+          E.conv_tensor != E.out_tensor && !g.dbl_out && g.n_pix == batch * g.OHW) {
+        const TensorPlan& to = T(E.out_tensor);
+        ca.y = base + to.offset; g.y_cp = to.Cp; g.y_off = E.out_off; g.avg_mult = L.endpool_mult;
+        st.sel = Launch::SEL_SK; st.avg_fused = 1;
+      } else
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
       if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
     } else if (pl->kind == KIND_SHIFT) {
@@ -479,7 +487,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en && !(l == 0 && stem_pool_fused)) {
       pool_step(l, tc, base + tc.offset, L.OH, L.OW);
-    } else if (L.endpool) {
+    } else if (L.endpool && !st.avg_fused) {
       Launch sa; sa.kind = Launch::AVG; sa.layer = l;
       AvgArgs& aa = sa.avg;
       const TensorPlan& to = T(E.out_tensor);

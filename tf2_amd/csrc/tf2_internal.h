@@ -87,6 +87,8 @@ struct ConvGeom {
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
   int32_t flags;             // bits 1,2: conv_mfma2 block-shape A/B switches (TF2_AMD_EXP)
   int32_t dbl_out;           // the output tensor has doubled channels (PackLayer::off_dbl): header word 0 of a row = -128 or 0
+  int32_t avg_mult;          // conv_mfma_sk AVG: != 0 -> the layer's global average (full_size_pool.cl) is computed in the launch:
+                             // y / y_cp / y_off then describe the AVERAGED tensor [batch][y_cp], one pixel tile = one image
 };
 
 // n / d for 0 <= n < 2^31 as one 32x32->hi multiply and a shift: L = ceil(log2 d), m = floor(2^(31+L) / d) + 1,
