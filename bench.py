@@ -104,6 +104,9 @@ def main():
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
+    ap.add_argument("--partition", type=int, default=1,
+                    help="1: every in-flight stream gets its own XCDs (hipExtStreamCreateWithCUMask, tf2_amd/streams.py) when the number of "
+                         "batches in flight divides 8; 0: plain streams")
     ap.add_argument("--stagger-layer", type=int, default=-1,
                     help=">= 0: stage-interlocked pipelining of the batches in flight -- step k+1's stream waits (hipStreamWaitEvent) for an "
                          "event that step k's run records once its layers 0..L are enqueued (tf2_net_run_ex mark_event), so a batch "
@@ -161,7 +164,17 @@ def main():
         torch.cuda.synchronize(device)
 
     n_inflight = max(1, args.inflight)
-    fl_streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)] if n_inflight > 1 else []
+    fl_streams, partitioned = [], False
+    if n_inflight > 1:
+        if args.partition and 8 % n_inflight == 0:
+            try:
+                from tf2_amd import streams as tstreams
+                fl_streams = tstreams.partitioned_streams(n_inflight, device)
+                partitioned = True
+            except (OSError, RuntimeError, AttributeError) as e:
+                print(f"bench.py: XCD-partitioned streams unavailable ({e}); plain streams", file=sys.stderr)
+        if not fl_streams:
+            fl_streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)]
     fl_runners = [network.Runner(None, net) for _ in range(n_inflight)] if n_inflight > 1 else []
     step_no = [0]
     graphs = {}
@@ -191,7 +204,7 @@ def main():
                     one(fl_runners[i], x, concurrency=1, mark=(ev, args.stagger_layer))
                     prev_mark[0] = ev
                 else:
-                    one(fl_runners[i], x)
+                    one(fl_runners[i], x, concurrency=1)      # the caller's own statement: other batches are in flight
             return
         if args.graph:
             key = (x.data_ptr(), x.shape[0])
@@ -416,7 +429,8 @@ def main():
                                          f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
                                 sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph),
-                                stage_interlock_layer=(args.stagger_layer if stagger else None)),
+                                stage_interlock_layer=(args.stagger_layer if stagger else None),
+                                xcd_partitions=(n_inflight if partitioned else None)),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

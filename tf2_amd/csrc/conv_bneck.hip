@@ -46,6 +46,9 @@ __device__ __forceinline__ void bn_static_for(F& fn) {
 }
 
 constexpr int kBneckPasses = 4;
+#ifndef TF2_BNECK_PF
+#define TF2_BNECK_PF 1          // weight-fragment prefetch distance (1 or 2 steps)
+#endif
 
 // WM x WN = 8 waves, wave tile 32 x (32 * NTN): TM = 32 * WM channels of the 3x3 (= K of the expand), TN = 32 * NTN * WN pixels.
 template <int WM, int WN, int NTN, bool DUAL1, bool DUAL2>
@@ -151,8 +154,10 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     const int8_t* p = a.w2 + (size_t)(mt * NSL + sl) * A2_BYTES + win * (TM * 64) + a_row_off;
     f.k[0] = *reinterpret_cast<const i32x4*>(p); f.k[1] = *reinterpret_cast<const i32x4*>(p + 32);
   };
-  Afr f0, f1;
+  Afr f0, f1, f2;                                        // weight fragments: two steps ahead of the MFMAs (PF = 2)
+  constexpr int PF = TF2_BNECK_PF;
   load_a1(f0, 0);
+  if (PF == 2 && NW1 * NE1 > 1) load_a1(f1, 1);
 
   i32x16 acc[NTN];
 #pragma unroll
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   auto step1 = [&](auto v_c) {
     constexpr int v = decltype(v_c)::value;
     constexpr int win = v / NE1, e = v % NE1, t = e / NSL, s = e % NSL;
-    Afr& cur = (v & 1) ? f1 : f0;
-    Afr& nxt = (v & 1) ? f0 : f1;
-    if (v + 1 < NW1 * NE1 && !(prb & kProbeNoA)) load_a1(nxt, v + 1);
+    Afr& cur = PF == 2 ? (v % 3 == 0 ? f0 : v % 3 == 1 ? f1 : f2) : ((v & 1) ? f1 : f0);
+    Afr& nxt = PF == 2 ? ((v + 2) % 3 == 0 ? f0 : (v + 2) % 3 == 1 ? f1 : f2) : ((v & 1) ? f0 : f1);
+    if (v + PF < NW1 * NE1 && !(prb & kProbeNoA)) load_a1(nxt, v + PF);
     if (win == 1 && e == 0) window_shift(prm1 + kPrmWordsPerRow * TM);
     const int8_t* B = mid1 + s * slabb;
     int ba[NTN];
@@ -203,9 +208,12 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   };
   bn_static_for<0, NW1 * NE1>(step1);
   // the expand's first weight fragments and the first residual tile are on their way while the 3x3 is requantised
-  Afr& g0 = ((NW1 * NE1) & 1) ? f1 : f0;
-  Afr& g1 = ((NW1 * NE1) & 1) ? f0 : f1;
+  // phase 2 rotates the same three buffers from index 0 again (phase 1 has consumed all of its fragments)
+  Afr& g0 = f0;
+  Afr& g1 = f1;
+  Afr& g2 = f2;
   load_a2(g0, 0, 0);
+  if (PF == 2 && kBneckPasses * (NW2 * NSL) > 1) load_a2(g1, 1 / (NW2 * NSL), 1 % (NW2 * NSL));
   i32x4 res0[NTN], res1[NTN];
   load_res(res0, 0);
 
@@ -252,9 +260,9 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   auto step2 = [&](auto u_c) {
     constexpr int u = decltype(u_c)::value;
     constexpr int mt = u / NV2, v = u % NV2, win = v / NSL, s = v % NSL;
-    Afr& cur = (u & 1) ? g1 : g0;
-    Afr& nxt = (u & 1) ? g0 : g1;
-    if (u + 1 < kBneckPasses * NV2 && !(prb & kProbeNoA)) load_a2(nxt, (u + 1) / NV2, (u + 1) % NV2);
+    Afr& cur = PF == 2 ? (u % 3 == 0 ? g0 : u % 3 == 1 ? g1 : g2) : ((u & 1) ? g1 : g0);
+    Afr& nxt = PF == 2 ? ((u + 2) % 3 == 0 ? g0 : (u + 2) % 3 == 1 ? g1 : g2) : ((u & 1) ? g0 : g1);
+    if (u + PF < kBneckPasses * NV2 && !(prb & kProbeNoA)) load_a2(nxt, (u + PF) / NV2, (u + PF) % NV2);
     if (v == 0 && mt + 1 < kBneckPasses) { if (mt & 1) load_res(res0, mt + 1); else load_res(res1, mt + 1); }
     if (win == 1 && s == 0) window_shift(reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(prm2) + (size_t)mt * a.hdr2_used) + kPrmWordsPerRow * TM);
     const int8_t* B = mid2 + s * (TN * 64);

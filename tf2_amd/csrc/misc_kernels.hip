@@ -6,6 +6,7 @@
 //   global_avg : full_size_pool.cl:95-125.
 // All are one pass over their tensors with 16-byte (pool) or coalesced accesses.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "tf2_internal.h"
 #include "tf2_device.h"
 
@@ -156,6 +157,73 @@ __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
   }
 }
 
+// The x-only space-to-depth input of conv_stem.hip, every image element quantised ONCE.  prep_rewrite3_kernel gathers 27 source
+// values per output pixel straight from global memory (each image element is fetched and quantised 2.3 times, scalar loads);
+// here a block owns two output rows of one image: the five image rows they look at (3 channels x 224 floats each) come in with
+// coalesced 16-byte loads, are quantised (runner.cpp:158-163) into an int8 LDS tile with the zero border of the pad-3 image
+// (input_loader.cpp:36-72), and every thread then assembles one output pixel's 27 bytes from LDS and stores its 32 bytes.
+// Same bytes as prep_rewrite3_kernel<*, true> (tests/test_gpu_parity.py checks the network input tensor).
+template <bool SRC_Q>
+__global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
+  constexpr int kPadL = 4, kMaxW = 256;                    // image width <= 248 (launcher-checked); 4 border columns: aligned word stores
+  __shared__ __attribute__((aligned(16))) int8_t img[3][5][kMaxW + 8];
+  const int rows_per_img = (a.OH + 1) / 2;
+  const int b = blockIdx.x / rows_per_img;
+  const int oh0 = (blockIdx.x - b * rows_per_img) * 2;
+  const int r_first = 2 * oh0 - 3;                         // image row of tile row 0
+  const int tid = threadIdx.x;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  // zero the borders (image columns -4..-1 and W..W+3 of every tile row)
+  for (int i = tid; i < 15 * 8; i += 256) {
+    const int rr = i >> 3, k = i & 7;
+    img[rr / 5][rr % 5][k < kPadL ? k : kPadL + a.W + (k - kPadL)] = 0;
+  }
+  // 15 (channel, row) lines of W elements, 4 elements per thread and pass
+  const int w4 = a.W >> 2;                                 // W % 4 == 0 (launcher-checked)
+  for (int i = tid; i < 15 * w4; i += 256) {
+    const int line = i / w4, x4 = i - line * w4;
+    const int ci = line / 5, rr = line - ci * 5;
+    const int sr = r_first + rr;
+    int q[4] = {0, 0, 0, 0};
+    if ((unsigned)sr < (unsigned)a.H) {
+      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x4 * 4;
+      if (SRC_Q) {
+        const int v = *reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = (int)(signed char)((v >> (8 * j)) & 0xff);
+      } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = quant_input(v[j], trans);
+      }
+    }
+    *reinterpret_cast<unsigned*>(&img[ci][rr][kPadL + x4 * 4]) =
+        (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+  }
+  __syncthreads();
+  // one thread per output pixel: sub-channel k of image channel ci = pad3[2 oh + roff][2 ow + coff] (feature_trans)
+  const int rsel = tid / a.OW;                             // 0 or 1: which of the block's two output rows
+  const int ow = tid - rsel * a.OW;
+  const int oh = oh0 + rsel;
+  if (rsel < 2 && oh < a.OH) {
+    unsigned w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int roff = k < 6 ? (k & 1) : 2;
+        const int coff = k < 6 ? (k >> 1) : (k - 6);
+        const unsigned v = (unsigned)(unsigned char)img[ci][2 * rsel + roff][2 * ow + coff + 1];  // tile col = image col + 4 = (2 ow + coff - 3) + 4
+        const int c = ci * 9 + k;
+        w[c >> 2] |= v << (8 * (c & 3));
+      }
+    int8_t* dst = a.y + ((size_t)(b * a.OH + oh) * a.OW + ow) * 32;
+    *reinterpret_cast<i32x4*>(dst) = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    *reinterpret_cast<i32x4*>(dst + 16) = i32x4{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
   // one thread per (output pixel, 16-channel group)
   const long long total = (long long)a.B * a.PH * a.PW * a.C16;
@@ -279,6 +347,14 @@ int launch_prep_input(const PrepArgs& a, void* stream) {
   const long long pixels = (long long)a.B * a.OH * a.OW;
   if (a.rewrite && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
+    static const bool rows_off = getenv("TF2_AMD_PREP_ROWS") != nullptr && atoi(getenv("TF2_AMD_PREP_ROWS")) == 0;
+    if (a.xonly && !rows_off && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2) {
+      const unsigned gridr = (unsigned)(a.B * ((a.OH + 1) / 2));
+      TF2_LAUNCH_NAME("prep_rewrite3_rows_kernel");
+      if (a.src_is_q) TF2_LAUNCH((prep_rewrite3_rows_kernel<true>), dim3(gridr), dim3(256), 0, (hipStream_t)stream, a);
+      else TF2_LAUNCH((prep_rewrite3_rows_kernel<false>), dim3(gridr), dim3(256), 0, (hipStream_t)stream, a);
+      return launch_ok() ? 0 : -1;
+    }
     if (a.xonly) {
       if (a.src_is_q) { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
       else { TF2_LAUNCH_NAME("prep_rewrite3_kernel"); TF2_LAUNCH((prep_rewrite3_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
