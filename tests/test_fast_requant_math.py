@@ -66,3 +66,41 @@ def test_generic_form_equals_reference_under_wrap_around():
         alpha = int(rng.integers(-2 ** 31, 2 ** 31))
         beta = int(rng.integers(-2 ** 31, 2 ** 31))
         assert clamp8(generic_kernel(acc, lo, bias, alpha, beta)) == clamp8(reference(acc, lo, bias, alpha, beta))
+
+
+def semi_kernel(acc, lo, bias, alpha, beta):
+    """The 4-instruction form for rows whose v may wrap (requant_epilogue.h SEMI): the wrap of v kept, then one 64-bit
+    multiply-add and one shift."""
+    v = wrap32(bias + wrap32(acc << lo))
+    return (v * alpha + (beta << 20) + 2 ** 34) >> 35
+
+
+def semi_provable(alpha, beta):
+    return (abs(alpha) << 31) + (abs(beta) << 20) + 2 ** 34 < 2 ** 51
+
+
+def test_semi_form_equals_reference_when_v_wraps_but_x_cannot():
+    """weight_pack.cpp packs a layer SEMI when 2^31 |alpha| + |beta << 20| + 2^34 < 2^51 for every row: then the form equals
+    the reference for EVERY 32-bit accumulator, bias and shift, wrapped or not (before and after the clamp)."""
+    rng = np.random.default_rng(19)
+    checked = 0
+    for _ in range(40000):
+        lo = int(rng.integers(0, 31))
+        acc = int(rng.integers(-2 ** 31, 2 ** 31))
+        bias = int(rng.integers(-2 ** 31, 2 ** 31))
+        alpha = int(rng.integers(-2 ** 20, 2 ** 20) >> int(rng.integers(0, 12)))
+        beta = int(rng.integers(-2 ** 30, 2 ** 30) >> int(rng.integers(0, 12)))
+        if not semi_provable(alpha, beta):
+            continue
+        want = reference(acc, lo, bias, alpha, beta)
+        got = semi_kernel(acc, lo, bias, alpha, beta)
+        assert got == want, (acc, lo, bias, alpha, beta)
+        checked += 1
+    assert checked > 30000
+    # at the edge of the criterion: alpha just below 2^20 - something, extreme v
+    for alpha in (2 ** 19, -(2 ** 19), 2 ** 20 - 2 ** 14, -(2 ** 20 - 2 ** 14)):
+        for beta in (0, 2 ** 29, -(2 ** 29)):
+            if not semi_provable(alpha, beta):
+                continue
+            for v in (2 ** 31 - 1, -(2 ** 31), 0, 1, -1):
+                assert semi_kernel(v, 0, 0, alpha, beta) == reference(v, 0, 0, alpha, beta)

@@ -198,4 +198,4 @@ def test_resnet50_doubled_channels(golden_dir):
     assert set(producers) == {2, 5, 6, 8, 12, 13, 15, 16, 18, 19, 22, 25, 26, 28, 29}, producers
     assert set(consumers) == {3, 6, 7, 9, 13, 14, 16, 17, 19, 20, 23, 26, 27, 29, 30}, consumers
     assert all(int(pls[i]["n_phases"]) == 1 for i in consumers)
-    assert int(pls[28]["fast"]) == 0        # a producer with the generic requantisation: the -128 rides in its rows' shift word
+    assert int(pls[28]["fast"]) == 2        # a producer off the FAST proof (SEMI form): the -128 rides in its rows' shift word

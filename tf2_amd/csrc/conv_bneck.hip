@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-        const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores, a.dbl_mid != 0);
+        const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores, a.dbl_mid != 0, a.fast1 == 2);
         const int row = wn * WTN + j * 32 + (lane & 31);
         const int c = (chl & 63) >> 4;
         *reinterpret_cast<i32x4*>(mid2 + (chl >> 6) * (TN * 64) + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
           *reinterpret_cast<i32x4*>(a.y_mid + (size_t)(pix_base + row) * a.ymid_cp + chl) = out;
       }
     };
-    if (a.fast1) to_mid(std::true_type{}); else to_mid(std::false_type{});
+    if (a.fast1 == 1) to_mid(std::true_type{}); else to_mid(std::false_type{});
   }
 #pragma unroll
   for (int j = 0; j < NTN; j++)
@@ -289,14 +289,14 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
           int a16[16];
 #pragma unroll
           for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-          const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j], a.dbl_out != 0);
+          const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j], a.dbl_out != 0, a.fast2 == 2);
           const int p = wn * WTN + j * 32 + (lane & 31);
           if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
           if (p < n_px && chl + 16 <= a.y_nvalid)
             *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
         }
       };
-      if (a.fast2) { if (a.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
+      if (a.fast2 == 1) { if (a.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
       else { if (a.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
 #pragma unroll
       for (int j = 0; j < NTN; j++)

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
         int a16[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j], g.dbl_out != 0);
+        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j], g.dbl_out != 0, g.fast == 2);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl);
           *dst = out;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
       }
     }
   };
-  if (g.fast) { if (g.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
+  if (g.fast == 1) { if (g.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
   if (adbg2 && tid == 0) {

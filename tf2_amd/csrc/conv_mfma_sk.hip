@@ -330,10 +330,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 #pragma unroll
     for (int r = 0; r < 4; r++) a16[G * 4 + r] = sum[G][r];
   i32x4 out;
-  if (g.fast) out = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
-                              : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
-  else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
-                       : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
+  if (g.fast == 1) out = g.has_res ? requant_tile16<true, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv)
+                                   : requant_tile16<false, 0, true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0);
+  else out = g.has_res ? requant_tile16<true>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, false, g.fast == 2)
+                       : requant_tile16<false>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv, g.dbl_out != 0, g.fast == 2);
   const int chl = tile_ch + 16 * half;
   if (AVG) {
     // per-channel sum of this wave's 32 pixel columns (dead columns count 0), then over the two pixel halves of the tile

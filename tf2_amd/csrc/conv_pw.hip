@@ -129,10 +129,10 @@ __global__ __launch_bounds__(512, 4) void conv_pw_kernel(ConvArgs a, int n_t32, 
     const int row0 = wr * 32 + 4 * half;
     if (prb & kProbeNoEpi) out = i32x4{a16[0] + a16[4], a16[1] + a16[5], a16[2] + a16[6] + a16[8] + a16[12], a16[3] + a16[7] + T.res[0]};
     else
-    if (g.fast) out = g.has_res ? requant_tile16<true, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res)
-                                : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
-    else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res)
-                         : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
+    if (g.fast == 1) out = g.has_res ? requant_tile16<true, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res)
+                                     : requant_tile16<false, 2, true>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0);
+    else out = g.has_res ? requant_tile16<true, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res, false, g.fast == 2)
+                         : requant_tile16<false, 2, false>(a16, prm, TM, row0, lo_bound, rlo, T.res, g.dbl_out != 0, g.fast == 2);
     const int px = t * 32 + (lane & 31);
     if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); return; }
     if (px <= last_px && ch_ok)

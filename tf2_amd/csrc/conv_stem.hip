@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
             int a16[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) a16[r] = acc[rt][j][r];
-            const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm, 64, rt * 32 + 4 * half, lo_bound, -128, nores, a.dbl_out != 0);
+            const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm, 64, rt * 32 + 4 * half, lo_bound, -128, nores, a.dbl_out != 0, a.fast == 2);
             const int p = tile * 64 + j * 32 + (lane & 31);
             const int chl = rt * 32 + 16 * half;
             if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
           }
       };
       if (prb & kProbeNoEpi) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1])); continue; }
-      if (a.fast) epilogue(std::true_type{}); else epilogue(std::false_type{});
+      if (a.fast == 1) epilogue(std::true_type{}); else epilogue(std::false_type{});
     }
   };
   if (quirk) run(std::true_type{}); else run(std::false_type{});
@@ -281,8 +281,9 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
 // block (two outputs per tap step), so that inside every wave the matrix pipe and the VALU are busy at the same time.  The
 // nine B fragments of a pixel column tile stay in registers for both of its channel halves (and yield the unit-tap sum S);
 // A fragments come from LDS one step ahead.
-template <bool DBL, bool FAST>
+template <bool DBL, int MODE /* PackLayer::fast: 0 generic, 1 fast, 2 semi (requant_epilogue.h) */>
 __global__ __launch_bounds__(512, 4) void conv_stem_pipe_kernel(StemArgs a) {
+  constexpr bool FAST = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -380,12 +381,12 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pipe_kernel(StemArgs a) {
           const long long pp = (long long)pend[k] * (long long)pr[1] + b64;
           y = (int)(pp >> 32) >> (kAlphaInflat + kInflat - 32);
           kd = pr[0];
-        } else {                                               // generic rows: 32-bit wrap of the reference kept (pe.cl:191-193)
+        } else {                                               // generic / semi rows: 32-bit wrap of v kept (pe.cl:191-193)
           const int lo = prm[4 * 64 + pend_rt * 32 + 4 * half + 8 * (k >> 2) + (k & 3)];
           const int v = (int)((unsigned)pr[0] + ((unsigned)pend[k] << (lo & 31)));
           const long long pp = (long long)v * (long long)pr[1] + b64;
-          const int x = (int)(pp >> kAlphaInflat);
-          y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+          if (MODE == 2) y = (int)(pp >> 32) >> (kAlphaInflat + kInflat - 32);
+          else { const int x = (int)(pp >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
           kd = lo >> 8;
         }
         int c;
@@ -491,8 +492,9 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pipe_kernel(StemArgs a) {
 // bytes and stores the pooled NHWC bytes.  The channel split halves the tile (25 KiB) and the weight image (9 KiB) so that two
 // blocks still share a CU (68 KiB each); the K loop / requantisation pipeline is conv_stem_pipe_kernel's (UNIT form).
 // 25.7 MB of conv map per batch of 32 neither written nor read back, one launch less.
-template <bool FAST>
+template <int MODE /* PackLayer::fast: 0 generic, 1 fast, 2 semi */>
 __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
+  constexpr bool FAST = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
         } else {                                               // the low window's base is 0: v = bias + acc (pe.cl:176-180 wrap kept)
           const int v = (int)((unsigned)pr[0] + (unsigned)pend[k]);
           const long long pp = (long long)v * (long long)pr[1] + b64;
-          const int x = (int)(pp >> kAlphaInflat);
-          y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
+          if (MODE == 2) y = (int)(pp >> 32) >> (kAlphaInflat + kInflat - 32);
+          else { const int x = (int)(pp >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
         }
         int c;
         asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
@@ -747,19 +749,19 @@ int launch_conv_stem(const StemArgs& a, int nwin, void* stream) {
     const size_t ldp = conv_stem_pool_lds_bytes(a.pk, a.W, a.OW, (size_t)a.hdr_used);
     if (ldp > 160 * 1024) return 1;
     const int gridp = a.B * a.bands_per_img * 2;
-    if (a.fast) { auto fn = conv_stem_pool_kernel<true>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
-                  TF2_LAUNCH_NAME("conv_stem_pool_kernel<fast>"); TF2_LAUNCH(fn, dim3(gridp), dim3(512), ldp, s, a); }
-    else { auto fn = conv_stem_pool_kernel<false>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
-           TF2_LAUNCH_NAME("conv_stem_pool_kernel<generic>"); TF2_LAUNCH(fn, dim3(gridp), dim3(512), ldp, s, a); }
+#define TF2_STEMQ(M_, label) do { auto fn = conv_stem_pool_kernel<M_>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
+                                  TF2_LAUNCH_NAME("conv_stem_pool_kernel<%s>", label); TF2_LAUNCH(fn, dim3(gridp), dim3(512), ldp, s, a); } while (0)
+    if (a.fast == 1) TF2_STEMQ(1, "fast"); else if (a.fast == 2) TF2_STEMQ(2, "semi"); else TF2_STEMQ(0, "generic");
+#undef TF2_STEMQ
     return launch_ok() ? 0 : -1;
   }
   static const bool no_pipe = getenv("TF2_AMD_STEM_NOPIPE") != nullptr;
   if (unit && !no_pipe) {
-#define TF2_STEMP(D_, F_) do { auto fn = conv_stem_pipe_kernel<D_, F_>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
-                               TF2_LAUNCH_NAME("conv_stem_pipe_kernel<%s,%s>", D_ ? "doubled" : "plain", F_ ? "fast" : "generic"); \
+#define TF2_STEMP(D_, M_) do { auto fn = conv_stem_pipe_kernel<D_, M_>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
+                               TF2_LAUNCH_NAME("conv_stem_pipe_kernel<%s,%s>", D_ ? "doubled" : "plain", M_ == 1 ? "fast" : M_ == 2 ? "semi" : "generic"); \
                                TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, a); } while (0)
-    if (a.dbl_out) { if (a.fast) TF2_STEMP(true, true); else TF2_STEMP(true, false); }
-    else { if (a.fast) TF2_STEMP(false, true); else TF2_STEMP(false, false); }
+    if (a.dbl_out) { if (a.fast == 1) TF2_STEMP(true, 1); else if (a.fast == 2) TF2_STEMP(true, 2); else TF2_STEMP(true, 0); }
+    else { if (a.fast == 1) TF2_STEMP(false, 1); else if (a.fast == 2) TF2_STEMP(false, 2); else TF2_STEMP(false, 0); }
 #undef TF2_STEMP
   }
   else if (unit) TF2_STEM(1, true, "1 window + unit taps");

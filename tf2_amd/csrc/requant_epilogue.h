@@ -8,8 +8,13 @@
 //                                                              and both clamp to 127 where they differ
 //   c = clamp(y, relu ? 0 : -128, 127);  with a residual:  c = clamp(c + res, add_relu ? 0 : -128, 127)
 //
-// FAST (PackLayer::fast, proven per layer at pack time): y = (sum * (alpha << lo) + B') >> 35 with
+// FAST (PackLayer::fast == 1, proven per layer at pack time): y = (sum * (alpha << lo) + B') >> 35 with
 // B' = bias * alpha + (beta << 20) + 2^34 -- mad_i64_i32, ashr, med3.
+// SEMI (PackLayer::fast == 2): v = bias + (sum << lo) MAY wrap (the reference's int32 accumulator, pe.cl:43) and is computed
+// as such, but 2^31 * |alpha| + |beta << 20| + 2^34 < 2^51 for every row, so x = (v * alpha + (beta << 20)) >> 20 fits 32 bits
+// and x + 2^14 cannot saturate: y = (v * alpha + B'') >> 35 with B'' = (beta << 20) + 2^34 (floor of floor) -- lshl_add,
+// mad_i64_i32, ashr, med3: four instead of six.  ResNet-50's three layers that fail the FAST proof (conv1, two long-K layers)
+// take this path.
 //
 // The epilogue is VALU-issue bound on the short-K layers (measured: ~13.5 issue slots per output before this
 // header existed, 8.1k of a block's 15.6k cycles at 3 waves/SIMD), so the per-output instruction count is the
@@ -36,7 +41,7 @@ constexpr int kPrmWordsPerRow = 5;
 // DBL (layers without a residual whose output tensor has "doubled" channels, weight_pack.cpp): header word 0 of a row (FAST;
 // generic rows: bits 8.. of the row's shift word) is -128 for a doubled channel, 0 otherwise, and the stored value is
 // (c << 1) - 128 resp. c.
-template <bool HAS_RES, int LEAN, bool FAST, bool DBL>
+template <bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
                                                         int lo_bound, int rlo, const rq_i32x4& resv) {
   unsigned rd[4] = {0, 0, 0, 0};
@@ -76,6 +81,11 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
         // rows proven at pack time (weight_pack.cpp): y = (acc * (alpha << lo) + B') >> 35, no wrap anywhere
         const long long p = (long long)a16[k] * (long long)pr[1] + b64;
         y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+      } else if (SEMI) {
+        // the 32-bit wrap of v kept; rows hold B'' = (beta << 20) + 2^34 as their 64-bit addend (weight_pack.cpp)
+        const int v = (int)((unsigned)pr[0] + ((unsigned)a16[k] << (lo4[r] & 31)));
+        const long long p = (long long)v * (long long)pr[1] + b64;
+        y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
       } else {
         const int v = (int)((unsigned)pr[0] + ((unsigned)a16[k] << (lo4[r] & 31)));
         const long long p = (long long)v * (long long)pr[1] + b64;
@@ -106,9 +116,18 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
   return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
 }
 
+// FAST = the layer's PackLayer::fast == 1; semi (wave-uniform, only read when !FAST) = PackLayer::fast == 2
 template <bool HAS_RES, int LEAN = 0, bool FAST = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0, int lo_bound, int rlo, const rq_i32x4& resv,
-                                                   bool dbl = false /* wave-uniform */) {
+                                                   bool dbl = false /* wave-uniform */, bool semi = false) {
+  if constexpr (!FAST) {
+    if (semi) {
+      if constexpr (!HAS_RES) {
+        if (dbl) return requant_tile16_impl<false, LEAN, false, true, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
+      }
+      return requant_tile16_impl<HAS_RES, LEAN, false, false, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
+    }
+  }
   if constexpr (!HAS_RES) {
     if (dbl) return requant_tile16_impl<false, LEAN, FAST, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
   }

@@ -478,7 +478,15 @@ tf2_status Net::pack(int mode) {
         else if ((aa << lo_last[n]) >= (one << 31)) fast = false;
         else if ((amax + ab) * aa + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) fast = false;
       }
-      pl.fast = fast ? 1 : 0;
+      // SEMI (requant_epilogue.h): the rows that may wrap v still get the short form when x cannot leave 32 bits
+      bool semi = !fast && getenv("TF2_AMD_NOFAST") == nullptr && getenv("TF2_AMD_NOSEMI") == nullptr;
+      for (int n = 0; n < N && semi; n++) {
+        const unsigned __int128 aa = (unsigned __int128)std::llabs((long long)m.alpha[n]);
+        const unsigned __int128 abeta = (unsigned __int128)std::llabs((long long)m.beta[n]);
+        const unsigned __int128 one = 1;
+        if ((aa << 31) + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) semi = false;
+      }
+      pl.fast = fast ? 1 : (semi ? 2 : 0);
       if (!dbl[l].empty()) {
         std::vector<uint8_t> f(Np, 0);
         std::copy(dbl[l].begin(), dbl[l].end(), f.begin());
@@ -510,9 +518,10 @@ tf2_status Net::pack(int mode) {
               pr[2] = (int32_t)(uint32_t)((uint64_t)bp & 0xffffffffu);
               pr[3] = (int32_t)(uint32_t)((uint64_t)bp >> 32);
             } else {
+              const int64_t add = b64 + (semi ? ((int64_t)1 << 34) : 0);       // SEMI rows: B'' = (beta << 20) + 2^34
               pr[0] = n < N ? m.bias[n] : 0; pr[1] = n < N ? m.alpha[n] : 0;
-              pr[2] = (int32_t)(uint32_t)((uint64_t)b64 & 0xffffffffu);
-              pr[3] = (int32_t)(uint32_t)((uint64_t)b64 >> 32);
+              pr[2] = (int32_t)(uint32_t)((uint64_t)add & 0xffffffffu);
+              pr[3] = (int32_t)(uint32_t)((uint64_t)add >> 32);
             }
             // the final shift; generic rows of a doubled channel carry the -128 above it (FAST rows: word 0)
             h[4 * TM + r] = lo_last[n] | ((!fast && n < N && !dbl[l].empty() && dbl[l][n]) ? (int32_t)0xffff8000 : 0);
