@@ -73,8 +73,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DENSE (ConvArgs::dense): the gather words of a step come from its index (tf2_device.h dense_gather) instead of the header's
 // goff / ghw tables and the m-tile's entry range is mtile * nslab .. + nslab: nothing in front of the first DMAs but the
 // kernel arguments (one dependent scalar-load round trip and the LDS table reads of every step less).
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
+// PF (single-window DENSE layers on small grids, S >= 4): the fragments of step it + 1 are read from LDS while the MFMAs of
+// step it run -- the wait + barrier for stage it + 1 moves in front of step it, so one ring stage of DMA slack is spent on
+// covering the LDS read latency.  With one block per CU (the 98-block 14x14 layers of the several-streams plan) a step was
+// wait -> barrier -> 6 ds_read_b128 -> 4 MFMAs strictly in sequence, two waves per SIMD and nobody to fill the gaps.
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
+  static_assert(!PF || (!DUAL && DENSE && S >= 4), "fragment prefetch: single-window dense layers, four ring stages");
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int NTM = WTM / 32, NTN = WTN / 32;   // 32x32 MFMA tiles per wave (rows, columns)
@@ -369,6 +374,62 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
 
+  if constexpr (PF) {
+    // ---- K loop with the next step's fragments in flight -------------------------------------------------------------
+    struct Frag { i32x4 a[2][NTM], b[2][NTN]; };
+    auto read_frag = [&](Frag& f, int slot) {
+      const int8_t* A = lds + slot * STAGE;
+      const int8_t* B = A + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < NTM; i++) {
+          const int row = wm * WTM + i * 32 + (lane & 31);
+          f.a[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; j++) {
+          const int row = wn * WTN + j * 32 + (lane & 31);
+          f.b[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        }
+      }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < NTM; i++)
+#pragma unroll
+          for (int j = 0; j < NTN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
+    };
+    Frag f0, f1;
+    read_frag(f0, 0);                        // stage 0 landed (wait + barrier above)
+    int rslot = 1;                           // ring slot of stage it + 1
+    // one step: stage it + 1 complete for everybody -> issue stage it + S - 1 into the slot of stage it - 1 -> read it + 1 -> MFMAs of it
+    auto pf_step = [&](int it_, const Frag& cur, Frag& nxt) {
+      if (it_ + 1 < n_ent) {
+        // stages it + 2 .. it + S - 2 may still fly -- while that many have been issued; in the tail everything must have landed
+        if (it_ + S - 2 < n_ent) { if (ni_hi) wait_vmcnt<(S - 3) * NI_HI>(); else wait_vmcnt<(S - 3) * NI_LO>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it_ + S - 1 < n_ent) {
+          issue_stage(e_begin + it_ + S - 1, off_nx, hw_nx, islot);
+          islot = islot + 1 == S ? 0 : islot + 1;
+          gather_of(it_ + S, off_nx, hw_nx);
+        }
+        read_frag(nxt, rslot);
+        rslot = rslot + 1 == S ? 0 : rslot + 1;
+      }
+      mma(cur);
+    };
+    for (int it_ = 0; it_ < n_ent; it_ += 2) {
+      pf_step(it_, f0, f1);
+      if (it_ + 1 < n_ent) pf_step(it_ + 1, f1, f0);
+    }
+  } else {
   int it = 0;
   long long t_wait = 0, t_bar = 0, t_body = 0;     // dbg (tools/layer_times.py --stamps): cycles of block 0 / wave 0 in the vmcnt wait, the barrier, the step body
   for (; it < n_main; it++) {
@@ -394,6 +455,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
     }
     body(it, false);
   }
+  }   // !PF
   if (DUAL) {
     // combine the two windows: (hi << dshift[1][row]) + lo   (Z/2^32, as the Horner form)
 #pragma unroll
@@ -456,16 +518,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
 static int launch_cfg3(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, PF>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
-  TF2_LAUNCH_NAME("conv_mfma2_kernel<%dx%d waves of %dx%d,S%d,%s%s%s>", WM, WN, WTM, WTN, S, PADCHK ? "pad," : "", DUAL ? "dual," : "", DENSE ? "dense" : "tables");
+  TF2_LAUNCH_NAME("conv_mfma2_kernel<%dx%d waves of %dx%d,S%d,%s%s%s%s>", WM, WN, WTM, WTN, S, PADCHK ? "pad," : "", DUAL ? "dual," : "", DENSE ? "dense" : "tables", PF ? ",prefetch" : "");
   TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
   return launch_ok() ? 0 : -1;
 }
@@ -500,7 +562,16 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
     if (TM == 64) return blocks256 >= t256 ? launch_dual<2, 4, 32, 64, 3, 2>(a, s) : launch_dual<2, 2, 32, 32, 4, 4>(a, s);
     return -1;
   }
-  if (TM == 128) return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
+  if (TM == 128) {
+    // small grids with a long slab list (the 14x14 / 7x7 layers of the several-streams plan): fragment prefetch, four ring stages
+    static const long pf_blocks = getenv("TF2_AMD_PF_BLOCKS") ? atol(getenv("TF2_AMD_PF_BLOCKS")) : 256;
+    const long blocks128 = (long)((a.g.n_pix + 127) / 128) * a.n_mtiles;
+    if (!w4 && !w16 && a.dense && blocks128 <= pf_blocks && a.nslab >= 8) {
+      return (a.g.pad_h | a.g.pad_w) ? launch_cfg3<4, 2, 32, 64, 4, 2, true, false, true, true>(a, s)
+                                      : launch_cfg3<4, 2, 32, 64, 4, 2, false, false, true, true>(a, s);
+    }
+    return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
+  }
   if (TM == 64) {
     if (blocks256 >= t256) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
