@@ -396,3 +396,17 @@ def test_doubled_channels_written_by_conv_stem_and_by_a_fused_expand(which, monk
     else:
         assert int(pls[2]["off_dbl"]) != 0 and int(pls[2]["fused_into"]) == 1 and any("conv_bneck" in l["kernel"] for l in launches)
     rig.check_all_layers(synth.synth_images(t, 4, 3))
+
+
+@pytest.mark.parametrize("conc", ["0", "1"])
+def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
+    """conv_mfma2's PF instantiation (next step's fragments read during the current step's MFMAs, four ring stages; off by default,
+    TF2_AMD_PF_BLOCKS): the small-grid single-window layers of both launch plans, batch 32, against the oracle."""
+    monkeypatch.setenv("TF2_AMD_PF_BLOCKS", "256")
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    rig = Rig(*r50, 0)
+    assert any("prefetch" in l["kernel"] for l in rig.net.describe_launches(32, int(conc)))
+    x = synth.synth_images(rig.t, 32, 21)
+    got = rig.run(x, keep_all=False)
+    np.testing.assert_array_equal(got[:3], rig.ref.logits(rig.ref.run(x[:3])))
+    np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))

@@ -165,7 +165,7 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     assert len(many) == len(one) + 3
     # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation
     ring = [r for r in one if "conv_mfma" in r["kernel"]]
-    assert ring and all(r["kernel"].endswith("dense>") for r in ring)
+    assert ring and all("dense" in r["kernel"] for r in ring)
     assert all(0 < r["grid"] and r["block"] in (256, 512) and 0 <= r["lds_bytes"] <= 160 * 1024 for r in one)
     # batch 1: small grids, the split-K kernel on the 64-row layers
     assert any("conv_mfma_sk" in r["kernel"] for r in net.describe_launches(1, 0))

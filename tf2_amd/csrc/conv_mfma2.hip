@@ -564,9 +564,8 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   }
   if (TM == 128) {
     // small grids with a long slab list (the 14x14 / 7x7 layers of the several-streams plan): fragment prefetch, four ring stages
-    static const long pf_blocks = getenv("TF2_AMD_PF_BLOCKS") ? atol(getenv("TF2_AMD_PF_BLOCKS")) : 256;
-    const long blocks128 = (long)((a.g.n_pix + 127) / 128) * a.n_mtiles;
-    if (!w4 && !w16 && a.dense && blocks128 <= pf_blocks && a.nslab >= 8) {
+    // (ConvGeom::flags bit 12, set by net.hip from TF2_AMD_PF_BLOCKS; measured: no gain, profiles/r03_experiments.txt -- off by default)
+    if (!w4 && !w16 && a.dense && (a.g.flags & 0x1000) && a.nslab >= 8) {
       return (a.g.pad_h | a.g.pad_w) ? launch_cfg3<4, 2, 32, 64, 4, 2, true, false, true, true>(a, s)
                                       : launch_cfg3<4, 2, 32, 64, 4, 2, false, false, true, true>(a, s);
     }

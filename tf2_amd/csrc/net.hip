@@ -238,6 +238,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
   if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
@@ -358,6 +359,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;
     }
     g.flags = opts.flags;
+    if (pl->TM == 128 && ((long)batch * L.OH * L.OW + 127) / 128 * pl->n_mtiles <= opts.pf_blocks) g.flags |= 0x1000;   // conv_mfma2 fragment-prefetch variant
     st.TM = pl->TM; st.signed_in = pl->signed_in; st.mul24 = pl->max_shift <= 22;
     if (pl->kind == KIND_MFMA) {
       // small grid + long slab list: the four (or eight) waves of a block split K (conv_mfma_sk.hip)

@@ -74,6 +74,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
+  long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
   int stem_pool = 1;       // TF2_AMD_STEM_POOL: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
