@@ -77,8 +77,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // step it run -- the wait + barrier for stage it + 1 moves in front of step it, so one ring stage of DMA slack is spent on
 // covering the LDS read latency.  With one block per CU (the 98-block 14x14 layers of the several-streams plan) a step was
 // wait -> barrier -> 6 ds_read_b128 -> 4 MFMAs strictly in sequence, two waves per SIMD and nobody to fill the gaps.
+// The body is a device function of (argument block, block index, grid size) so that ONE launch can carry two independent layers
+// (conv_mfma2_pair_kernel below: a stage's shortcut convolution next to the first 1x1 of its first bottleneck -- same input, no
+// dependence, same instantiation): blocks [0, n0) work on the first argument block, the rest on the second.
 template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk_x, const int nblk_x) {
   static_assert(!PF || (!DUAL && DENSE && S >= 4), "fragment prefetch: single-window dense layers, four ring stages");
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   const bool ni_hi = REM == 0 || wave < REM;         // wave-uniform DMA class
   const int wm = wave / WN, wn = wave % WN;
   const bool stamps = (adbg != nullptr) | (adbg2 != nullptr);     // one test on the production path
-  const bool dbg_on = adbg != nullptr && blockIdx.x == 0 && tid == 0;
+  const bool dbg_on = adbg != nullptr && blk_x == 0 && tid == 0;
 #define TF2_STAMP(i) do { if (stamps) { if (dbg_on) adbg[i] = (long long)__builtin_readcyclecounter(); if (adbg2) tstamp[i] = (long long)__builtin_readcyclecounter(); } } while (0)
   long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TF2_STAMP(0);
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   int* const ghw = goff + a_max_ent * 4;
 
   // XCD-aware remap: consecutive logical tiles (same pixel tile, all channel tiles) on one XCD
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
+  const int nblk = nblk_x;
+  int bid = blk_x;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
@@ -509,13 +512,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_
   else { if (g.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
   if (adbg2 && tid == 0) {
-    long long* d = adbg2 + (size_t)blockIdx.x * 8;
+    long long* d = adbg2 + (size_t)blk_x * 8;
     d[0] = tstamp[0]; d[1] = (long long)__builtin_readcyclecounter();
     d[4] = tstamp[1]; d[5] = tstamp[2]; d[6] = tstamp[3];
     d[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID (id 4), 32 bits
     d[3] = wall0; d[7] = (long long)wall_clock64();                        // 100 MHz, chip-wide
   }
 #undef TF2_STAMP
+}
+
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
+  conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, PF>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two independent layers of the same instantiation in one launch
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_pair_kernel(ConvArgs a0, ConvArgs a1, int n0) {
+  const int b = (int)blockIdx.x;
+  if (b < n0) conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, false>(a0, b, n0);
+  else conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, false>(a1, b - n0, (int)gridDim.x - n0);
 }
 
 template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
@@ -576,6 +592,33 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }
   return -1;
+}
+
+// ---- pair launch: the 128-row 8-wave shape, both layers dense and unpadded, same window form ---------------------------------
+template <bool DUAL>
+static int launch_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
+  constexpr int TM = 128, TN = 128, S = 3;
+  constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
+  const size_t lds = (size_t)S * STAGE + (size_t)(a0.hdr_bytes > a1.hdr_bytes ? a0.hdr_bytes : a1.hdr_bytes) + 64;
+  auto fn = conv_mfma2_pair_kernel<4, 2, 32, 64, 3, 2, false, DUAL, true>;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
+  if (lds > 160 * 1024) return -3;
+  const int n0 = ((a0.g.n_pix + TN - 1) / TN) * a0.n_mtiles, n1 = ((a1.g.n_pix + TN - 1) / TN) * a1.n_mtiles;
+  TF2_LAUNCH_NAME("conv_mfma2_pair_kernel<4x2 waves of 32x64,S3,%sdense> (%d + %d blocks)", DUAL ? "dual," : "", n0, n1);
+  TF2_LAUNCH(fn, dim3(n0 + n1), dim3(512), lds, s, a0, a1, n0);
+  return launch_ok() ? 0 : -1;
+}
+
+bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
+  if (TM0 != 128 || TM1 != 128 || !a0.dense || !a1.dense || a0.dual != a1.dual) return false;
+  if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
+  if ((a0.g.flags | a1.g.flags) & (2 | 4 | 0x1000)) return false;            // A/B block shapes, prefetch variant: single launches only
+  return true;
+}
+
+int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return a0.dual ? launch_pair2<true>(a0, a1, s) : launch_pair2<false>(a0, a1, s);
 }
 
 }  // namespace tf2

@@ -161,10 +161,12 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   if (packed_valid)
     for (int l = 0; l < nl; l++) {
       const PackLayer* pl = pack_layer(l);
-      if (!pl || pl->fuse_next <= 0) continue;
-      const int b = pl->fuse_next;
+      int b = pl ? pl->fuse_next : 0;
+      if (b <= 0 && opts.pair_mode && pair_candidate(l) && !(l >= 2 && pair_candidate(l - 1))) b = l + 1;   // (pairs do not chain)
+      if (b <= 0) continue;
       TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
       tin.last_use = std::max(tin.last_use, b);
+      if (wp.exec[l].res_tensor >= 0) wp.tensors[wp.exec[l].res_tensor].last_use = std::max(wp.tensors[wp.exec[l].res_tensor].last_use, b);
       for (size_t t = 0; t < wp.tensors.size(); t++)
         if (born[t] == b) born[t] = l;
     }
@@ -218,6 +220,22 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   return &res.first->second;
 }
 
+// Rows l and l + 1 may share a launch (conv_mfma2_pair_kernel): plain convolution rows (no pool / average / concat slice /
+// L2Norm), neither reads what the other writes, neither is part of a fused bottleneck pair.  In ResNet-50: a stage's shortcut
+// convolution and the first 1x1 of its first bottleneck (both read the previous stage's output).
+bool Net::pair_candidate(int l) const {
+  if (l < 1 || l + 1 >= nd.n_layers) return false;
+  const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1];
+  for (const tf2_layer_desc* L : {&A, &B})
+    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->src < 0) return false;
+  if (B.src == l || B.add_src == l) return false;
+  if (A.add_src >= 0 || B.add_src >= 0) return false;          // (a residual source may be the partner's input chain; keep it simple)
+  const PackLayer* pa = pack_layer(l); const PackLayer* pb = pack_layer(l + 1);
+  if (!pa || !pb || pa->kind != KIND_MFMA || pb->kind != KIND_MFMA) return false;
+  if (pa->fuse_next > 0 || pa->fused_into >= 0 || pb->fuse_next > 0 || pb->fused_into >= 0) return false;
+  return true;
+}
+
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
 // space-to-depth prep applies; the input tensor then carries 32 bytes per pixel in the same allocation.
 bool Net::stem_selected(int batch) const {
@@ -239,6 +257,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
+  if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
   if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
@@ -251,6 +270,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
   opts = o;
   launch_plans.clear();
+  plans.clear();             // tensor lifetimes depend on which rows may share a launch (TF2_AMD_PAIR)
 }
 
 // ---- launch plan: every kernel argument block of one step, resolved once per (batch, workspace, packed image) ----
@@ -383,8 +403,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     return true;
   };
-  std::vector<char> fused_done(nl, 0);
+  std::vector<char> fused_done(nl, 0), pair_done(nl, 0);
   bool stem_pool_fused = false;
+  const bool profiling_pairs_off = false;
   for (int l = 0; l < nl; l++) {
     const tf2_layer_desc& L = layers[l];
     const LayerExec& E = wp->exec[l];
@@ -406,6 +427,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
+    if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1
     Launch st;
     // a fused launch needs enough row bands to fill the chip (one block per band): small batches run the two layers on their own
     const int bn_TN = pl->TM == 64 ? 256 : 128;
@@ -436,6 +458,15 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.R = std::min(TN / L.W, L.H);
       f.tiles_per_img = (L.H + f.R - 1) / f.R;
       st.sel = Launch::SEL_BNECK; st.shape = TN;
+    }
+    // this row and the next in one launch (independent rows, same ring-kernel instantiation)?
+    if (opts.pair_mode && !fuse_now && !profiling_pairs_off && st.sel == Launch::SEL_MFMA2 && pair_candidate(l) && !(l >= 2 && pair_candidate(l - 1))) {
+      Launch sb;
+      if (!make_conv(l + 1, sb, true)) return nullptr;
+      if (sb.sel == Launch::SEL_MFMA2 && conv_mfma2_pair_eligible(st.conv, st.TM, sb.conv, sb.TM)) {
+        st.conv2 = sb.conv; st.sel = Launch::SEL_PAIR;
+        fused_done[l + 1] = 1; pair_done[l + 1] = 1;
+      }
     }
     if (l == 0 && stem) {
       const ConvArgs& ca = st.conv;
@@ -527,6 +558,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
           return launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream);
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
+        case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
         case Launch::SEL_STEM: return launch_conv_stem(st.stem, st.shape, stream);
         default: return launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream);
       }

@@ -210,6 +210,8 @@ struct PrepArgs {
 
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
+bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
+int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);

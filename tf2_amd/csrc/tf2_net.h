@@ -41,11 +41,12 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
   ConvArgs conv{};
+  ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
   BneckArgs bneck{};
   StemArgs stem{};
@@ -75,6 +76,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
+  int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
   int stem_pool = 1;       // TF2_AMD_STEM_POOL: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
@@ -127,6 +129,7 @@ struct Net {
   bool stem_selected(int batch) const;     // layer 0 runs on conv_stem.hip (x-only image tensor)
   const PackLayer* pack_layer(int l) const;
   const PackLayer* pack_layer_alt(int l) const;
+  bool pair_candidate(int l) const;        // rows l and l + 1 are independent plain conv rows (one launch may compute both)
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);

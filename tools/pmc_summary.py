@@ -30,10 +30,10 @@ _plan = cfg.build_plan(_t)
 _launches = [l for l in _net.describe_launches(B, 0) if "conv_" in l["kernel"]]
 launch_layers = [l["layer"] for l in _launches]
 fused_into = {}
-for k, l in enumerate(_launches):
-    if "conv_bneck" in l["kernel"]:
-        nxt = launch_layers[k + 1] if k + 1 < len(launch_layers) else len(_plan)
-        for j in range(l["layer"] + 1, nxt):
+for k, l in enumerate(_launches):          # a launch that computes several table rows (conv_bneck pair, conv_mfma2 pair launch)
+    nxt = launch_layers[k + 1] if k + 1 < len(launch_layers) else len(_plan)
+    for j in range(l["layer"] + 1, nxt):
+        if not _plan[j].ipool:
             fused_into[j] = l["layer"]
 n = len(launch_layers)
 sq1, sq2, t1, t2 = (table(d)[-n:] for d in ("sq1", "sq2", "tcc1", "tcc2"))
