@@ -410,3 +410,23 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
     got = rig.run(x, keep_all=False)
     np.testing.assert_array_equal(got[:3], rig.ref.logits(rig.ref.run(x[:3])))
     np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))
+
+
+@pytest.mark.parametrize("off", ["TF2_AMD_NOPERM", "TF2_AMD_NOGROUP"])
+def test_q_sorted_tensors_and_channel_group_phases_on_and_off(r50, monkeypatch, off):
+    """Multi-Q tensors are stored with their channels sorted by Q and their consumers packed with one Horner phase per channel
+    group (weight_pack.cpp); every other ResNet-50 test runs that default.  Here the two switches that turn it off -- identity
+    channel order, exponent-window phases -- every layer against the oracle, and the default form's launch list for contrast."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_packed as emu
+    base = Rig(*r50, 0)
+    _, pls = emu.parse(base.net.packed_host())
+    assert sum(1 for p in pls if int(p["off_perm"])) >= 12 and sum(1 for p in pls if int(p["n_phases"]) == 3) >= 10
+    monkeypatch.setenv(off, "1")
+    rig = Rig(*r50, 0)
+    _, pls = emu.parse(rig.net.packed_host())
+    assert all(int(p["n_phases"]) <= 2 for p in pls)
+    if off == "TF2_AMD_NOPERM":
+        assert not any(int(p["off_perm"]) for p in pls)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 33))

@@ -166,9 +166,11 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # several-streams plan, stage 5) next to the first 1x1 of the stage's first bottleneck
     assert {r["layer"] for r in one if "pair" in r["kernel"]} == {11, 24} and {r["layer"] for r in many if "pair" in r["kernel"]} == {11, 24, 43}
     assert len(many) == len(one) + 3 - 1
-    # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation
+    # ring-kernel launches: the arithmetic-gather instantiation for single-window / dual layers, the header tables for the layers
+    # packed with one Horner phase per input-channel group (the consumers of the three-Q stage tensors)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]
-    assert ring and all("dense" in r["kernel"] for r in ring)
+    assert ring and all(("dense" in r["kernel"]) != ("tables" in r["kernel"]) for r in ring)
+    assert {r["layer"] for r in ring if "tables" in r["kernel"]} == {5, 8, 11, 15, 18, 21, 24, 47, 50, 53}
     assert all(0 < r["grid"] and r["block"] in (256, 512) and 0 <= r["lds_bytes"] <= 160 * 1024 for r in one)
     # batch 1: small grids, the split-K kernel on the 64-row layers
     assert any("conv_mfma_sk" in r["kernel"] for r in net.describe_launches(1, 0))

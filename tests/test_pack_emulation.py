@@ -44,7 +44,7 @@ def check_net(t, q, model, images, mode, layers=None):
             S = plan[L.src]
             if S.concat >= 0:
                 pytest.skip("concat sources are covered by the GPU tests")
-            x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
+            x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16), perm=emu.perm_of(blob, pls[L.src], S.N))
         else:
             cid = -(L.src + 2)
             members = [M for M in plan if M.concat == cid]
@@ -178,7 +178,7 @@ def test_resnet50_wide_tile_alternatives(golden_dir):
     for i in (wide[0], k3[0], k3[-1], [j for j in wide if not R.plan[j].endpool][-1], narrow[0], n3[0], n3[-1], narrow[-1]):
         L = R.plan[i]
         S = R.plan[L.src]
-        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
+        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16), perm=emu.perm_of(blob, pls[L.src], S.N))
         res = outs[L.add_src] if L.add_src >= 0 else None
         y = emu.conv_from_packed(blob, alts[i], L, x_t, res)
         np.testing.assert_array_equal(y, outs[i], err_msg=f"layer {i} wide-tile alternative")

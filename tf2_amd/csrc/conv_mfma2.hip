@@ -595,22 +595,22 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
 }
 
 // ---- pair launch: the 128-row 8-wave shape, both layers dense and unpadded, same window form ---------------------------------
-template <bool DUAL>
+template <bool DUAL, bool DENSE>
 static int launch_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
   constexpr int TM = 128, TN = 128, S = 3;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)(a0.hdr_bytes > a1.hdr_bytes ? a0.hdr_bytes : a1.hdr_bytes) + 64;
-  auto fn = conv_mfma2_pair_kernel<4, 2, 32, 64, 3, 2, false, DUAL, true>;
+  auto fn = conv_mfma2_pair_kernel<4, 2, 32, 64, 3, 2, false, DUAL, DENSE>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int n0 = ((a0.g.n_pix + TN - 1) / TN) * a0.n_mtiles, n1 = ((a1.g.n_pix + TN - 1) / TN) * a1.n_mtiles;
-  TF2_LAUNCH_NAME("conv_mfma2_pair_kernel<4x2 waves of 32x64,S3,%sdense> (%d + %d blocks)", DUAL ? "dual," : "", n0, n1);
+  TF2_LAUNCH_NAME("conv_mfma2_pair_kernel<4x2 waves of 32x64,S3,%s%s> (%d + %d blocks)", DUAL ? "dual," : "", DENSE ? "dense" : "tables", n0, n1);
   TF2_LAUNCH(fn, dim3(n0 + n1), dim3(512), lds, s, a0, a1, n0);
   return launch_ok() ? 0 : -1;
 }
 
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
-  if (TM0 != 128 || TM1 != 128 || !a0.dense || !a1.dense || a0.dual != a1.dual) return false;
+  if (TM0 != 128 || TM1 != 128 || a0.dense != a1.dense || a0.dual != a1.dual) return false;
   if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
   if ((a0.g.flags | a1.g.flags) & (2 | 4 | 0x1000)) return false;            // A/B block shapes, prefetch variant: single launches only
   return true;
@@ -618,7 +618,8 @@ bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, i
 
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  return a0.dual ? launch_pair2<true>(a0, a1, s) : launch_pair2<false>(a0, a1, s);
+  if (a0.dense) return a0.dual ? launch_pair2<true, true>(a0, a1, s) : launch_pair2<false, true>(a0, a1, s);
+  return a0.dual ? launch_pair2<true, false>(a0, a1, s) : launch_pair2<false, false>(a0, a1, s);
 }
 
 }  // namespace tf2

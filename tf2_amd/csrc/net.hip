@@ -270,7 +270,12 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
   opts = o;
   launch_plans.clear();
-  plans.clear();             // tensor lifetimes depend on which rows may share a launch (TF2_AMD_PAIR)
+  // tensor lifetimes depend on which rows may share a launch (TF2_AMD_PAIR): re-plan what was planned (a caller's keep_all
+  // workspace keeps being recognised by run / read_layer)
+  std::vector<std::pair<int, int>> keys;
+  for (const auto& kv : plans) keys.push_back(kv.first);
+  plans.clear();
+  for (const auto& k : keys) (void)plan(k.first, k.second != 0);
 }
 
 // ---- launch plan: every kernel argument block of one step, resolved once per (batch, workspace, packed image) ----
@@ -707,9 +712,9 @@ void Net::drain_profile() {
 }
 
 tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, size_t cap, void* stream) {
-  auto itk = plans.find(std::make_pair(batch, 1));
-  if (itk == plans.end()) { set_error("tf2_net_read_layer: plan the workspace with keep_all first"); return TF2_ERR_STATE; }
-  const WorkPlan& wp = itk->second;
+  // the keep_all plan of this batch (planning is deterministic: rebuilt if tf2_net_reload_options dropped it since the run)
+  if (batch <= 0) { set_error("tf2_net_read_layer: batch must be positive"); return TF2_ERR_ARG; }
+  const WorkPlan& wp = *plan(batch, true);
   if (layer < -1 || layer >= nd.n_layers) { set_error("tf2_net_read_layer: bad layer"); return TF2_ERR_ARG; }
   int tid, off, C;
   if (layer == -1) { tid = wp.input_tensor; off = 0; C = layers[0].C; }
@@ -725,10 +730,12 @@ tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, si
   // doubled channels are stored as 2y - 128 (weight_pack.cpp): hand back y
   const PackLayer* pl = layer >= 0 ? pack_layer(layer) : nullptr;
   const uint8_t* dblf = (pl && pl->off_dbl) ? packed.data() + pl->off_dbl : nullptr;
+  // channels of a multi-Q tensor are stored sorted by Q (PackLayer::off_perm): hand back logical order
+  const int32_t* permf = (pl && pl->off_perm) ? reinterpret_cast<const int32_t*>(packed.data() + pl->off_perm) : nullptr;
   for (int b = 0; b < batch; b++)
     for (int c = 0; c < C; c++)
       for (size_t p = 0; p < HW; p++) {
-        int8_t v = tmp[((size_t)b * HW + p) * Cp + off + c];
+        int8_t v = tmp[((size_t)b * HW + p) * Cp + off + (permf ? permf[c] : c)];
         if (dblf && dblf[c]) v = (int8_t)(((int)v + 128) >> 1);
         dst[((size_t)b * C + c) * HW + p] = v;
       }

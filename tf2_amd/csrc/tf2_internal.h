@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 27;
+constexpr uint32_t kPackVersion = 28;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -56,6 +56,8 @@ struct PackLayer {
   uint64_t off_dbl;      // uint8[Np]: 1 = this layer stores output channel n as 2y - 128 (0: no such channel)
   uint64_t off_pad;      // uint8[Cp_in + 16]: what an out-of-range tap reads (the stored form of x = 0: -128 on doubled input
                          // channels), 0: the zero page
+  uint64_t off_perm;     // int32[N]: physical position of logical output channel n in this layer's output tensor (0: identity).  Tensors
+                         // with several Q values are stored sorted by Q so that their consumers' K slabs are Q-uniform (weight_pack.cpp)
   uint64_t off_unit;     // conv_stem only, != 0: the layer's LOW exponent window is nothing but unit taps (+x << 0, the conv1
                          // rewrite's memset rows, model_loader.cpp:244-257), the same (tap, channel) set in every output row:
                          // int8[9][32] 0/1 mask; off_w2 then holds the HIGH window alone and the kernel adds the per-pixel sum
