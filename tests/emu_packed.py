@@ -8,7 +8,7 @@ import numpy as np
 HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir_bytes", "<u4"),
                 ("total_bytes", "<u8"), ("tables_hash", "<u8"), ("zero_off", "<u8")])
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
-                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into")] +
+                                     "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into", "w_share", "w_main_TM")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
                                     "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_perm", "off_unit")])
 
@@ -94,8 +94,23 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         dsh = i32(blob, int(pl["off_dshift"]), P * Np).reshape(P, Np).astype(np.int64)
         dual = int(pl["dual"])
         nt = 2 if dual else 1                      # weight tiles per entry
-        wt = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * nt * TM * 64].tobytes(), np.int8)
-        wt = wt.reshape(-1, nt, TM, 64)
+        # weight tiles: the layer's own storage, or (alternative entries, PackLayer::w_share) the main entry's tiles of the other
+        # height -- halves of 128-row tiles / pairs of the 64-row tiles of two neighbouring m-tiles (ConvArgs w_* in the kernels)
+        sTM = int(pl["w_main_TM"]) if int(pl["w_share"]) else TM
+        st = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * nt * sTM * 64].tobytes(), np.int8)
+        st = st.reshape(-1, nt, sTM, 64)
+        nent0 = int(dirs[0, P] - dirs[0, 0])
+
+        class _Tiles:
+            def __getitem__(self, key):
+                e, w = key
+                if sTM == TM:
+                    return st[e, w]
+                if sTM == 2 * TM:
+                    return st[e, w][(cur_mt[0] & 1) * TM:(cur_mt[0] & 1) * TM + TM]
+                return np.concatenate([st[e, w], st[e + nent0, w]], axis=0)
+        wt = _Tiles()
+        cur_mt = [0]
         # gather all slabs once: Bmat[slab] = [npix, 64]
         pb, poh, pow_ = np.unravel_index(np.arange(npix), (B, OH, OW))
         slabs = {}
@@ -122,6 +137,7 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
 
         acc = np.zeros((Np, npix), np.int64)
         for mt in range(nm):
+            cur_mt[0] = mt
             a = np.zeros((TM, npix), np.int64)
             if dual:
                 # both exponent windows per entry: (hi << dshift[1]) + lo, combined once (weight_pack.cpp)

@@ -414,15 +414,19 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
 
 @pytest.mark.parametrize("off", ["TF2_AMD_NOPERM", "TF2_AMD_NOGROUP"])
 def test_q_sorted_tensors_and_channel_group_phases_on_and_off(r50, monkeypatch, off):
-    """Multi-Q tensors are stored with their channels sorted by Q and their consumers packed with one Horner phase per channel
-    group (weight_pack.cpp); every other ResNet-50 test runs that default.  Here the two switches that turn it off -- identity
-    channel order, exponent-window phases -- every layer against the oracle, and the default form's launch list for contrast."""
+    """TF2_AMD_GROUP=1: multi-Q tensors stored with their channels sorted by Q, their consumers packed with one Horner phase per
+    channel group (weight_pack.cpp) -- every layer against the oracle and the batch-32 logits; then each half switched off again
+    (identity channel order / exponent-window phases), every layer against the oracle."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import emu_packed as emu
+    monkeypatch.setenv("TF2_AMD_GROUP", "1")          # the form is opt-in at pack time (weight_pack.cpp: measured +-0)
     base = Rig(*r50, 0)
     _, pls = emu.parse(base.net.packed_host())
     assert sum(1 for p in pls if int(p["off_perm"])) >= 12 and sum(1 for p in pls if int(p["n_phases"]) == 3) >= 10
+    base.check_all_layers(synth.synth_images(base.t, 2, 34))
+    x32 = synth.synth_images(base.t, 32, 35)
+    np.testing.assert_array_equal(base.run(x32, keep_all=False)[:2], base.ref.logits(base.ref.run(x32[:2])))
     monkeypatch.setenv(off, "1")
     rig = Rig(*r50, 0)
     _, pls = emu.parse(rig.net.packed_host())

@@ -166,16 +166,32 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # several-streams plan, stage 5) next to the first 1x1 of the stage's first bottleneck
     assert {r["layer"] for r in one if "pair" in r["kernel"]} == {11, 24} and {r["layer"] for r in many if "pair" in r["kernel"]} == {11, 24, 43}
     assert len(many) == len(one) + 3 - 1
-    # ring-kernel launches: the arithmetic-gather instantiation for single-window / dual layers, the header tables for the layers
-    # packed with one Horner phase per input-channel group (the consumers of the three-Q stage tensors)
+    # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation (single-window and dual layers are dense)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]
-    assert ring and all(("dense" in r["kernel"]) != ("tables" in r["kernel"]) for r in ring)
-    assert {r["layer"] for r in ring if "tables" in r["kernel"]} == {5, 8, 11, 15, 18, 21, 24, 47, 50, 53}
+    assert ring and all("dense" in r["kernel"] and "tables" not in r["kernel"] for r in ring)
     assert all(0 < r["grid"] and r["block"] in (256, 512) and 0 <= r["lds_bytes"] <= 160 * 1024 for r in one)
     # batch 1: small grids, the split-K kernel on the 64-row layers
     assert any("conv_mfma_sk" in r["kernel"] for r in net.describe_launches(1, 0))
     with pytest.raises(_lib.Tf2Error):
         net.describe_launches(0, 0)
+
+
+def test_group_phase_packing_is_table_driven(golden_dir, monkeypatch):
+    """TF2_AMD_GROUP=1 (pack time): multi-Q tensors sorted by Q, their consumers packed with one Horner phase per channel group:
+    those launches read the header tables, and the packed image shrinks."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+    sizes = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("TF2_AMD_GROUP", on)
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+        sizes[on] = net.packed_host().size
+        ring = [r for r in net.describe_launches(32, 0) if "conv_mfma" in r["kernel"]]
+        tabled = {r["layer"] for r in ring if "tables" in r["kernel"]}
+        assert tabled == (set() if on == "0" else {5, 8, 11, 15, 18, 21, 24, 47, 50, 53})
+    assert sizes["1"] < sizes["0"] < 40e6
 
 
 def test_run_ex_rejects_bad_options_without_touching_the_device():

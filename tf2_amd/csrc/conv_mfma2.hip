@@ -159,7 +159,7 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     off = o + lane_c16; hw = h + (lane_c16 << 16);
   };
   if (DENSE) {
-    n_ent = a_nslab; e_begin = mtile * n_ent;
+    n_ent = a_nslab; e_begin = ((mtile << a_e_shl) >> a_e_shr) * n_ent;
 #pragma unroll
     for (int s = 0; s < S - 1; s++) gather_of(s, pro_off[s], pro_hw[s]);
   } else {
@@ -222,10 +222,21 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     }
   }
 
+  // where this wave's weight row groups sit inside a storage entry (ConvArgs w_*: own tiles, halves of 128-row tiles, pairs of
+  // 64-row tiles): group gi = 16 rows = 1 KiB
+  const int w_sub = (mtile & 1) * a_w_sub;
+  int a_goff[NI_HI];
+#pragma unroll
+  for (int j = 0; j < NI_HI; j++) {
+    const int gi = wave + NW * j;
+    constexpr int RG = TM / 16;                      // row groups of one window
+    const int r = gi % RG, win = gi / RG;
+    a_goff[j] = (r & 3) * 1024 + (TM == 128 ? ((r >> 2) & 1) * a_w_half : 0) + win * a_w_win;
+  }
   // one stage = entry e (weights) + this lane's gather words off/hw (activations) into ring slot slot_idx
   auto issue_stage = [&](int e, int off, int hw, int slot_idx, bool in_loop = false) {
     int8_t* const slot = lds + slot_idx * STAGE;
-    const int8_t* wsrc = aw + (size_t)e * A_BYTES + a_lane_off;
+    const int8_t* wsrc = aw + (size_t)e * a_w_ent + a_lane_off + w_sub;
     int dh = 0, dw = 0, pc = 0;              // pc: the segment's channel offset = its place in the layer's pad row
     if (PADCHK) { dh = hw & 0xff; dw = (hw >> 8) & 0xff; pc = (int)((unsigned)hw >> 16); }
 #pragma unroll
@@ -233,7 +244,7 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
       const int gi = wave + NW * j;
       if (STATIC_GRP ? j < NA : gi < AG) {
         if (!((prb & kProbeNoA) && in_loop))
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + gi * 1024), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(wsrc + a_goff[j]), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
       } else if ((j < NI_LO || ni_hi) && !((prb & kProbeNoB) && in_loop)) {
         bool ok = off >= 0 && brow_ok[j];
         if (PADCHK && !(prb & kProbeNoPad)) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   // this m-tile's {first, end} entry: the last two words of steps[] in its header image (weight_pack.cpp)
   typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
   int e_begin, n_ent;
-  if (DENSE) { n_ent = a_nslab; e_begin = mtile * n_ent; }
+  if (DENSE) { n_ent = a_nslab; e_begin = ((mtile << a_e_shl) >> a_e_shr) * n_ent; }
   else {
     const auto ee = *(cvec2_p)(unsigned long long)(ahdr + (size_t)mtile * (size_t)(a_hdr_bytes >> 2) + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
     e_begin = ee[0];
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 
   auto issue_A = [&](int k, int slot_idx) {                     // k-th entry of this wave
     int8_t* const slot = ring + slot_idx * STAGE;
-    const int8_t* wsrc = aw + (size_t)(e_begin + ent_of(k)) * ((DUAL ? 2 : 1) * A_BYTES) + (DUAL ? (wave & 1) * A_BYTES : 0) + a_lane_off;
+    // (64-row tiles: own storage, or the halves of the main entry's 128-row tiles -- ConvArgs w_*)
+    const int8_t* wsrc = aw + (size_t)(e_begin + ent_of(k)) * a_w_ent + (DUAL ? (wave & 1) * a_w_win : 0) + (mtile & 1) * a_w_sub + a_lane_off;
 #pragma unroll
     for (int j = 0; j < AI; j++)
       if (!(prb & kProbeNoA) || k < S - 1)

@@ -346,6 +346,18 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     ca.zero = (const int8_t*)(pk + (pl->off_pad ? pl->off_pad : zero_off)); ca.max_ent = pl->max_ent;
     ca.dual = pl->dual;
     set_fast_div((uint32_t)pl->n_mtiles, &ca.mt_m, &ca.mt_s);
+    // weight-tile addressing (tf2_internal.h ConvArgs): own storage, or the main entry's tiles of the other height
+    {
+      const int wins = pl->dual ? 2 : 1;
+      const int sTM = pl->w_share ? pl->w_main_TM : pl->TM;            // rows of a storage tile
+      ca.w_ent_bytes = wins * sTM * 64; ca.w_win_stride = sTM * 64; ca.w_half_stride = 4096; ca.w_sub_step = 0; ca.e_mt_shl = 0; ca.e_mt_shr = 0;
+      if (pl->w_share && sTM == 2 * pl->TM) { ca.w_sub_step = 4096; ca.e_mt_shr = 1; }                       // halves of 128-row tiles
+      if (pl->w_share && 2 * sTM == pl->TM) {                                                               // pairs of 64-row tiles
+        const int32_t* hd0 = reinterpret_cast<const int32_t*>(packed.data() + pl->off_dir);
+        const int nent = hd0[pl->n_phases] - hd0[0];
+        ca.w_half_stride = nent * ca.w_ent_bytes; ca.e_mt_shl = 1;
+      }
+    }
     bool dense = false;
     if (pl->kind == KIND_MFMA) {
       ca.hdr = (const int32_t*)(pk + pl->off_hdr); ca.hdr_bytes = (int32_t)pl->hdr_bytes;
@@ -400,7 +412,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         st.sel = Launch::SEL_SK; st.avg_fused = 1;
       } else
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
-      if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
+      if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
     } else if (pl->kind == KIND_SHIFT) {
       st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {

@@ -28,6 +28,9 @@ __device__ __forceinline__ int fast_div(int n, uint32_t m, int s) {
   const unsigned mt_m = (a).mt_m; const int mt_s = (a).mt_s;                                                               \
   const int a_nslab = (a).nslab, a_cslabs = (a).cslabs, a_cs_s = (a).cs_s, a_k = (a).k, a_kk_s = (a).kk_s, a_dil = (a).dil;   \
   const unsigned a_cs_m = (a).cs_m, a_kk_m = (a).kk_m;                                                                      \
+  const int a_w_ent = (a).w_ent_bytes, a_w_win = (a).w_win_stride, a_w_half = (a).w_half_stride, a_w_sub = (a).w_sub_step;    \
+  const int a_e_shl = (a).e_mt_shl, a_e_shr = (a).e_mt_shr;                                                                  \
+  asm volatile("" :: "s"(a_w_ent), "s"(a_w_win), "s"(a_w_half), "s"(a_w_sub), "s"(a_e_shl), "s"(a_e_shr));                   \
   asm volatile("" :: "s"(a_nslab), "s"(a_cslabs), "s"(a_cs_s), "s"(a_k), "s"(a_kk_s), "s"(a_dil), "s"(a_cs_m), "s"(a_kk_m)); \
   asm volatile("" :: "s"(g.H), "s"(g.W), "s"(g.Cp_in), "s"(g.OW), "s"(g.OHW), "s"(g.ohw_m), "s"(g.ow_m), "s"(g.ohw_s),     \
                "s"(g.ow_s), "s"(g.stride), "s"(g.pad_h), "s"(g.pad_w), "s"(g.n_pix), "s"(g.y_cp), "s"(g.y_off), "s"(g.y_nvalid)); \

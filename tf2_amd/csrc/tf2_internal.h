@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 28;
+constexpr uint32_t kPackVersion = 29;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -39,6 +39,8 @@ struct PackLayer {
   int32_t fuse_next;   // > 0: this 3x3 layer and layer `fuse_next` (its only consumer, the 1x1 expand) run as ONE conv_bneck launch;
                        // both are packed with TM = this layer's channel count (64 / 128 / 256)
   int32_t fused_into;  // >= 0: the layer whose launch computes this one (-1 otherwise)
+  int32_t w_share;     // alternative entries only: 1 = off_w is the MAIN entry's tile storage (tiles of w_main_TM rows); the kernels
+  int32_t w_main_TM;   //   address half tiles / tile pairs of it (ConvArgs w_* fields) instead of a second copy of the weights
   uint64_t off_w;        // MFMA: n_entries * TM * 64 bytes; SHIFT: int32 weights (pos [, negmag])
   uint64_t off_w2;       // SHIFT signed mode: magnitudes of negative weights
   uint64_t off_entries;  // int32[n_entries] slab id
@@ -129,6 +131,14 @@ struct ConvArgs {
   // "Dense" layers (net.hip make_conv: every m-tile holds all nslab slabs in order, one window or dual, Cp_in a multiple of 64):
   // the ring kernels then derive a step's gather words from its index -- slab sl = (tap t, channel slab cs), t = sl / cslabs --
   // instead of reading them from the header image, so the first activation DMAs need nothing but the kernel arguments.
+  // Where a block finds its weight tiles.  An entry of the storage holds (dual ? 2 : 1) windows of `storage TM` rows x 64 bytes;
+  // a kernel with 64-row tiles can read the halves of 128-row storage tiles and a kernel with 128-row tiles can read pairs of
+  // 64-row storage tiles (PackLayer::w_share: a layer's alternative tile height without a second copy of its weights):
+  //   tile row group gi (16 rows, 1 KiB) of entry e = w + e * w_ent_bytes + (mtile & 1) * w_sub_step
+  //                                                  + (gi & 3) * 1024 + [TM = 128: ((gi >> 2) & 1) * w_half_stride] + window(gi) * w_win_stride
+  //   first entry of m-tile mt (DENSE) = ((mt << e_mt_shl) >> e_mt_shr) * nslab
+  int32_t w_ent_bytes, w_win_stride, w_half_stride, w_sub_step;
+  int32_t e_mt_shl, e_mt_shr;
   int32_t dense;             // 1: arithmetic gather (conv_mfma2 / conv_mfma_sk DENSE instantiations)
   int32_t cslabs;            // Cp_in / 64
   uint32_t cs_m; int32_t cs_s; // set_fast_div(cslabs)

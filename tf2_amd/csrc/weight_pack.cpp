@@ -197,8 +197,13 @@ tf2_status Net::pack(int mode) {
   // perm[p][n] = physical position of logical output channel n of layer p (empty: identity).  A permuted tensor is read only by
   // MFMA convolutions (as input or residual -- residual partners carry the same Q vector, hence the same order);
   // tf2_net_read_layer hands back logical order (PackLayer::off_perm).
+  // Measured on ResNet-50 (profiles/r03_experiments.txt): 12 layers walk 6 / 10 / 34 weight tiles per m-tile instead of 8 / 16 / 64 and
+  // the packed image loses 7 MB, but those layers leave the arithmetic-gather (DENSE) prologue for the table-driven one: four batches
+  // in flight +1 %, one batch at a time +-0, batch-1 latency +2.5 %.  Hence OFF by default; TF2_AMD_GROUP=1 at pack time turns
+  // both halves on (sorted tensors + group phases), TF2_AMD_NOPERM / TF2_AMD_NOGROUP then switch the halves off individually.
+  const bool group_on = getenv("TF2_AMD_GROUP") != nullptr && atoi(getenv("TF2_AMD_GROUP")) != 0;
   std::vector<std::vector<int>> perm(nl);
-  if (mode == 0 && getenv("TF2_AMD_NOPERM") == nullptr) {
+  if (mode == 0 && group_on && getenv("TF2_AMD_NOPERM") == nullptr) {
     const int M = nd.max_out_channel;
     std::vector<char> cand(nl, 0);
     auto qrow_eq = [&](int a, int b) { return layers[a].N == layers[b].N && std::memcmp(q.data() + (size_t)(a + 1) * M, q.data() + (size_t)(b + 1) * M, layers[a].N) == 0; };
@@ -278,6 +283,10 @@ tf2_status Net::pack(int mode) {
       continue;
     }
     int alt_TM = 0;
+    // the main variant's entry structure, for the alternative to share its tile storage (PackLayer::w_share)
+    std::vector<int32_t> main_entries, main_dir;
+    int main_TM = 0, main_P = 0, main_dual = 0, main_nm = 0;
+    uint64_t main_off_w = 0;
     for (int variant = 0; variant < 2; variant++) {        // 0: the layer's own entry, 1: its alternative tile height (if any)
     if (variant == 1) {
       const PackLayer& p0 = *(blob.at<PackLayer>(sizeof(PackHeader)) + l);
@@ -385,7 +394,7 @@ tf2_status Net::pack(int mode) {
       int G = 1;
       bool grp = false;
       std::vector<int32_t> glo;
-      if (mode == 0 && P >= 2 && L.src >= 0 && layers[L.src].concat < 0 && !is_image && !in_dbl && getenv("TF2_AMD_NOGROUP") == nullptr) {
+      if (mode == 0 && group_on && P >= 2 && L.src >= 0 && layers[L.src].concat < 0 && !is_image && !in_dbl && getenv("TF2_AMD_NOGROUP") == nullptr) {
         const int M = nd.max_out_channel;
         const int8_t* q_in = q.data() + (size_t)L.q_in_row * M;
         std::vector<int> vals;
@@ -568,8 +577,45 @@ tf2_status Net::pack(int mode) {
           std::memcpy(blob.at<uint8_t>(pl.off_unit), unit.data(), unit.size());
         }
       }
-      pl.off_w = blob.alloc(std::max<size_t>(tiles.size(), 64));
-      std::memcpy(blob.at<uint8_t>(pl.off_w), tiles.data(), tiles.size());
+      // An alternative (the same layer with the other tile height) reads the MAIN entry's tiles when every m-tile of both walks
+      // the same slab list phase by phase (dense weights always do): a 64-row tile is half of a 128-row storage tile, a 128-row
+      // tile is the pair of storage tiles of two neighbouring m-tiles.  Saves the second copy of the weights.
+      bool share = false;
+      // (Only the WIDE alternatives -- 128-row tiles as pairs of the main 64-row tiles, 22 of the 24 duplicate MB of ResNet-50 -- share
+      //  by default: the narrow ones serve the tiny grids of batch 1-2, where reading halves of 8-KiB-strided tiles measured +2 % on the
+      //  batch-1 latency; TF2_AMD_SHARE=2 shares those too, TF2_AMD_NOSHARE=1 none.)
+      const int share_mode = getenv("TF2_AMD_NOSHARE") ? 0 : (getenv("TF2_AMD_SHARE") ? atoi(getenv("TF2_AMD_SHARE")) : 1);
+      if (variant == 1 && main_TM && share_mode && main_P == P && main_dual == (dual ? 1 : 0) &&
+          (2 * main_TM == TM || (share_mode >= 2 && main_TM == 2 * TM))) {
+        share = true;
+        auto same_lists = [&](const std::vector<int32_t>& ent, const std::vector<int32_t>& dr, int nm) {
+          for (int mt = 0; mt < nm && share; mt++)
+            for (int p2 = 0; p2 < P && share; p2++) {
+              const int a0 = dr[(size_t)mt * (P + 1) + p2], a1 = dr[(size_t)mt * (P + 1) + p2 + 1];
+              const int r0 = main_dir[p2], r1 = main_dir[p2 + 1];
+              if (a1 - a0 != r1 - r0) { share = false; break; }
+              for (int i = 0; i < a1 - a0; i++) if (ent[a0 + i] != main_entries[r0 + i]) { share = false; break; }
+            }
+        };
+        same_lists(main_entries, main_dir, main_nm);
+        same_lists(entries, dir, n_mtiles);
+      }
+      if (share) {
+        pl.off_w = main_off_w; pl.w_share = 1; pl.w_main_TM = main_TM;
+        // the alternative's m-tile mt starts at the main m-tile's first entry: mt / 2 (halves of 128-row tiles) or 2 mt (pairs)
+        const int nent = main_dir[P] - main_dir[0];
+        for (int mt = 0; mt < n_mtiles; mt++) {
+          const int mm_ = main_TM == 2 * TM ? mt >> 1 : 2 * mt;
+          for (int p2 = 0; p2 <= P; p2++) dir[(size_t)mt * (P + 1) + p2] = mm_ * nent + (main_dir[p2] - main_dir[0]);
+        }
+        // (entries[] is indexed by these storage entry numbers from here on: the main list repeated per main m-tile)
+        entries = main_entries;
+        pl.n_entries = (int32_t)entries.size();
+      } else {
+        pl.off_w = blob.alloc(std::max<size_t>(tiles.size(), 64));
+        std::memcpy(blob.at<uint8_t>(pl.off_w), tiles.data(), tiles.size());
+      }
+      if (variant == 0) { main_entries = entries; main_dir = dir; main_TM = TM; main_P = P; main_dual = dual ? 1 : 0; main_nm = n_mtiles; main_off_w = pl.off_w; }
       pl.off_entries = blob.alloc(std::max<size_t>(entries.size(), 1) * 4);
       std::memcpy(blob.at<uint8_t>(pl.off_entries), entries.data(), entries.size() * 4);
       pl.off_dir = blob.alloc(dir.size() * 4);
