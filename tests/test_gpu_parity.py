@@ -412,6 +412,30 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
     np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))
 
 
+@pytest.mark.parametrize("conc", ["0", "1"])
+def test_chain_launches_against_the_oracle(r50, monkeypatch, conc):
+    """TF2_AMD_CHAIN=1 (off by default): consecutive 128-row ring-kernel rows in ONE launch (conv_mfma2_chain_kernel), blocks ordered
+    only by per-pixel-tile completion counters, activations through agent-scope loads / stores, every tensor of a chain alive
+    to its end (Net::plan).  Every layer at batch 2 and 32 against the oracle (keep_all workspace), then the batch-32 logits of
+    repeated runs on a liveness-planned workspace (the memory layout the counters protect)."""
+    monkeypatch.setenv("TF2_AMD_CHAIN", "1")
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    rig = Rig(*r50, 0)
+    launches = rig.net.describe_launches(32, int(conc))
+    chains = [l for l in launches if "chain" in l["kernel"]]
+    assert chains and (conc == "0" or len(launches) <= 22)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 51))
+    x = synth.synth_images(rig.t, 32, 52)
+    want3 = rig.ref.logits(rig.ref.run(x[:3]))
+    first = rig.run(x, keep_all=False).copy()
+    np.testing.assert_array_equal(first[:3], want3)
+    for _ in range(10):
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
+    monkeypatch.setenv("TF2_AMD_CHAIN", "0")
+    plain = Rig(*r50, 0)
+    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
+
+
 @pytest.mark.parametrize("off", ["TF2_AMD_NOPERM", "TF2_AMD_NOGROUP"])
 def test_q_sorted_tensors_and_channel_group_phases_on_and_off(r50, monkeypatch, off):
     """TF2_AMD_GROUP=1: multi-Q tensors stored with their channels sorted by Q, their consumers packed with one Horner phase per

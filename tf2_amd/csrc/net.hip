@@ -170,6 +170,27 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       for (size_t t = 0; t < wp.tensors.size(); t++)
         if (born[t] == b) born[t] = l;
     }
+  // Chain launches (conv_mfma2_chain_kernel, TF2_AMD_CHAIN): blocks of consecutive rows run concurrently, ordered only by the
+  // data they read -- so nothing a chain touches may share memory: every tensor whose life ends inside a run of chainable rows
+  // lives until the run's last row.  (Which rows actually share a launch is decided per launch plan; always inside these runs.)
+  wp.chain_end.assign(nl, -1);
+  if (packed_valid && opts.chain_mode) {
+    size_t tiles = 0;
+    for (int l = 0; l < nl;) {
+      if (!chain_row(l)) { l++; continue; }
+      int e = l;
+      while (e + 1 < nl && chain_row(e + 1)) e++;
+      for (int k = l; k <= e; k++) {
+        wp.chain_end[k] = e;
+        tiles += ((size_t)batch * layers[k].OH * layers[k].OW + 127) / 128;
+      }
+      if (e > l)
+        for (TensorPlan& t : wp.tensors)
+          if (t.last_use >= l && t.last_use < e) t.last_use = e;
+      l = e + 1;
+    }
+    wp.chain_ctr_bytes = (tiles * kChainCtrStride * 4 + 255) / 256 * 256;
+  }
   // ---- offsets ----
   struct Seg { size_t off, len; };
   std::vector<Seg> free_list;           // sorted by offset
@@ -215,7 +236,8 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           release(wp.tensors[t].offset, wp.tensors[t].bytes); freed[t] = 1;
         }
   }
-  wp.total_bytes = (top + 255) / 256 * 256 + 256;
+  wp.chain_off = (top + 255) / 256 * 256 + 256;
+  wp.total_bytes = wp.chain_off + (wp.chain_ctr_bytes ? kChainTablesBytes + 2 * wp.chain_ctr_bytes : 0);
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
@@ -234,6 +256,17 @@ bool Net::pair_candidate(int l) const {
   if (!pa || !pb || pa->kind != KIND_MFMA || pb->kind != KIND_MFMA) return false;
   if (pa->fuse_next > 0 || pa->fused_into >= 0 || pb->fuse_next > 0 || pb->fused_into >= 0) return false;
   return true;
+}
+
+// Row l could be a segment of a chain launch: a plain convolution row whose packed form (or wide-tile alternative) has 128-row
+// tiles for the ring kernel.  Static (tables + packed image); the launch plan decides per batch and concurrency.
+bool Net::chain_row(int l) const {
+  const tf2_layer_desc& L = layers[l];
+  if (l < 1 || L.ipool || L.pool_en || L.endpool || L.concat >= 0 || L.src < 0) return false;
+  if (L.add_src >= 0 && layers[L.add_src].concat >= 0) return false;
+  const PackLayer* pl = pack_layer(l); const PackLayer* pa = pack_layer_alt(l);
+  if (!pl || pl->kind != KIND_MFMA) return false;
+  return pl->TM == 128 || (pa && pa->TM == 128);
 }
 
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
@@ -257,6 +290,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
+  if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
@@ -547,6 +581,77 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       lp.steps.push_back(sa);
     }
   }
+  // ---- chain launches: runs of consecutive ring-kernel steps of the 8-wave 128 x 128 dense shape become ONE launch each ----
+  // (conv_mfma2_chain_kernel: a block of a later layer waits in place for the pixel tiles it reads instead of for a kernel
+  //  boundary -- no launch, no drain, no empty chip between the layers, and layers overlap wherever the data allows)
+  if (opts.chain_mode && wp->chain_ctr_bytes) {
+    auto chainable = [&](const Launch& st) {
+      if (st.kind != Launch::CONV || (lp.logits_direct >= 0 && &st == &lp.steps[lp.logits_direct])) return false;
+      if (wp->chain_end[st.layer] < 0) return false;
+      if (st.sel == Launch::SEL_MFMA2) return conv_mfma2_chain_eligible(st.conv, st.TM);
+      if (st.sel == Launch::SEL_PAIR) return wp->chain_end[st.layer + 1] >= 0 && conv_mfma2_chain_eligible(st.conv, 128) && conv_mfma2_chain_eligible(st.conv2, 128);
+      return false;
+    };
+    std::vector<Launch> out;
+    size_t table_used = 0, ctr_used = 0;          // segments / counters handed out so far
+    const size_t table_base = wp->chain_off + (concurrent ? kChainTableSegs * kChainSegStride : 0);
+    const size_t ctr_base = wp->chain_off + kChainTablesBytes + (concurrent ? wp->chain_ctr_bytes : 0);
+    for (size_t i = 0; i < lp.steps.size();) {
+      size_t j = i; int nseg = 0;
+      while (j < lp.steps.size() && chainable(lp.steps[j]) && wp->chain_end[lp.steps[j].layer] == wp->chain_end[lp.steps[i].layer]) {
+        const int add = lp.steps[j].sel == Launch::SEL_PAIR ? 2 : 1;
+        if (nseg + add > kChainMaxSegs || table_used + nseg + add > kChainTableSegs) break;
+        nseg += add; j++;
+      }
+      if (j - i < 2) { out.push_back(lp.steps[i]); i++; continue; }
+      Launch ch; ch.kind = Launch::CONV; ch.sel = Launch::SEL_CHAIN; ch.layer = lp.steps[i].layer;
+      int next_block = 0;
+      const size_t ctr0 = ctr_used;
+      std::map<int, int> seg_of_layer;
+      auto add_seg = [&](const ConvArgs& ca, int layer) {
+        const tf2_layer_desc& L = layers[layer];
+        ChainSeg sg{};
+        sg.a = ca; sg.layer = layer;
+        const int ntiles = (ca.g.n_pix + 127) / 128;
+        sg.first_block = next_block;
+        sg.n_blocks = ntiles * ca.n_mtiles;
+        sg.variant = ((ca.g.pad_h | ca.g.pad_w) ? 1 : 0) | (ca.dual ? 2 : 0);
+        sg.ctr_off = (int)(ctr_used - ctr0); ctr_used += (size_t)ntiles;
+        sg.src_ctr = sg.res_ctr = -1;
+        auto ps = seg_of_layer.find(L.src);
+        if (ps != seg_of_layer.end()) { sg.src_ctr = ch.chain_segs[ps->second].ctr_off; sg.src_need = ch.chain_segs[ps->second].a.n_mtiles; }
+        auto pr = L.add_src >= 0 ? seg_of_layer.find(L.add_src) : seg_of_layer.end();
+        if (pr != seg_of_layer.end()) { sg.res_ctr = ch.chain_segs[pr->second].ctr_off; sg.res_need = ch.chain_segs[pr->second].a.n_mtiles; }
+        ch.chain.seg_first[ch.chain_segs.size()] = next_block;
+        next_block = (next_block + sg.n_blocks + 7) / 8 * 8;
+        seg_of_layer[layer] = (int)ch.chain_segs.size();
+        ch.chain_segs.push_back(sg);
+      };
+      for (size_t k = i; k < j; k++) {
+        const Launch& st = lp.steps[k];
+        add_seg(st.conv, st.layer);
+        if (st.sel == Launch::SEL_PAIR) add_seg(st.conv2, st.layer + 1);
+      }
+      ch.chain.n_segs = (int)ch.chain_segs.size();
+      for (int k = ch.chain.n_segs; k <= kChainMaxSegs; k++) ch.chain.seg_first[k] = next_block;
+      ch.chain_table_off = table_base + table_used * kChainSegStride;
+      ch.chain.segs = reinterpret_cast<const ChainSeg*>(base + ch.chain_table_off);
+      ch.chain.ctr = reinterpret_cast<unsigned*>(base + ctr_base + ctr0 * kChainCtrStride * 4);
+      ch.chain_ctr_bytes = (ctr_used - ctr0) * kChainCtrStride * 4;
+      table_used += ch.chain_segs.size();
+      out.push_back(std::move(ch));
+      lp.n_chains++;
+      i = j;
+    }
+    if (ctr_used * kChainCtrStride * 4 > wp->chain_ctr_bytes) return fail("chain counters outgrew the workspace plan");
+    if (lp.n_chains) {
+      if (lp.logits_direct >= 0) {          // (the direct-logits step is never part of a chain; find it again)
+        const int layer = lp.steps[lp.logits_direct].layer;
+        for (size_t k = 0; k < out.size(); k++) if (out[k].layer == layer && out[k].sel == Launch::SEL_SK) lp.logits_direct = (int)k;
+      }
+      lp.steps = std::move(out);
+    }
+  }
   launch_plans.push_back(std::move(lp));
   return &launch_plans.back();
 }
@@ -576,6 +681,9 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_CHAIN:
+          if (!launch_recorder() && hipMemsetAsync(st.chain.ctr, 0, st.chain_ctr_bytes, (hipStream_t)stream) != hipSuccess) return -1;
+          return launch_conv_mfma2_chain(st.chain, st.chain_segs.data(), stream);
         case Launch::SEL_STEM: return launch_conv_stem(st.stem, st.shape, stream);
         default: return launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream);
       }
@@ -658,6 +766,14 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     }
     return TF2_OK;
   };
+  if (lp->n_chains && !lp->chain_uploaded) {
+    // the segment tables of the chain launches go into the workspace once per (workspace, plan); stream order covers the launches
+    for (const Launch& st : lp->steps)
+      if (st.sel == Launch::SEL_CHAIN && st.kind == Launch::CONV)
+        for (size_t k = 0; k < st.chain_segs.size(); k++)
+          HIP_OK(hipMemcpyAsync((int8_t*)ws + st.chain_table_off + k * sizeof(ChainSeg), &st.chain_segs[k], sizeof(ChainSeg), hipMemcpyHostToDevice, s));
+    const_cast<LaunchPlan*>(lp)->chain_uploaded = true;
+  }
   bool mark_pending = mark_event != nullptr;
 #ifdef TF2_PROBES
   // tools/probe_run.py: leave out the launches of a layer range (results are then wrong; only durations are read)

@@ -146,6 +146,34 @@ struct ConvArgs {
   ConvGeom g;
 };
 
+// conv_mfma2_chain_kernel (conv_mfma2.hip): consecutive table rows in ONE launch.  Segment i owns the hardware blocks
+// [first_block, first_block + n_blocks) of the grid (first_block a multiple of 8: the XCD-aware block remap of the ring kernel
+// keeps working); blocks are dispatched in ascending order, so a block that waits for earlier segments never occupies a slot
+// that a block it waits for still needs (chain launches).  Dependencies are per PIXEL TILE (128 output
+// pixels): every block adds 1 to its segment's counter of its pixel tile when its stores are acknowledged, and a block starts
+// its first activation load when the tiles of the producing segment that cover its input pixels hold n_mtiles(producer) each
+// (and its own tile of the residual's producer likewise).  Counters are zeroed by the host before every launch.  Activations
+// written and read inside a chain bypass the XCD-private L2s (sc1 loads / stores): within a kernel the L2 of one XCD is not
+// coherent with another's.  The workspace planner keeps every tensor a chain touches alive until the chain's last row
+// (Net::plan), so the only ordering a segment needs is on the data it reads.
+struct ChainSeg {
+  ConvArgs a;
+  int32_t first_block, n_blocks;
+  int32_t variant;           // bit 0: padded taps (PADCHK), bit 1: dual-window tiles
+  int32_t ctr_off;           // this segment's counters: ctr[(ctr_off + pixel tile) * kChainCtrStride]
+  int32_t src_ctr, src_need; // producer of the input tensor inside the chain: its ctr_off (-1: none) and n_mtiles
+  int32_t res_ctr, res_need; // the same for the residual tensor
+  int32_t layer;             // table row (diagnostics)
+};
+constexpr int kChainMaxSegs = 48;
+constexpr int kChainCtrStride = 8;         // counters sit 32 bytes apart (in 32-bit words)
+struct ChainArgs {
+  const ChainSeg* segs;      // device copy of the segment table
+  unsigned* ctr;             // completion counters, kChainCtrStride words apart
+  int32_t n_segs;
+  int32_t seg_first[kChainMaxSegs + 1];
+};
+
 // conv_bneck.hip: layer C (3x3 / stride 1 / pad 1, C -> C channels, C = 64 / 128 / 256) followed by its only consumer E
 // (1x1, C -> 4C, + residual): one launch per R x W pixel band of an image.
 struct BneckArgs {
@@ -224,6 +252,8 @@ struct PrepArgs {
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
+bool conv_mfma2_chain_eligible(const ConvArgs& a, int TM);                                  // the 8-wave 128 x 128 dense shape
+int launch_conv_mfma2_chain(const ChainArgs& c, const ChainSeg* host_segs, void* stream);   // host_segs: the same table on the host (grid, LDS size, description)
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);

@@ -35,19 +35,33 @@ struct WorkPlan {
   std::vector<LayerExec> exec;
   int input_tensor = -1;
   int final_tensor = -1;
+  size_t chain_off = 0;     // end of the workspace: segment tables (kChainTablesBytes), then the counters of chain launches
+  size_t chain_ctr_bytes = 0;   // counters of ONE plan (one batch at a time / several in flight): one per pixel tile of every chainable row
+  std::vector<int> chain_end;   // per row: last row of the chainable run it belongs to (-1: not chainable); see Net::plan
   size_t total_bytes = 0;
 };
+
+// chain area of a workspace: two segment tables (one batch at a time / several in flight: both plans may exist for one
+// workspace) of kChainTableSegs entries each, then their counters
+constexpr size_t kChainTableSegs = 64;
+constexpr size_t kChainSegStride = 512;
+constexpr size_t kChainTablesBytes = 2 * kChainTableSegs * kChainSegStride;
+static_assert(sizeof(ChainSeg) <= kChainSegStride, "ChainSeg outgrew its table slot");
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
   ConvArgs conv{};
   ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
+  std::vector<ChainSeg> chain_segs;   // SEL_CHAIN: the launch's segments (host copy of the device table)
+  ChainArgs chain{};
+  size_t chain_table_off = 0;         // where the device table sits in the workspace
+  size_t chain_ctr_bytes = 0;         // counters of this launch (zeroed before every launch)
   BneckArgs bneck{};
   StemArgs stem{};
   PoolArgs pool{};
@@ -64,6 +78,8 @@ struct LaunchPlan {
   int concurrent = 0;               // built for several batches in flight (wide-tile alternatives from a smaller grid on)
   std::vector<Launch> steps;
   int logits_direct = -1;           // index of the conv step that writes the dense logits itself (its y is patched per call), else -1
+  bool chain_uploaded = false;      // the chain launches' segment tables are in the workspace (copied by the first run)
+  int n_chains = 0;
 };
 
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
@@ -76,6 +92,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
+  int chain_mode = 0;      // TF2_AMD_CHAIN: consecutive ring-kernel layers in one launch (conv_mfma2_chain_kernel): 0 never, 1 where eligible
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
   int stem_pool = 1;       // TF2_AMD_STEM_POOL: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
@@ -133,6 +150,7 @@ struct Net {
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  bool chain_row(int l) const;             // row l could be a segment of a chain launch (plain conv row with a 128-row ring-kernel form)
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
   int recent_pos = 0;
   void load_options();
