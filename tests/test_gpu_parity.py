@@ -412,6 +412,27 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
     np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))
 
 
+def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
+    """TF2_AMD_BGROUP=1: the five identity bottlenecks of stage 4 (rows 28-42) as ONE launch each, eight blocks per image meeting at
+    counters between the layers (conv_bgroup.hip).  Every layer against the oracle at batch 2 and 5, then batch-32 logits of
+    repeated runs on the liveness-planned workspace."""
+    monkeypatch.setenv("TF2_AMD_BGROUP", "1")
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
+    rig = Rig(*r50, 0)
+    rows = rig.net.describe_launches(32, 0)
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [28, 31, 34, 37, 40]
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
+    rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
+    x = synth.synth_images(rig.t, 32, 73)
+    first = rig.run(x, keep_all=False).copy()
+    np.testing.assert_array_equal(first[:3], rig.ref.logits(rig.ref.run(x[:3])))
+    for _ in range(10):
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
+    monkeypatch.setenv("TF2_AMD_BGROUP", "0")
+    plain = Rig(*r50, 0)
+    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
+
+
 @pytest.mark.parametrize("conc", ["0", "1"])
 def test_chain_launches_against_the_oracle(r50, monkeypatch, conc):
     """TF2_AMD_CHAIN=1 (off by default): consecutive 128-row ring-kernel rows in ONE launch (conv_mfma2_chain_kernel), blocks ordered

@@ -30,7 +30,13 @@ __device__ __forceinline__ int quant_input(float x, float trans) {
   return (int)r;
 }
 
+// side job of the step's first kernel: advance the workspace's step counter (conv_bgroup.hip: the value a set group flag carries)
+__device__ __forceinline__ void prep_zero_ctrl(const PrepArgs& a) {
+  if (a.epoch_ptr && blockIdx.x == 0 && threadIdx.x == 0) a.epoch_ptr[0] = a.epoch_ptr[0] + 1u;
+}
+
 __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
+  prep_zero_ctrl(a);
   // one thread per (image, output pixel, 16-channel group of the x half): 16 gathered source
   // values -> one 16-byte store of x and one of xneg.  Channel slots >= Cl are the zero padding.
   const int Cl = a.rewrite ? a.C * 9 : a.C;
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
 // XONLY: 32 bytes of x per pixel and no xneg half -- the input of conv_stem.hip, which handles x = -128 itself.
 template <bool SRC_Q, bool XONLY>
 __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
+  prep_zero_ctrl(a);
   __shared__ __attribute__((aligned(16))) int tile[256][17];        // 64 B per pixel (+1 word: bank spread)
   const int total = a.B * a.OH * a.OW;
   const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
 // Same bytes as prep_rewrite3_kernel<*, true> (tests/test_gpu_parity.py checks the network input tensor).
 template <bool SRC_Q>
 __global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
+  prep_zero_ctrl(a);
   constexpr int kPadL = 4, kMaxW = 256;                    // image width <= 248 (launcher-checked); 4 border columns: aligned word stores
   __shared__ __attribute__((aligned(16))) int8_t img[3][5][kMaxW + 8];
   const int rows_per_img = (a.OH + 1) / 2;

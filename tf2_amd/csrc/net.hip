@@ -170,6 +170,21 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       for (size_t t = 0; t < wp.tensors.size(); t++)
         if (born[t] == b) born[t] = l;
     }
+  // Group launches (conv_bgroup.hip: rows l .. l + 2 in one launch, images at different layers at the same time): what the launch
+  // reads stays live to its last row, what it writes exists from its first
+  if (packed_valid && opts.bgroup_mode)
+    for (int l = 0; l + 2 < nl; l++) {
+      if (!bgroup_at(l)) continue;
+      TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
+      tin.last_use = std::max(tin.last_use, l + 2);
+      TensorPlan& tm1 = wp.tensors[wp.exec[l].out_tensor];
+      tm1.last_use = std::max(tm1.last_use, l + 2);
+      for (size_t t = 0; t < wp.tensors.size(); t++)
+        if (born[t] == l + 1 || born[t] == l + 2) born[t] = l;
+      if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;                         // the step counter
+      wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 64;            // two rows of eight flag words per image
+      l += 2;
+    }
   // Chain launches (conv_mfma2_chain_kernel, TF2_AMD_CHAIN): blocks of consecutive rows run concurrently, ordered only by the
   // data they read -- so nothing a chain touches may share memory: every tensor whose life ends inside a run of chainable rows
   // lives until the run's last row.  (Which rows actually share a launch is decided per launch plan; always inside these runs.)
@@ -236,7 +251,9 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           release(wp.tensors[t].offset, wp.tensors[t].bytes); freed[t] = 1;
         }
   }
-  wp.chain_off = (top + 255) / 256 * 256 + 256;
+  wp.ctrl_off = (top + 255) / 256 * 256 + 256;
+  wp.ctrl_bytes = (wp.ctrl_bytes + 255) / 256 * 256;
+  wp.chain_off = wp.ctrl_off + wp.ctrl_bytes;
   wp.total_bytes = wp.chain_off + (wp.chain_ctr_bytes ? kChainTablesBytes + 2 * wp.chain_ctr_bytes : 0);
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
@@ -255,6 +272,26 @@ bool Net::pair_candidate(int l) const {
   const PackLayer* pa = pack_layer(l); const PackLayer* pb = pack_layer(l + 1);
   if (!pa || !pb || pa->kind != KIND_MFMA || pb->kind != KIND_MFMA) return false;
   if (pa->fuse_next > 0 || pa->fused_into >= 0 || pb->fuse_next > 0 || pb->fused_into >= 0) return false;
+  return true;
+}
+
+// Rows l, l + 1, l + 2 = 1x1 reduce, 3x3 / 1 / pad 1, 1x1 expand + residual from the reduce's input, of a shape conv_bgroup.hip
+// is instantiated for, every row single-window in 64- or 128-row dense tiles.
+bool Net::bgroup_at(int l) const {
+  if (l < 1 || l + 2 >= nd.n_layers) return false;
+  const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1]; const tf2_layer_desc& E = layers[l + 2];
+  for (const tf2_layer_desc* L : {&A, &B, &E})
+    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->stride != 1 || L->dil != 1) return false;
+  if (A.src < 0 || A.k != 1 || A.pad_h || A.pad_w || A.add_src >= 0) return false;
+  if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
+  if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
+  if (layers[A.src].concat >= 0 || A.H != A.W || !conv_bgroup_shape_ok(A.H, A.C, A.N)) return false;
+  for (int k = l; k <= l + 2; k++) {
+    const PackLayer* pl = pack_layer(k);
+    if (!pl || pl->kind != KIND_MFMA || pl->n_phases != 1 || pl->dual || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+    if (pl->TM != 64) return false;                    // (the kernel keeps one 2 KiB header slot per m-tile)
+    if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
+  }
   return true;
 }
 
@@ -290,6 +327,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
+  if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
@@ -455,6 +493,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     return true;
   };
   std::vector<char> fused_done(nl, 0), pair_done(nl, 0);
+  int bg_used = 0;                                           // group launches so far (each has its own counters)
   bool stem_pool_fused = false;
   const bool profiling_pairs_off = false;
   for (int l = 0; l < nl; l++) {
@@ -478,7 +517,38 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
-    if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1
+    if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
+    // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
+    // sharing CUs could hold each other's slots while their groups wait)
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+      Launch s0, s1, s2;
+      if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
+      if (s0.conv.dense && s1.conv.dense && s2.conv.dense) {
+        Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BGROUP; st.layer = l;
+        BGroupArgs& f = st.bgroup;
+        const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
+        f.x = c0.x; f.mid1 = c0.y; f.mid2 = c1.y; f.y = c2.y; f.res = c2.res;
+        f.w1 = c0.w; f.w2 = c1.w; f.w3 = c2.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr3 = c2.hdr;
+        f.hdr1_bytes = c0.hdr_bytes; f.hdr2_bytes = c1.hdr_bytes; f.hdr3_bytes = c2.hdr_bytes;
+        f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
+        f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
+        f.epoch = reinterpret_cast<const unsigned*>(base + wp->ctrl_off);
+        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 16;
+        f.B = batch;
+        f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
+        f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
+        f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
+        f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
+        f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
+        st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
+        // the step's first kernel (input preparation) advances the step counter
+        lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
+        bg_used++;
+        pair_done[l + 1] = 1; pair_done[l + 2] = 1;
+        lp.steps.push_back(st);
+        continue;
+      }
+    }
     Launch st;
     // a fused launch needs enough row bands to fill the chip (one block per band): small batches run the two layers on their own
     const int bn_TN = pl->TM == 64 ? 256 : 128;
@@ -681,6 +751,8 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_BGROUP:
+          return launch_conv_bgroup(st.bgroup, st.bg_hw, st.bg_c, st.bg_m, stream);
         case Launch::SEL_CHAIN:
           if (!launch_recorder() && hipMemsetAsync(st.chain.ctr, 0, st.chain_ctr_bytes, (hipStream_t)stream) != hipSuccess) return -1;
           return launch_conv_mfma2_chain(st.chain, st.chain_segs.data(), stream);

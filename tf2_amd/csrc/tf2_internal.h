@@ -195,6 +195,31 @@ struct BneckArgs {
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
 };
 
+// conv_bgroup.hip: an identity bottleneck of a small map (1x1 reduce C -> M, 3x3 / 1 / pad 1 M -> M, 1x1 expand M -> C + residual)
+// in one launch, eight blocks per image; the intermediates go through the workspace tensors of the three rows
+struct BGroupArgs {
+  const int8_t* x;           // the bottleneck's input [B][HW*HW][C] (the residual is read through res / res_cp / res_off)
+  int8_t* mid1;              // reduce output  [B][HW*HW][M]
+  int8_t* mid2;              // 3x3 output     [B][HW*HW][M]
+  int8_t* y;                 // expand output
+  const int8_t* res;
+  const int8_t* w1; const int8_t* w2; const int8_t* w3;        // dense weight tiles [m-tile * nslab + slab][tm rows][64]
+  const int32_t* hdr1; const int32_t* hdr2; const int32_t* hdr3;
+  const int8_t* zero;        // zero page
+  const int8_t* zero2;       // the 3x3's pad row (the stored form of x = 0 of its input tensor)
+  unsigned* ctr;             // [B][2][8] flag words of this launch's groups (conv_bgroup.hip bg_signal / bg_wait)
+  const unsigned* epoch;     // the workspace's step counter (incremented by the step's first kernel): the value a set flag carries
+  long long* dbg;            // optional: 16 wall-clock stamps per block (tools/bgroup_timeline.py), else null
+  int32_t hdr1_bytes, hdr2_bytes, hdr3_bytes;
+  int32_t tm1, tm2, tm3;     // rows per m-tile of the three layers (64 or 128)
+  int32_t B;                 // images of the batch
+  int32_t img0;              // first image of this launch (a launch takes at most 32: one block per CU)
+  int32_t relu1, relu2, relu3, add_relu, has_res;
+  int32_t fast1, fast2, fast3;     // PackLayer::fast
+  int32_t dbl1, dbl2, dbl3;        // the layer's output tensor has doubled channels
+  int32_t res_cp, res_off, y_cp, y_off;
+};
+
 // conv_stem.hip: layer 0 in its executed 3x3 / stride 1 / pad 0 form on the x-only image tensor (32 bytes per pixel)
 struct StemArgs {
   const int8_t* x;           // [B][H][W][32]: 27 (or fewer) channels of x, zero padded
@@ -246,6 +271,8 @@ struct PrepArgs {
   int32_t q0;                 // runtime (negated) Q of image channel 0
   int32_t src_is_q;           // 1: source already int8
   int32_t xonly;              // 1 (rewrite form only): 32 bytes of x per pixel, no xneg half (conv_stem.hip)
+  unsigned* epoch_ptr;        // side job of the step's first kernel: the workspace's step counter += 1 (the value the flags of the
+                              // step's conv_bgroup launches carry), or null
 };
 
 // kernel launchers (tf2_kernels.hip)
@@ -259,6 +286,8 @@ bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);  
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
+bool conv_bgroup_shape_ok(int HW, int C, int M);
+int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream);
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit

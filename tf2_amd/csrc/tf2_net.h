@@ -35,6 +35,7 @@ struct WorkPlan {
   std::vector<LayerExec> exec;
   int input_tensor = -1;
   int final_tensor = -1;
+  size_t ctrl_off = 0, ctrl_bytes = 0;   // group counters of conv_bgroup launches (two words per image and launch)
   size_t chain_off = 0;     // end of the workspace: segment tables (kChainTablesBytes), then the counters of chain launches
   size_t chain_ctr_bytes = 0;   // counters of ONE plan (one batch at a time / several in flight): one per pixel tile of every chainable row
   std::vector<int> chain_end;   // per row: last row of the chainable run it belongs to (-1: not chainable); see Net::plan
@@ -51,7 +52,7 @@ static_assert(sizeof(ChainSeg) <= kChainSegStride, "ChainSeg outgrew its table s
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN, SEL_BGROUP } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -63,6 +64,8 @@ struct Launch {
   size_t chain_table_off = 0;         // where the device table sits in the workspace
   size_t chain_ctr_bytes = 0;         // counters of this launch (zeroed before every launch)
   BneckArgs bneck{};
+  BGroupArgs bgroup{};       // SEL_BGROUP: rows layer .. layer + 2 (an identity bottleneck) in one launch
+  int bg_hw = 0, bg_c = 0, bg_m = 0;
   StemArgs stem{};
   PoolArgs pool{};
   AvgArgs avg{};
@@ -92,6 +95,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
+  int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
   int chain_mode = 0;      // TF2_AMD_CHAIN: consecutive ring-kernel layers in one launch (conv_mfma2_chain_kernel): 0 never, 1 where eligible
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
@@ -150,6 +154,7 @@ struct Net {
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
   bool chain_row(int l) const;             // row l could be a segment of a chain launch (plain conv row with a 128-row ring-kernel form)
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
   int recent_pos = 0;
