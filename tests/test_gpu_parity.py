@@ -413,14 +413,18 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
 
 
 def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
-    """TF2_AMD_BGROUP=1: the five identity bottlenecks of stage 4 (rows 28-42) as ONE launch each, eight blocks per image meeting at
-    counters between the layers (conv_bgroup.hip).  Every layer against the oracle at batch 2 and 5, then batch-32 logits of
+    """TF2_AMD_BGROUP=1 (the default): the five identity bottlenecks of stage 4 (rows 28-42) and the two of stage 5 (rows 47-52, the
+    second one ending in the global average) as ONE launch each, eight blocks per image meeting at epoch-tagged flags between
+    the layers (conv_bgroup.hip).  Every layer against the oracle at batch 2 and 5, then batch-32 logits of
     repeated runs on the liveness-planned workspace."""
     monkeypatch.setenv("TF2_AMD_BGROUP", "1")
+    monkeypatch.setenv("TF2_AMD_BGROUP_MIN7", "1")          # (by default batches below 12 keep the separate launches: measured equal or faster there)
+    monkeypatch.setenv("TF2_AMD_BGROUP_MIN14", "1")
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [28, 31, 34, 37, 40]
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [28, 31, 34, 37, 40, 47, 50]
+    assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == 50][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
     x = synth.synth_images(rig.t, 32, 73)

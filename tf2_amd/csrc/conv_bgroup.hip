@@ -50,11 +50,12 @@ constexpr int kBgHdrSlot = 2048;             // LDS bytes reserved per header im
 
 template <int N>
 __device__ __forceinline__ void bg_wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 4 || N == 6, "prepared immediates");
+  static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8, "prepared immediates");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
 // The eight members of an image meet at eight flag words.  A flag is (epoch << 8) | XCC id of the member: the epoch is a word of the
@@ -376,20 +377,358 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 #undef BG_STAMP
 }
 
+// ---- the 7 x 7 maps (ResNet-50 stage 5: C = 2048, M = 512) --------------------------------------------------------------------
+// 49 pixels are two 32-pixel column tiles, so the parallelism of a member comes from its channels and from K: a member owns
+// 64 intermediate channels (one 64-row m-tile) and C / 8 = 256 expand channels; in the reduce and the 3x3 wave w works on
+// 32-row tile (w & 1) and on K quarter (w >> 1) for both column tiles, the four quarters meet in LDS; in the expand wave w owns
+// the 32-row tile w.  A member's weights do not fit LDS here (the 3x3's 64 rows are 295 KB): every wave streams its own weight
+// rows through a private LDS-DMA ring.  The reduce may be a two-window layer (DUAL1: it reads the stage's multi-Q input):
+// an entry then holds [hi 64 rows | lo 64 rows], a wave keeps an accumulator per window and combines them (hi << dshift) + lo
+// before the quarters are added -- the same value in Z/2^32.  AVG: the bottleneck ends in the global average
+// (full_size_pool.cl:95-125): the expand's wave sums its 49 requantised + residual-added columns per channel and stores the
+// averaged vector; the 7 x 7 map of the last layer never reaches memory.
+template <bool DUAL1, bool AVG>
+__global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
+  constexpr int HW = 7, C = 2048, M = 512;
+  constexpr int NPX = HW * HW;
+  constexpr int KS1 = C / 64, KS2 = M / 64;              // 32, 8
+  constexpr int NE = 9 * KS2;                            // 72 (tap, slab) steps of the 3x3
+  constexpr int NW1 = DUAL1 ? 2 : 1;
+  constexpr int HC = 16, HALO = (HW + 2) * HC * 64;      // halo grid 9 x 16 per 64-channel slab
+  constexpr int kHdrSlots = 6;                           // reduce, 3x3, four m-tiles of the expand
+  constexpr int STA = NW1 * 2048 + 4096;                 // reduce ring stage: 32 weight rows per window | 64 pixels
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  int8_t* const hdr_lds = lds;
+  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;     // 72 KB: weight rings (phases B, C); reduction partials
+  int8_t* const work = wreg + 72 * 1024;                 // 72 KB: halo | expand tiles.  Phase A rings span both regions.
+  int* const ctl = reinterpret_cast<int*>(work + 72 * 1024);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= a.B) return;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const int drow = lane >> 2;
+  const size_t px_img = (size_t)img * NPX;
+  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  const i32x4 nores = {0, 0, 0, 0};
+  const int ct = wave & 1, kq = wave >> 1;               // phases A, B: 32-row tile of the member's m-tile, K quarter
+  const int c1 = 64 * m;                                 // first intermediate channel of this member (m-tile m of 64 rows)
+
+  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {        // 32 rows x 64 bytes starting at tile row row0
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
+  };
+  {
+    auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int slot) {
+      const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
+      for (int i = wave; i < kBgHdrSlot / 1024; i += 8)              // rows | lo | dshift of a 64-row m-tile: <= 1792 bytes
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kBgHdrSlot + i * 1024), 16, 0, 0);
+    };
+    hdr_dma(a.hdr1, a.hdr1_bytes, m, 0);
+    hdr_dma(a.hdr2, a.hdr2_bytes, m, 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, 4 * m + q, 2 + q);
+    if (tid == 64 * 7) {
+      unsigned e;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = (int)e;
+    }
+  }
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
+  const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
+
+  // the four K quarters of a 32-row tile meet: quarters 1..3 park their two column tiles in LDS, quarter 0 adds them up
+  auto reduce_quarters = [&](i32x16 (&acc)[2], int8_t* park) {
+    if (kq > 0) {
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+        for (int G = 0; G < 4; G++)
+          reinterpret_cast<i32x4*>(park)[(((ct * 3 + kq - 1) * 2 + pt) * 4 + G) * 64 + lane] = i32x4{acc[pt][4 * G], acc[pt][4 * G + 1], acc[pt][4 * G + 2], acc[pt][4 * G + 3]};
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+          for (int G = 0; G < 4; G++) {
+            const i32x4 v = reinterpret_cast<const i32x4*>(park)[(((ct * 3 + q) * 2 + pt) * 4 + G) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[pt][4 * G + r] = (int)((unsigned)acc[pt][4 * G + r] + (unsigned)v[r]);
+          }
+    }
+  };
+  // requantise the member's [32 rows of tile ct] x [two column tiles] and store them into a mid tensor (M bytes per pixel)
+  auto store_mid = [&](i32x16 (&acc)[2], const int* prm, int fast, int relu, int dbl, int8_t* mid) {
+    const int lo_b = relu ? 0 : -128;
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[pt][r];
+      i32x4 out;
+      if (fast == 1) out = requant_tile16<false, 0, true>(a16, prm, 64, 32 * ct + 4 * half, lo_b, -128, nores, dbl != 0, false);
+      else out = requant_tile16<false, 0, false>(a16, prm, 64, 32 * ct + 4 * half, lo_b, -128, nores, dbl != 0, fast == 2);
+      const int p = 32 * pt + (lane & 31);
+      if (p < NPX) {
+        int8_t* dst = mid + (px_img + p) * M + c1 + 32 * ct + 16 * half;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+      }
+    }
+  };
+
+  // =================================== phase A: reduce, 1x1 C -> M ===================================
+  unsigned tag = 0;
+  {
+    constexpr int NS = KS1 / 4;                            // slabs of a K quarter
+    constexpr int NI = 2 * NW1 + 4;                        // LDS-DMAs of a stage
+    int8_t* const ring = wreg + wave * (2 * STA);
+    const int8_t* const wbase = a.w1;                      // entry e = m * KS1 + s: [window][64 rows][64]
+    auto issue = [&](int s, int slot) {
+      int8_t* const st = ring + slot * STA;
+      const size_t e = (size_t)m * KS1 + (kq * NS + s);
+#pragma unroll
+      for (int win = 0; win < NW1; win++) w_dma(wbase, (e * NW1 + win) * 64 + 32 * ct, st + win * 2048);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int p = 16 * g4 + drow;
+        const int8_t* src = p < NPX ? a.x + (px_img + p) * C + (kq * NS + s) * 64 + chunk * 16 : a.zero + chunk * 16;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(st + NW1 * 2048 + g4 * 1024), 16, 0, 0);
+      }
+    };
+    // (the header pieces and the step counter of this wave are older in its queue than its ring stages)
+    issue(0, 0); issue(1, 1);
+    i32x16 acc[2], accl[DUAL1 ? 2 : 1];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[pt][r] = 0; if (DUAL1) accl[pt][r] = 0; }
+    for (int s = 0; s < NS; s++) {
+      if (s + 1 < NS) bg_wait_vmcnt<NI>(); else bg_wait_vmcnt<0>();
+      const int8_t* A = ring + (s & 1) * STA;
+      const int8_t* B = A + NW1 * 2048;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const i32x4 ah = *reinterpret_cast<const i32x4*>(A + (fr0 ^ (ks << 5)));
+        i32x4 al = ah;
+        if (DUAL1) al = *reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ (ks << 5)));
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          const i32x4 b = *reinterpret_cast<const i32x4*>(B + pt * 2048 + (fr0 ^ (ks << 5)));
+          acc[pt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc[pt], 0, 0, 0);
+          if (DUAL1) accl[pt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, accl[pt], 0, 0, 0);
+        }
+      }
+      if (s + 2 < NS) issue(s + 2, s & 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // every wave is done with its ring; headers (fetched by every wave) are in LDS
+    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    if (DUAL1) {
+      // combine the windows: (hi << dshift[1][row]) + lo
+      const int* dsh = prm1 + (kPrmWordsPerRow + 1) * 64;
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 32 * ct + 4 * half + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int pt = 0; pt < 2; pt++)
+            acc[pt][G * 4 + r] = (int)(((unsigned)acc[pt][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[pt][G * 4 + r]);
+      }
+    }
+    reduce_quarters(acc, wreg);
+    if (kq == 0) store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1);
+  }
+  bg_signal(ctr, m, tag, tid);
+  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+
+  // =================================== phase B: 3x3 / pad 1, M -> M ===================================
+  {
+    int8_t* const halo = work;                             // [KS2][9 x 16 halo pixels][64], halo (r, c) = pixel (r - 1, c - 1)
+    constexpr int NGRP = (HW + 2) * HC / 16;               // 9 groups of 16 halo pixels per slab
+    for (int gi = wave; gi < KS2 * NGRP; gi += 8) {
+      const int s = gi / NGRP, grp = gi - s * NGRP;
+      const int h = grp * 16 + drow;
+      const int row = (h >> 4) - 1, col = (h & 15) - 1;
+      const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
+      const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + s * 64 + chunk * 16 : a.zero2 + s * 64 + chunk * 16;
+      if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 16);
+    }
+    constexpr int NS = NE / 4, S = 4;                      // 18 steps per K quarter, private ring of 32 weight rows per stage
+    int8_t* const ring = wreg + wave * (S * 2048);
+    auto issue = [&](int s, int slot) {
+      const size_t e = (size_t)m * NE + (kq * NS + s);
+      w_dma(a.w2, e * 64 + 32 * ct, ring + slot * 2048);
+    };
+#pragma unroll
+    for (int s = 0; s < S - 1; s++) issue(s, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // halo complete in every wave (and this wave's first stages)
+    int h0[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+      int p = 32 * pt + (lane & 31);
+      if (p >= NPX) p = 0;
+      const int oh = p / HW;
+      h0[pt] = oh * HC + (p - oh * HW);
+    }
+    i32x16 acc[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[pt][r] = 0;
+    int cs = 0, is = S - 1;
+    for (int s = 0; s < NS; s++) {
+      if (s >= S - 1) { if (s + 2 < NS) bg_wait_vmcnt<4>(); else if (s + 1 < NS) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+      const int e = kq * NS + s;
+      const int tap = e / KS2, sl = e - tap * KS2;
+      const int8_t* A = ring + cs * 2048;
+      const i32x4 a0 = *reinterpret_cast<const i32x4*>(A + fr0), a1 = *reinterpret_cast<const i32x4*>(A + (fr0 ^ 32));
+      const int toff = (tap / 3) * HC + tap % 3;
+      i32x4 b0[2], b1[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) {
+        const int h = h0[pt] + toff;
+        const int ba = sl * HALO + h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
+        b0[pt] = *reinterpret_cast<const i32x4*>(halo + ba); b1[pt] = *reinterpret_cast<const i32x4*>(halo + (ba ^ 32));
+      }
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0[0], acc[0], 0, 0, 0);      // the two column tiles alternate
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0[1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1[1], acc[1], 0, 0, 0);
+      if (s + S - 1 < NS) { issue(s + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
+      cs = cs + 1 == S ? 0 : cs + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // rings are dead: the partials may use the region
+    reduce_quarters(acc, wreg);
+    if (kq == 0) store_mid(acc, prm2, a.fast2, a.relu2, a.dbl2, a.mid2);
+  }
+  bg_signal(ctr + 8, m, tag, tid);
+  // residual tiles of this wave's 32-row tile of the expand (the bottleneck's input: ordinary loads)
+  const int ch3 = (C / kBgMembers) * m + 32 * wave;        // first channel of this wave's tile
+  i32x4 rv[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    const int p = 32 * pt + (lane & 31);
+    const int8_t* rp = (a.has_res && p < NPX) ? a.res + (px_img + p) * a.res_cp + a.res_off + ch3 + 16 * half : a.zero;
+    rv[pt] = *reinterpret_cast<const i32x4*>(rp);
+  }
+  // the expand's weights of this wave: private ring, first stages on their way while the group gathers
+  constexpr int S3 = 4;
+  int8_t* const ring3 = wreg + wave * (S3 * 2048);
+  const int mt3 = ch3 / 64, ro3 = ch3 % 64;
+  auto issue3 = [&](int s, int slot) { w_dma(a.w3, ((size_t)mt3 * KS2 + s) * 64 + ro3, ring3 + slot * 2048); };
+#pragma unroll
+  for (int s = 0; s < S3 - 1; s++) issue3(s, s);
+  const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+
+  // =================================== phase C: expand, 1x1 M -> C, + residual (+ global average) ===================================
+  {
+    int8_t* const tiles = work;                            // [KS2][64 pixels][64]: both column tiles of the image
+    for (int gi = wave; gi < KS2 * 4; gi += 8) {
+      const int s = gi >> 2, g4 = gi & 3;
+      const int p = 16 * g4 + drow;
+      const int8_t* src = p < NPX ? a.mid2 + (px_img + p) * M + s * 64 + chunk * 16 : a.zero + chunk * 16;
+      if (local2) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tiles + s * 4096 + g4 * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tiles + s * 4096 + g4 * 1024), 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // the image's tiles (fetched by every wave)
+    i32x16 acc[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[pt][r] = 0;
+    int cs = 0, is = S3 - 1;
+    for (int s = 0; s < KS2; s++) {
+      if (s >= S3 - 1) { if (s + 2 < KS2) bg_wait_vmcnt<4>(); else if (s + 1 < KS2) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+      const int8_t* A = ring3 + cs * 2048;
+      const i32x4 a0 = *reinterpret_cast<const i32x4*>(A + fr0), a1 = *reinterpret_cast<const i32x4*>(A + (fr0 ^ 32));
+      const int8_t* B = tiles + s * 4096;
+      const i32x4 b00 = *reinterpret_cast<const i32x4*>(B + fr0), b01 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+      const i32x4 b10 = *reinterpret_cast<const i32x4*>(B + 2048 + fr0), b11 = *reinterpret_cast<const i32x4*>(B + 2048 + (fr0 ^ 32));
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b00, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b10, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b01, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b11, acc[1], 0, 0, 0);
+      if (s + S3 - 1 < KS2) { issue3(s + S3 - 1, is); is = is + 1 == S3 ? 0 : is + 1; }
+      cs = cs + 1 == S3 ? 0 : cs + 1;
+    }
+    const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
+    const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + (mt3 - 4 * m)) * kBgHdrSlot);
+    int sum16[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) sum16[q] = 0;
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[pt][r];
+      i32x4 out;
+      if (a.fast3 == 1) {
+        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, false);
+        else out = requant_tile16<false, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
+      } else {
+        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, a.fast3 == 2);
+        else out = requant_tile16<false, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
+      }
+      const int p = 32 * pt + (lane & 31);
+      if (AVG) {
+        // per-channel sum over this tile's live columns (lanes 0-31 and 32-63 hold different channels: reduce inside a half)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          int v = p < NPX ? (int)(signed char)(((unsigned)out[q >> 2] >> (8 * (q & 3))) & 0xff) : 0;
+#pragma unroll
+          for (int mm = 16; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm, 64);
+          sum16[q] += v;
+        }
+      } else if (p < NPX) {
+        *reinterpret_cast<i32x4*>(a.y + (px_img + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+      }
+    }
+    if (AVG && (lane & 31) == 0) {
+      unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int sv = (int)(short)sum16[q];                                         // int16 accumulator wrap (types.h:30)
+        int mv = (((sv * a.avg_mult) >> 14) + 1) >> 1;                               // full_size_pool.cl:115-118
+        mv = mv > 127 ? 127 : (mv < -128 ? -128 : mv);
+        o[q >> 2] |= (unsigned)(mv & 0xff) << (8 * (q & 3));
+      }
+      *reinterpret_cast<i32x4*>(a.y + (size_t)img * a.y_cp + a.y_off + ch3 + 16 * half) = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    }
+  }
+}
+
 size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
-  const int NT = (HW * HW + 31) / 32, KS1 = C / 64, KS2 = M / 64;
-  (void)NT; (void)KS1;
+  if (HW == 7) return 6 * (size_t)kBgHdrSlot + 72 * 1024 + 72 * 1024 + 64;
+  const int KS2 = M / 64;
   return 4 * (size_t)kBgHdrSlot + (size_t)9 * KS2 * 2048 + (size_t)KS2 * 256 * 64 + 64 + 64;     // + the control words behind the work region
 }
 
-bool conv_bgroup_shape_ok(int HW, int C, int M) { return HW == 14 && C == 1024 && M == 256; }
+bool conv_bgroup_shape_ok(int HW, int C, int M) { return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512); }
 
 int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bgroup_shape_ok(HW, C, M)) return 1;
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
-  auto fn = conv_bgroup_kernel<14, 1024, 256>;
-  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
+  const void* fn = nullptr;
+  if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
+  else if (a.dual1) fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
+  else fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<false, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<false, false>);
+  if (!lds_attr_once(fn)) return -1;
   if (lds > 160 * 1024) return -3;
   // at most 32 images = 256 blocks = one block per CU per launch: every group is resident from the start, and the blocks of a
   // launch that fits the chip go to XCD (block % 8) -- larger grids were seen to place late blocks elsewhere (tools/bgroup_stress.py)
@@ -397,8 +736,14 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
     BGroupArgs b = a;
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
-    TF2_LAUNCH_NAME("conv_bgroup_kernel<%dx%d,C%d,M%d> (8 blocks per image, images %d..%d)", HW, HW, C, M, i0, i0 + n - 1);
-    TF2_LAUNCH(fn, dim3(kBgMembers * ((n + 7) / 8 * 8)), dim3(512), lds, s, b);
+    const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
+    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : "", HW, HW, C, M,
+                    (HW == 7 && a.dual1) ? ",dual reduce" : "", a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
+    if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, b);
+    else if (a.dual1 && a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, b);
+    else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, b);
+    else if (a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, b);
+    else TF2_LAUNCH((conv_bgroup7_kernel<false, false>), grid, dim3(512), lds, s, b);
     if (!launch_ok()) return -1;
   }
   return 0;

@@ -281,14 +281,18 @@ bool Net::bgroup_at(int l) const {
   if (l < 1 || l + 2 >= nd.n_layers) return false;
   const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1]; const tf2_layer_desc& E = layers[l + 2];
   for (const tf2_layer_desc* L : {&A, &B, &E})
-    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->stride != 1 || L->dil != 1) return false;
+    if (L->ipool || L->pool_en || L->concat >= 0 || L->stride != 1 || L->dil != 1) return false;
+  // a global average may end the bottleneck where the split-K kernel could fuse it as well (7 x 7 shape only)
+  if (A.endpool || B.endpool || (E.endpool && !(opts.avg_fuse && A.H == 7))) return false;
   if (A.src < 0 || A.k != 1 || A.pad_h || A.pad_w || A.add_src >= 0) return false;
   if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
   if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
   if (layers[A.src].concat >= 0 || A.H != A.W || !conv_bgroup_shape_ok(A.H, A.C, A.N)) return false;
   for (int k = l; k <= l + 2; k++) {
     const PackLayer* pl = pack_layer(k);
-    if (!pl || pl->kind != KIND_MFMA || pl->n_phases != 1 || pl->dual || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+    if (!pl || pl->kind != KIND_MFMA || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+    // one exponent window; the reduce of the 7 x 7 shape may be a two-window layer packed dual
+    if (!(pl->n_phases == 1 && !pl->dual) && !(k == l && A.H == 7 && pl->n_phases == 2 && pl->dual)) return false;
     if (pl->TM != 64) return false;                    // (the kernel keeps one 2 KiB header slot per m-tile)
     if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
   }
@@ -327,6 +331,8 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -520,10 +526,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
-      if (s0.conv.dense && s1.conv.dense && s2.conv.dense) {
+      if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
         Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BGROUP; st.layer = l;
         BGroupArgs& f = st.bgroup;
         const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
@@ -539,6 +545,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
         f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
         f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
+        f.dual1 = c0.dual; f.avg_mult = c2.g.avg_mult;
         f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
         st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
         // the step's first kernel (input preparation) advances the step counter
