@@ -377,6 +377,281 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 #undef BG_STAMP
 }
 
+// ---- the 28 x 28 maps (ResNet-50 stage 3: C = 512, M = 128) --------------------------------------------------------------------
+// 784 pixels are too many for one block's LDS and the intermediates have only 128 channels: the eight members of an image are
+// FOUR row bands of seven rows (196 pixels = seven 32-pixel column tiles, as on the 14 x 14 maps) times TWO channel halves (64
+// intermediate channels = two 32-row tiles, 256 expand channels = eight).  Reduce and 3x3: wave w < 7 owns column tile w of the
+// band and both 32-row tiles (the reduce may be a two-window layer: one accumulator per window, combined (hi << dshift) + lo);
+// weights LDS-resident, pixels through private rings (reduce) / the band's halo tile (3x3: 9 rows x 32 columns per slab; the rows
+// above and below come from the neighbouring bands' members through the same meeting).  Expand: wave w owns 32-row tile w of the
+// member's 256 channels with its weights in REGISTERS (K = 128: four fragments) and sweeps the band's seven column tiles.
+template <bool DUAL1>
+__global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
+  constexpr int HW = 28, C = 512, M = 128, PR = 7;       // PR: rows of a band
+  constexpr int NPX = HW * HW, NPB = PR * HW;            // pixels of the image / of a band (196)
+  constexpr int NT = (NPB + 31) / 32;                    // 7 column tiles per band
+  constexpr int KS1 = C / 64, KS2 = M / 64;              // 8, 2
+  constexpr int NE = 9 * KS2;                            // 18
+  constexpr int NW1 = DUAL1 ? 2 : 1;
+  constexpr int HC = 32, HALO = (PR + 2) * HC * 64;      // halo tile of a band: 9 rows x 32 columns (30 used) per 64-channel slab
+  constexpr int S = 5, STAGE = 2048;
+  constexpr int kHdrSlot = 4096;                         // rows | lo | dshift of a 128-row m-tile: <= 3584 bytes
+  constexpr int W_BYTES = 72 * 1024, R_BYTES = NT * S * STAGE;
+  static_assert(W_BYTES >= KS1 * NW1 * 4096 && W_BYTES >= NE * 4096 && R_BYTES >= KS2 * HALO && R_BYTES >= NT * KS2 * 2048, "phase regions");
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  int8_t* const hdr_lds = lds;                           // slots: reduce, 3x3, two m-tiles of the expand
+  int8_t* const wreg = lds + 4 * kHdrSlot;
+  int8_t* const work = wreg + W_BYTES;
+  int* const ctl = reinterpret_cast<int*>(work + R_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= a.B) return;
+  const int sp = m >> 1, cm = m & 1;                     // row band, channel half
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const int drow = lane >> 2;
+  const size_t px_img = (size_t)img * NPX;
+  const size_t px_band = px_img + (size_t)sp * NPB;      // first pixel of the band
+  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  const i32x4 nores = {0, 0, 0, 0};
+  const int c1 = 64 * cm;                                // first intermediate channel of this member
+  const int mt1 = c1 / a.tm1, ro1 = c1 % a.tm1;
+  const int mt2 = c1 / a.tm2, ro2 = c1 % a.tm2;
+  const int c3 = 256 * cm;
+
+  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {        // 32 rows x 64 bytes starting at row row0 of the tile storage
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
+  };
+  {
+    auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int tm, int nwords, int slot) {
+      const int used = (nwords * tm * 4 + 1023) & ~1023;
+      const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
+      for (int i = wave; i * 1024 < used; i += 8)
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kHdrSlot + i * 1024), 16, 0, 0);
+    };
+    hdr_dma(a.hdr1, a.hdr1_bytes, mt1, a.tm1, kPrmWordsPerRow + 2, 0);
+    hdr_dma(a.hdr2, a.hdr2_bytes, mt2, a.tm2, kPrmWordsPerRow, 1);
+    hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3, a.tm3, kPrmWordsPerRow, 2);
+    if (a.tm3 < 256) hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3 + 1, a.tm3, kPrmWordsPerRow, 3);       // (64-row m-tiles: the kernel needs 4 slots -- not instantiated)
+    // the reduce's weights: [slab][window][two 32-row tiles]
+    for (int u = wave; u < KS1 * NW1 * 2; u += 8) {
+      const int s = u / (NW1 * 2), win = (u / 2) % NW1, ctq = u & 1;
+      w_dma(a.w1, (((size_t)mt1 * KS1 + s) * NW1 + win) * a.tm1 + ro1 + 32 * ctq, wreg + u * 2048);
+    }
+    if (tid == 64 * 7) {
+      unsigned e;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = (int)e;
+    }
+  }
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
+  const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kHdrSlot);
+  const int t = wave;
+  const bool worker = wave < NT;
+  const int p_lane = 32 * t + (lane & 31);               // pixel of this lane's column inside the band (phases A, B)
+  const bool p_ok = worker && p_lane < NPB;
+  unsigned tag = 0;
+
+  // requantise [two 32-row tiles] x [column tile t] and store into a mid tensor
+  auto store_mid = [&](i32x16 (&acc)[2], const int* prm, int tm, int ro, int fast, int relu, int dbl, int8_t* mid) {
+    const int lo_b = relu ? 0 : -128;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+      i32x4 out;
+      if (fast == 1) out = requant_tile16<false, 0, true>(a16, prm, tm, ro + 32 * q + 4 * half, lo_b, -128, nores, dbl != 0, false);
+      else out = requant_tile16<false, 0, false>(a16, prm, tm, ro + 32 * q + 4 * half, lo_b, -128, nores, dbl != 0, fast == 2);
+      if (p_ok) {
+        int8_t* dst = mid + (px_band + p_lane) * M + c1 + 32 * q + 16 * half;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+      }
+    }
+  };
+
+  // =================================== phase A: reduce, 1x1 C -> M ===================================
+  {
+    int8_t* const ring = work + wave * (S * STAGE);
+    auto issue = [&](int s, int slot) {
+#pragma unroll
+      for (int g2 = 0; g2 < 2; g2++) {
+        const int p = 32 * t + 16 * g2 + drow;
+        const int8_t* src = p < NPB ? a.x + (px_band + p) * C + s * 64 + chunk * 16 : a.zero + chunk * 16;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * STAGE + g2 * 1024), 16, 0, 0);
+      }
+    };
+    if (worker) {
+#pragma unroll
+      for (int s = 0; s < S - 1; s++) issue(s, s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // headers and the reduce's weights are in LDS
+    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    i32x16 acc[2], accl[DUAL1 ? 2 : 1];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[q][r] = 0; if (DUAL1) accl[q][r] = 0; }
+    if (worker) {
+      int cs = 0, is = S - 1;
+      for (int s = 0; s < KS1; s++) {
+        if (s >= S - 1) { if (s + 3 < KS1) bg_wait_vmcnt<6>(); else if (s + 2 < KS1) bg_wait_vmcnt<4>(); else if (s + 1 < KS1) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+        const int8_t* A = wreg + s * (NW1 * 4096);         // [window][tile q][32 rows][64]
+        const int8_t* B = ring + cs * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          const i32x4 b = *reinterpret_cast<const i32x4*>(B + (fr0 ^ (ks << 5)));
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const i32x4 ah = *reinterpret_cast<const i32x4*>(A + q * 2048 + (fr0 ^ (ks << 5)));
+            acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc[q], 0, 0, 0);
+            if (DUAL1) {
+              const i32x4 al = *reinterpret_cast<const i32x4*>(A + 4096 + q * 2048 + (fr0 ^ (ks << 5)));
+              accl[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, accl[q], 0, 0, 0);
+            }
+          }
+        }
+        if (s + S - 1 < KS1) { issue(s + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
+        cs = cs + 1 == S ? 0 : cs + 1;
+      }
+      if (DUAL1) {
+        const int* dsh = prm1 + (kPrmWordsPerRow + 1) * a.tm1;      // dshift[1][row]
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int G = 0; G < 4; G++) {
+            const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + ro1 + 32 * q + 4 * half + 8 * G);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
+          }
+      }
+      store_mid(acc, prm1, a.tm1, ro1, a.fast1, a.relu1, a.dbl1, a.mid1);
+    }
+  }
+  bg_signal(ctr, m, tag, tid);
+  // the 3x3's weights: [step e][two 32-row tiles]
+  for (int u = wave; u < NE * 2; u += 8)
+    w_dma(a.w2, ((size_t)mt2 * NE + (u >> 1)) * a.tm2 + ro2 + 32 * (u & 1), wreg + u * 2048);
+  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+
+  // =================================== phase B: 3x3 / pad 1, M -> M ===================================
+  {
+    int8_t* const halo = work;                             // [KS2][9 x 32 halo pixels][64], halo (r, c) = pixel (7 sp - 1 + r, c - 1)
+    constexpr int NGRP = (PR + 2) * HC / 16;               // 18 groups of 16 halo pixels per slab
+    for (int gi = wave; gi < KS2 * NGRP; gi += 8) {
+      const int s = gi / NGRP, grp = gi - s * NGRP;
+      const int h = grp * 16 + drow;
+      const int row = sp * PR - 1 + (h >> 5), col = (h & 31) - 1;
+      const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
+      const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + s * 64 + chunk * 16 : a.zero2 + s * 64 + chunk * 16;
+      if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // halo and weights complete in every wave
+    if (worker) {
+      const int pq = p_ok ? p_lane : 0;
+      const int oh = pq / HW, ow = pq - oh * HW;
+      const int h0 = oh * HC + ow;
+      i32x16 acc[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0;
+      auto step = [&](auto e_c) {
+        constexpr int e = decltype(e_c)::value;
+        constexpr int tap = e / KS2, sl = e % KS2;
+        const int8_t* A = wreg + e * 4096;
+        const int h = h0 + (tap / 3) * HC + tap % 3;
+        const int ba = sl * HALO + h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(halo + ba), b1 = *reinterpret_cast<const i32x4*>(halo + (ba ^ 32));
+        const i32x4 a00 = *reinterpret_cast<const i32x4*>(A + fr0), a01 = *reinterpret_cast<const i32x4*>(A + (fr0 ^ 32));
+        const i32x4 a10 = *reinterpret_cast<const i32x4*>(A + 2048 + fr0), a11 = *reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32));
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a00, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, b0, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01, b1, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
+      };
+      bg_static_for<0, NE>(step);
+      store_mid(acc, prm2, a.tm2, ro2, a.fast2, a.relu2, a.dbl2, a.mid2);
+    }
+  }
+  bg_signal(ctr + 8, m, tag, tid);
+  // the expand's weights of this wave (32-row tile `wave` of the member's 256 channels): K = 128 -> four fragments, in registers
+  const int ch3 = c3 + 32 * wave;
+  i32x4 wf[KS2][2];
+  {
+    const int mt = ch3 / a.tm3, ro = ch3 % a.tm3;
+#pragma unroll
+    for (int s = 0; s < KS2; s++) {
+      const int8_t* p = a.w3 + (((size_t)mt * KS2 + s) * a.tm3 + ro + frow) * 64 + half * 16;
+      wf[s][0] = *reinterpret_cast<const i32x4*>(p); wf[s][1] = *reinterpret_cast<const i32x4*>(p + 32);
+    }
+  }
+  const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+
+  // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
+  {
+    int8_t* const tiles = work;                            // [column tile][KS2][32 pixels][64]: the band's 3x3 output
+    for (int gi = wave; gi < NT * KS2 * 2; gi += 8) {
+      const int tt = gi / (KS2 * 2), s = (gi >> 1) % KS2, g2 = gi & 1;
+      const int p = 32 * tt + 16 * g2 + drow;
+      const int8_t* src = p < NPB ? a.mid2 + (px_band + p) * M + s * 64 + chunk * 16 : a.zero + chunk * 16;
+      if (local2) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tiles + (tt * KS2 + s) * 2048 + g2 * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tiles + (tt * KS2 + s) * 2048 + g2 * 1024), 16, 0, 16);
+    }
+    const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
+    const int mt = ch3 / a.tm3, ro = ch3 % a.tm3;
+    const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + (mt - c3 / a.tm3)) * kHdrSlot);
+    auto load_res = [&](int tt) -> i32x4 {
+      const int p = 32 * tt + (lane & 31);
+      const int8_t* rp = (a.has_res && p < NPB) ? a.res + (px_band + p) * a.res_cp + a.res_off + ch3 + 16 * half : a.zero;
+      return *reinterpret_cast<const i32x4*>(rp);
+    };
+    i32x4 rnext = load_res(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // the band's tiles (fetched by every wave)
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+      const i32x4 rcur = rnext;
+      if (tt + 1 < NT) rnext = load_res(tt + 1);
+      i32x16 acc, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; }
+#pragma unroll
+      for (int s = 0; s < KS2; s++) {
+        const int8_t* B = tiles + (tt * KS2 + s) * 2048;
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s][0], b0, acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s][1], b1, acc1, 0, 0, 0);
+      }
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
+      i32x4 out;
+      if (a.fast3 == 1) {
+        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, false);
+        else out = requant_tile16<false, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
+      } else {
+        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
+        else out = requant_tile16<false, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
+      }
+      const int p = 32 * tt + (lane & 31);
+      if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+    }
+  }
+}
+
 // ---- the 7 x 7 maps (ResNet-50 stage 5: C = 2048, M = 512) --------------------------------------------------------------------
 // 49 pixels are two 32-pixel column tiles, so the parallelism of a member comes from its channels and from K: a member owns
 // 64 intermediate channels (one 64-row m-tile) and C / 8 = 256 expand channels; in the reduce and the 3x3 wave w works on
@@ -394,14 +669,14 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   constexpr int KS1 = C / 64, KS2 = M / 64;              // 32, 8
   constexpr int NE = 9 * KS2;                            // 72 (tap, slab) steps of the 3x3
   constexpr int NW1 = DUAL1 ? 2 : 1;
-  constexpr int HC = 16, HALO = (HW + 2) * HC * 64;      // halo grid 9 x 16 per 64-channel slab
+  constexpr int HC = 10, NHALO = 96, HALO = NHALO * 64;  // halo grid 9 x 10 (90 of 96 slots) per 64-channel slab
   constexpr int kHdrSlots = 6;                           // reduce, 3x3, four m-tiles of the expand
   constexpr int STA = NW1 * 2048 + 4096;                 // reduce ring stage: 32 weight rows per window | 64 pixels
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   int8_t* const hdr_lds = lds;
-  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;     // 72 KB: weight rings (phases B, C); reduction partials
-  int8_t* const work = wreg + 72 * 1024;                 // 72 KB: halo | expand tiles.  Phase A rings span both regions.
-  int* const ctl = reinterpret_cast<int*>(work + 72 * 1024);
+  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;     // 96 KB: weight rings (phases B, C); reduction partials
+  int8_t* const work = wreg + 96 * 1024;                 // 48 KB: halo | expand tiles.  Phase A rings span both regions.
+  int* const ctl = reinterpret_cast<int*>(work + 48 * 1024);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -413,6 +688,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   unsigned* const ctr = a.ctr + (size_t)img * 16;
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
   const int frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
   const i32x4 nores = {0, 0, 0, 0};
@@ -532,6 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // every wave is done with its ring; headers (fetched by every wave) are in LDS
+    BG_STAMP(1);
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
     if (DUAL1) {
       // combine the windows: (hi << dshift[1][row]) + lo
@@ -548,24 +827,28 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     }
     reduce_quarters(acc, wreg);
     if (kq == 0) store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1);
+    BG_STAMP(2);
   }
   bg_signal(ctr, m, tag, tid);
+  BG_STAMP(3);
   const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
   {
-    int8_t* const halo = work;                             // [KS2][9 x 16 halo pixels][64], halo (r, c) = pixel (r - 1, c - 1)
-    constexpr int NGRP = (HW + 2) * HC / 16;               // 9 groups of 16 halo pixels per slab
+    int8_t* const halo = work;                             // [KS2][9 x 10 halo pixels (+ 6 spare)][64], halo (r, c) = pixel (r - 1, c - 1)
+    constexpr int NGRP = NHALO / 16;                       // 6 groups of 16 halo pixels per slab
     for (int gi = wave; gi < KS2 * NGRP; gi += 8) {
       const int s = gi / NGRP, grp = gi - s * NGRP;
       const int h = grp * 16 + drow;
-      const int row = (h >> 4) - 1, col = (h & 15) - 1;
+      const int hr = h / HC;
+      const int row = hr - 1, col = h - hr * HC - 1;
       const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
       const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + s * 64 + chunk * 16 : a.zero2 + s * 64 + chunk * 16;
       if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 1);
       else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + s * HALO + grp * 1024), 16, 0, 16);
     }
-    constexpr int NS = NE / 4, S = 4;                      // 18 steps per K quarter, private ring of 32 weight rows per stage
+    constexpr int NS = NE / 4, S = 6;                      // 18 steps per K quarter, private ring of 32 weight rows per stage
     int8_t* const ring = wreg + wave * (S * 2048);
     auto issue = [&](int s, int slot) {
       const size_t e = (size_t)m * NE + (kq * NS + s);
@@ -575,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     for (int s = 0; s < S - 1; s++) issue(s, s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // halo complete in every wave (and this wave's first stages)
+    BG_STAMP(5);
     int h0[2];
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
@@ -590,7 +874,11 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       for (int r = 0; r < 16; r++) acc[pt][r] = 0;
     int cs = 0, is = S - 1;
     for (int s = 0; s < NS; s++) {
-      if (s >= S - 1) { if (s + 2 < NS) bg_wait_vmcnt<4>(); else if (s + 1 < NS) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+      // stages 0 .. S-2 landed above; later S-2 younger stages (2 DMAs each) may fly while that many have been issued
+      if (s >= S - 1) {
+        if (s + 4 < NS) bg_wait_vmcnt<8>(); else if (s + 3 < NS) bg_wait_vmcnt<6>(); else if (s + 2 < NS) bg_wait_vmcnt<4>();
+        else if (s + 1 < NS) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>();
+      }
       const int e = kq * NS + s;
       const int tap = e / KS2, sl = e - tap * KS2;
       const int8_t* A = ring + cs * 2048;
@@ -612,10 +900,12 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // rings are dead: the partials may use the region
+    BG_STAMP(6);
     reduce_quarters(acc, wreg);
     if (kq == 0) store_mid(acc, prm2, a.fast2, a.relu2, a.dbl2, a.mid2);
   }
   bg_signal(ctr + 8, m, tag, tid);
+  BG_STAMP(7);
   // residual tiles of this wave's 32-row tile of the expand (the bottleneck's input: ordinary loads)
   const int ch3 = (C / kBgMembers) * m + 32 * wave;        // first channel of this wave's tile
   i32x4 rv[2];
@@ -633,6 +923,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
 #pragma unroll
   for (int s = 0; s < S3 - 1; s++) issue3(s, s);
   const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+  BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual (+ global average) ===================================
   {
@@ -646,6 +937,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // the image's tiles (fetched by every wave)
+    BG_STAMP(9);
     i32x16 acc[2];
 #pragma unroll
     for (int pt = 0; pt < 2; pt++)
@@ -710,15 +1002,20 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       *reinterpret_cast<i32x4*>(a.y + (size_t)img * a.y_cp + a.y_off + ch3 + 16 * half) = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
     }
   }
+  BG_STAMP(10);
+#undef BG_STAMP
 }
 
 size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
-  if (HW == 7) return 6 * (size_t)kBgHdrSlot + 72 * 1024 + 72 * 1024 + 64;
+  if (HW == 7) return 6 * (size_t)kBgHdrSlot + 96 * 1024 + 48 * 1024 + 64;
+  if (HW == 28) return 4 * 4096 + 72 * 1024 + 7 * 5 * 2048 + 64;
   const int KS2 = M / 64;
   return 4 * (size_t)kBgHdrSlot + (size_t)9 * KS2 * 2048 + (size_t)KS2 * 256 * 64 + 64 + 64;     // + the control words behind the work region
 }
 
-bool conv_bgroup_shape_ok(int HW, int C, int M) { return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512); }
+bool conv_bgroup_shape_ok(int HW, int C, int M) {
+  return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128);
+}
 
 int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -726,6 +1023,7 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
+  else if (HW == 28) fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false>);
   else if (a.dual1) fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
   else fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<false, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<false, false>);
   if (!lds_attr_once(fn)) return -1;
@@ -737,9 +1035,11 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : "", HW, HW, C, M,
-                    (HW == 7 && a.dual1) ? ",dual reduce" : "", a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
+    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
+                    (HW != 14 && a.dual1) ? ",dual reduce" : "", a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
     if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, b);
+    else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true>), grid, dim3(512), lds, s, b);
+    else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false>), grid, dim3(512), lds, s, b);
     else if (a.dual1 && a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, b);
     else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, b);
     else if (a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, b);

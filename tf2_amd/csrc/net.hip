@@ -290,11 +290,18 @@ bool Net::bgroup_at(int l) const {
   if (layers[A.src].concat >= 0 || A.H != A.W || !conv_bgroup_shape_ok(A.H, A.C, A.N)) return false;
   for (int k = l; k <= l + 2; k++) {
     const PackLayer* pl = pack_layer(k);
-    if (!pl || pl->kind != KIND_MFMA || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
-    // one exponent window; the reduce of the 7 x 7 shape may be a two-window layer packed dual
-    if (!(pl->n_phases == 1 && !pl->dual) && !(k == l && A.H == 7 && pl->n_phases == 2 && pl->dual)) return false;
-    if (pl->TM != 64) return false;                    // (the kernel keeps one 2 KiB header slot per m-tile)
+    if (!pl || pl->kind != KIND_MFMA) return false;
     if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
+    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+    if (A.H == 28) {
+      // the 28 x 28 kernel: 64- or 128-row tiles (its header slots hold a 128-row m-tile), the expand in 128-row tiles; the reduce
+      // may be a two-window layer; rows packed for a conv_bneck pair qualify (the pair's own entries are one dense m-tile)
+      if ((pl->TM != 64 && pl->TM != 128) || (k == l + 2 && pl->TM != 128)) return false;
+      if (!(one_window || (k == l && dual))) return false;
+    } else {
+      if (pl->fuse_next > 0 || pl->fused_into >= 0 || pl->TM != 64) return false;      // (2 KiB header slots: 64-row m-tiles)
+      if (!(one_window || (k == l && A.H == 7 && dual))) return false;                 // the 7 x 7 kernel's reduce may be two-window
+    }
   }
   return true;
 }
@@ -333,6 +340,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -526,7 +534,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
       if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
