@@ -385,7 +385,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 // weights LDS-resident, pixels through private rings (reduce) / the band's halo tile (3x3: 9 rows x 32 columns per slab; the rows
 // above and below come from the neighbouring bands' members through the same meeting).  Expand: wave w owns 32-row tile w of the
 // member's 256 channels with its weights in REGISTERS (K = 128: four fragments) and sweeps the band's seven column tiles.
-template <bool DUAL1>
+// DUAL2: the 3x3 is a two-window layer: its weights are swept window by window (72 KB each: they share the LDS region, the low
+// window is fetched while the high one's accumulators wait) and combined like the reduce's.
+template <bool DUAL1, bool DUAL2>
 __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   constexpr int HW = 28, C = 512, M = 128, PR = 7;       // PR: rows of a band
   constexpr int NPX = HW * HW, NPB = PR * HW;            // pixels of the image / of a band (196)
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
         __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kHdrSlot + i * 1024), 16, 0, 0);
     };
     hdr_dma(a.hdr1, a.hdr1_bytes, mt1, a.tm1, kPrmWordsPerRow + 2, 0);
-    hdr_dma(a.hdr2, a.hdr2_bytes, mt2, a.tm2, kPrmWordsPerRow, 1);
+    hdr_dma(a.hdr2, a.hdr2_bytes, mt2, a.tm2, kPrmWordsPerRow + 2, 1);
     hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3, a.tm3, kPrmWordsPerRow, 2);
     if (a.tm3 < 256) hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3 + 1, a.tm3, kPrmWordsPerRow, 3);       // (64-row m-tiles: the kernel needs 4 slots -- not instantiated)
     // the reduce's weights: [slab][window][two 32-row tiles]
@@ -539,9 +541,13 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
   }
   bg_signal(ctr, m, tag, tid);
-  // the 3x3's weights: [step e][two 32-row tiles]
-  for (int u = wave; u < NE * 2; u += 8)
-    w_dma(a.w2, ((size_t)mt2 * NE + (u >> 1)) * a.tm2 + ro2 + 32 * (u & 1), wreg + u * 2048);
+  // the 3x3's weights (of one window): [step e][two 32-row tiles]
+  constexpr int NW2 = DUAL2 ? 2 : 1;
+  auto load_w2 = [&](int win) {
+    for (int u = wave; u < NE * 2; u += 8)
+      w_dma(a.w2, (((size_t)mt2 * NE + (u >> 1)) * NW2 + win) * a.tm2 + ro2 + 32 * (u & 1), wreg + u * 2048);
+  };
+  load_w2(0);
   const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -559,15 +565,28 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // halo and weights complete in every wave
-    if (worker) {
-      const int pq = p_ok ? p_lane : 0;
-      const int oh = pq / HW, ow = pq - oh * HW;
-      const int h0 = oh * HC + ow;
-      i32x16 acc[2];
+    const int pq = p_ok ? p_lane : 0;
+    const int oh = pq / HW, ow = pq - oh * HW;
+    const int h0 = oh * HC + ow;
+    i32x16 acc[2], acch[DUAL2 ? 2 : 1];
+#pragma unroll
+    for (int win = 0; win < NW2; win++) {
+      if (win == 1) {
+        // the high window is done: keep its sums, fetch the low window's weights into the same region
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acch[q][r] = acc[q][r];
+        __syncthreads();                                   // every wave is done reading the high window
+        load_w2(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
 #pragma unroll
       for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[q][r] = 0;
+    if (worker) {
       auto step = [&](auto e_c) {
         constexpr int e = decltype(e_c)::value;
         constexpr int tap = e / KS2, sl = e % KS2;
@@ -583,6 +602,21 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
         acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
       };
       bg_static_for<0, NE>(step);
+    }
+    }   // windows
+    if (worker) {
+      if (DUAL2) {
+        const int* dsh = prm2 + (kPrmWordsPerRow + 1) * a.tm2;      // dshift[1][row]: (hi << d) + lo
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int G = 0; G < 4; G++) {
+            const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + ro2 + 32 * q + 4 * half + 8 * G);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              acc[q][G * 4 + r] = (int)(((unsigned)acch[q][G * 4 + r] << (d[r] & 31)) + (unsigned)acc[q][G * 4 + r]);
+          }
+      }
       store_mid(acc, prm2, a.tm2, ro2, a.fast2, a.relu2, a.dbl2, a.mid2);
     }
   }
@@ -1023,7 +1057,8 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
-  else if (HW == 28) fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false>);
+  else if (HW == 28) fn = a.dual2 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, true>))
+                                  : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, false>));
   else if (a.dual1) fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
   else fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<false, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<false, false>);
   if (!lds_attr_once(fn)) return -1;
@@ -1036,10 +1071,12 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
     TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
-                    (HW != 14 && a.dual1) ? ",dual reduce" : "", a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
+                    (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
     if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, b);
-    else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true>), grid, dim3(512), lds, s, b);
-    else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false>), grid, dim3(512), lds, s, b);
+    else if (HW == 28 && a.dual2 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, true>), grid, dim3(512), lds, s, b);
+    else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, b);
+    else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, b);
+    else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false, false>), grid, dim3(512), lds, s, b);
     else if (a.dual1 && a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, b);
     else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, b);
     else if (a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, b);

@@ -297,7 +297,7 @@ bool Net::bgroup_at(int l) const {
       // the 28 x 28 kernel: 64- or 128-row tiles (its header slots hold a 128-row m-tile), the expand in 128-row tiles; the reduce
       // may be a two-window layer; rows packed for a conv_bneck pair qualify (the pair's own entries are one dense m-tile)
       if ((pl->TM != 64 && pl->TM != 128) || (k == l + 2 && pl->TM != 128)) return false;
-      if (!(one_window || (k == l && dual))) return false;
+      if (!(one_window || (k <= l + 1 && dual))) return false;
     } else {
       if (pl->fuse_next > 0 || pl->fused_into >= 0 || pl->TM != 64) return false;      // (2 KiB header slots: 64-row m-tiles)
       if (!(one_window || (k == l && A.H == 7 && dual))) return false;                 // the 7 x 7 kernel's reduce may be two-window
@@ -553,7 +553,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
         f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
         f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
-        f.dual1 = c0.dual; f.avg_mult = c2.g.avg_mult;
+        f.dual1 = c0.dual; f.dual2 = c1.dual; f.avg_mult = c2.g.avg_mult;
         f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
         st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
         // the step's first kernel (input preparation) advances the step counter
