@@ -377,6 +377,290 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 #undef BG_STAMP
 }
 
+// ---- the 56 x 56 maps (ResNet-50 stage 2: C = 256, M = 64) ---------------------------------------------------------------------
+// 3136 pixels per image and only 64 intermediate channels: the eight members are eight row bands of seven rows (392 pixels =
+// thirteen 32-pixel column tiles), each with ALL channels.  Reduce and 3x3: wave w owns column tiles w and w + 8 (two rounds) and
+// both 32-row tiles; the band's 3x3 output stays in LDS (the member needs nobody else's: ONE meeting per launch, after the
+// reduce, for the halo rows of the neighbouring bands).  Expand: wave w owns 32-row tile w of the 256 channels, weights in
+// registers (K = 64), thirteen column tiles.  Reduce and expand may be two-window layers (DUAL1 / DUAL3).
+template <bool DUAL1, bool DUAL3>
+__global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
+  constexpr int HW = 56, C = 256, M = 64, PR = 7;
+  constexpr int NPX = HW * HW, NPB = PR * HW;            // 3136, 392
+  constexpr int NT = (NPB + 31) / 32;                    // 13 column tiles per band
+  constexpr int KS1 = C / 64;                            // 4
+  constexpr int NW1 = DUAL1 ? 2 : 1, NW3 = DUAL3 ? 2 : 1;
+  constexpr int HC = 64, HALO = (PR + 2) * HC * 64;      // 9 rows x 64 columns (58 used), one 64-channel slab: 36 KB
+  constexpr int kHdrSlots = 6;                           // reduce, 3x3, four 64-row m-tiles of the expand
+  constexpr int W_BYTES = 36 * 1024, R_BYTES = 64 * 1024;
+  static_assert(W_BYTES >= KS1 * NW1 * 4096 && W_BYTES >= 9 * 4096 && R_BYTES >= HALO + NT * 2048, "phase regions");
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  int8_t* const hdr_lds = lds;
+  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;
+  int8_t* const work = wreg + W_BYTES;
+  int* const ctl = reinterpret_cast<int*>(work + R_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= a.B) return;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const int drow = lane >> 2;
+  const size_t px_img = (size_t)img * NPX;
+  const size_t px_band = px_img + (size_t)m * NPB;
+  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  const i32x4 nores = {0, 0, 0, 0};
+
+  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
+  };
+  {
+    auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int slot) {
+      const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
+      for (int i = wave; i < kBgHdrSlot / 1024; i += 8)
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kBgHdrSlot + i * 1024), 16, 0, 0);
+    };
+    hdr_dma(a.hdr1, a.hdr1_bytes, 0, 0);
+    hdr_dma(a.hdr2, a.hdr2_bytes, 0, 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, q, 2 + q);
+    // the reduce's weights: [slab][window][two 32-row tiles]
+    for (int u = wave; u < KS1 * NW1 * 2; u += 8) {
+      const int s = u / (NW1 * 2), win = (u / 2) % NW1, ctq = u & 1;
+      w_dma(a.w1, ((size_t)s * NW1 + win) * 64 + 32 * ctq, wreg + u * 2048);
+    }
+    if (tid == 64 * 7) {
+      unsigned e;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = (int)e;
+    }
+  }
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
+  const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
+  unsigned tag = 0;
+
+  // =================================== phase A: reduce, 1x1 C -> M, two rounds of column tiles ===================================
+  {
+    int8_t* const ring = work + wave * (KS1 * 2048);        // all four slabs of a column tile in flight at once
+    auto issue_tile = [&](int t) {
+#pragma unroll
+      for (int s = 0; s < KS1; s++)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++) {
+          const int p = 32 * t + 16 * g2 + drow;
+          const int8_t* src = (t < NT && p < NPB) ? a.x + (px_band + p) * C + s * 64 + chunk * 16 : a.zero + chunk * 16;
+          __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + s * 2048 + g2 * 1024), 16, 0, 0);
+        }
+    };
+    issue_tile(wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // headers and the reduce's weights are in LDS
+    BG_STAMP(1);
+    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    const int lo_b = a.relu1 ? 0 : -128;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      const int t = wave + 8 * rd;
+      i32x16 acc[2], accl[DUAL1 ? 2 : 1];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[q][r] = 0; if (DUAL1) accl[q][r] = 0; }
+      if (rd == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (round 0's stores and this round's pixels)
+#pragma unroll
+      for (int s = 0; s < KS1; s++) {
+        const int8_t* A = wreg + s * (NW1 * 4096);
+        const int8_t* B = ring + s * 2048;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          const i32x4 b = *reinterpret_cast<const i32x4*>(B + (fr0 ^ (ks << 5)));
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const i32x4 ah = *reinterpret_cast<const i32x4*>(A + q * 2048 + (fr0 ^ (ks << 5)));
+            acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc[q], 0, 0, 0);
+            if (DUAL1) {
+              const i32x4 al = *reinterpret_cast<const i32x4*>(A + 4096 + q * 2048 + (fr0 ^ (ks << 5)));
+              accl[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, accl[q], 0, 0, 0);
+            }
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      if (rd == 0) issue_tile(wave + 8);                   // next round's pixels fly behind this round's requantisation
+      if (DUAL1) {
+        const int* dsh = prm1 + (kPrmWordsPerRow + 1) * 64;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int G = 0; G < 4; G++) {
+            const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 32 * q + 4 * half + 8 * G);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
+          }
+      }
+      const int p = 32 * t + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        int a16[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+        i32x4 out;
+        if (a.fast1 == 1) out = requant_tile16<false, 0, true>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, false);
+        else out = requant_tile16<false, 0, false>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
+        if (t < NT && p < NPB) {
+          int8_t* dst = a.mid1 + (px_band + p) * M + 32 * q + 16 * half;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+        }
+      }
+    }
+  }
+  BG_STAMP(2);
+  bg_signal(ctr, m, tag, tid);
+  BG_STAMP(3);
+  // the 3x3's weights: [tap][two 32-row tiles]
+  for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);
+  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  BG_STAMP(4);
+
+  // =================================== phase B: 3x3 / pad 1, M -> M; the band's output stays in LDS ===================================
+  int8_t* const tiles = work + HALO;                       // [column tile][32 pixels][64]: B operand of the expand
+  {
+    int8_t* const halo = work;                             // [9 x 64 halo pixels][64], halo (r, c) = pixel (7 m - 1 + r, c - 1)
+    constexpr int NGRP = (PR + 2) * HC / 16;               // 36 groups of 16 halo pixels
+    for (int grp = wave; grp < NGRP; grp += 8) {
+      const int h = grp * 16 + drow;
+      const int row = m * PR - 1 + (h >> 6), col = (h & 63) - 1;
+      const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
+      const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + chunk * 16 : a.zero2 + chunk * 16;
+      if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // halo and weights complete in every wave
+    BG_STAMP(5);
+    const int lo_b = a.relu2 ? 0 : -128;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      const int t = wave + 8 * rd;
+      if (t < NT) {
+        int p = 32 * t + (lane & 31);
+        const bool ok = p < NPB;
+        if (!ok) p = 0;
+        const int oh = p / HW, ow = p - oh * HW;
+        const int h0 = oh * HC + ow;
+        i32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[q][r] = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+          const int8_t* A = wreg + tap * 4096;
+          const int h = h0 + (tap / 3) * HC + tap % 3;
+          const int ba = h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
+          const i32x4 b0 = *reinterpret_cast<const i32x4*>(halo + ba), b1 = *reinterpret_cast<const i32x4*>(halo + (ba ^ 32));
+          const i32x4 a00 = *reinterpret_cast<const i32x4*>(A + fr0), a01 = *reinterpret_cast<const i32x4*>(A + (fr0 ^ 32));
+          const i32x4 a10 = *reinterpret_cast<const i32x4*>(A + 2048 + fr0), a11 = *reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32));
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a00, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, b0, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01, b1, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          int a16[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+          i32x4 out;
+          if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, false);
+          else out = requant_tile16<false, 0, false>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
+          const int row = lane & 31, c = 2 * q + half;    // B-operand layout of the expand: pixel row, 16-byte chunk c of its 64 channels
+          *reinterpret_cast<i32x4*>(tiles + t * 2048 + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;
+          if (ok) *reinterpret_cast<i32x4*>(a.mid2 + (px_band + 32 * t + row) * M + 32 * q + 16 * half) = out;      // (the row's own tensor: tf2_net_read_layer)
+        }
+      }
+    }
+  }
+  BG_STAMP(6);
+  // the expand's weights of this wave (32-row tile `wave` of the 256 channels): K = 64 -> two fragments per window, in registers
+  const int ch3 = 32 * wave;
+  const int mt3 = ch3 / 64, ro3 = ch3 % 64;
+  i32x4 wf[NW3][2];
+#pragma unroll
+  for (int win = 0; win < NW3; win++) {
+    const int8_t* p = a.w3 + (((size_t)mt3 * NW3 + win) * 64 + ro3 + frow) * 64 + half * 16;
+    wf[win][0] = *reinterpret_cast<const i32x4*>(p); wf[win][1] = *reinterpret_cast<const i32x4*>(p + 32);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                         // the band's 3x3 output is complete in LDS
+  BG_STAMP(7); BG_STAMP(8); BG_STAMP(9);
+
+  // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
+  {
+    const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
+    const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + mt3) * kBgHdrSlot);
+    auto load_res = [&](int tt) -> i32x4 {
+      const int p = 32 * tt + (lane & 31);
+      const int8_t* rp = (a.has_res && p < NPB) ? a.res + (px_band + p) * a.res_cp + a.res_off + ch3 + 16 * half : a.zero;
+      return *reinterpret_cast<const i32x4*>(rp);
+    };
+    i32x4 rnext = load_res(0);
+#pragma unroll 1
+    for (int tt = 0; tt < NT; tt++) {
+      const i32x4 rcur = rnext;
+      if (tt + 1 < NT) rnext = load_res(tt + 1);
+      const int8_t* B = tiles + tt * 2048;
+      const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+      i32x16 acc, acc1, accl, accl1;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; accl[r] = 0; accl1[r] = 0; }
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][0], b0, acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][1], b1, acc1, 0, 0, 0);
+      if (DUAL3) {
+        accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NW3 - 1][0], b0, accl, 0, 0, 0);
+        accl1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NW3 - 1][1], b1, accl1, 0, 0, 0);
+      }
+      int a16[16];
+      if (DUAL3) {
+        const int* dsh = pm + (kPrmWordsPerRow + 1) * 64;
+#pragma unroll
+        for (int G = 0; G < 4; G++) {
+          const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + ro3 + 4 * half + 8 * G);
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            a16[G * 4 + r] = (int)((((unsigned)acc[G * 4 + r] + (unsigned)acc1[G * 4 + r]) << (d[r] & 31)) + (unsigned)accl[G * 4 + r] + (unsigned)accl1[G * 4 + r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
+      }
+      i32x4 out;
+      if (a.fast3 == 1) {
+        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rcur, false, false);
+        else out = requant_tile16<false, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
+      } else {
+        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
+        else out = requant_tile16<false, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
+      }
+      const int p = 32 * tt + (lane & 31);
+      if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+    }
+  }
+  BG_STAMP(10);
+#undef BG_STAMP
+}
+
 // ---- the 28 x 28 maps (ResNet-50 stage 3: C = 512, M = 128) --------------------------------------------------------------------
 // 784 pixels are too many for one block's LDS and the intermediates have only 128 channels: the eight members of an image are
 // FOUR row bands of seven rows (196 pixels = seven 32-pixel column tiles, as on the 14 x 14 maps) times TWO channel halves (64
@@ -1043,12 +1327,14 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
 size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
   if (HW == 7) return 6 * (size_t)kBgHdrSlot + 96 * 1024 + 48 * 1024 + 64;
   if (HW == 28) return 4 * 4096 + 72 * 1024 + 7 * 5 * 2048 + 64;
+  if (HW == 56) return 6 * (size_t)kBgHdrSlot + 36 * 1024 + 64 * 1024 + 64;
   const int KS2 = M / 64;
   return 4 * (size_t)kBgHdrSlot + (size_t)9 * KS2 * 2048 + (size_t)KS2 * 256 * 64 + 64 + 64;     // + the control words behind the work region
 }
 
 bool conv_bgroup_shape_ok(int HW, int C, int M) {
-  return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128);
+  return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128) ||
+         (HW == 56 && C == 256 && M == 64);
 }
 
 int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) {
@@ -1057,6 +1343,8 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
+  else if (HW == 56) fn = a.dual3 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup56_kernel<false, true>))
+                                  : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup56_kernel<false, false>));
   else if (HW == 28) fn = a.dual2 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, true>))
                                   : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, false>));
   else if (a.dual1) fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
@@ -1070,9 +1358,14 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
-                    (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
+    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
+                    (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.dual3 ? ",dual expand" : "",
+                    a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
     if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, b);
+    else if (HW == 56 && a.dual1 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<true, true>), grid, dim3(512), lds, s, b);
+    else if (HW == 56 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<false, true>), grid, dim3(512), lds, s, b);
+    else if (HW == 56 && a.dual1) TF2_LAUNCH((conv_bgroup56_kernel<true, false>), grid, dim3(512), lds, s, b);
+    else if (HW == 56) TF2_LAUNCH((conv_bgroup56_kernel<false, false>), grid, dim3(512), lds, s, b);
     else if (HW == 28 && a.dual2 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, true>), grid, dim3(512), lds, s, b);
     else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, b);
     else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, b);

@@ -298,6 +298,10 @@ bool Net::bgroup_at(int l) const {
       // may be a two-window layer; rows packed for a conv_bneck pair qualify (the pair's own entries are one dense m-tile)
       if ((pl->TM != 64 && pl->TM != 128) || (k == l + 2 && pl->TM != 128)) return false;
       if (!(one_window || (k <= l + 1 && dual))) return false;
+    } else if (A.H == 56) {
+      // the 56 x 56 kernel: 64-row tiles; reduce and expand may be two-window layers; conv_bneck pairs qualify
+      if (pl->TM != 64) return false;
+      if (!(one_window || (k != l + 1 && dual))) return false;
     } else {
       if (pl->fuse_next > 0 || pl->fused_into >= 0 || pl->TM != 64) return false;      // (2 KiB header slots: 64-row m-tiles)
       if (!(one_window || (k == l && A.H == 7 && dual))) return false;                 // the 7 x 7 kernel's reduce may be two-window
@@ -341,6 +345,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN56")) o.bgroup_min56 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -534,7 +539,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
       if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
@@ -553,7 +558,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
         f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
         f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
-        f.dual1 = c0.dual; f.dual2 = c1.dual; f.avg_mult = c2.g.avg_mult;
+        f.dual1 = c0.dual; f.dual2 = c1.dual; f.dual3 = c2.dual; f.avg_mult = c2.g.avg_mult;
         f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
         st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
         // the step's first kernel (input preparation) advances the step counter

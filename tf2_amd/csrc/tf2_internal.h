@@ -219,6 +219,7 @@ struct BGroupArgs {
   int32_t dbl1, dbl2, dbl3;        // the layer's output tensor has doubled channels
   int32_t dual1;                   // the reduce is a two-window layer: entries [hi rows | lo rows] (7 x 7 and 28 x 28 kernels)
   int32_t dual2;                   // the 3x3 is a two-window layer (28 x 28 kernel only)
+  int32_t dual3;                   // the expand is a two-window layer (56 x 56 kernel only)
   int32_t avg_mult;                // != 0: the bottleneck ends in the global average (full_size_pool.cl); y / y_cp / y_off then
                                    // describe the AVERAGED tensor [B][y_cp] (7 x 7 kernel only)
   int32_t res_cp, res_off, y_cp, y_off;
