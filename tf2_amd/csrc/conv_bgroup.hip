@@ -661,6 +661,255 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
 #undef BG_STAMP
 }
 
+// ---- the FIRST bottleneck of the 56 x 56 stage (ResNet-50 rows 1-4: projection shortcut 64 -> 256 | reduce 64 -> 64, 3x3, expand + residual)
+// Same bands as conv_bgroup56_kernel, with C_in = 64: the band's input pixels (392 x 64 bytes) stay in LDS from the reduce on, and
+// the expand's wave computes the SHORTCUT tile it needs as residual itself (K = 64: two MFMAs per window on the resident input
+// tile, its own requantisation) -- the shortcut's 25.7 MB map is neither written nor read back (with keep_s it is written, for
+// tf2_net_read_layer).  DUAL: reduce, expand and shortcut are two-window layers (ResNet-50), else all single.
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
+  constexpr int HW = 56, CIN = 64, M = 64, PR = 7;
+  constexpr int NPX = HW * HW, NPB = PR * HW;
+  constexpr int NT = (NPB + 31) / 32;                    // 13
+  constexpr int NWN = DUAL ? 2 : 1;
+  constexpr int HC = 64, HALO = (PR + 2) * HC * 64;      // 36 KB
+  constexpr int kHdrSlots = 10;                          // reduce, 3x3, four m-tiles of the expand, four of the shortcut
+  constexpr int W_BYTES = 36 * 1024;                     // reduce weights (<= 16 KB), then the 3x3's (36 KB)
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  int8_t* const hdr_lds = lds;
+  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;
+  int8_t* const halo = wreg + W_BYTES;                   // 36 KB
+  int8_t* const tiles = halo + HALO;                     // 26 KB: the band's 3x3 output, B operand of the expand
+  int8_t* const xt = tiles + NT * 2048;                  // 26 KB: the band's input, B operand of reduce and shortcut
+  int* const ctl = reinterpret_cast<int*>(xt + NT * 2048);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= a.B) return;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const int drow = lane >> 2;
+  const size_t px_img = (size_t)img * NPX;
+  const size_t px_band = px_img + (size_t)m * NPB;
+  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  const i32x4 nores = {0, 0, 0, 0};
+
+  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
+  };
+  {
+    auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int slot) {
+      const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
+      for (int i = wave; i < kBgHdrSlot / 1024; i += 8)
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kBgHdrSlot + i * 1024), 16, 0, 0);
+    };
+    hdr_dma(a.hdr1, a.hdr1_bytes, 0, 0);
+    hdr_dma(a.hdr2, a.hdr2_bytes, 0, 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, q, 2 + q);
+    {
+      // the shortcut's m-tiles (64 or 128 rows each) share the last four slots
+      const int n_mt = 256 / a.tms, per = (4 * kBgHdrSlot / n_mt) >> 10;       // KiB pieces per m-tile
+      for (int i = wave; i < n_mt * per; i += 8) {
+        const int mt = i / per, kk = i - mt * per;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(reinterpret_cast<const int8_t*>(a.hdrs) + (size_t)mt * a.hdrs_bytes + kk * 1024 + lane * 16),
+                                         TF2_LDS_PTR(hdr_lds + 6 * kBgHdrSlot + i * 1024), 16, 0, 0);
+      }
+    }
+    for (int u = wave; u < NWN * 2; u += 8) w_dma(a.w1, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);      // reduce: [window][two 32-row tiles]
+    // the band's input pixels: thirteen tiles of 32 pixels x 64 channels
+    for (int gi = wave; gi < NT * 2; gi += 8) {
+      const int p = 16 * gi + drow;
+      const int8_t* src = p < NPB ? a.x + (px_band + p) * CIN + chunk * 16 : a.zero + chunk * 16;
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(xt + gi * 1024), 16, 0, 0);
+    }
+    if (tid == 64 * 7) {
+      unsigned e;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = (int)e;
+    }
+  }
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
+  const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                         // headers, reduce weights and the band's input are in LDS
+  const unsigned tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+
+  // two-window combine of a 32 x 32 tile: (hi << dshift[1][row]) + lo
+  auto combine = [&](i32x16& hi, const i32x16& lo, const int* prm, int row0, int tm = 64) {
+    const int* dsh = prm + (kPrmWordsPerRow + 1) * tm;
+#pragma unroll
+    for (int G = 0; G < 4; G++) {
+      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + row0 + 4 * half + 8 * G);
+#pragma unroll
+      for (int r = 0; r < 4; r++) hi[G * 4 + r] = (int)(((unsigned)hi[G * 4 + r] << (d[r] & 31)) + (unsigned)lo[G * 4 + r]);
+    }
+  };
+
+  // =================================== phase A: reduce, 1x1 64 -> 64 (K = one slab) ===================================
+  {
+    const int lo_b = a.relu1 ? 0 : -128;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      const int t = wave + 8 * rd;
+      if (t < NT) {
+        const int8_t* B = xt + t * 2048;
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+        const int p = 32 * t + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          i32x16 acc, accl;
+#pragma unroll
+          for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
+          const int8_t* A = wreg + q * 2048;
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), b1, acc, 0, 0, 0);
+          if (DUAL) {
+            accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 4096 + fr0), b0, accl, 0, 0, 0);
+            accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 4096 + (fr0 ^ 32)), b1, accl, 0, 0, 0);
+            combine(acc, accl, prm1, 32 * q);
+          }
+          int a16[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16[r] = acc[r];
+          i32x4 out;
+          if (a.fast1 == 1) out = requant_tile16<false, 0, true>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, false);
+          else out = requant_tile16<false, 0, false>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
+          if (p < NPB) {
+            int8_t* dst = a.mid1 + (px_band + p) * M + 32 * q + 16 * half;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+          }
+        }
+      }
+    }
+  }
+  bg_signal(ctr, m, tag, tid);
+  for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);      // the 3x3's weights: [tap][two 32-row tiles]
+  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+
+  // =================================== phase B: 3x3 / pad 1; the band's output stays in LDS ===================================
+  {
+    constexpr int NGRP = (PR + 2) * HC / 16;
+    for (int grp = wave; grp < NGRP; grp += 8) {
+      const int h = grp * 16 + drow;
+      const int row = m * PR - 1 + (h >> 6), col = (h & 63) - 1;
+      const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
+      const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + chunk * 16 : a.zero2 + chunk * 16;
+      if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 1);
+      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int lo_b = a.relu2 ? 0 : -128;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      const int t = wave + 8 * rd;
+      if (t < NT) {
+        int p = 32 * t + (lane & 31);
+        const bool ok = p < NPB;
+        if (!ok) p = 0;
+        const int oh = p / HW, ow = p - oh * HW;
+        const int h0 = oh * HC + ow;
+        i32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[q][r] = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+          const int8_t* A = wreg + tap * 4096;
+          const int h = h0 + (tap / 3) * HC + tap % 3;
+          const int ba = h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
+          const i32x4 b0 = *reinterpret_cast<const i32x4*>(halo + ba), b1 = *reinterpret_cast<const i32x4*>(halo + (ba ^ 32));
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + fr0), b0, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), b1, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32)), b1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          int a16[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+          i32x4 out;
+          if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, false);
+          else out = requant_tile16<false, 0, false>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
+          const int row = lane & 31, c = 2 * q + half;
+          *reinterpret_cast<i32x4*>(tiles + t * 2048 + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;
+          if (ok) *reinterpret_cast<i32x4*>(a.mid2 + (px_band + 32 * t + row) * M + 32 * q + 16 * half) = out;
+        }
+      }
+    }
+  }
+  // this wave's 32-row tile of the 256 output channels: expand and shortcut weights in registers (K = 64 each)
+  const int ch3 = 32 * wave;
+  const int mt3 = ch3 / 64, ro3 = ch3 % 64;
+  i32x4 wf[NWN][2], wsf[NWN][2];
+#pragma unroll
+  for (int win = 0; win < NWN; win++) {
+    const int8_t* p = a.w3 + (((size_t)mt3 * NWN + win) * 64 + ro3 + frow) * 64 + half * 16;
+    wf[win][0] = *reinterpret_cast<const i32x4*>(p); wf[win][1] = *reinterpret_cast<const i32x4*>(p + 32);
+    const int8_t* ps = a.ws + (((size_t)(ch3 / a.tms) * NWN + win) * a.tms + ch3 % a.tms + frow) * 64 + half * 16;
+    wsf[win][0] = *reinterpret_cast<const i32x4*>(ps); wsf[win][1] = *reinterpret_cast<const i32x4*>(ps + 32);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                         // the band's 3x3 output is complete in LDS
+
+  // =================================== phase C: shortcut tile -> residual, expand + residual ===================================
+  {
+    const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128, lo_s = a.relu_s ? 0 : -128;
+    const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + mt3) * kBgHdrSlot);
+    const int ros = ch3 % a.tms;
+    const int* ps = reinterpret_cast<const int*>(hdr_lds + 6 * kBgHdrSlot + (ch3 / a.tms) * (4 * kBgHdrSlot / (256 / a.tms)));
+#pragma unroll 1
+    for (int tt = 0; tt < NT; tt++) {
+      const int p = 32 * tt + (lane & 31);
+      // the shortcut convolution of this tile (1x1 64 -> 256 on the band's input), requantised: the residual
+      i32x4 rs;
+      {
+        const int8_t* B = xt + tt * 2048;
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+        i32x16 acc, accl;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf[0][0], b0, acc, 0, 0, 0);
+        if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf[NWN - 1][0], b0, accl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf[0][1], b1, acc, 0, 0, 0);
+        if (DUAL) { accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf[NWN - 1][1], b1, accl, 0, 0, 0); combine(acc, accl, ps, ros, a.tms); }
+        int a16[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16[r] = acc[r];
+        if (a.fast_s == 1) rs = requant_tile16<false, 0, true>(a16, ps, a.tms, ros + 4 * half, lo_s, -128, nores, false, false);
+        else rs = requant_tile16<false, 0, false>(a16, ps, a.tms, ros + 4 * half, lo_s, -128, nores, false, a.fast_s == 2);
+        if (a.keep_s && p < NPB) *reinterpret_cast<i32x4*>(a.ys + (px_band + p) * a.ys_cp + ch3 + 16 * half) = rs;
+      }
+      const int8_t* B = tiles + tt * 2048;
+      const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+      i32x16 acc, accl;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][0], b0, acc, 0, 0, 0);
+      if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NWN - 1][0], b0, accl, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][1], b1, acc, 0, 0, 0);
+      if (DUAL) { accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NWN - 1][1], b1, accl, 0, 0, 0); combine(acc, accl, pm, ro3); }
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[r];
+      i32x4 out;
+      if (a.fast3 == 1) out = requant_tile16<true, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rs, false, false);
+      else out = requant_tile16<true, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rs, false, a.fast3 == 2);
+      if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+    }
+  }
+}
+
 // ---- the 28 x 28 maps (ResNet-50 stage 3: C = 512, M = 128) --------------------------------------------------------------------
 // 784 pixels are too many for one block's LDS and the intermediates have only 128 channels: the eight members of an image are
 // FOUR row bands of seven rows (196 pixels = seven 32-pixel column tiles, as on the 14 x 14 maps) times TWO channel halves (64
@@ -1335,6 +1584,26 @@ size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
 bool conv_bgroup_shape_ok(int HW, int C, int M) {
   return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128) ||
          (HW == 56 && C == 256 && M == 64);
+}
+
+// the first bottleneck of the 56 x 56 stage (rows: shortcut, reduce, 3x3, expand): conv_bgroup56f_kernel
+int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = 10 * (size_t)kBgHdrSlot + 36 * 1024 + 36 * 1024 + 2 * 13 * 2048 + 64;
+  const void* fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56f_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup56f_kernel<false>);
+  if (!lds_attr_once(fn)) return -1;
+  if (lds > 160 * 1024) return -3;
+  for (int i0 = 0; i0 < a.B; i0 += 32) {
+    BGroupArgs b = a;
+    b.img0 = i0;
+    const int n = std::min(32, a.B - i0);
+    const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
+    TF2_LAUNCH_NAME("conv_bgroup56f_kernel<56x56,shortcut 64->256 | 64->64->64->256%s> (8 blocks per image, images %d..%d)", a.dual1 ? ",dual" : "", i0, i0 + n - 1);
+    if (a.dual1) TF2_LAUNCH((conv_bgroup56f_kernel<true>), grid, dim3(512), lds, s, b);
+    else TF2_LAUNCH((conv_bgroup56f_kernel<false>), grid, dim3(512), lds, s, b);
+    if (!launch_ok()) return -1;
+  }
+  return 0;
 }
 
 int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) {

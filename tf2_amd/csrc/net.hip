@@ -174,6 +174,18 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // reads stays live to its last row, what it writes exists from its first
   if (packed_valid && opts.bgroup_mode)
     for (int l = 0; l + 2 < nl; l++) {
+      if (bgroup_first_at(l)) {
+        TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
+        tin.last_use = std::max(tin.last_use, l + 3);
+        TensorPlan& tm1 = wp.tensors[wp.exec[l + 1].out_tensor];
+        tm1.last_use = std::max(tm1.last_use, l + 3);
+        for (size_t t = 0; t < wp.tensors.size(); t++)
+          if (born[t] > l && born[t] <= l + 3) born[t] = l;
+        if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
+        wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 64;
+        l += 3;
+        continue;
+      }
       if (!bgroup_at(l)) continue;
       TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
       tin.last_use = std::max(tin.last_use, l + 2);
@@ -275,6 +287,30 @@ bool Net::pair_candidate(int l) const {
   return true;
 }
 
+// Rows l .. l + 3 = projection shortcut (1x1, 64 -> 256) and reduce (1x1, 64 -> 64) of the same 56 x 56 input, 3x3, expand +
+// residual from the shortcut: conv_bgroup56f_kernel.  Shortcut, reduce and expand all two-window (packed dual) or all one-window.
+bool Net::bgroup_first_at(int l) const {
+  if (l < 1 || l + 3 >= nd.n_layers) return false;
+  const tf2_layer_desc& S = layers[l]; const tf2_layer_desc& A = layers[l + 1]; const tf2_layer_desc& B = layers[l + 2]; const tf2_layer_desc& E = layers[l + 3];
+  for (const tf2_layer_desc* L : {&S, &A, &B, &E})
+    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->stride != 1 || L->dil != 1 || L->H != 56 || L->W != 56) return false;
+  if (S.src < 0 || S.src != A.src || layers[S.src].concat >= 0 || S.k != 1 || A.k != 1 || S.pad_h || A.pad_h || S.add_src >= 0 || A.add_src >= 0) return false;
+  if (S.C != 64 || S.N != 256 || A.C != 64 || A.N != 64) return false;
+  if (B.src != l + 1 || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != 64 || B.N != 64) return false;
+  if (E.src != l + 2 || E.k != 1 || E.pad_h || E.add_src != l || E.C != 64 || E.N != 256) return false;
+  int n_dual = 0;
+  for (int k = l; k <= l + 3; k++) {
+    const PackLayer* pl = pack_layer(k);
+    if (!pl || pl->kind != KIND_MFMA || pl->Cp_in != 64 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
+    if (k == l ? (pl->TM != 64 && pl->TM != 128) : pl->TM != 64) return false;
+    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+    if (!one_window && !dual) return false;
+    if (k == l + 2) { if (!one_window) return false; } else n_dual += dual ? 1 : 0;
+    if (k == l && pl->off_dbl) return false;            // (the shortcut's output is only ever a residual)
+  }
+  return n_dual == 0 || n_dual == 3;
+}
+
 // Rows l, l + 1, l + 2 = 1x1 reduce, 3x3 / 1 / pad 1, 1x1 expand + residual from the reduce's input, of a shape conv_bgroup.hip
 // is instantiated for, every row single-window in 64- or 128-row dense tiles.
 bool Net::bgroup_at(int l) const {
@@ -346,6 +382,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56")) o.bgroup_min56 = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -537,6 +574,37 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
+    // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
+        256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+      Launch ss, s0, s1, s2;
+      if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
+      if (ss.conv.dense && s0.conv.dense && s1.conv.dense && s2.conv.dense) {
+        Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BGROUPF; st.layer = l;
+        BGroupArgs& f = st.bgroup;
+        const ConvArgs& cs = ss.conv; const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
+        f.x = c0.x; f.mid1 = c0.y; f.mid2 = c1.y; f.y = c2.y; f.res = nullptr;
+        f.w1 = c0.w; f.w2 = c1.w; f.w3 = c2.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr3 = c2.hdr;
+        f.hdr1_bytes = c0.hdr_bytes; f.hdr2_bytes = c1.hdr_bytes; f.hdr3_bytes = c2.hdr_bytes;
+        f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
+        f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
+        f.epoch = reinterpret_cast<const unsigned*>(base + wp->ctrl_off);
+        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 16;
+        f.B = batch;
+        f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = 1;
+        f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
+        f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = 0;
+        f.dual1 = c0.dual; f.dual2 = 0; f.dual3 = c2.dual;
+        f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
+        f.ws = cs.w; f.hdrs = cs.hdr; f.hdrs_bytes = cs.hdr_bytes; f.tms = ss.TM; f.relu_s = cs.g.relu; f.fast_s = cs.g.fast;
+        f.ys = cs.y; f.ys_cp = cs.g.y_cp; f.keep_s = wp->keep_all ? 1 : 0;
+        lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
+        bg_used++;
+        pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
+        lp.steps.push_back(st);
+        continue;
+      }
+    }
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
     if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
@@ -771,6 +839,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:
           return launch_conv_bgroup(st.bgroup, st.bg_hw, st.bg_c, st.bg_m, stream);
         case Launch::SEL_CHAIN:

@@ -223,6 +223,10 @@ struct BGroupArgs {
   int32_t avg_mult;                // != 0: the bottleneck ends in the global average (full_size_pool.cl); y / y_cp / y_off then
                                    // describe the AVERAGED tensor [B][y_cp] (7 x 7 kernel only)
   int32_t res_cp, res_off, y_cp, y_off;
+  // conv_bgroup56f_kernel only (the stage's first bottleneck): the projection shortcut computed inside the launch
+  const int8_t* ws; const int32_t* hdrs;     // its dense weight tiles and header images
+  int8_t* ys;                                // its own output tensor (written only with keep_s)
+  int32_t hdrs_bytes, tms, relu_s, fast_s, keep_s, ys_cp;      // tms: rows per m-tile of the shortcut (64 or 128)
 };
 
 // conv_stem.hip: layer 0 in its executed 3x3 / stride 1 / pad 0 form on the x-only image tensor (32 bytes per pixel)
@@ -293,6 +297,7 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, 
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
 int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream);
+int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit

@@ -52,7 +52,7 @@ static_assert(sizeof(ChainSeg) <= kChainSegStride, "ChainSeg outgrew its table s
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN, SEL_BGROUP } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN, SEL_BGROUP, SEL_BGROUPF } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -96,7 +96,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
-  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30;   // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
+  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12;   // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
      // TF2_AMD_BGROUP_MIN7 / _MIN14: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int chain_mode = 0;      // TF2_AMD_CHAIN: consecutive ring-kernel layers in one launch (conv_mfma2_chain_kernel): 0 never, 1 where eligible
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
@@ -156,6 +156,7 @@ struct Net {
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
   bool chain_row(int l) const;             // row l could be a segment of a chain launch (plain conv row with a 128-row ring-kernel form)
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
