@@ -100,6 +100,33 @@ __device__ __forceinline__ bool bg_wait(const unsigned* flags, unsigned tag, int
   return *lds_word != 0;
 }
 
+// Roll call: every member posts its flag once at the start of the launch; by the time the first exchange stores are due everybody
+// has long arrived, and a member that finds the whole group on its own XCD (the normal case) writes its exchange data with
+// ordinary stores -- acknowledged by the L2 in a fraction of the time a write-through to the memory side takes.
+__device__ __forceinline__ void bg_rollcall_post(unsigned* flags, int member, unsigned tag, int tid) {
+  if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(flags + member), "v"(tag) : "memory");
+}
+// the calling WAVE reads the roll call (no block barrier): true = all eight members run on this wave's XCD
+__device__ __forceinline__ bool bg_rollcall_wave(const unsigned* flags, unsigned tag, int lane) {
+  int polls = 0;
+  unsigned f = tag;
+  for (;;) {
+    if (lane < kBgMembers) {
+      if ((polls & 3) == 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + lane) : "memory");
+      else asm volatile("buffer_inv sc0\n\tglobal_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + lane) : "memory");
+    }
+    if (__builtin_amdgcn_ballot_w64((f >> 8) != (tag >> 8)) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (++polls > (1 << 24)) __builtin_trap();
+  }
+  return __builtin_amdgcn_ballot_w64((f & 0xff) != (tag & 0xff)) == 0;
+}
+// one 16-byte piece of an exchanged tensor
+__device__ __forceinline__ void bg_store_x(int8_t* dst, const i32x4& v, bool local) {
+  if (local) *reinterpret_cast<i32x4*>(dst) = v;
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+}
+
 // HW: map side; C: channels of the bottleneck's input / output; M: channels of the intermediates (M / 8 = 32 per member)
 template <int HW, int C, int M>
 __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // LDS-DMA: lane l fills row l >> 2, slot l & 3, which holds chunk slot ^ ((row >> 2) & 3)
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
-  unsigned* const ctr = a.ctr + (size_t)img * 16;         // two rows of eight flags
+  unsigned* const ctr = a.ctr + (size_t)img * 32;         // three rows of eight flags: roll call, two meetings
 
   long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py: 100 MHz wall clock per phase
 #define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
@@ -183,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 
   const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID, 4 bits
   unsigned tag = 0;                                         // this member's flag value: (epoch << 8) | XCC id
+  bool local0 = false;                                      // the whole group on this XCD (roll call): exchange stores need no write-through
 
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
@@ -203,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
     __syncthreads();                                       // headers and the reduce's weights are in LDS (pieces fetched by every wave)
     BG_STAMP(1);
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);          // (the epoch word was stored before the barrier)
+    bg_rollcall_post(ctr, m, tag, tid);
     // two accumulators (one per K half): a dependent MFMA would wait out the 16 passes of its predecessor
     i32x16 acc, acc1;
 #pragma unroll
@@ -224,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] += acc1[r];
       BG_STAMP(2);
-      // requantise, write this member's 32 channels of mid1 (agent scope: the other members read them next)
+      local0 = bg_rollcall_wave(ctr, tag, lane);
+      // requantise, write this member's 32 channels of mid1 (the other members read them next)
       int a16[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) a16[r] = acc[r];
@@ -234,15 +264,15 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
       else out = requant_tile16<false, 0, false>(a16, prm1, a.tm1, ro1 + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
       if (p_ok) {
         int8_t* dst = a.mid1 + (px_img + p_lane) * M + c1 + 16 * half;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+        bg_store_x(dst, out, local0);
       }
     }
   }
-  bg_signal(ctr, m, tag, tid);
+  bg_signal(ctr + 8, m, tag, tid);
   BG_STAMP(3);
   // the 3x3's weights (this member's 32 rows of all 9 x KS2 steps) on their way while the group gathers
   for (int e = wave; e < NE; e += 8) w_dma(a.w2, a.tm2, mt2 * NE + e, ro2, wreg + e * 2048);
-  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -292,11 +322,11 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
       else out = requant_tile16<false, 0, false>(a16, prm2, a.tm2, ro2 + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
       if (p_ok) {
         int8_t* dst = a.mid2 + (px_img + p_lane) * M + c1 + 16 * half;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+        bg_store_x(dst, out, local0);
       }
     }
   }
-  bg_signal(ctr + 8, m, tag, tid);
+  bg_signal(ctr + 16, m, tag, tid);
   BG_STAMP(7);
   // the expand's weights: [32-row tile][slab] of this member's C / 8 rows, into the 3x3's weight region
   for (int u = wave; u < CT * KS2; u += 8) {
@@ -310,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
     const int8_t* rp = (a.has_res && p_ok) ? a.res + (px_img + p_lane) * a.res_cp + a.res_off + c3 + 32 * q + 16 * half : a.zero;
     rv[q] = *reinterpret_cast<const i32x4*>(rp);
   }
-  const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
   BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
@@ -410,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   const size_t px_band = px_img + (size_t)m * NPB;
-  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
   long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
 #define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
   BG_STAMP(0);
@@ -448,6 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
   unsigned tag = 0;
+  bool local0 = false;                                      // roll call: the whole group on this XCD
 
   // =================================== phase A: reduce, 1x1 C -> M, two rounds of column tiles ===================================
   {
@@ -467,6 +498,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
     __syncthreads();                                       // headers and the reduce's weights are in LDS
     BG_STAMP(1);
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    bg_rollcall_post(ctr, m, tag, tid);
     const int lo_b = a.relu1 ? 0 : -128;
 #pragma unroll
     for (int rd = 0; rd < 2; rd++) {
@@ -510,6 +542,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
           }
       }
       const int p = 32 * t + (lane & 31);
+      if (rd == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         int a16[16];
@@ -520,17 +553,17 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
         else out = requant_tile16<false, 0, false>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
         if (t < NT && p < NPB) {
           int8_t* dst = a.mid1 + (px_band + p) * M + 32 * q + 16 * half;
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+          bg_store_x(dst, out, local0);
         }
       }
     }
   }
   BG_STAMP(2);
-  bg_signal(ctr, m, tag, tid);
+  bg_signal(ctr + 8, m, tag, tid);
   BG_STAMP(3);
   // the 3x3's weights: [tap][two 32-row tiles]
   for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);
-  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M; the band's output stays in LDS ===================================
@@ -693,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   const size_t px_band = px_img + (size_t)m * NPB;
-  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
   const int frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
   const i32x4 nores = {0, 0, 0, 0};
@@ -741,6 +774,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                         // headers, reduce weights and the band's input are in LDS
   const unsigned tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+  bg_rollcall_post(ctr, m, tag, tid);
+  bool local0 = false;
 
   // two-window combine of a 32 x 32 tile: (hi << dshift[1][row]) + lo
   auto combine = [&](i32x16& hi, const i32x16& lo, const int* prm, int row0, int tm = 64) {
@@ -756,6 +791,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   // =================================== phase A: reduce, 1x1 64 -> 64 (K = one slab) ===================================
   {
     const int lo_b = a.relu1 ? 0 : -128;
+    local0 = bg_rollcall_wave(ctr, tag, lane);
 #pragma unroll
     for (int rd = 0; rd < 2; rd++) {
       const int t = wave + 8 * rd;
@@ -784,15 +820,15 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
           else out = requant_tile16<false, 0, false>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
           if (p < NPB) {
             int8_t* dst = a.mid1 + (px_band + p) * M + 32 * q + 16 * half;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+            bg_store_x(dst, out, local0);
           }
         }
       }
     }
   }
-  bg_signal(ctr, m, tag, tid);
+  bg_signal(ctr + 8, m, tag, tid);
   for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);      // the 3x3's weights: [tap][two 32-row tiles]
-  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
 
   // =================================== phase B: 3x3 / pad 1; the band's output stays in LDS ===================================
   {
@@ -950,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   const size_t px_band = px_img + (size_t)sp * NPB;      // first pixel of the band
-  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
   const int frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
   const i32x4 nores = {0, 0, 0, 0};
@@ -994,6 +1030,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   const int p_lane = 32 * t + (lane & 31);               // pixel of this lane's column inside the band (phases A, B)
   const bool p_ok = worker && p_lane < NPB;
   unsigned tag = 0;
+  bool local0 = false;                                      // roll call: the whole group on this XCD
 
   // requantise [two 32-row tiles] x [column tile t] and store into a mid tensor
   auto store_mid = [&](i32x16 (&acc)[2], const int* prm, int tm, int ro, int fast, int relu, int dbl, int8_t* mid) {
@@ -1008,7 +1045,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       else out = requant_tile16<false, 0, false>(a16, prm, tm, ro + 32 * q + 4 * half, lo_b, -128, nores, dbl != 0, fast == 2);
       if (p_ok) {
         int8_t* dst = mid + (px_band + p_lane) * M + c1 + 32 * q + 16 * half;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+        bg_store_x(dst, out, local0);
       }
     }
   };
@@ -1031,6 +1068,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // headers and the reduce's weights are in LDS
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    bg_rollcall_post(ctr, m, tag, tid);
     i32x16 acc[2], accl[DUAL1 ? 2 : 1];
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -1070,10 +1108,11 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
               acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
           }
       }
+      local0 = bg_rollcall_wave(ctr, tag, lane);
       store_mid(acc, prm1, a.tm1, ro1, a.fast1, a.relu1, a.dbl1, a.mid1);
     }
   }
-  bg_signal(ctr, m, tag, tid);
+  bg_signal(ctr + 8, m, tag, tid);
   // the 3x3's weights (of one window): [step e][two 32-row tiles]
   constexpr int NW2 = DUAL2 ? 2 : 1;
   auto load_w2 = [&](int win) {
@@ -1081,7 +1120,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       w_dma(a.w2, (((size_t)mt2 * NE + (u >> 1)) * NW2 + win) * a.tm2 + ro2 + 32 * (u & 1), wreg + u * 2048);
   };
   load_w2(0);
-  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
   {
@@ -1153,7 +1192,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       store_mid(acc, prm2, a.tm2, ro2, a.fast2, a.relu2, a.dbl2, a.mid2);
     }
   }
-  bg_signal(ctr + 8, m, tag, tid);
+  bg_signal(ctr + 16, m, tag, tid);
   // the expand's weights of this wave (32-row tile `wave` of the member's 256 channels): K = 128 -> four fragments, in registers
   const int ch3 = c3 + 32 * wave;
   i32x4 wf[KS2][2];
@@ -1165,7 +1204,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       wf[s][0] = *reinterpret_cast<const i32x4*>(p); wf[s][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
   }
-  const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
   {
@@ -1254,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
-  unsigned* const ctr = a.ctr + (size_t)img * 16;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
   long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
 #define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
   BG_STAMP(0);
@@ -1289,6 +1328,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
 
+  bool local0 = false;                                      // roll call: the whole group on this XCD
   // the four K quarters of a 32-row tile meet: quarters 1..3 park their two column tiles in LDS, quarter 0 adds them up
   auto reduce_quarters = [&](i32x16 (&acc)[2], int8_t* park) {
     if (kq > 0) {
@@ -1326,7 +1366,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       const int p = 32 * pt + (lane & 31);
       if (p < NPX) {
         int8_t* dst = mid + (px_img + p) * M + c1 + 32 * ct + 16 * half;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
+        bg_store_x(dst, out, local0);
       }
     }
   };
@@ -1379,6 +1419,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     __syncthreads();                                       // every wave is done with its ring; headers (fetched by every wave) are in LDS
     BG_STAMP(1);
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    bg_rollcall_post(ctr, m, tag, tid);
     if (DUAL1) {
       // combine the windows: (hi << dshift[1][row]) + lo
       const int* dsh = prm1 + (kPrmWordsPerRow + 1) * 64;
@@ -1393,12 +1434,12 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       }
     }
     reduce_quarters(acc, wreg);
-    if (kq == 0) store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1);
+    if (kq == 0) { local0 = bg_rollcall_wave(ctr, tag, lane); store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1); }
     BG_STAMP(2);
   }
-  bg_signal(ctr, m, tag, tid);
+  bg_signal(ctr + 8, m, tag, tid);
   BG_STAMP(3);
-  const bool local1 = bg_wait(ctr, tag, tid, ctl + 1);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -1471,7 +1512,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     reduce_quarters(acc, wreg);
     if (kq == 0) store_mid(acc, prm2, a.fast2, a.relu2, a.dbl2, a.mid2);
   }
-  bg_signal(ctr + 8, m, tag, tid);
+  bg_signal(ctr + 16, m, tag, tid);
   BG_STAMP(7);
   // residual tiles of this wave's 32-row tile of the expand (the bottleneck's input: ordinary loads)
   const int ch3 = (C / kBgMembers) * m + 32 * wave;        // first channel of this wave's tile
@@ -1489,7 +1530,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   auto issue3 = [&](int s, int slot) { w_dma(a.w3, ((size_t)mt3 * KS2 + s) * 64 + ro3, ring3 + slot * 2048); };
 #pragma unroll
   for (int s = 0; s < S3 - 1; s++) issue3(s, s);
-  const bool local2 = bg_wait(ctr + 8, tag, tid, ctl + 2);
+  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
   BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual (+ global average) ===================================

@@ -182,7 +182,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
         for (size_t t = 0; t < wp.tensors.size(); t++)
           if (born[t] > l && born[t] <= l + 3) born[t] = l;
         if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
-        wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 64;
+        wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;
         l += 3;
         continue;
       }
@@ -194,7 +194,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       for (size_t t = 0; t < wp.tensors.size(); t++)
         if (born[t] == l + 1 || born[t] == l + 2) born[t] = l;
       if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;                         // the step counter
-      wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 64;            // two rows of eight flag words per image
+      wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;            // three rows of eight flag words per image (roll call, two meetings)
       l += 2;
     }
   // Chain launches (conv_mfma2_chain_kernel, TF2_AMD_CHAIN): blocks of consecutive rows run concurrently, ordered only by the
@@ -576,7 +576,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
     if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
-        256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+        256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch ss, s0, s1, s2;
       if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
       if (ss.conv.dense && s0.conv.dense && s1.conv.dense && s2.conv.dense) {
@@ -589,7 +589,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
         f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
         f.epoch = reinterpret_cast<const unsigned*>(base + wp->ctrl_off);
-        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 16;
+        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 32;
         f.B = batch;
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = 1;
         f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
@@ -607,7 +607,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 64 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
       if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
@@ -620,7 +620,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
         f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
         f.epoch = reinterpret_cast<const unsigned*>(base + wp->ctrl_off);
-        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 16;
+        f.ctr = reinterpret_cast<unsigned*>(base + wp->ctrl_off + 256) + (size_t)bg_used * ((batch + 7) / 8 * 8) * 32;
         f.B = batch;
         f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
