@@ -388,6 +388,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
+  if (const char* e = getenv("TF2_AMD_DENSE_MAX")) o.dense_max_slabs = atoi(e);
   if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
   if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
@@ -498,7 +499,11 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       // arithmetic gather (tf2_internal.h ConvArgs::dense): no header read in front of the first activation DMAs
       const int taps_l = L.k * L.k;
       ca.cslabs = pl->Cp_in / 64;
-      if (opts.dense_mode && dense && (pl->n_phases == 1 || pl->dual) && pl->Cp_in % 64 == 0 && pl->nslab == taps_l * ca.cslabs && L.k <= 15) {
+      // (long slab lists on large maps pay more for the per-step arithmetic than the shorter prologue saves: VGG16 -7 % with every
+      //  layer dense; layers of more than dense_max_slabs slabs whose grid runs in several rounds keep the header tables)
+      const long blocks_d = ((long)batch * L.OH * L.OW + 127) / 128 * std::max(1, pl->Np / 128);
+      const bool dense_pays = pl->nslab <= opts.dense_max_slabs || blocks_d <= 512;
+      if (opts.dense_mode && dense && dense_pays && (pl->n_phases == 1 || pl->dual) && pl->Cp_in % 64 == 0 && pl->nslab == taps_l * ca.cslabs && L.k <= 15) {
         ca.dense = 1;
         set_fast_div((uint32_t)ca.cslabs, &ca.cs_m, &ca.cs_s); set_fast_div((uint32_t)L.k, &ca.kk_m, &ca.kk_s);
       }

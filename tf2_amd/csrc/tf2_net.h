@@ -93,6 +93,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
+  int dense_max_slabs = 17;   // TF2_AMD_DENSE_MAX: layers with more K slabs than this on grids of more than one round keep the header tables
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
