@@ -987,6 +987,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   const size_t px_img = (size_t)img * NPX;
   const size_t px_band = px_img + (size_t)sp * NPB;      // first pixel of the band
   unsigned* const ctr = a.ctr + (size_t)img * 32;
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
   const int frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
   const i32x4 nores = {0, 0, 0, 0};
@@ -1067,6 +1070,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // headers and the reduce's weights are in LDS
+    BG_STAMP(1);
     tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
     bg_rollcall_post(ctr, m, tag, tid);
     i32x16 acc[2], accl[DUAL1 ? 2 : 1];
@@ -1112,7 +1116,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       store_mid(acc, prm1, a.tm1, ro1, a.fast1, a.relu1, a.dbl1, a.mid1);
     }
   }
+  BG_STAMP(2);
   bg_signal(ctr + 8, m, tag, tid);
+  BG_STAMP(3);
   // the 3x3's weights (of one window): [step e][two 32-row tiles]
   constexpr int NW2 = DUAL2 ? 2 : 1;
   auto load_w2 = [&](int win) {
@@ -1121,6 +1127,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   };
   load_w2(0);
   const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
   {
@@ -1137,6 +1144,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // halo and weights complete in every wave
+    BG_STAMP(5);
     const int pq = p_ok ? p_lane : 0;
     const int oh = pq / HW, ow = pq - oh * HW;
     const int h0 = oh * HC + ow;
@@ -1192,7 +1200,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       store_mid(acc, prm2, a.tm2, ro2, a.fast2, a.relu2, a.dbl2, a.mid2);
     }
   }
+  BG_STAMP(6);
   bg_signal(ctr + 16, m, tag, tid);
+  BG_STAMP(7);
   // the expand's weights of this wave (32-row tile `wave` of the member's 256 channels): K = 128 -> four fragments, in registers
   const int ch3 = c3 + 32 * wave;
   i32x4 wf[KS2][2];
@@ -1205,6 +1215,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
   }
   const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
+  BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
   {
@@ -1219,18 +1230,26 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
     const int mt = ch3 / a.tm3, ro = ch3 % a.tm3;
     const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + (mt - c3 / a.tm3)) * kHdrSlot);
-    auto load_res = [&](int tt) -> i32x4 {
-      const int p = 32 * tt + (lane & 31);
-      const int8_t* rp = (a.has_res && p < NPB) ? a.res + (px_band + p) * a.res_cp + a.res_off + ch3 + 16 * half : a.zero;
-      return *reinterpret_cast<const i32x4*>(rp);
-    };
-    i32x4 rnext = load_res(0);
+    // Residual in, outputs out: through an LDS image of the band's [196 pixels][256 channels of this member] so that the global
+    // side moves whole 256-byte pixel rows (a wave-tile's own pieces are 16 bytes at a stride of y_cp: 3.6 TB/s measured that way).
+    // Row px keeps its sixteen 16-byte pieces XOR-swizzled with px & 15: a column read (32 pixels, one piece) is conflict-free.
+    int8_t* const stage = wreg;                            // (the 3x3's weights are dead)
+    constexpr int NCHUNK = (NPB * 256 + 1023) / 1024;      // 1 KiB = four pixel rows
+    if (a.has_res) {
+      for (int ci = wave; ci < NCHUNK; ci += 8) {
+        const int px = 4 * ci + (lane >> 4), q = (lane & 15) ^ (px & 15);
+        const int8_t* src = px < NPB ? a.res + (px_band + px) * a.res_cp + a.res_off + c3 + q * 16 : a.zero;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 0);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // the band's tiles (fetched by every wave)
+    BG_STAMP(9);
 #pragma unroll
     for (int tt = 0; tt < NT; tt++) {
-      const i32x4 rcur = rnext;
-      if (tt + 1 < NT) rnext = load_res(tt + 1);
+      const int pxl = 32 * tt + (lane & 31);
+      int8_t* const slot = stage + pxl * 256 + ((((2 * wave + half) ^ (pxl & 15))) << 4);
+      const i32x4 rcur = *reinterpret_cast<const i32x4*>(slot);
       i32x16 acc, acc1;
 #pragma unroll
       for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; }
@@ -1252,10 +1271,18 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
         if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
         else out = requant_tile16<false, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
       }
-      const int p = 32 * tt + (lane & 31);
-      if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+      *reinterpret_cast<i32x4*>(slot) = out;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                       // the band's outputs are complete in LDS
+    for (int ci = wave; ci < NCHUNK; ci += 8) {
+      const int px = 4 * ci + (lane >> 4), q = (lane & 15) ^ (px & 15);
+      const i32x4 v = *reinterpret_cast<const i32x4*>(stage + ci * 1024 + lane * 16);
+      if (px < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + px) * a.y_cp + a.y_off + c3 + q * 16) = v;
     }
   }
+  BG_STAMP(10);
+#undef BG_STAMP
 }
 
 // ---- the 7 x 7 maps (ResNet-50 stage 5: C = 2048, M = 512) --------------------------------------------------------------------

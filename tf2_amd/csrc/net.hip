@@ -407,6 +407,18 @@ void Net::load_options() {
   for (const auto& k : keys) (void)plan(k.first, k.second != 0);
 }
 
+// Group launches (conv_bgroup.hip) keep eight blocks per image resident together, one block per CU: they need a device (or
+// device partition) of at least 64 CUs.  No device (describing a plan on the CPU): assume the full chip.
+static bool device_fits_group_launches() {
+  static int n_cu = -1;
+  if (n_cu < 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    else n_cu = 256;
+  }
+  return n_cu >= 64;
+}
+
 // ---- launch plan: every kernel argument block of one step, resolved once per (batch, workspace, packed image) ----
 // Net::run used to rebuild ~60 argument structs, scan the packed directory and read a dozen environment variables
 // per call; at batch 1 (57 launches of a few microseconds) that host work was the step.  Now a step is a loop over
@@ -555,6 +567,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   };
   std::vector<char> fused_done(nl, 0), pair_done(nl, 0);
   int bg_used = 0;                                           // group launches so far (each has its own counters)
+  const bool groups_fit = device_fits_group_launches();
   bool stem_pool_fused = false;
   const bool profiling_pairs_off = false;
   for (int l = 0; l < nl; l++) {
@@ -580,7 +593,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
         256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch ss, s0, s1, s2;
       if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
@@ -612,7 +625,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
       if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
