@@ -94,15 +94,18 @@ def test_vgg16_batch32_properties():
     np.testing.assert_array_equal(rig.run(x[20:22], keep_all=False), got[20:22])
 
 
-@pytest.mark.parametrize("batch", [1, 4])
+@pytest.mark.parametrize("batch", [1, 4, 16])
 def test_hip_graph_replay_equals_run_batch(r50_rig, batch):
     """Runner.capture: the step recorded once into a HIP graph; replays on refilled input buffers give the logits of
-    run_batch (and of the oracle)."""
+    run_batch (and of the oracle).  Batch 16 takes the group launches (conv_bgroup.hip): their flags carry a step counter that
+    the replayed input-preparation kernel advances, so a replay is as good as a launch."""
     torch = _torch()
     rig = r50_rig
+    if batch >= 12:
+        assert any("conv_bgroup" in r["kernel"] for r in rig.net.describe_launches(batch, 0))
     xs = [synth.synth_images(rig.t, batch, 70 + i) for i in range(3)]
     want = [rig.run(x, keep_all=False) for x in xs]
-    np.testing.assert_array_equal(want[0], rig.ref.logits(rig.ref.run(xs[0])))
+    np.testing.assert_array_equal(want[0][:2], rig.ref.logits(rig.ref.run(xs[0][:2])))
     runner = network.Runner(None, rig.net)
     buf = torch.from_numpy(xs[0]).to("cuda:0")
     replay = runner.capture(buf)
