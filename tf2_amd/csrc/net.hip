@@ -617,7 +617,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.ws = cs.w; f.hdrs = cs.hdr; f.hdrs_bytes = cs.hdr_bytes; f.tms = ss.TM; f.relu_s = cs.g.relu; f.fast_s = cs.g.fast;
         f.ys = cs.y; f.ys_cp = cs.g.y_cp; f.keep_s = wp->keep_all ? 1 : 0;
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
-        bg_used++;
+        bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
         lp.steps.push_back(st);
         continue;
@@ -649,7 +649,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
         // the step's first kernel (input preparation) advances the step counter
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
-        bg_used++;
+        bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1;
         lp.steps.push_back(st);
         continue;
@@ -945,6 +945,12 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     }
     return TF2_OK;
   };
+  if (lp->n_groups && !lp->ctrl_zeroed) {
+    // first step of this plan on this workspace: the control words (step counter, group flags) start from zero -- whatever the
+    // memory held before must not look like a set flag
+    HIP_OK(hipMemsetAsync((int8_t*)ws + wp->ctrl_off, 0, wp->ctrl_bytes, s));
+    const_cast<LaunchPlan*>(lp)->ctrl_zeroed = true;
+  }
   if (lp->n_chains && !lp->chain_uploaded) {
     // the segment tables of the chain launches go into the workspace once per (workspace, plan); stream order covers the launches
     for (const Launch& st : lp->steps)

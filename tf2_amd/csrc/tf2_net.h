@@ -83,6 +83,8 @@ struct LaunchPlan {
   int logits_direct = -1;           // index of the conv step that writes the dense logits itself (its y is patched per call), else -1
   bool chain_uploaded = false;      // the chain launches' segment tables are in the workspace (copied by the first run)
   int n_chains = 0;
+  int n_groups = 0;                 // group launches (conv_bgroup.hip) in the plan
+  bool ctrl_zeroed = false;         // the workspace's control words were zeroed for this plan (first run)
 };
 
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
