@@ -423,10 +423,11 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN28", "1")
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN56", "1")          # (off by default: measured equal)
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN56F", "1")
+    monkeypatch.setenv("TF2_AMD_BGROUP_MIN14F", "1")
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 28, 31, 34, 37, 40, 47, 50]
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24, 28, 31, 34, 37, 40, 47, 50]
     assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == 50][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))

@@ -946,6 +946,377 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   }
 }
 
+// ---- the FIRST bottleneck of the 14 x 14 stage (ResNet-50 rows 24-27: projection shortcut 512 -> 1024 / stride 2 | reduce 512 -> 256 on
+// the 28 x 28 map, 3x3 / stride 2 / pad 1, expand 256 -> 1024 + residual) in one launch.  Members by channel as on the 14 x 14 maps:
+// 32 intermediate channels, 128 output channels each.  Phases:
+//   A  reduce on the 784 input pixels: wave w streams column tiles w, w + 8, ... (25 tiles) through its private ring, the member's
+//      32 weight rows (both windows) LDS-resident; the requantised tiles wait in registers and are stored behind the K stream;
+//   S  the shortcut, between "signal" and "wait" of the first meeting (it needs nobody else's data): 1x1 / stride 2 on the even
+//      pixels, two passes of two 32-row tiles (64 KB of weights per pass), its requantised output goes to the shortcut's own
+//      tensor and comes back in phase C as the residual;
+//   B  3x3 / stride 2: one 64-channel slab of the 28 x 28 intermediate at a time (30 rows x 32 columns, the columns split by parity so
+//      that a tap's 32 output pixels read consecutive LDS slots), 72 KB of weights resident;
+//   C  expand + residual, outputs and residual through an LDS image of the member's [196 pixels][128 channels].
+// DUAL: reduce and shortcut are two-window layers.
+template <bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv_bgroup14f_kernel(BGroupArgs a) {
+  constexpr int HWI = 28, HWO = 14, CIN = 512, M = 256, COUT = 1024;
+  constexpr int NPI = HWI * HWI, NPO = HWO * HWO;        // 784, 196
+  constexpr int NTI = (NPI + 31) / 32, NTO = (NPO + 31) / 32;      // 25, 7
+  constexpr int KS1 = CIN / 64, KS2 = M / 64;            // 8, 4
+  constexpr int NWN = DUAL ? 2 : 1;
+  constexpr int S = 4;
+  constexpr int HROWS = HWI + 2, HSLAB = HROWS * 32 * 64;         // halo slab: 30 rows x 32 slots (parity-split columns): 60 KB
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  int8_t* const hdr_lds = lds;                           // [reduce 4 KB][3x3 2 KB][pad 2 KB][expand 2 x 2 KB][shortcut 2 x 2 KB]
+  int8_t* const wreg = lds + 16 * 1024;                  // 72 KB
+  int8_t* const work = wreg + 72 * 1024;                 // 64 KB
+  int* const ctl = reinterpret_cast<int*>(work + 64 * 1024);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= a.B) return;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const int drow = lane >> 2;
+  const size_t pxi_img = (size_t)img * NPI, pxo_img = (size_t)img * NPO;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  const i32x4 nores = {0, 0, 0, 0};
+  const int c1 = 32 * m;                                 // first intermediate channel of this member
+  const int mt1 = c1 / a.tm1, ro1 = c1 % a.tm1;
+  const int mt2 = c1 / a.tm2, ro2 = c1 % a.tm2;
+  const int c3 = 128 * m;                                // first output channel (expand and shortcut)
+
+  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
+  };
+  auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int tm, int nwords, int8_t* dst) {
+    const int used = (nwords * tm * 4 + 1023) & ~1023;
+    const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
+    for (int i = wave; i * 1024 < used; i += 8)
+      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(dst + i * 1024), 16, 0, 0);
+  };
+  int8_t* const hdr1 = hdr_lds, * const hdr2 = hdr_lds + 4096, * const hdr3 = hdr_lds + 8192, * const hdrs = hdr_lds + 12288;
+  hdr_dma(a.hdr1, a.hdr1_bytes, mt1, a.tm1, kPrmWordsPerRow + 2, hdr1);
+  hdr_dma(a.hdr2, a.hdr2_bytes, mt2, a.tm2, kPrmWordsPerRow, hdr2);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    hdr_dma(a.hdr3, a.hdr3_bytes, c3 / 64 + q, 64, kPrmWordsPerRow, hdr3 + q * 2048);
+    hdr_dma(a.hdrs, a.hdrs_bytes, c3 / 64 + q, 64, kPrmWordsPerRow + 2, hdrs + q * 2048);
+  }
+  // the reduce's weights: [slab][window][32 rows]
+  for (int u = wave; u < KS1 * NWN; u += 8) {
+    const int sl = u / NWN, win = u % NWN;
+    w_dma(a.w1, (((size_t)mt1 * KS1 + sl) * NWN + win) * a.tm1 + ro1, wreg + u * 2048);
+  }
+  if (tid == 64 * 7) {
+    unsigned e;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+    ctl[0] = (int)e;
+  }
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int* const prm1 = reinterpret_cast<const int*>(hdr1);
+  const int* const prm2 = reinterpret_cast<const int*>(hdr2);
+  int8_t* const ring = work + wave * (S * 2048);
+
+  auto combine = [&](i32x16& hi, const i32x16& lo, const int* prm, int tm, int row0) {     // (hi << dshift[1][row]) + lo
+    const int* dsh = prm + (kPrmWordsPerRow + 1) * tm;
+#pragma unroll
+    for (int G = 0; G < 4; G++) {
+      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + row0 + 4 * half + 8 * G);
+#pragma unroll
+      for (int r = 0; r < 4; r++) hi[G * 4 + r] = (int)(((unsigned)hi[G * 4 + r] << (d[r] & 31)) + (unsigned)lo[G * 4 + r]);
+    }
+  };
+
+  // =================================== phase A: reduce, 1x1 CIN -> M on the 28 x 28 map ===================================
+  unsigned tag = 0;
+  bool local0 = false;
+  {
+    const int ntl = (NTI - wave + 7) / 8;                  // column tiles of this wave: wave, wave + 8, ...
+    const int nstep = ntl * KS1;
+    auto issue = [&](int g, int slot) {
+      const int t = wave + 8 * (g / KS1), sl = g % KS1;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; g2++) {
+        const int p = 32 * t + 16 * g2 + drow;
+        const int8_t* src = p < NPI ? a.x + (pxi_img + p) * CIN + sl * 64 + chunk * 16 : a.zero + chunk * 16;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * 2048 + g2 * 1024), 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < S - 1; g++) issue(g, g);          // (every wave has at least three tiles)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // headers and the reduce's weights are in LDS
+    BG_STAMP(1);
+    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+    bg_rollcall_post(ctr, m, tag, tid);
+    i32x4 outs[4];                                         // the requantised tiles of this wave, stored behind the K stream
+    i32x16 acc, accl;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
+    const int lo_b = a.relu1 ? 0 : -128;
+    int cs = 0, is = S - 1;
+    for (int g = 0; g < nstep; g++) {
+      if (g >= S - 1) { if (g + 2 < nstep) bg_wait_vmcnt<4>(); else if (g + 1 < nstep) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+      const int sl = g % KS1;
+      const int8_t* A = wreg + sl * (NWN * 2048);
+      const int8_t* B = ring + cs * 2048;
+      const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), b0, acc, 0, 0, 0);
+      if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + fr0), b0, accl, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), b1, acc, 0, 0, 0);
+      if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32)), b1, accl, 0, 0, 0);
+      if (g + S - 1 < nstep) { issue(g + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
+      cs = cs + 1 == S ? 0 : cs + 1;
+      if (sl == KS1 - 1) {
+        if (DUAL) combine(acc, accl, prm1, a.tm1, ro1);
+        int a16[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16[r] = acc[r];
+        i32x4 out;
+        if (a.fast1 == 1) out = requant_tile16<false, 0, true>(a16, prm1, a.tm1, ro1 + 4 * half, lo_b, -128, nores, a.dbl1 != 0, false);
+        else out = requant_tile16<false, 0, false>(a16, prm1, a.tm1, ro1 + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
+        const int ti = g / KS1;
+        if (ti == 0) outs[0] = out; else if (ti == 1) outs[1] = out; else if (ti == 2) outs[2] = out; else outs[3] = out;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
+      }
+    }
+    BG_STAMP(2);
+    local0 = bg_rollcall_wave(ctr, tag, lane);
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++) {
+      const int p = 32 * (wave + 8 * ti) + (lane & 31);
+      if (ti < ntl && p < NPI) bg_store_x(a.mid1 + (pxi_img + p) * M + c1 + 16 * half, outs[ti], local0);
+    }
+  }
+  bg_signal(ctr + 8, m, tag, tid);
+  BG_STAMP(3);
+
+  // =================================== phase S: the shortcut, 1x1 / stride 2 CIN -> COUT (this member: 128 channels) ===================================
+  {
+    const bool worker = wave < NTO;
+    const int t = wave;
+    // this lane's LDS-DMA rows: output pixel p -> input pixel (2 oh) * 28 + 2 ow
+    auto src_px = [&](int p) { const int oh = p / HWO, ow = p - oh * HWO; return (2 * oh) * HWI + 2 * ow; };
+    int srow[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++) { const int p = 32 * t + 16 * g2 + drow; srow[g2] = (worker && p < NPO) ? src_px(p) : -1; }
+    auto issue = [&](int sl, int slot) {
+#pragma unroll
+      for (int g2 = 0; g2 < 2; g2++) {
+        const int8_t* src = srow[g2] >= 0 ? a.x + (pxi_img + srow[g2]) * CIN + sl * 64 + chunk * 16 : a.zero + chunk * 16;
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * 2048 + g2 * 1024), 16, 0, 0);
+      }
+    };
+    const int lo_s = a.relu_s ? 0 : -128;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+      // weights of the pass: [slab][window][two 32-row tiles] of channels c3 + 64 pass ..
+      for (int u = wave; u < KS1 * NWN * 2; u += 8) {
+        const int sl = u / (NWN * 2), win = (u / 2) % NWN, q = u & 1;
+        const int ch = c3 + 64 * pass + 32 * q;
+        w_dma(a.ws, (((size_t)(ch / 64) * KS1 + sl) * NWN + win) * 64 + ch % 64, wreg + u * 2048);
+      }
+      if (worker) {
+#pragma unroll
+        for (int sl = 0; sl < S - 1; sl++) issue(sl, sl);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                     // the pass's weights are in LDS
+      if (worker) {
+        i32x16 acc[2], accl[DUAL ? 2 : 1];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) { acc[q][r] = 0; if (DUAL) accl[q][r] = 0; }
+        int cs = 0, is = S - 1;
+        for (int sl = 0; sl < KS1; sl++) {
+          if (sl >= S - 1) { if (sl + 2 < KS1) bg_wait_vmcnt<4>(); else if (sl + 1 < KS1) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
+          const int8_t* A = wreg + sl * (NWN * 4096);
+          const int8_t* B = ring + cs * 2048;
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) {
+            const i32x4 b = *reinterpret_cast<const i32x4*>(B + (fr0 ^ (ks << 5)));
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + q * 2048 + (fr0 ^ (ks << 5))), b, acc[q], 0, 0, 0);
+              if (DUAL) accl[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 4096 + q * 2048 + (fr0 ^ (ks << 5))), b, accl[q], 0, 0, 0);
+            }
+          }
+          if (sl + S - 1 < KS1) { issue(sl + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
+          cs = cs + 1 == S ? 0 : cs + 1;
+        }
+        const int p = 32 * t + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int ch = c3 + 64 * pass + 32 * q;
+          const int* ps = reinterpret_cast<const int*>(hdrs + pass * 2048);
+          if (DUAL) combine(acc[q], accl[q], ps, 64, 32 * q);
+          int a16[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+          i32x4 rs;
+          if (a.fast_s == 1) rs = requant_tile16<false, 0, true>(a16, ps, 64, 32 * q + 4 * half, lo_s, -128, nores, false, false);
+          else rs = requant_tile16<false, 0, false>(a16, ps, 64, 32 * q + 4 * half, lo_s, -128, nores, false, a.fast_s == 2);
+          if (p < NPO) *reinterpret_cast<i32x4*>(a.ys + (pxo_img + p) * a.ys_cp + ch + 16 * half) = rs;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                                     // every wave is done with the pass's weights
+    }
+  }
+  BG_STAMP(4);
+  // the 3x3's weights: [step e = tap * KS2 + slab][32 rows]
+  for (int e = wave; e < 9 * KS2; e += 8) w_dma(a.w2, ((size_t)mt2 * 9 * KS2 + e) * a.tm2 + ro2, wreg + e * 2048);
+  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  BG_STAMP(5);
+
+  // =================================== phase B: 3x3 / stride 2 / pad 1, one input slab at a time ===================================
+  {
+    int8_t* const halo = work;                             // [30 rows][parity 2][16 columns][64]: halo (r, c) = pixel (r - 1, c - 1)
+    const bool worker = wave < NTO;
+    int p = 32 * wave + (lane & 31);
+    const bool p_ok = worker && p < NPO;
+    if (!p_ok) p = 0;
+    const int oh = p / HWO, ow = p - oh * HWO;
+    i32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; }
+#pragma unroll 1
+    for (int sl = 0; sl < KS2; sl++) {
+      if (sl) __syncthreads();                             // every wave is done with the previous slab
+      for (int grp = wave; grp < HROWS * 2; grp += 8) {   // 60 groups of 16 slots
+        const int h = grp * 16 + drow;
+        const int hr = h >> 5, par = (h >> 4) & 1, j = h & 15;
+        const int row = hr - 1, col = 2 * j + par - 1;
+        const bool ok = (unsigned)row < (unsigned)HWI && (unsigned)col < (unsigned)HWI;
+        const int8_t* src = ok ? a.mid1 + (pxi_img + row * HWI + col) * M + sl * 64 + chunk * 16 : a.zero2 + sl * 64 + chunk * 16;
+        if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 1);
+        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                     // the slab (and, the first time, the weights) complete in every wave
+      if (worker) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+          const int dh = tap / 3, dw = tap % 3;
+          // input pixel (2 oh - 1 + dh, 2 ow - 1 + dw) -> halo (2 oh + dh, 2 ow + dw): parity dw & 1, slot ow + (dw >> 1)
+          const int h = (2 * oh + dh) * 32 + (dw & 1) * 16 + ow + (dw >> 1);
+          const int ba = h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
+          const int8_t* A = wreg + (tap * KS2 + sl) * 2048;
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), *reinterpret_cast<const i32x4*>(halo + ba), acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), *reinterpret_cast<const i32x4*>(halo + (ba ^ 32)), acc1, 0, 0, 0);
+        }
+      }
+    }
+    if (worker) {
+      int a16[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
+      const int lo_b = a.relu2 ? 0 : -128;
+      i32x4 out;
+      if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm2, a.tm2, ro2 + 4 * half, lo_b, -128, nores, a.dbl2 != 0, false);
+      else out = requant_tile16<false, 0, false>(a16, prm2, a.tm2, ro2 + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
+      if (p_ok) bg_store_x(a.mid2 + (pxo_img + p) * M + c1 + 16 * half, out, local0);
+    }
+  }
+  BG_STAMP(6);
+  bg_signal(ctr + 16, m, tag, tid);
+  BG_STAMP(7);
+  // the expand's weights: [32-row tile][slab]; the shortcut's output of this member comes back as the residual, through an LDS image
+  // [196 pixels][128 channels] (row px keeps its eight 16-byte pieces XOR-swizzled with px & 7), which then takes the outputs
+  for (int u = wave; u < 4 * KS2; u += 8) {
+    const int ch = c3 + 32 * (u / KS2);
+    w_dma(a.w3, ((size_t)(ch / 64) * KS2 + u % KS2) * 64 + ch % 64, wreg + u * 2048);
+  }
+  int8_t* const stage = wreg + 4 * KS2 * 2048;             // 32 KB of weights, then 25 KB of staging
+  constexpr int NCHUNK = (NPO * 128 + 1023) / 1024;        // 1 KiB = eight pixel rows of 128 bytes
+  for (int ci = wave; ci < NCHUNK; ci += 8) {
+    const int px = 8 * ci + (lane >> 3), q = (lane & 7) ^ (px & 7);
+    const int8_t* src = px < NPO ? a.ys + (pxo_img + px) * a.ys_cp + c3 + q * 16 : a.zero;
+    __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 0);
+  }
+  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
+  BG_STAMP(8);
+
+  // =================================== phase C: expand, 1x1 M -> COUT, + residual ===================================
+  {
+    const bool worker = wave < NTO;
+    const int t = wave;
+    int8_t* const tile = work + wave * (KS2 * 2048);
+    if (worker) {
+#pragma unroll
+      for (int sl = 0; sl < KS2; sl++)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++) {
+          const int p = 32 * t + 16 * g2 + drow;
+          const int8_t* src = p < NPO ? a.mid2 + (pxo_img + p) * M + sl * 64 + chunk * 16 : a.zero + chunk * 16;
+          if (local2) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tile + sl * 2048 + g2 * 1024), 16, 0, 1);
+          else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tile + sl * 2048 + g2 * 1024), 16, 0, 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // expand weights, residual image (fetched by every wave), this wave's tile
+    BG_STAMP(9);
+    if (worker) {
+      const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
+      const int pxl = 32 * t + (lane & 31);
+#pragma unroll
+      for (int pair = 0; pair < 2; pair++) {
+        i32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[q][r] = 0;
+#pragma unroll
+        for (int sl = 0; sl < KS2; sl++) {
+          const i32x4 b0 = *reinterpret_cast<const i32x4*>(tile + sl * 2048 + fr0), b1 = *reinterpret_cast<const i32x4*>(tile + sl * 2048 + (fr0 ^ 32));
+          const int8_t* A0 = wreg + ((2 * pair + 0) * KS2 + sl) * 2048;
+          const int8_t* A1 = wreg + ((2 * pair + 1) * KS2 + sl) * 2048;
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A0 + fr0), b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A1 + fr0), b0, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A0 + (fr0 ^ 32)), b1, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A1 + (fr0 ^ 32)), b1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int ctq = 2 * pair + q;
+          const int* pm = reinterpret_cast<const int*>(hdr3 + (ctq >> 1) * 2048);
+          int8_t* const slot = stage + pxl * 128 + ((((2 * ctq + half) ^ (pxl & 7))) << 4);
+          const i32x4 rcur = *reinterpret_cast<const i32x4*>(slot);
+          int a16[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
+          i32x4 out;
+          if (a.fast3 == 1) out = requant_tile16<true, 0, true>(a16, pm, 64, 32 * (ctq & 1) + 4 * half, lo_b, rlo, rcur, false, false);
+          else out = requant_tile16<true, 0, false>(a16, pm, 64, 32 * (ctq & 1) + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
+          *reinterpret_cast<i32x4*>(slot) = out;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                       // the member's outputs are complete in LDS
+    for (int ci = wave; ci < NCHUNK; ci += 8) {
+      const int px = 8 * ci + (lane >> 3), q = (lane & 7) ^ (px & 7);
+      const i32x4 v = *reinterpret_cast<const i32x4*>(stage + ci * 1024 + lane * 16);
+      if (px < NPO) *reinterpret_cast<i32x4*>(a.y + (pxo_img + px) * a.y_cp + a.y_off + c3 + q * 16) = v;
+    }
+  }
+  BG_STAMP(10);
+#undef BG_STAMP
+}
+
 // ---- the 28 x 28 maps (ResNet-50 stage 3: C = 512, M = 128) --------------------------------------------------------------------
 // 784 pixels are too many for one block's LDS and the intermediates have only 128 channels: the eight members of an image are
 // FOUR row bands of seven rows (196 pixels = seven 32-pixel column tiles, as on the 14 x 14 maps) times TWO channel halves (64
@@ -1654,9 +2025,29 @@ bool conv_bgroup_shape_ok(int HW, int C, int M) {
          (HW == 56 && C == 256 && M == 64);
 }
 
-// the first bottleneck of the 56 x 56 stage (rows: shortcut, reduce, 3x3, expand): conv_bgroup56f_kernel
+// the first bottleneck of the 14 x 14 stage (rows: shortcut / 2, reduce on 28 x 28, 3x3 / 2, expand): conv_bgroup14f_kernel
+static int launch_conv_bgroup_first14(const BGroupArgs& a, hipStream_t s) {
+  const size_t lds = 16 * 1024 + 72 * 1024 + 64 * 1024 + 64;
+  const void* fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup14f_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup14f_kernel<false>);
+  if (!lds_attr_once(fn)) return -1;
+  for (int i0 = 0; i0 < a.B; i0 += 32) {
+    BGroupArgs b = a;
+    b.img0 = i0;
+    const int n = std::min(32, a.B - i0);
+    const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
+    TF2_LAUNCH_NAME("conv_bgroup14f_kernel<shortcut 512->1024 /2 | 512->256 on 28x28, 3x3 /2, ->1024%s> (8 blocks per image, images %d..%d)", a.dual1 ? ",dual" : "", i0, i0 + n - 1);
+    if (a.dual1) TF2_LAUNCH((conv_bgroup14f_kernel<true>), grid, dim3(512), lds, s, b);
+    else TF2_LAUNCH((conv_bgroup14f_kernel<false>), grid, dim3(512), lds, s, b);
+    if (!launch_ok()) return -1;
+  }
+  return 0;
+}
+
+// the first bottleneck of the 56 x 56 stage (rows: shortcut, reduce, 3x3, expand): conv_bgroup56f_kernel; a.first_shape == 14: the
+// 14 x 14 stage's
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.first_shape == 14) return launch_conv_bgroup_first14(a, s);
   const size_t lds = 10 * (size_t)kBgHdrSlot + 36 * 1024 + 36 * 1024 + 2 * 13 * 2048 + 64;
   const void* fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56f_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup56f_kernel<false>);
   if (!lds_attr_once(fn)) return -1;

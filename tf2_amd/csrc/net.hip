@@ -174,7 +174,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // reads stays live to its last row, what it writes exists from its first
   if (packed_valid && opts.bgroup_mode)
     for (int l = 0; l + 2 < nl; l++) {
-      if (bgroup_first_at(l)) {
+      if (bgroup_first_at(l) || bgroup_first14_at(l)) {
         TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
         tin.last_use = std::max(tin.last_use, l + 3);
         TensorPlan& tm1 = wp.tensors[wp.exec[l + 1].out_tensor];
@@ -311,6 +311,32 @@ bool Net::bgroup_first_at(int l) const {
   return n_dual == 0 || n_dual == 3;
 }
 
+// Rows l .. l + 3 = projection shortcut (1x1 / stride 2, 512 -> 1024) and reduce (1x1, 512 -> 256) of the same 28 x 28 input, 3x3 /
+// stride 2 / pad 1, expand + residual from the shortcut: conv_bgroup14f_kernel.  Shortcut and reduce both two-window or both not.
+bool Net::bgroup_first14_at(int l) const {
+  if (l < 1 || l + 3 >= nd.n_layers) return false;
+  const tf2_layer_desc& S = layers[l]; const tf2_layer_desc& A = layers[l + 1]; const tf2_layer_desc& B = layers[l + 2]; const tf2_layer_desc& E = layers[l + 3];
+  for (const tf2_layer_desc* L : {&S, &A, &B, &E})
+    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->dil != 1) return false;
+  if (S.src < 0 || S.src != A.src || layers[S.src].concat >= 0 || S.add_src >= 0 || A.add_src >= 0 || B.add_src >= 0) return false;
+  if (S.k != 1 || S.stride != 2 || S.pad_h || S.H != 28 || S.W != 28 || S.OH != 14 || S.OW != 14 || S.C != 512 || S.N != 1024) return false;
+  if (A.k != 1 || A.stride != 1 || A.pad_h || A.H != 28 || A.W != 28 || A.C != 512 || A.N != 256) return false;
+  if (B.src != l + 1 || B.k != 3 || B.stride != 2 || B.pad_h != 1 || B.pad_w != 1 || B.H != 28 || B.OH != 14 || B.OW != 14 || B.C != 256 || B.N != 256) return false;
+  if (E.src != l + 2 || E.k != 1 || E.stride != 1 || E.pad_h || E.H != 14 || E.add_src != l || E.C != 256 || E.N != 1024) return false;
+  int duals = 0;
+  for (int k = l; k <= l + 3; k++) {
+    const PackLayer* pl = pack_layer(k);
+    if (!pl || pl->kind != KIND_MFMA || pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
+    if (pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+    if (k == l + 1 ? (pl->TM != 64 && pl->TM != 128) : pl->TM != 64) return false;
+    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+    if (k >= l + 2) { if (!one_window) return false; }
+    else { if (!one_window && !dual) return false; duals += dual ? 1 : 0; }
+    if (k == l && pl->off_dbl) return false;
+  }
+  return duals == 0 || duals == 2;
+}
+
 // Rows l, l + 1, l + 2 = 1x1 reduce, 3x3 / 1 / pad 1, 1x1 expand + residual from the reduce's input, of a shape conv_bgroup.hip
 // is instantiated for, every row single-window in 64- or 128-row dense tiles.
 bool Net::bgroup_at(int l) const {
@@ -383,6 +409,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56")) o.bgroup_min56 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BGROUP_MIN14F")) o.bgroup_min14f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -593,7 +620,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
+    const bool first14 = opts.bgroup_mode && bgroup_first14_at(l) && batch >= opts.bgroup_min14f;
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && (first14 || (bgroup_first_at(l) && batch >= opts.bgroup_min56f)) &&
         256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch ss, s0, s1, s2;
       if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
@@ -616,6 +644,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
         f.ws = cs.w; f.hdrs = cs.hdr; f.hdrs_bytes = cs.hdr_bytes; f.tms = ss.TM; f.relu_s = cs.g.relu; f.fast_s = cs.g.fast;
         f.ys = cs.y; f.ys_cp = cs.g.y_cp; f.keep_s = wp->keep_all ? 1 : 0;
+        f.first_shape = first14 ? 14 : 56;
+        f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;

@@ -227,6 +227,7 @@ struct BGroupArgs {
   const int8_t* ws; const int32_t* hdrs;     // its dense weight tiles and header images
   int8_t* ys;                                // its own output tensor (written only with keep_s)
   int32_t hdrs_bytes, tms, relu_s, fast_s, keep_s, ys_cp;      // tms: rows per m-tile of the shortcut (64 or 128)
+  int32_t first_shape;       // 56: conv_bgroup56f_kernel; 14: conv_bgroup14f_kernel (stride-2 first bottleneck whose output map is 14 x 14)
 };
 
 // conv_stem.hip: layer 0 in its executed 3x3 / stride 1 / pad 0 form on the x-only image tensor (32 bytes per pixel)

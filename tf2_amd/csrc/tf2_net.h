@@ -99,7 +99,8 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
-  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12;   // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
+  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12, bgroup_min14f = 1 << 30;   // (14f: measured equal to its three launches -- every member streams the whole 28 x 28 input: off unless asked for)
+    // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
      // TF2_AMD_BGROUP_MIN7 / _MIN14: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int chain_mode = 0;      // TF2_AMD_CHAIN: consecutive ring-kernel layers in one launch (conv_mfma2_chain_kernel): 0 never, 1 where eligible
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
@@ -159,6 +160,7 @@ struct Net {
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  bool bgroup_first14_at(int l) const;     // rows l .. l + 3 = the stride-2 first bottleneck whose output map is 14 x 14 (conv_bgroup14f_kernel)
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
   bool chain_row(int l) const;             // row l could be a segment of a chain launch (plain conv row with a 128-row ring-kernel form)
