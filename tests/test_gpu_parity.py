@@ -441,6 +441,24 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
 
 
+@pytest.mark.parametrize("pack_switch", ["TF2_AMD_NOFAST", "TF2_AMD_NODBL", "TF2_AMD_NOSEMI"])
+def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
+    """The group kernels share requant_epilogue.h with everything else: the wrap-exact generic requantisation on every row
+    (TF2_AMD_NOFAST), plain instead of doubled channels (TF2_AMD_NODBL: more two-window rows -- some bottlenecks then fall back to
+    separate launches, by the library's own eligibility rules), no SEMI rows.  Every layer against the oracle, group launches on."""
+    monkeypatch.setenv(pack_switch, "1")
+    for k in ("TF2_AMD_BGROUP_MIN7", "TF2_AMD_BGROUP_MIN14", "TF2_AMD_BGROUP_MIN28", "TF2_AMD_BGROUP_MIN56", "TF2_AMD_BGROUP_MIN56F", "TF2_AMD_BGROUP_MIN14F"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
+    rig = Rig(*r50, 0)
+    assert sum(1 for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]) >= 5
+    x = synth.synth_images(rig.t, 3, 81, kind="int8")
+    x[0, :, :3, :] = -128                                  # the negate quirk of pe.cl:32-37 on the way in
+    rig.check_all_layers(x)
+    x32 = synth.synth_images(rig.t, 32, 82)
+    np.testing.assert_array_equal(rig.run(x32, keep_all=False)[:2], rig.ref.logits(rig.ref.run(x32[:2])))
+
+
 @pytest.mark.parametrize("conc", ["0", "1"])
 def test_chain_launches_against_the_oracle(r50, monkeypatch, conc):
     """TF2_AMD_CHAIN=1 (off by default): consecutive 128-row ring-kernel rows in ONE launch (conv_mfma2_chain_kernel), blocks ordered
