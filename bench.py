@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=4,
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
+    ap.add_argument("--feeder", type=int, default=0,
+                    help="1: one host thread per in-flight stream enqueues that stream's steps (tf2_amd/feeder.py); 0: one thread feeds all "
+                         "(measured equal at 20 steps: the streams then start together, and steps that run in lock-step take longer)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
     ap.add_argument("--partition", type=int, default=1,
                     help="1: every in-flight stream gets its own XCDs (hipExtStreamCreateWithCUMask, tf2_amd/streams.py) when the number of "
@@ -157,7 +160,11 @@ def main():
     tdist.broadcast_network(net, model, qfile, device, pack_mode=args.mode)
     runner = network.Runner(None, net)
 
+    feeder = [None]
+
     def barrier():
+        if feeder[0] is not None:
+            feeder[0].drain()             # every step handed to the feeder threads is enqueued
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -184,6 +191,9 @@ def main():
         return rn.run_split(x, args.split) if args.split > 1 else rn.run_batch(x, **kw)
 
     stagger = args.stagger_layer >= 0 and n_inflight > 1 and not args.graph and args.split == 1
+    if args.feeder and n_inflight > 1 and not args.graph and not stagger and args.split == 1:
+        from tf2_amd.feeder import StreamFeeder
+        feeder[0] = StreamFeeder(fl_streams, fl_runners, device)
     mark_ring = [torch.cuda.Event() for _ in range(2 * n_inflight)] if stagger else []
     prev_mark = [None]
 
@@ -191,6 +201,9 @@ def main():
         if n_inflight > 1 and not serial[0]:
             i = step_no[0] % n_inflight
             step_no[0] += 1
+            if feeder[0] is not None:
+                feeder[0].submit(i, lambda rn: rn.run_batch(x, concurrency=1))
+                return
             with torch.cuda.stream(fl_streams[i]):
                 if args.graph:
                     key = (i, x.data_ptr(), x.shape[0])
@@ -430,7 +443,8 @@ def main():
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
                                 sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph),
                                 stage_interlock_layer=(args.stagger_layer if stagger else None),
-                                xcd_partitions=(n_inflight if partitioned else None)),
+                                xcd_partitions=(n_inflight if partitioned else None),
+                                host_feeder_threads=(n_inflight if feeder[0] is not None else 1)),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

@@ -149,8 +149,9 @@ tf2_status tf2_net_run_q(tf2_net* net, const int8_t* images_q_dev, int batch, vo
  *                   has been enqueued (ignored when mark_event is NULL).  A caller that pipelines batches lets the next
  *                   batch's stream wait for it (hipStreamWaitEvent), so that batch k+1 enters the chip-filling first
  *                   stage when batch k has left it instead of competing with it; bench.py does.
- * Threading: a handle may be used from several host threads, one stream per thread; the calls serialise on an internal
- * mutex while they look up / build the launch plan and enqueue (kernel execution is asynchronous as always).  Everything
+ * Threading: a handle may be used from several host threads, one stream AND one workspace per thread; the calls serialise
+ * on an internal mutex only while they look up / build the launch plan, the enqueue of the step's launches runs side by side
+ * (calls that share a workspace serialise for the whole enqueue; kernel execution is asynchronous as always).  Everything
  * else on a handle (create / set_q / load / pack / bind / reload_options / profile / destroy) must not run concurrently
  * with a run on the same handle.  tf2_last_error is per thread.                                                          */
 typedef struct tf2_run_opts {

@@ -215,6 +215,36 @@ def test_four_batches_in_flight_as_bench_times_them(r50, graph):
         np.testing.assert_array_equal(got, serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl} (graph={graph})")
 
 
+def test_feeder_threads_enqueue_side_by_side(r50):
+    """tf2_amd/feeder.py: four host threads, one per stream and workspace, call tf2_net_run_ex on ONE handle at the same time
+    (include/tf2_amd.h threading note: the enqueue runs outside the handle's mutex).  40 steps over eight inputs with no
+    synchronisation; the last four steps' logits against serial runs of the same inputs; the XCD-partitioned streams of
+    bench.py."""
+    torch = _torch()
+    from tf2_amd import streams as tstreams
+    from tf2_amd.feeder import StreamFeeder
+    rig = Rig(*r50, 0)
+    n_fl, n_in, n_steps = 4, 8, 40
+    xs = [synth.synth_images(rig.t, 32, 400 + i) for i in range(n_in)]
+    xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
+    serial = [rig.run(x, keep_all=False).copy() for x in xs]
+    streams = tstreams.partitioned_streams(n_fl, "cuda:0")
+    runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
+    feeder = StreamFeeder(streams, runners, torch.device("cuda:0"))
+    try:
+        for k in range(n_steps):
+            feeder.submit(k % n_fl, lambda rn, x=xd[k % n_in]: rn.run_batch(x, concurrency=1))
+        feeder.drain()
+        torch.cuda.synchronize()
+        for k in range(n_steps - n_fl, n_steps):
+            np.testing.assert_array_equal(runners[k % n_fl]._logits.cpu().numpy(), serial[k % n_in], err_msg=f"step {k} on feeder {k % n_fl}")
+        feeder.submit(0, lambda rn: rn.run_batch(xd[0][:, :, :5]))            # an error on a feeder thread surfaces in drain()
+        with pytest.raises(Exception):
+            feeder.drain()
+    finally:
+        feeder.close()
+
+
 def test_cli_on_the_shipped_image(r50, golden_dir, tmp_path, capsys):
     """The reference's host CLI (main.cpp:19-61: model_file q_file image_file verify_file num_images) through tf2_amd.cli: the
     shipped test image and Q file, a model file in the float32 LoadModel stream format, the shipped golden logits as the verify

@@ -412,12 +412,15 @@ def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
     np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))
 
 
-def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
+@pytest.mark.parametrize("chain", ["5", "2", "1"])
+def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     """TF2_AMD_BGROUP=1 (the default): the five identity bottlenecks of stage 4 (rows 28-42) and the two of stage 5 (rows 47-52, the
     second one ending in the global average) as ONE launch each, eight blocks per image meeting at epoch-tagged flags between
-    the layers (conv_bgroup.hip).  Every layer against the oracle at batch 2 and 5, then batch-32 logits of
-    repeated runs on the liveness-planned workspace."""
+    the layers (conv_bgroup.hip); stage 4's five in ONE launch together (TF2_AMD_BGROUP_CHAIN=5, the default), as 2 + 2 + 1, or
+    one by one.  Every layer against the oracle at batch 2 and 5, then batch-32 logits of repeated runs on the
+    liveness-planned workspace."""
     monkeypatch.setenv("TF2_AMD_BGROUP", "1")
+    monkeypatch.setenv("TF2_AMD_BGROUP_CHAIN", chain)
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN7", "1")          # (by default batches below 12 keep the separate launches: measured equal or faster there)
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN14", "1")
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN28", "1")
@@ -427,7 +430,8 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch):
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24, 28, 31, 34, 37, 40, 47, 50]
+    stage4 = {"5": [28], "2": [28, 34, 40], "1": [28, 31, 34, 37, 40]}[chain]
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24] + stage4 + [47, 50]
     assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == 50][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
@@ -451,7 +455,8 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
         monkeypatch.setenv(k, "1")
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
-    assert sum(1 for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]) >= 5
+    groups = [r["kernel"] for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]]
+    assert len(groups) >= 3 and any("bottlenecks" in k for k in groups)        # (stage 4's bottlenecks share a launch)
     x = synth.synth_images(rig.t, 3, 81, kind="int8")
     x[0, :, :3, :] = -128                                  # the negate quirk of pe.cl:32-37 on the way in
     rig.check_all_layers(x)

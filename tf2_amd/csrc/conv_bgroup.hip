@@ -128,8 +128,11 @@ __device__ __forceinline__ void bg_store_x(int8_t* dst, const i32x4& v, bool loc
 }
 
 // HW: map side; C: channels of the bottleneck's input / output; M: channels of the intermediates (M / 8 = 32 per member)
+// Chained: a launch carries up to kBgMaxChain consecutive bottlenecks (the five of ResNet-50's stage 4): the eight blocks of an
+// image run them one after the other with a third meeting in between ("this bottleneck's output is complete") instead of a
+// launch boundary -- the next one's headers and reduce weights are fetched while the group gathers.
 template <int HW, int C, int M>
-__global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
   static_assert(M == 32 * kBgMembers && C % (32 * kBgMembers) == 0 && HW <= 14, "member slices are whole 32-row MFMA tiles; the halo grid is 16 x 16");
   constexpr int NPX = HW * HW;
   constexpr int NT = (NPX + 31) / 32;                    // 32-pixel column tiles = working waves
@@ -153,14 +156,29 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
   // block b -> XCD b % 8; image = the XCD's (b / 64)-th, member = (b / 8) % 8: a group sits on one XCD
-  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
-  if (img >= a.B) return;
+  const int img = c.b[0].img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= c.b[0].B) return;
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // LDS-DMA: lane l fills row l >> 2, slot l & 3, which holds chunk slot ^ ((row >> 2) & 3)
   const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
-  unsigned* const ctr = a.ctr + (size_t)img * 32;         // three rows of eight flags: roll call, two meetings
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID, 4 bits
+  unsigned tag = 0;                                         // this member's flag value: (epoch << 8) | XCC id
+  bool local0 = false;                                      // the whole group on this XCD (roll call): exchange stores need no write-through
+  const int t = wave;                                    // this wave's column tile
+  const bool worker = wave < NT;
+  const int p_lane = 32 * t + (lane & 31);               // the pixel of this lane's MFMA column
+  const bool p_ok = worker && p_lane < NPX;
+  const i32x4 nores = {0, 0, 0, 0};
+  // fragment address inside a [32 rows][64 bytes] swizzled tile: row = lane & 31, chunk c = 2 * ks + half
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + (((0 + half) ^ ((frow >> 2) & 3)) << 4);      // ks = 0; ks = 1 is the same address ^ 32
 
-  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py: 100 MHz wall clock per phase
+#pragma unroll 1
+  for (int kb = 0; kb < c.n; kb++) {
+  const BGroupArgs& a = c.b[kb];
+  unsigned* const ctr = a.ctr + (size_t)img * 32;         // three rows of eight flags: roll call (kb > 0: "input complete"), two meetings
+
+  long long* const dbg = (a.dbg && kb == 0) ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py: 100 MHz wall clock per phase
 #define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
   BG_STAMP(0);
 
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
     hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3, a.tm3, 2);
     if (a.tm3 < C / kBgMembers) hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3 + 1, a.tm3, 3);
     for (int s = wave; s < KS1; s += 8) w_dma(a.w1, a.tm1, mt1 * KS1 + s, ro1, work + s * 2048);
-    if (tid == 64 * 7) {                                   // the step counter, from the memory side (wave 7 has no tile of its own)
+    if (kb == 0 && tid == 64 * 7) {                        // the step counter, from the memory side (wave 7 has no tile of its own)
       unsigned e;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
       ctl[0] = (int)e;
@@ -199,18 +217,11 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
 
-  const int t = wave;                                    // this wave's column tile
-  const bool worker = wave < NT;
-  const int p_lane = 32 * t + (lane & 31);               // the pixel of this lane's MFMA column
-  const bool p_ok = worker && p_lane < NPX;
-  const i32x4 nores = {0, 0, 0, 0};
-  // fragment address inside a [32 rows][64 bytes] swizzled tile: row = lane & 31, chunk c = 2 * ks + half
-  const int frow = lane & 31;
-  const int fr0 = frow * 64 + (((0 + half) ^ ((frow >> 2) & 3)) << 4);      // ks = 0; ks = 1 is the same address ^ 32
 
-  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID, 4 bits
-  unsigned tag = 0;                                         // this member's flag value: (epoch << 8) | XCC id
-  bool local0 = false;                                      // the whole group on this XCD (roll call): exchange stores need no write-through
+  // kb > 0: the input is the previous bottleneck's output, written by all eight members: they meet at this one's roll-call row
+  // (signalled behind the previous expand's stores) before the first pixel is fetched
+  bool local_in = false;
+  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
 
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
@@ -220,7 +231,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
       for (int g2 = 0; g2 < 2; g2++) {
         const int p = 32 * t + 16 * g2 + drow;
         const int8_t* src = p < NPX ? a.x + (px_img + p) * C + s * 64 + chunk * 16 : a.zero + chunk * 16;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * STAGE + g2 * 1024), 16, 0, 0);
+        int8_t* const dst = ring + slot * STAGE + g2 * 1024;
+        if (kb == 0) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 0);                // written before this launch
+        else if (local_in) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 1);        // by this group, in this XCD's L2
+        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 16);
       }
     };
     if (worker) {
@@ -230,8 +244,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // headers and the reduce's weights are in LDS (pieces fetched by every wave)
     BG_STAMP(1);
-    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);          // (the epoch word was stored before the barrier)
-    bg_rollcall_post(ctr, m, tag, tid);
+    if (kb == 0) {
+      tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);        // (the epoch word was stored before the barrier)
+      bg_rollcall_post(ctr, m, tag, tid);
+    }
     // two accumulators (one per K half): a dependent MFMA would wait out the 16 passes of its predecessor
     i32x16 acc, acc1;
 #pragma unroll
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] += acc1[r];
       BG_STAMP(2);
-      local0 = bg_rollcall_wave(ctr, tag, lane);
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
       // requantise, write this member's 32 channels of mid1 (the other members read them next)
       int a16[16];
 #pragma unroll
@@ -333,7 +349,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
     const int ch = c3 + 32 * (u / KS2);
     w_dma(a.w3, a.tm3, (ch / a.tm3) * KS2 + u % KS2, ch % a.tm3, wreg + u * 2048);
   }
-  // residual tiles (the bottleneck's input, written before this launch: ordinary loads), all CT of them
+  // residual tiles, all CT of them (the bottleneck's input, written before this launch -- or, inside a chain, by THIS thread in the
+  // previous bottleneck's expand: ordinary loads either way)
   i32x4 rv[CT];
 #pragma unroll
   for (int q = 0; q < CT; q++) {
@@ -398,13 +415,17 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupArgs a) {
             if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rv[2 * pair + q], false, a.fast3 == 2);
             else out = requant_tile16<false, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
           }
-          if (p_ok) *reinterpret_cast<i32x4*>(a.y + (px_img + p_lane) * a.y_cp + a.y_off + ch + 16 * half) = out;
+          // (the launch's last output is read by later kernels: ordinary stores; an inner one by the group, like mid1 / mid2)
+          if (p_ok) bg_store_x(a.y + (px_img + p_lane) * a.y_cp + a.y_off + ch + 16 * half, out, local0 || kb + 1 == c.n);
         }
       }
     }
   }
   BG_STAMP(10);
 #undef BG_STAMP
+  // every store of this member acknowledged and every wave done with the LDS regions, then its flag at the next bottleneck's roll call
+  if (kb + 1 < c.n) bg_signal(c.b[kb + 1].ctr + (size_t)img * 32, m, tag, tid);
+  }
 }
 
 // ---- the 56 x 56 maps (ResNet-50 stage 2: C = 256, M = 64) ---------------------------------------------------------------------
@@ -2065,9 +2086,11 @@ int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
   return 0;
 }
 
-int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) {
+int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bgroup_shape_ok(HW, C, M)) return 1;
+  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW != 14)) return 1;
+  const BGroupArgs& a = chain[0];
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
@@ -2086,10 +2109,16 @@ int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream) 
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
+    if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup_kernel<%dx%d,C%d,M%d> x %d bottlenecks (8 blocks per image, images %d..%d)", HW, HW, C, M, n_chain, i0, i0 + n - 1);
+    else TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
                     (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.dual3 ? ",dual expand" : "",
                     a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
-    if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, b);
+    if (HW == 14) {
+      BGroupChain c;
+      c.n = n_chain;
+      for (int k = 0; k < n_chain; k++) { c.b[k] = chain[k]; c.b[k].img0 = i0; }
+      TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, c);
+    }
     else if (HW == 56 && a.dual1 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<true, true>), grid, dim3(512), lds, s, b);
     else if (HW == 56 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<false, true>), grid, dim3(512), lds, s, b);
     else if (HW == 56 && a.dual1) TF2_LAUNCH((conv_bgroup56_kernel<true, false>), grid, dim3(512), lds, s, b);

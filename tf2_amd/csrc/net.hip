@@ -197,6 +197,20 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;            // three rows of eight flag words per image (roll call, two meetings)
       l += 2;
     }
+  // ... and consecutive identity bottlenecks of the 14 x 14 maps may share a launch (bgroup_chain): nothing such a run touches
+  // shares memory (the exchange inside a launch is ordered by flags and cache scopes, not by kernel boundaries)
+  if (packed_valid && opts.bgroup_mode && opts.bgroup_chain > 1)
+    for (int l = 0; l + 2 < nl;) {
+      if (!bgroup_at(l) || layers[l].H != 14) { l++; continue; }
+      int e = l + 2;
+      while (e + 3 < nl && bgroup_at(e + 1) && layers[e + 1].H == 14) e += 3;
+      if (e > l + 2)
+        for (size_t t = 0; t < wp.tensors.size(); t++) {
+          if (born[t] > l && born[t] <= e) born[t] = l;
+          if (wp.tensors[t].last_use >= l && wp.tensors[t].last_use < e && born[t] <= e) wp.tensors[t].last_use = e;
+        }
+      l = e + 1;
+    }
   // Chain launches (conv_mfma2_chain_kernel, TF2_AMD_CHAIN): blocks of consecutive rows run concurrently, ordered only by the
   // data they read -- so nothing a chain touches may share memory: every tensor whose life ends inside a run of chainable rows
   // lives until the run's last row.  (Which rows actually share a launch is decided per launch plan; always inside these runs.)
@@ -410,6 +424,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56")) o.bgroup_min56 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN14F")) o.bgroup_min14f = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BGROUP_CHAIN")) o.bgroup_chain = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
   if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
@@ -453,7 +468,9 @@ static bool device_fits_group_launches() {
 const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent) {
   for (const LaunchPlan& lp : launch_plans)
     if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0)) return &lp;
-  if (launch_plans.size() >= 64) launch_plans.pop_front();
+  if (launch_plans.size() >= 64)                       // evict the oldest plan nobody is walking
+    for (auto it = launch_plans.begin(); it != launch_plans.end(); ++it)
+      if (it->walkers == 0) { launch_plans.erase(it); break; }
   LaunchPlan lp;
   lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0;
   int8_t* base = (int8_t*)ws;
@@ -681,6 +698,19 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1;
+        // the 14 x 14 stage's identity bottlenecks follow one another: the groups of the previous launch carry on with this one
+        // (its roll-call row doubles as the meeting "input complete")
+        if (opts.bgroup_chain > 1 && L.H == 14 && !lp.steps.empty() && !f.dbg) {
+          Launch& pv = lp.steps.back();
+          const int pn = pv.bg_chain.empty() ? 1 : (int)pv.bg_chain.size();
+          if (pv.kind == Launch::CONV && pv.sel == Launch::SEL_BGROUP && pv.bg_hw == 14 && pv.layer + 3 * pn == l && pn < std::min(kBgMaxChain, opts.bgroup_chain) &&
+              !pv.bgroup.dbg && f.x == pv.bg_chain_last().y && f.has_res && f.res == f.x && f.res_off == 0 && pv.bg_chain_last().y_off == 0 &&
+              f.res_cp == pv.bg_chain_last().y_cp) {
+            if (pv.bg_chain.empty()) pv.bg_chain.push_back(pv.bgroup);
+            pv.bg_chain.push_back(f);
+            continue;
+          }
+        }
         lp.steps.push_back(st);
         continue;
       }
@@ -889,7 +919,8 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:
-          return launch_conv_bgroup(st.bgroup, st.bg_hw, st.bg_c, st.bg_m, stream);
+          if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);
+          return launch_conv_bgroup(&st.bgroup, 1, st.bg_hw, st.bg_c, st.bg_m, stream);
         case Launch::SEL_CHAIN:
           if (!launch_recorder() && hipMemsetAsync(st.chain.ctr, 0, st.chain_ctr_bytes, (hipStream_t)stream) != hipSuccess) return -1;
           return launch_conv_mfma2_chain(st.chain, st.chain_segs.data(), stream);
@@ -937,7 +968,7 @@ size_t Net::logits_bytes(int batch) const {
 
 tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
                     int8_t* logits, void* stream, int concurrency, void* mark_event, int mark_after_layer) {
-  std::lock_guard<std::mutex> lock(run_mutex);
+  std::unique_lock<std::mutex> lock(run_mutex);
   if (!packed_valid) { set_error("tf2_net_run: no packed image (tf2_net_pack / tf2_net_packed_adopt)"); return TF2_ERR_STATE; }
   if (!packed_dev) { set_error("tf2_net_run: packed image not bound to the device (tf2_net_bind_device)"); return TF2_ERR_STATE; }
   if (q.empty()) { set_error("tf2_net_run: q table not set"); return TF2_ERR_STATE; }
@@ -962,6 +993,21 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   if (!lp) return TF2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nl = nd.n_layers;
+  // The enqueue itself runs outside the handle's mutex, under the plan's own (tf2_amd.h threading note): host threads that
+  // feed different streams issue their ~40 launches per step side by side.  (Profiling runs keep the handle's mutex: the
+  // event lists are the handle's.)
+  struct Walk {
+    LaunchPlan* lp; std::unique_lock<std::mutex>& net_lock; std::unique_lock<std::mutex> plan_lock;
+    ~Walk() {
+      if (plan_lock.owns_lock()) plan_lock.unlock();
+      if (!net_lock.owns_lock()) net_lock.lock();
+      lp->walkers--;
+    }
+  } walk{const_cast<LaunchPlan*>(lp), lock, {}};
+  walk.lp->walkers++;
+  const std::shared_ptr<std::mutex> plan_mutex = lp->enqueue;
+  if (!profiling && !profiling_loop) lock.unlock();
+  walk.plan_lock = std::unique_lock<std::mutex>(*plan_mutex);
 
   hipEvent_t loop0 = nullptr, loop1 = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -230,6 +230,13 @@ struct BGroupArgs {
   int32_t first_shape;       // 56: conv_bgroup56f_kernel; 14: conv_bgroup14f_kernel (stride-2 first bottleneck whose output map is 14 x 14)
 };
 
+// consecutive identity bottlenecks of the 14 x 14 maps in one launch (conv_bgroup_kernel: the groups run them back to back)
+constexpr int kBgMaxChain = 5;
+struct BGroupChain {
+  int32_t n;
+  BGroupArgs b[kBgMaxChain];
+};
+
 // conv_stem.hip: layer 0 in its executed 3x3 / stride 1 / pad 0 form on the x-only image tensor (32 bytes per pixel)
 struct StemArgs {
   const int8_t* x;           // [B][H][W][32]: 27 (or fewer) channels of x, zero padded
@@ -297,7 +304,7 @@ int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
-int launch_conv_bgroup(const BGroupArgs& a, int HW, int C, int M, void* stream);
+int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream);     // n_chain > 1: 14 x 14 only
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -66,6 +67,8 @@ struct Launch {
   BneckArgs bneck{};
   BGroupArgs bgroup{};       // SEL_BGROUP: rows layer .. layer + 2 (an identity bottleneck) in one launch
   int bg_hw = 0, bg_c = 0, bg_m = 0;
+  const BGroupArgs& bg_chain_last() const { return bg_chain.empty() ? bgroup : bg_chain.back(); }
+  std::vector<BGroupArgs> bg_chain;   // SEL_BGROUP of the 14 x 14 maps: this and the following identity bottlenecks in ONE launch (bgroup first)
   StemArgs stem{};
   PoolArgs pool{};
   AvgArgs avg{};
@@ -85,6 +88,11 @@ struct LaunchPlan {
   int n_chains = 0;
   int n_groups = 0;                 // group launches (conv_bgroup.hip) in the plan
   bool ctrl_zeroed = false;         // the workspace's control words were zeroed for this plan (first run)
+  // Net::run walks a plan OUTSIDE the handle's mutex (several host threads, one stream and workspace each, enqueue at the same
+  // time): `enqueue` serialises walks of this plan (one workspace = one step at a time anyway), `walkers` (under the handle's
+  // mutex) keeps the plan from being evicted while somebody walks it
+  std::shared_ptr<std::mutex> enqueue = std::make_shared<std::mutex>();
+  int walkers = 0;
 };
 
 struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
@@ -99,6 +107,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
+  int bgroup_chain = 5;             // consecutive identity bottlenecks of the 14 x 14 maps per group launch (1: one launch each)
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12, bgroup_min14f = 1 << 30;   // (14f: measured equal to its three launches -- every member streams the whole 28 x 28 input: off unless asked for)
     // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
      // TF2_AMD_BGROUP_MIN7 / _MIN14: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
