@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=4,
                     help="steps (whole batches) in flight: step i runs on HIP stream i %% inflight with its own workspace; "
                          "consecutive batches are independent, so their kernels may overlap on the GPU")
+    ap.add_argument("--spinup-ms", type=float, default=600.0,
+                    help="untimed steps for this long before the warm-up steps: an idle MI355X sits at ~150 MHz and takes ~0.4 s of load "
+                         "to reach its 2.4 GHz engine clock (tools/clock_sample.py); 0: none")
     ap.add_argument("--feeder", type=int, default=0,
                     help="1: one host thread per in-flight stream enqueues that stream's steps (tf2_amd/feeder.py); 0: one thread feeds all "
                          "(measured equal at 20 steps: the streams then start together, and steps that run in lock-step take longer)")
@@ -235,6 +238,12 @@ def main():
                 with torch.cuda.stream(st):
                     one(rn, x)
         torch.cuda.synchronize(device)
+        if args.spinup_ms > 0:                 # bring the device out of its idle power state (set-up, not a step)
+            t_end = time.perf_counter() + args.spinup_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    step(x)
+                barrier()
         for _ in range(warmup):
             step(x)
         barrier()
@@ -444,7 +453,11 @@ def main():
                                 sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=bool(args.graph),
                                 stage_interlock_layer=(args.stagger_layer if stagger else None),
                                 xcd_partitions=(n_inflight if partitioned else None),
-                                host_feeder_threads=(n_inflight if feeder[0] is not None else 1)),
+                                host_feeder_threads=(n_inflight if feeder[0] is not None else 1),
+                                spinup_ms=args.spinup_ms,
+                                spinup_note="untimed steps for spinup_ms before the W warm-up steps of every timed leg: an idle MI355X sits "
+                                            "at ~150 MHz and needs ~0.4 s of load to reach 2.4 GHz (tools/clock_sample.py); the timed region is "
+                                            "still exactly K steps between barrier + synchronize"),
                     roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),

@@ -52,9 +52,16 @@ def region(record):
             if record is not None:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(sts[i])
+                h0 = time.perf_counter()
             rns[i].run_batch(x, concurrency=1 if nfl > 1 else 0)
             if record is not None:
-                e1.record(sts[i]); record.append((e0, e1, time.perf_counter(), 0.0, i))
+                e1.record(sts[i]); record.append((e0, e1, time.perf_counter(), h0, i))
+    t_spin = time.perf_counter() + 0.6          # out of the idle power state first (tools/clock_sample.py)
+    while time.perf_counter() < t_spin:
+        for _ in range(4):
+            step()
+        if feeder is not None: feeder.drain()
+        torch.cuda.synchronize()
     for _ in range(warm):
         step()
     if feeder is not None: feeder.drain()

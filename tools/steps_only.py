@@ -14,6 +14,9 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=0, help="untimed steps are kernels too: keep 0 for profiles, the summary divides by --steps")
 ap.add_argument("--conc", type=int, default=0, help="launch plan: 0 one batch at a time, 1 the several-batches-in-flight choice")
+ap.add_argument("--spinup-ms", type=float, default=600.0,
+                help="keep the device busy this long with torch matrix products first (other kernel names: they do not enter the tf2 rows "
+                     "of the profile): an idle MI355X needs ~0.4 s of load to reach its engine clock (tools/clock_sample.py)")
 ap.add_argument("--meta", default=None, help="write {batch, steps, launches} here")
 a = ap.parse_args()
 t = cfg.resnet50_tables()
@@ -21,6 +24,15 @@ qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device="cuda:0")
 r = network.Runner(None, net)
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
+if a.spinup_ms > 0:
+    import time
+    m = torch.randn(4096, 4096, device="cuda:0", dtype=torch.float16)
+    t_end = time.perf_counter() + a.spinup_ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            m2 = m @ m
+        torch.cuda.synchronize()
+    del m, m2
 for _ in range(a.warmup + a.steps):
     r.run_batch(x, concurrency=a.conc)
 torch.cuda.synchronize()
