@@ -94,21 +94,23 @@ def test_vgg16_batch32_properties():
     np.testing.assert_array_equal(rig.run(x[20:22], keep_all=False), got[20:22])
 
 
-@pytest.mark.parametrize("batch", [1, 4, 16])
-def test_hip_graph_replay_equals_run_batch(r50_rig, batch):
+@pytest.mark.parametrize("batch,conc", [(1, 0), (4, 0), (16, 0), (16, 1), (32, 0)])
+def test_hip_graph_replay_equals_run_batch(r50_rig, batch, conc):
     """Runner.capture: the step recorded once into a HIP graph; replays on refilled input buffers give the logits of
-    run_batch (and of the oracle).  Batch 16 takes the group launches (conv_bgroup.hip): their flags carry a step counter that
-    the replayed input-preparation kernel advances, so a replay is as good as a launch."""
+    run_batch (and of the oracle).  Batches 16 and 32 captured as "one batch at a time" take the group launches (conv_bgroup.hip;
+    batch 32: stage 4's five bottlenecks in one launch): their flags carry a step counter that the replayed input-preparation
+    kernel advances, so a replay is as good as a launch.  conc = 1: the several-batches-in-flight plan, as bench.py replays it."""
     torch = _torch()
     rig = r50_rig
     if batch >= 12:
         assert any("conv_bgroup" in r["kernel"] for r in rig.net.describe_launches(batch, 0))
+        assert not any("conv_bgroup" in r["kernel"] for r in rig.net.describe_launches(batch, 1))
     xs = [synth.synth_images(rig.t, batch, 70 + i) for i in range(3)]
     want = [rig.run(x, keep_all=False) for x in xs]
     np.testing.assert_array_equal(want[0][:2], rig.ref.logits(rig.ref.run(xs[0][:2])))
     runner = network.Runner(None, rig.net)
     buf = torch.from_numpy(xs[0]).to("cuda:0")
-    replay = runner.capture(buf)
+    replay = runner.capture(buf, concurrency=conc)
     for x, w in zip(xs, want):
         buf.copy_(torch.from_numpy(x))
         replay()

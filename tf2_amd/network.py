@@ -278,13 +278,15 @@ class Runner:
         self._logits = logits
         return logits
 
-    def capture(self, images, split: int = 1):
+    def capture(self, images, split: int = 1, concurrency: int = -1):
         """Capture one run_batch(images) into a HIP graph (launch-bound small batches: the ~57
         launches of a step replay as one graph launch).  `images` is a static input buffer: refill
-        it in place, call the returned function, read `self._logits`."""
+        it in place, call the returned function, read `self._logits`.
+        concurrency as in run_batch -- state it: the capture runs on a side stream, so the library's stream history (-1) takes
+        the step for one of several batches in flight and picks that launch plan (no group launches)."""
         import torch
         net = self.network
-        step = (lambda: self.run_split(images, split)) if split > 1 else (lambda: self.run_batch(images))
+        step = (lambda: self.run_split(images, split)) if split > 1 else (lambda: self.run_batch(images, concurrency=concurrency))
         step()                                      # warm-up: lazy attribute setup must not be captured
         torch.cuda.synchronize(net.device)
         g = torch.cuda.CUDAGraph()
