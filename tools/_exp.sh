@@ -1,9 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_configs.py -q -x -k "graph or in_flight" 2>&1 | tail -3
-run() { echo -n "$1: "; timeout 300 python bench.py --no-cpu --steps 20 --warmup 5 --extra-batches "" $2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['images_per_s_one_batch_at_a_time'], d['latency_batch1']['by_path'], d['config']['hip_graph'])"; }
+run() { echo -n "$1: "; timeout 300 python bench.py --no-cpu --steps 40 --warmup 5 --extra-batches "" $2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['xcd_partitions'])"; }
 for r in 1 2; do
 run default ""
-run graph0 "--graph 0"
-run graph1 "--graph 1"
+run five_parts "--inflight 5 --partition 2"
+run five_plain "--inflight 5 --partition 0"
+run six_parts "--inflight 6 --partition 2"
+run three_parts "--inflight 3 --partition 2"
 done
