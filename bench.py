@@ -245,10 +245,12 @@ def main():
         torch.cuda.synchronize(device)
         if args.spinup_ms > 0:                 # bring the device out of its idle power state (set-up, not a step)
             t_end = time.perf_counter() + args.spinup_ms * 1e-3
-            while time.perf_counter() < t_end:
+            while time.perf_counter() < t_end:          # time-bounded: ranks run different counts, so no collective in here
                 for _ in range(4):
                     step(x)
-                barrier()
+                if feeder[0] is not None:
+                    feeder[0].drain()
+                torch.cuda.synchronize(device)
         for _ in range(warmup):
             step(x)
         barrier()
