@@ -236,14 +236,14 @@ def main():
         else:
             one(runner, x)
 
-    def timed(batch, steps, warmup):
+    def timed(batch, steps, warmup, spin=True):
         x = torch.from_numpy(synth.synth_images(tables, batch, seed=100 + rank)).to(device)
         if n_inflight > 1 and not serial[0]:   # set-up, not a step: every in-flight runner allocates its workspace
             for st, rn in zip(fl_streams, fl_runners):
                 with torch.cuda.stream(st):
                     one(rn, x)
         torch.cuda.synchronize(device)
-        if args.spinup_ms > 0:                 # bring the device out of its idle power state (set-up, not a step)
+        if args.spinup_ms > 0 and spin:        # bring the device out of its idle power state (set-up, not a step)
             t_end = time.perf_counter() + args.spinup_ms * 1e-3
             while time.perf_counter() < t_end:          # time-bounded: ranks run different counts, so no collective in here
                 for _ in range(4):
@@ -266,6 +266,14 @@ def main():
             dt = float(tt.item())
         return dt, x
 
+    # the same W + K steps once BEFORE the device is brought to its clock, reported beside the figure of record: what the
+    # spin-up changes is then visible in every line this script prints
+    cold = None
+    if args.spinup_ms > 0:
+        dc, _ = timed(args.batch, args.steps, args.warmup, spin=False)
+        cold = dict(value=round(world * args.batch * args.steps / dc, 1), ms_per_step=round(dc / args.steps * 1e3, 4),
+                    note="the same W warm-up + K timed steps run first, without the spin-up, on the device as the host's set-up left it "
+                         "(idle power state, engine clock still ramping: tools/clock_sample.py)")
     dt, x = timed(args.batch, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
@@ -465,7 +473,7 @@ def main():
                                 spinup_note="untimed steps for spinup_ms before the W warm-up steps of every timed leg: an idle MI355X sits "
                                             "at ~150 MHz and needs ~0.4 s of load to reach 2.4 GHz (tools/clock_sample.py); the timed region is "
                                             "still exactly K steps between barrier + synchronize"),
-                    roofline=roofline, cpu_baseline=cpu,
+                    cold_start=cold, roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
                     per_layer_class=per_class, images_per_s_by_batch=sweep,

@@ -1,7 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout 200 python tools/bgroup_timeline.py --layer 31 2>&1 | tail -12
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "group_launches_of" 2>&1 | tail -2
-for c in 1 2; do
-  timeout 300 python bench.py --no-cpu --steps 100 --warmup 10 --extra-batches "" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['images_per_s_one_batch_at_a_time'], d['roofline']['frac'])"
-done
+mkdir -p gpurun_out/evidence
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/evidence/bench_default.log 2>&1; tail -1 gpurun_out/evidence/bench_default.log > gpurun_out/evidence/bench_default.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/evidence/bench_default.json').read())
+print(d['value'], d['ms_per_step'], d['cold_start'], d['images_per_s_one_batch_at_a_time'], d['roofline']['frac'], d['config']['spinup_ms'], d['config']['hip_graph'])
+PY
+timeout 300 python -m pytest tests/test_bench_contract.py -q -x 2>&1 | tail -2
