@@ -374,14 +374,27 @@ def main():
     if loop_n.value > 0 and per_layer_ms.sum() > 0:
         event_scale = min(1.0, (loop_ms.value / loop_n.value) / float(per_layer_ms.sum()))
     per_layer_ms = per_layer_ms * event_scale
+    # classes by LAUNCH: a launch that computes several table rows (conv_bneck: 3x3 + expand; pair launches; group launches: a
+    # whole bottleneck) is its own class, named after the rows it covers -- its time cannot be split between them
     classes = {}
+    groups = []
     for i, L in enumerate(plan):
-        c = classes.setdefault(lo[i]["cls"], dict(ops=0, bytes=0, ms=0.0, kernel=set()))
-        c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
-        c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift", 3: "l2norm"}.get(int(kinds[i]), "?"))
+        if nl[i] > 0 or not groups or kinds[i] == 0:
+            groups.append([i])
+        else:
+            groups[-1].append(i)                # no launch of its own: computed by the launch of the row(s) before it
+    for g in groups:
+        seq = [lo[i]["cls"] for i in g]
+        per = next(p for p in range(1, len(seq) + 1) if len(seq) % p == 0 and seq == seq[:p] * (len(seq) // p))
+        name = "+".join(seq[:per]) if per == len(seq) else f"{len(seq) // per} x ({'+'.join(seq[:per])})"
+        c = classes.setdefault(name, dict(ops=0, bytes=0, ms=0.0, kernel=set(), launches=0))
+        c["launches"] += 1
+        for i in g:
+            c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
+            c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift", 3: "l2norm"}.get(int(kinds[i]), "?"))
     PEAK_I8 = 5000.0    # TOP/s dense int8 MFMA (MI355X_MICROARCH.md: ~2x the 2.5 PF bf16 dense peak)
     PEAK_HBM = 8000.0   # GB/s
-    per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), ms=round(v["ms"], 4),
+    per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), launches=v["launches"], ms=round(v["ms"], 4),
                          tops=round(v["ops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                          frac_int8_peak=round(v["ops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_I8, 4) if v["ms"] > 0 else None,
                          gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,

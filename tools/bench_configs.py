@@ -15,13 +15,17 @@ def measure(name, t, batch, seed, steps=20, inflight=4):
     net = network.NetWork(t); net.Init(model, synth.q_text(q), device="cuda:0", pack_mode=0)
     x = torch.from_numpy(synth.synth_images(t, batch, seed)).to("cuda:0")
     r = network.Runner(None, net)
+    t_spin = time.perf_counter() + 0.6           # out of the idle power state first (tools/clock_sample.py; bench.py --spinup-ms)
+    while time.perf_counter() < t_spin:
+        for _ in range(2): r.run_batch(x)
+        torch.cuda.synchronize()
     for _ in range(3): r.run_batch(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): r.run_batch(x)
     torch.cuda.synchronize(); serial = batch * steps / (time.perf_counter() - t0)
     streams = [torch.cuda.Stream() for _ in range(inflight)]; runners = [network.Runner(None, net) for _ in range(inflight)]
-    for i in range(inflight):
-        with torch.cuda.stream(streams[i]): runners[i].run_batch(x)
+    for i in range(2 * inflight):
+        with torch.cuda.stream(streams[i % inflight]): runners[i % inflight].run_batch(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(steps * 2):
         with torch.cuda.stream(streams[k % inflight]): runners[k % inflight].run_batch(x)
