@@ -48,6 +48,24 @@ def layer_ops(plan):
     return rows
 
 
+def launch_groups(cls, launches, kinds):
+    """Table rows grouped by the launch that computes them: [(class name, [rows])].  A row without a launch of its own
+    (launches == 0, kinds != 0) belongs to the launch of the rows before it (conv_bneck: 3x3 + expand; pair launches; group
+    launches: a whole bottleneck, or stage 4's five).  Names: the rows' classes joined, repeats folded: '5 x (1x1+3x3+1x1)'."""
+    groups = []
+    for i in range(len(cls)):
+        if launches[i] > 0 or not groups or kinds[i] == 0:
+            groups.append([i])
+        else:
+            groups[-1].append(i)
+    out = []
+    for g in groups:
+        seq = [cls[i] for i in g]
+        per = next(p for p in range(1, len(seq) + 1) if len(seq) % p == 0 and seq == seq[:p] * (len(seq) // p))
+        out.append(("+".join(seq[:per]) if per == len(seq) else f"{len(seq) // per} x ({'+'.join(seq[:per])})", g))
+    return out
+
+
 def spawn_check(args):
     """The launch path alone: process group of --gpus ranks (RCCL on GPUs, gloo on CPU), rank -> device pinning, the ONE
     collective of the data path (broadcast of the packed weights) on a small network, and a CRC agreement check."""
@@ -377,16 +395,7 @@ def main():
     # classes by LAUNCH: a launch that computes several table rows (conv_bneck: 3x3 + expand; pair launches; group launches: a
     # whole bottleneck) is its own class, named after the rows it covers -- its time cannot be split between them
     classes = {}
-    groups = []
-    for i, L in enumerate(plan):
-        if nl[i] > 0 or not groups or kinds[i] == 0:
-            groups.append([i])
-        else:
-            groups[-1].append(i)                # no launch of its own: computed by the launch of the row(s) before it
-    for g in groups:
-        seq = [lo[i]["cls"] for i in g]
-        per = next(p for p in range(1, len(seq) + 1) if len(seq) % p == 0 and seq == seq[:p] * (len(seq) // p))
-        name = "+".join(seq[:per]) if per == len(seq) else f"{len(seq) // per} x ({'+'.join(seq[:per])})"
+    for name, g in launch_groups([r["cls"] for r in lo], nl, kinds):
         c = classes.setdefault(name, dict(ops=0, bytes=0, ms=0.0, kernel=set(), launches=0))
         c["launches"] += 1
         for i in g:

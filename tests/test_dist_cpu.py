@@ -73,3 +73,16 @@ def test_bench_py_refuses_a_world_size_mismatch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--spawn-check"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_bench_groups_table_rows_by_launch():
+    """bench.py per_layer_class: rows without a launch of their own belong to the launch before them; repeats are folded."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cls = ["conv1", "1x1", "1x1", "3x3", "1x1", "1x1", "3x3", "1x1"] + ["1x1", "3x3", "1x1"] * 5 + ["pool", "fc"]
+    launches = [1, 1, 0, 0, 0, 1, 1, 0] + [1] + [0] * 14 + [0, 1]
+    kinds = [1] * 23 + [0, 1]
+    got = bench.launch_groups(cls, launches, kinds)
+    assert [n for n, _ in got] == ["conv1", "1x1+1x1+3x3+1x1", "1x1", "3x3+1x1", "5 x (1x1+3x3+1x1)", "pool", "fc"]
+    assert [g for _, g in got][4] == list(range(8, 23)) and sum(len(g) for _, g in got) == len(cls)
+    assert bench.launch_groups(["1x1", "1x1"], [1, 0], [1, 1]) == [("2 x (1x1)", [0, 1])]
