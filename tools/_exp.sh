@@ -5,7 +5,6 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/evidence/bench_de
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/evidence/bench_default.json').read())
-print(d['value'], d['cold_start']['value'], d['images_per_s_one_batch_at_a_time'], d['roofline']['frac'])
-for k,v in d['per_layer_class'].items(): print(k, v)
+print(d['value'], d['cold_start']['value'], d['images_per_s_one_batch_at_a_time'], d['roofline']['frac'], list(d['per_layer_class'].keys()))
 PY
-timeout 600 python tools/bench_configs.py > gpurun_out/evidence/other_configs.txt 2>&1; tail -4 gpurun_out/evidence/other_configs.txt
+timeout 300 python tools/bgroup_stress.py 400 32,48,5,64,32 2>&1 | tail -5
