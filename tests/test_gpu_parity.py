@@ -430,9 +430,9 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
-    stage4 = {"5": [28], "2": [28, 34, 40], "1": [28, 31, 34, 37, 40]}[chain]
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24] + stage4 + [47, 50]
-    assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == 50][0]["kernel"]
+    stage45 = {"5": [28, 47], "2": [28, 34, 40, 47], "1": [28, 31, 34, 37, 40, 47, 50]}[chain]
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24] + stage45
+    assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == (50 if chain == "1" else 47)][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
     x = synth.synth_images(rig.t, 32, 73)
@@ -456,7 +456,7 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     groups = [r["kernel"] for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]]
-    assert len(groups) >= 3 and any("bottlenecks" in k for k in groups)        # (stage 4's bottlenecks share a launch)
+    assert len(groups) >= 2 and sum("bottlenecks" in k for k in groups) == 2      # (the bottlenecks of stages 4 and 5 share a launch each)
     x = synth.synth_images(rig.t, 3, 81, kind="int8")
     x[0, :, :3, :] = -128                                  # the negate quirk of pe.cl:32-37 on the way in
     rig.check_all_layers(x)

@@ -151,31 +151,33 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
   int8_t* const work = wreg + W_BYTES;
   int* const ctl = reinterpret_cast<int*>(work + R_BYTES);      // [0] epoch, [1] / [2]: "group on one XCD" of the two meetings
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // block b -> XCD b % 8; image = the XCD's (b / 64)-th, member = (b / 8) % 8: a group sits on one XCD
   const int img = c.b[0].img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
   if (img >= c.b[0].B) return;
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // LDS-DMA: lane l fills row l >> 2, slot l & 3, which holds chunk slot ^ ((row >> 2) & 3)
-  const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID, 4 bits
   unsigned tag = 0;                                         // this member's flag value: (epoch << 8) | XCC id
   bool local0 = false;                                      // the whole group on this XCD (roll call): exchange stores need no write-through
   const int t = wave;                                    // this wave's column tile
   const bool worker = wave < NT;
-  const int p_lane = 32 * t + (lane & 31);               // the pixel of this lane's MFMA column
-  const bool p_ok = worker && p_lane < NPX;
   const i32x4 nores = {0, 0, 0, 0};
-  // fragment address inside a [32 rows][64 bytes] swizzled tile: row = lane & 31, chunk c = 2 * ks + half
-  const int frow = lane & 31;
-  const int fr0 = frow * 64 + (((0 + half) ^ ((frow >> 2) & 3)) << 4);      // ks = 0; ks = 1 is the same address ^ 32
 
 #pragma unroll 1
   for (int kb = 0; kb < c.n; kb++) {
   const BGroupArgs& a = c.b[kb];
+  // per-lane basics re-derived from an opaque copy of the thread id: otherwise everything that depends only on the lane is hoisted
+  // out of this loop and kept in registers across it
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, half = lane >> 5;
+  // LDS-DMA: lane l fills row l >> 2, slot l & 3, which holds chunk slot ^ ((row >> 2) & 3)
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
+  const int p_lane = 32 * t + (lane & 31);               // the pixel of this lane's MFMA column
+  const bool p_ok = worker && p_lane < NPX;
+  // fragment address inside a [32 rows][64 bytes] swizzled tile: row = lane & 31, chunk c = 2 * ks + half
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + (((0 + half) ^ ((frow >> 2) & 3)) << 4);      // ks = 0; ks = 1 is the same address ^ 32
   unsigned* const ctr = a.ctr + (size_t)img * 32;         // three rows of eight flags: roll call (kb > 0: "input complete"), two meetings
 
   long long* const dbg = (a.dbg && kb == 0) ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py: 100 MHz wall clock per phase
@@ -1688,7 +1690,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
 // (full_size_pool.cl:95-125): the expand's wave sums its 49 requantised + residual-added columns per channel and stores the
 // averaged vector; the 7 x 7 map of the last layer never reaches memory.
 template <bool DUAL1, bool AVG>
-__global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {        // chained like conv_bgroup_kernel; AVG: the LAST one averages
   constexpr int HW = 7, C = 2048, M = 512;
   constexpr int NPX = HW * HW;
   constexpr int KS1 = C / 64, KS2 = M / 64;              // 32, 8
@@ -1703,24 +1705,33 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   int8_t* const work = wreg + 96 * 1024;                 // 48 KB: halo | expand tiles.  Phase A rings span both regions.
   int* const ctl = reinterpret_cast<int*>(work + 48 * 1024);
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
-  if (img >= a.B) return;
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const int drow = lane >> 2;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int img = c.b[0].img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= c.b[0].B) return;
   const size_t px_img = (size_t)img * NPX;
-  unsigned* const ctr = a.ctr + (size_t)img * 32;
-  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
-#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
-  BG_STAMP(0);
-  const int frow = lane & 31;
-  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
   const i32x4 nores = {0, 0, 0, 0};
   const int ct = wave & 1, kq = wave >> 1;               // phases A, B: 32-row tile of the member's m-tile, K quarter
   const int c1 = 64 * m;                                 // first intermediate channel of this member (m-tile m of 64 rows)
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  bool local0 = false;                                      // roll call: the whole group on this XCD
+  unsigned tag = 0;
+
+#pragma unroll 1
+  for (int kb = 0; kb < c.n; kb++) {
+  const BGroupArgs& a = c.b[kb];
+  const bool last = kb + 1 == c.n;
+  // per-lane basics re-derived from an opaque copy of the thread id: otherwise everything that depends only on the lane is hoisted
+  // out of this loop and kept in registers across it (256 VGPRs + scratch instead of 143)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, half = lane >> 5;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
+  const int frow = lane & 31;
+  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
+  long long* const dbg = (a.dbg && kb == 0) ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
 
   auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {        // 32 rows x 64 bytes starting at tile row row0
 #pragma unroll
@@ -1737,17 +1748,15 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     hdr_dma(a.hdr2, a.hdr2_bytes, m, 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, 4 * m + q, 2 + q);
-    if (tid == 64 * 7) {
+    if (kb == 0 && tid == 64 * 7) {
       unsigned e;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
       ctl[0] = (int)e;
     }
   }
-  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
 
-  bool local0 = false;                                      // roll call: the whole group on this XCD
   // the four K quarters of a 32-row tile meet: quarters 1..3 park their two column tiles in LDS, quarter 0 adds them up
   auto reduce_quarters = [&](i32x16 (&acc)[2], int8_t* park) {
     if (kq > 0) {
@@ -1790,8 +1799,11 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     }
   };
 
+  // kb > 0: the input is the previous bottleneck's output: the members meet at this one's roll-call row first
+  bool local_in = false;
+  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
+
   // =================================== phase A: reduce, 1x1 C -> M ===================================
-  unsigned tag = 0;
   {
     constexpr int NS = KS1 / 4;                            // slabs of a K quarter
     constexpr int NI = 2 * NW1 + 4;                        // LDS-DMAs of a stage
@@ -1806,7 +1818,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       for (int g4 = 0; g4 < 4; g4++) {
         const int p = 16 * g4 + drow;
         const int8_t* src = p < NPX ? a.x + (px_img + p) * C + (kq * NS + s) * 64 + chunk * 16 : a.zero + chunk * 16;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(st + NW1 * 2048 + g4 * 1024), 16, 0, 0);
+        int8_t* const dst = st + NW1 * 2048 + g4 * 1024;
+        if (kb == 0) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 0);               // written before this launch
+        else if (local_in) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 1);       // by this group, in this XCD's L2
+        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 16);
       }
     };
     // (the header pieces and the step counter of this wave are older in its queue than its ring stages)
@@ -1837,8 +1852,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // every wave is done with its ring; headers (fetched by every wave) are in LDS
     BG_STAMP(1);
-    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
-    bg_rollcall_post(ctr, m, tag, tid);
+    if (kb == 0) {
+      tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+      bg_rollcall_post(ctr, m, tag, tid);
+    }
     if (DUAL1) {
       // combine the windows: (hi << dshift[1][row]) + lo
       const int* dsh = prm1 + (kPrmWordsPerRow + 1) * 64;
@@ -1853,7 +1870,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
       }
     }
     reduce_quarters(acc, wreg);
-    if (kq == 0) { local0 = bg_rollcall_wave(ctr, tag, lane); store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1); }
+    if (kq == 0) {
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
+      store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1);
+    }
     BG_STAMP(2);
   }
   bg_signal(ctr + 8, m, tag, tid);
@@ -1933,7 +1953,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   }
   bg_signal(ctr + 16, m, tag, tid);
   BG_STAMP(7);
-  // residual tiles of this wave's 32-row tile of the expand (the bottleneck's input: ordinary loads)
+  // residual tiles of this wave's 32-row tile of the expand (the bottleneck's input, written before this launch or -- in a
+  // chain -- by THIS thread one bottleneck earlier: ordinary loads)
   const int ch3 = (C / kBgMembers) * m + 32 * wave;        // first channel of this wave's tile
   i32x4 rv[2];
 #pragma unroll
@@ -2004,7 +2025,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
         else out = requant_tile16<false, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
       }
       const int p = 32 * pt + (lane & 31);
-      if (AVG) {
+      if (AVG && a.avg_mult) {
         // per-channel sum over this tile's live columns (lanes 0-31 and 32-63 hold different channels: reduce inside a half)
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -2014,10 +2035,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
           sum16[q] += v;
         }
       } else if (p < NPX) {
-        *reinterpret_cast<i32x4*>(a.y + (px_img + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
+        bg_store_x(a.y + (px_img + p) * a.y_cp + a.y_off + ch3 + 16 * half, out, local2 || last);       // (an inner output is exchange data)
       }
     }
-    if (AVG && (lane & 31) == 0) {
+    if (AVG && a.avg_mult && (lane & 31) == 0) {
       unsigned o[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 16; q++) {
@@ -2031,6 +2052,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupArgs a) {
   }
   BG_STAMP(10);
 #undef BG_STAMP
+  if (!last) bg_signal(c.b[kb + 1].ctr + (size_t)img * 32, m, tag, tid);      // stores acknowledged, LDS free, then "my output is complete"
+  }
 }
 
 size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
@@ -2089,8 +2112,11 @@ int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bgroup_shape_ok(HW, C, M)) return 1;
-  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW != 14)) return 1;
+  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW != 14 && HW != 7)) return 1;
   const BGroupArgs& a = chain[0];
+  const BGroupArgs& z = chain[n_chain - 1];            // (7 x 7: the LAST bottleneck of a chain may end in the global average)
+  for (int k = 1; k < n_chain; k++)
+    if (chain[k].dual1 != a.dual1 || chain[k - 1].avg_mult) return 1;
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
@@ -2098,8 +2124,8 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
                                   : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup56_kernel<false, false>));
   else if (HW == 28) fn = a.dual2 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, true>))
                                   : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, false>));
-  else if (a.dual1) fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
-  else fn = a.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<false, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<false, false>);
+  else if (a.dual1) fn = z.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
+  else fn = z.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<false, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<false, false>);
   if (!lds_attr_once(fn)) return -1;
   if (lds > 160 * 1024) return -3;
   // at most 32 images = 256 blocks = one block per CU per launch: every group is resident from the start, and the blocks of a
@@ -2109,16 +2135,15 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup_kernel<%dx%d,C%d,M%d> x %d bottlenecks (8 blocks per image, images %d..%d)", HW, HW, C, M, n_chain, i0, i0 + n - 1);
+    if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> x %d bottlenecks (8 blocks per image, images %d..%d)", HW == 7 ? "7" : "", HW, HW, C, M,
+                                     (HW == 7 && a.dual1) ? ",dual reduce" : "", z.avg_mult ? ",global average" : "", n_chain, i0, i0 + n - 1);
     else TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
                     (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.dual3 ? ",dual expand" : "",
                     a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
-    if (HW == 14) {
-      BGroupChain c;
-      c.n = n_chain;
-      for (int k = 0; k < n_chain; k++) { c.b[k] = chain[k]; c.b[k].img0 = i0; }
-      TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, c);
-    }
+    BGroupChain c;
+    c.n = n_chain;
+    for (int k = 0; k < n_chain; k++) { c.b[k] = chain[k]; c.b[k].img0 = i0; }
+    if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, c);
     else if (HW == 56 && a.dual1 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<true, true>), grid, dim3(512), lds, s, b);
     else if (HW == 56 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<false, true>), grid, dim3(512), lds, s, b);
     else if (HW == 56 && a.dual1) TF2_LAUNCH((conv_bgroup56_kernel<true, false>), grid, dim3(512), lds, s, b);
@@ -2127,10 +2152,10 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
     else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, b);
     else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, b);
     else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false, false>), grid, dim3(512), lds, s, b);
-    else if (a.dual1 && a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, b);
-    else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, b);
-    else if (a.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, b);
-    else TF2_LAUNCH((conv_bgroup7_kernel<false, false>), grid, dim3(512), lds, s, b);
+    else if (a.dual1 && z.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, c);
+    else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, c);
+    else if (z.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, c);
+    else TF2_LAUNCH((conv_bgroup7_kernel<false, false>), grid, dim3(512), lds, s, c);
     if (!launch_ok()) return -1;
   }
   return 0;
