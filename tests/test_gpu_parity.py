@@ -431,7 +431,8 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
     stage45 = {"5": [28, 47], "2": [28, 34, 40, 47], "1": [28, 31, 34, 37, 40, 47, 50]}[chain]
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8, 15, 18, 21, 24] + stage45
+    stage3 = [15, 18, 21] if chain == "1" else [15, 21]      # (rows 15-20 share a launch; row 21's 3x3 is a two-window layer: another instantiation)
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8] + stage3 + [24] + stage45
     assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == (50 if chain == "1" else 47)][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
@@ -456,7 +457,7 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     groups = [r["kernel"] for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]]
-    assert len(groups) >= 2 and sum("bottlenecks" in k for k in groups) == 2      # (the bottlenecks of stages 4 and 5 share a launch each)
+    assert len(groups) >= 2 and sum("bottlenecks" in k for k in groups) >= 2      # (consecutive identity bottlenecks share a launch)
     x = synth.synth_images(rig.t, 3, 81, kind="int8")
     x[0, :, :3, :] = -128                                  # the negate quirk of pe.cl:32-37 on the way in
     rig.check_all_layers(x)

@@ -168,13 +168,14 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # one batch at a time the identity bottlenecks of stages 3 and 5 are ONE launch each (conv_bgroup.hip: rows 15-17 ..., 47-49, 50-52),
     # the five of stage 4 (rows 28-42) ONE launch together
     groups = [r for r in one if "conv_bgroup" in r["kernel"]]
-    assert [r["layer"] for r in groups] == [1, 15, 18, 21, 28, 47] and all(r["grid"] == 256 and r["block"] == 512 for r in groups)
+    assert [r["layer"] for r in groups] == [1, 15, 21, 28, 47] and all(r["grid"] == 256 and r["block"] == 512 for r in groups)
+    assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 15][0]["kernel"] and "dual 3x3" in [r for r in groups if r["layer"] == 21][0]["kernel"]
     assert "x 5 bottlenecks" in [r for r in groups if r["layer"] == 28][0]["kernel"]
     assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in groups if r["layer"] == 47][0]["kernel"]
     assert not any("conv_bgroup" in r["kernel"] for r in many)
     # seven groups of three rows one batch at a time (14 launches fewer), two more that replace a reduce + conv_bneck pair where the
     # several-streams plan runs three launches (4 fewer), row 22's pair fused only one batch at a time, three pairs against two
-    assert len(many) == len(one) + 14 + 6 + 2 - 1 + 4 + 1  # (+ the first bottleneck of stage 2: one launch instead of three; + the chains of stages 4 and 5)
+    assert len(many) == len(one) + 14 + 6 + 2 - 1 + 4 + 1 + 1  # (+ the first bottleneck of stage 2: one launch instead of three; + the chains of stages 3, 4 and 5)
     assert [r["grid"] for r in net.describe_launches(40, 0) if r["layer"] == 28] == [256, 64]     # at most 32 images per launch
     # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation (single-window and dual layers are dense)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]

@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup14f_kernel(BGroupArgs a) {
 // DUAL2: the 3x3 is a two-window layer: its weights are swept window by window (72 KB each: they share the LDS region, the low
 // window is fetched while the high one's accumulators wait) and combined like the reduce's.
 template <bool DUAL1, bool DUAL2>
-__global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) {       // chained like conv_bgroup_kernel
   constexpr int HW = 28, C = 512, M = 128, PR = 7;       // PR: rows of a band
   constexpr int NPX = HW * HW, NPB = PR * HW;            // pixels of the image / of a band (196)
   constexpr int NT = (NPB + 31) / 32;                    // 7 column tiles per band
@@ -1369,24 +1369,36 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
   int8_t* const work = wreg + W_BYTES;
   int* const ctl = reinterpret_cast<int*>(work + R_BYTES);
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
-  if (img >= a.B) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int img = c.b[0].img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
+  if (img >= c.b[0].B) return;
   const int sp = m >> 1, cm = m & 1;                     // row band, channel half
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const int drow = lane >> 2;
   const size_t px_img = (size_t)img * NPX;
   const size_t px_band = px_img + (size_t)sp * NPB;      // first pixel of the band
-  unsigned* const ctr = a.ctr + (size_t)img * 32;
-  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
-#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
-  BG_STAMP(0);
+  const i32x4 nores = {0, 0, 0, 0};
+  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+  const int t = wave;
+  const bool worker = wave < NT;
+  unsigned tag = 0;
+  bool local0 = false;                                      // roll call: the whole group on this XCD
+
+#pragma unroll 1
+  for (int kb = 0; kb < c.n; kb++) {
+  const BGroupArgs& a = c.b[kb];
+  const bool last = kb + 1 == c.n;
+  // per-lane basics re-derived from an opaque copy of the thread id (see conv_bgroup_kernel)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, half = lane >> 5;
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
   const int frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
-  const i32x4 nores = {0, 0, 0, 0};
+  const int p_lane = 32 * t + (lane & 31);               // pixel of this lane's column inside the band (phases A, B)
+  const bool p_ok = worker && p_lane < NPB;
+  unsigned* const ctr = a.ctr + (size_t)img * 32;
+  long long* const dbg = (a.dbg && kb == 0) ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
+#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  BG_STAMP(0);
   const int c1 = 64 * cm;                                // first intermediate channel of this member
   const int mt1 = c1 / a.tm1, ro1 = c1 % a.tm1;
   const int mt2 = c1 / a.tm2, ro2 = c1 % a.tm2;
@@ -1413,21 +1425,14 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       const int s = u / (NW1 * 2), win = (u / 2) % NW1, ctq = u & 1;
       w_dma(a.w1, (((size_t)mt1 * KS1 + s) * NW1 + win) * a.tm1 + ro1 + 32 * ctq, wreg + u * 2048);
     }
-    if (tid == 64 * 7) {
+    if (kb == 0 && tid == 64 * 7) {
       unsigned e;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
       ctl[0] = (int)e;
     }
   }
-  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kHdrSlot);
-  const int t = wave;
-  const bool worker = wave < NT;
-  const int p_lane = 32 * t + (lane & 31);               // pixel of this lane's column inside the band (phases A, B)
-  const bool p_ok = worker && p_lane < NPB;
-  unsigned tag = 0;
-  bool local0 = false;                                      // roll call: the whole group on this XCD
 
   // requantise [two 32-row tiles] x [column tile t] and store into a mid tensor
   auto store_mid = [&](i32x16 (&acc)[2], const int* prm, int tm, int ro, int fast, int relu, int dbl, int8_t* mid) {
@@ -1447,6 +1452,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     }
   };
 
+  // kb > 0: the input is the previous bottleneck's output: the members meet at this one's roll-call row first
+  bool local_in = false;
+  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
+
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
     int8_t* const ring = work + wave * (S * STAGE);
@@ -1455,7 +1464,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       for (int g2 = 0; g2 < 2; g2++) {
         const int p = 32 * t + 16 * g2 + drow;
         const int8_t* src = p < NPB ? a.x + (px_band + p) * C + s * 64 + chunk * 16 : a.zero + chunk * 16;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * STAGE + g2 * 1024), 16, 0, 0);
+        int8_t* const dst = ring + slot * STAGE + g2 * 1024;
+        if (kb == 0) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 0);               // written before this launch
+        else if (local_in) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 1);       // by this group, in this XCD's L2
+        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(dst), 16, 0, 16);
       }
     };
     if (worker) {
@@ -1465,8 +1477,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // headers and the reduce's weights are in LDS
     BG_STAMP(1);
-    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
-    bg_rollcall_post(ctr, m, tag, tid);
+    if (kb == 0) {
+      tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
+      bg_rollcall_post(ctr, m, tag, tid);
+    }
     i32x16 acc[2], accl[DUAL1 ? 2 : 1];
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -1506,7 +1520,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
               acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
           }
       }
-      local0 = bg_rollcall_wave(ctr, tag, lane);
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
       store_mid(acc, prm1, a.tm1, ro1, a.fast1, a.relu1, a.dbl1, a.mid1);
     }
   }
@@ -1633,7 +1647,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
       for (int ci = wave; ci < NCHUNK; ci += 8) {
         const int px = 4 * ci + (lane >> 4), q = (lane & 15) ^ (px & 15);
         const int8_t* src = px < NPB ? a.res + (px_band + px) * a.res_cp + a.res_off + c3 + q * 16 : a.zero;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 0);
+        // (kb > 0: this block's own output of one bottleneck earlier, stored like exchange data)
+        if (kb == 0) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 0);
+        else if (local2) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 1);
+        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 16);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1672,11 +1689,13 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupArgs a) {
     for (int ci = wave; ci < NCHUNK; ci += 8) {
       const int px = 4 * ci + (lane >> 4), q = (lane & 15) ^ (px & 15);
       const i32x4 v = *reinterpret_cast<const i32x4*>(stage + ci * 1024 + lane * 16);
-      if (px < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + px) * a.y_cp + a.y_off + c3 + q * 16) = v;
+      if (px < NPB) bg_store_x(a.y + (px_band + px) * a.y_cp + a.y_off + c3 + q * 16, v, local2 || last);      // (an inner output is exchange data)
     }
   }
   BG_STAMP(10);
 #undef BG_STAMP
+  if (!last) bg_signal(c.b[kb + 1].ctr + (size_t)img * 32, m, tag, tid);      // stores acknowledged, LDS free, then "my output is complete"
+  }
 }
 
 // ---- the 7 x 7 maps (ResNet-50 stage 5: C = 2048, M = 512) --------------------------------------------------------------------
@@ -2112,11 +2131,11 @@ int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bgroup_shape_ok(HW, C, M)) return 1;
-  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW != 14 && HW != 7)) return 1;
+  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW == 56)) return 1;
   const BGroupArgs& a = chain[0];
   const BGroupArgs& z = chain[n_chain - 1];            // (7 x 7: the LAST bottleneck of a chain may end in the global average)
   for (int k = 1; k < n_chain; k++)
-    if (chain[k].dual1 != a.dual1 || chain[k - 1].avg_mult) return 1;
+    if (chain[k].dual1 != a.dual1 || chain[k].dual2 != a.dual2 || chain[k - 1].avg_mult) return 1;
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
@@ -2135,8 +2154,8 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s> x %d bottlenecks (8 blocks per image, images %d..%d)", HW == 7 ? "7" : "", HW, HW, C, M,
-                                     (HW == 7 && a.dual1) ? ",dual reduce" : "", z.avg_mult ? ",global average" : "", n_chain, i0, i0 + n - 1);
+    if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> x %d bottlenecks (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
+                                     (HW != 14 && a.dual1) ? ",dual reduce" : "", a.dual2 ? ",dual 3x3" : "", z.avg_mult ? ",global average" : "", n_chain, i0, i0 + n - 1);
     else TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
                     (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.dual3 ? ",dual expand" : "",
                     a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
@@ -2148,10 +2167,10 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
     else if (HW == 56 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<false, true>), grid, dim3(512), lds, s, b);
     else if (HW == 56 && a.dual1) TF2_LAUNCH((conv_bgroup56_kernel<true, false>), grid, dim3(512), lds, s, b);
     else if (HW == 56) TF2_LAUNCH((conv_bgroup56_kernel<false, false>), grid, dim3(512), lds, s, b);
-    else if (HW == 28 && a.dual2 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, true>), grid, dim3(512), lds, s, b);
-    else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, b);
-    else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, b);
-    else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false, false>), grid, dim3(512), lds, s, b);
+    else if (HW == 28 && a.dual2 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, true>), grid, dim3(512), lds, s, c);
+    else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, c);
+    else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, c);
+    else if (HW == 28) TF2_LAUNCH((conv_bgroup28_kernel<false, false>), grid, dim3(512), lds, s, c);
     else if (a.dual1 && z.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<true, true>), grid, dim3(512), lds, s, c);
     else if (a.dual1) TF2_LAUNCH((conv_bgroup7_kernel<true, false>), grid, dim3(512), lds, s, c);
     else if (z.avg_mult) TF2_LAUNCH((conv_bgroup7_kernel<false, true>), grid, dim3(512), lds, s, c);

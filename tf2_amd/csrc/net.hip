@@ -201,7 +201,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // shares memory (the exchange inside a launch is ordered by flags and cache scopes, not by kernel boundaries)
   if (packed_valid && opts.bgroup_mode && opts.bgroup_chain > 1)
     for (int l = 0; l + 2 < nl;) {
-      if (!bgroup_at(l) || (layers[l].H != 14 && layers[l].H != 7)) { l++; continue; }
+      if (!bgroup_at(l) || layers[l].H == 56) { l++; continue; }
       int e = l + 2;
       while (e + 3 < nl && bgroup_at(e + 1) && layers[e + 1].H == layers[l].H) e += 3;
       if (e > l + 2)
@@ -700,10 +700,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         pair_done[l + 1] = 1; pair_done[l + 2] = 1;
         // the 14 x 14 stage's identity bottlenecks follow one another: the groups of the previous launch carry on with this one
         // (its roll-call row doubles as the meeting "input complete")
-        if (opts.bgroup_chain > 1 && (L.H == 14 || L.H == 7) && !lp.steps.empty() && !f.dbg) {
+        if (opts.bgroup_chain > 1 && L.H != 56 && !lp.steps.empty() && !f.dbg) {
           Launch& pv = lp.steps.back();
           const int pn = pv.bg_chain.empty() ? 1 : (int)pv.bg_chain.size();
-          if (pv.kind == Launch::CONV && pv.sel == Launch::SEL_BGROUP && pv.bg_hw == L.H && pv.layer + 3 * pn == l && f.dual1 == pv.bgroup.dual1 && !pv.bg_chain_last().avg_mult && pn < std::min(kBgMaxChain, opts.bgroup_chain) &&
+          if (pv.kind == Launch::CONV && pv.sel == Launch::SEL_BGROUP && pv.bg_hw == L.H && pv.layer + 3 * pn == l && f.dual1 == pv.bgroup.dual1 && f.dual2 == pv.bgroup.dual2 && !pv.bg_chain_last().avg_mult && pn < std::min(kBgMaxChain, opts.bgroup_chain) &&
               !pv.bgroup.dbg && f.x == pv.bg_chain_last().y && f.has_res && f.res == f.x && f.res_off == 0 && pv.bg_chain_last().y_off == 0 &&
               f.res_cp == pv.bg_chain_last().y_cp) {
             if (pv.bg_chain.empty()) pv.bg_chain.push_back(pv.bgroup);
