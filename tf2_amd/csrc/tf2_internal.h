@@ -230,8 +230,8 @@ struct BGroupArgs {
   int32_t first_shape;       // 56: conv_bgroup56f_kernel; 14: conv_bgroup14f_kernel (stride-2 first bottleneck whose output map is 14 x 14)
 };
 
-// consecutive identity bottlenecks of the 14 x 14 or 7 x 7 maps in one launch (conv_bgroup_kernel / conv_bgroup7_kernel: the groups
-// run them back to back)
+// consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
+// conv_bgroup7_kernel: the groups run them back to back)
 constexpr int kBgMaxChain = 5;
 struct BGroupChain {
   int32_t n;

@@ -107,7 +107,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
   long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
-  int bgroup_chain = 5;             // consecutive identity bottlenecks of the 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
+  int bgroup_chain = 5;             // consecutive identity bottlenecks of the 28 x 28 / 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12, bgroup_min14f = 1 << 30;   // (14f: measured equal to its three launches -- every member streams the whole 28 x 28 input: off unless asked for)
     // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
      // TF2_AMD_BGROUP_MIN7 / _MIN14: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
