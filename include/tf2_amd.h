@@ -172,6 +172,16 @@ typedef struct tf2_launch_info {
   char kernel[96];
 } tf2_launch_info;
 tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, tf2_launch_info* rows, int capacity, int* n);
+/* The liveness-planned workspace of `batch` images (no device needed): tensor t occupies [offset, offset + bytes) from table row
+ * first_row (-1: the input) to last_row (n_layers: the network output); row_capacity >= n_layers entries of `rows` say which
+ * tensors a row reads (in, res: -1 = none) and writes (conv: the convolution's own result; out: after pool / average).  Rows that
+ * share a launch (fused pairs, group launches and their chains) keep everything they touch alive for the whole launch: two
+ * tensors of such rows never overlap (tests/test_host_abi.py).  The reference has no counterpart (its feature maps live in
+ * fixed on-chip buffers, feature_writer.cl:88-151).                                                                          */
+typedef struct tf2_tensor_info { int64_t offset, bytes; int32_t first_row, last_row; } tf2_tensor_info;
+typedef struct tf2_row_tensors { int32_t in_tensor, out_tensor, conv_tensor, res_tensor; } tf2_row_tensors;
+tf2_status tf2_net_describe_workspace(tf2_net* net, int batch, int keep_all, tf2_tensor_info* tensors, int tensor_capacity, int* n_tensors,
+                                      tf2_row_tensors* rows, int row_capacity);
 /* After a keep_all run: copy layer `layer`'s output to the host as dense NCHW int8
  * [batch][N][PH][PW] (or [batch][N] after an end pool).  layer == -1: the quantised,
  * transformed network input [batch][C0][H0][W0].  Synchronises the stream.

@@ -254,3 +254,42 @@ def test_run_ex_rejects_bad_options_without_touching_the_device():
               _lib.RunOpts(24, 0, 0, 999, C.cast(buf, C.c_void_p))):  # mark layer outside the table
         assert L.tf2_net_run_ex(net._h, buf, 1, buf, 64, buf, None, C.byref(o)) == -1, L.tf2_last_error()
     assert L.tf2_net_run_ex(net._h, buf, 1, buf, 64, buf, None, None) == -1
+
+
+@pytest.mark.parametrize("batch", [5, 32, 40])
+def test_rows_that_share_a_launch_never_share_memory(golden_dir, batch):
+    """tf2_net_describe_workspace: (1) the first-fit planner never gives two tensors that are alive at the same table row overlapping
+    bytes; (2) every launch that computes several rows -- conv_bneck pairs, pair launches, group launches and their chains of up
+    to five bottlenecks, whose blocks are ordered by flags and cache scopes instead of kernel boundaries -- touches pairwise
+    disjoint memory, and everything it touches is alive for the whole launch (Net::plan).  One batch at a time and the
+    several-streams plan; no device needed."""
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
+    tensors, rows = net.describe_workspace(batch)
+    nl = len(rows)
+    assert nl == 54 and all(0 <= x["offset"] and 0 < x["bytes"] and x["first_row"] <= x["last_row"] for x in tensors)
+    assert max(x["offset"] + x["bytes"] for x in tensors) <= net.workspace_size(batch)
+
+    def overlap(a, b):
+        return a["offset"] < b["offset"] + b["bytes"] and b["offset"] < a["offset"] + a["bytes"]
+
+    for i, a in enumerate(tensors):
+        for b in tensors[i + 1:]:
+            if a["first_row"] <= b["last_row"] and b["first_row"] <= a["last_row"]:
+                assert not overlap(a, b), (a, b)
+    n_multi = 0
+    for conc in (0, 1):
+        starts = sorted({r["layer"] for r in net.describe_launches(batch, conc) if r["layer"] >= 0})
+        for k, l in enumerate(starts):
+            end = (starts[k + 1] if k + 1 < len(starts) else nl) - 1         # rows l .. end belong to this launch
+            if end == l:
+                continue
+            n_multi += 1
+            ids = sorted({rows[r][key] for r in range(l, end + 1) for key in ("in_tensor", "out_tensor", "conv_tensor", "res_tensor")} - {-1})
+            for i, a in enumerate(ids):
+                assert tensors[a]["first_row"] <= l and tensors[a]["last_row"] >= min(end, nl), (l, end, a, tensors[a])
+                for b in ids[i + 1:]:
+                    assert not overlap(tensors[a], tensors[b]), (l, end, a, b)
+    assert n_multi >= (10 if batch >= 12 else 2)                  # (small batches: few fused launches, by the library's own rules)

@@ -45,6 +45,16 @@ class LaunchInfo(C.Structure):
                 ("kernel", C.c_char * 96)]
 
 
+class TensorInfo(C.Structure):
+    """tf2_tensor_info (include/tf2_amd.h)."""
+    _fields_ = [("offset", C.c_int64), ("bytes", C.c_int64), ("first_row", C.c_int32), ("last_row", C.c_int32)]
+
+
+class RowTensors(C.Structure):
+    """tf2_row_tensors (include/tf2_amd.h)."""
+    _fields_ = [("in_tensor", C.c_int32), ("out_tensor", C.c_int32), ("conv_tensor", C.c_int32), ("res_tensor", C.c_int32)]
+
+
 class NetDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_layers", "n_conv", "n_q_rows", "max_out_channel", "image_c", "image_h", "image_w",
@@ -105,6 +115,7 @@ def lib() -> C.CDLL:
     L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_ex.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp, C.POINTER(RunOpts)]
     L.tf2_net_describe_launches.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LaunchInfo), C.c_int, C.POINTER(C.c_int)]
+    L.tf2_net_describe_workspace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TensorInfo), C.c_int, C.POINTER(C.c_int), C.POINTER(RowTensors), C.c_int]
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
     L.tf2_net_profile.argtypes = [vp, C.c_int]
     L.tf2_net_profile_read.argtypes = [vp, vp, vp, vp, C.c_int]
@@ -119,7 +130,7 @@ EXPORTED = [
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
-    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_describe_launches", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
+    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
 def check(status: int) -> None:

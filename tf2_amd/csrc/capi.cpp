@@ -200,6 +200,26 @@ tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, t
   return TF2_OK;
 }
 
+tf2_status tf2_net_describe_workspace(tf2_net* net, int batch, int keep_all, tf2_tensor_info* tensors, int tensor_capacity, int* n_tensors,
+                                      tf2_row_tensors* rows, int row_capacity) {
+  CHECK_NET(net);
+  if (!n_tensors || (tensor_capacity > 0 && !tensors) || (row_capacity > 0 && !rows)) { set_error("tf2_net_describe_workspace: null argument"); return TF2_ERR_ARG; }
+  std::vector<tf2::TensorPlan> t;
+  std::vector<tf2::LayerExec> r;
+  tf2_status st = net->impl.describe_workspace(batch, keep_all != 0, &t, &r);
+  if (st != TF2_OK) return st;
+  *n_tensors = (int)t.size();
+  if ((int)t.size() > tensor_capacity || (int)r.size() > row_capacity) { set_error("tf2_net_describe_workspace: " + std::to_string(t.size()) + " tensors, " + std::to_string(r.size()) + " rows: capacity too small"); return TF2_ERR_SIZE; }
+  for (size_t i = 0; i < t.size(); i++) {
+    tensors[i].offset = (int64_t)t[i].offset; tensors[i].bytes = (int64_t)t[i].bytes;
+    tensors[i].first_row = t[i].first_use; tensors[i].last_row = t[i].last_use;
+  }
+  for (size_t i = 0; i < r.size(); i++) {
+    rows[i].in_tensor = r[i].in_tensor; rows[i].out_tensor = r[i].out_tensor; rows[i].conv_tensor = r[i].conv_tensor; rows[i].res_tensor = r[i].res_tensor;
+  }
+  return TF2_OK;
+}
+
 tf2_status tf2_net_read_layer(tf2_net* net, int layer, int batch, const void* ws, int8_t* host_dst,
                               size_t capacity, void* hip_stream) {
   CHECK_NET(net);

@@ -265,6 +265,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       free_list[i - 1].len += free_list[i].len; free_list.erase(free_list.begin() + i);
     }
   };
+  for (size_t t = 0; t < wp.tensors.size(); t++) wp.tensors[t].first_use = born[t];
   std::vector<char> placed(wp.tensors.size(), 0), freed(wp.tensors.size(), 0);
   wp.tensors[wp.input_tensor].offset = alloc(wp.tensors[wp.input_tensor].bytes);
   placed[wp.input_tensor] = 1;
@@ -957,6 +958,19 @@ tf2_status Net::describe_launches(int batch, bool concurrent, std::vector<std::p
   for (auto it = launch_plans.begin(); it != launch_plans.end(); ++it)       // the description's plan is not a run plan
     if (&*it == lp) { launch_plans.erase(it); break; }
   if (rc) { set_error("tf2_net_describe_launches: " + std::string(device_last_error())); return TF2_ERR_HIP; }
+  return TF2_OK;
+}
+
+// The liveness-planned workspace of `batch` images as the library lays it out: every tensor's byte range and the rows between which
+// it holds memory, and per row the tensors it reads / writes.  No device needed (tests/test_host_abi.py checks with it that rows
+// sharing a launch never share memory).
+tf2_status Net::describe_workspace(int batch, bool keep_all, std::vector<TensorPlan>* tensors, std::vector<LayerExec>* rows) {
+  std::lock_guard<std::mutex> lock(run_mutex);
+  if (!packed_valid) { set_error("tf2_net_describe_workspace: no packed image"); return TF2_ERR_STATE; }
+  if (batch <= 0) { set_error("tf2_net_describe_workspace: batch must be positive"); return TF2_ERR_ARG; }
+  const WorkPlan* wp = plan(batch, keep_all);
+  *tensors = wp->tensors;
+  *rows = wp->exec;
   return TF2_OK;
 }
 

@@ -18,6 +18,7 @@ struct TensorPlan {
   size_t bytes = 0;        // for the planned batch
   size_t offset = 0;
   int last_use = -1;       // last layer index reading it (n_layers = network output)
+  int first_use = -1;      // the row from which the tensor holds memory (-1: the input); earlier than its producer when rows share a launch
 };
 
 struct LayerExec {
@@ -169,6 +170,7 @@ struct Net {
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
   const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  tf2_status describe_workspace(int batch, bool keep_all, std::vector<TensorPlan>* tensors, std::vector<LayerExec>* rows);
   bool bgroup_first14_at(int l) const;     // rows l .. l + 3 = the stride-2 first bottleneck whose output map is 14 x 14 (conv_bgroup14f_kernel)
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)

@@ -181,6 +181,18 @@ class NetWork:
         return [dict(layer=r.layer, kernel=r.kernel.decode(), grid=r.grid, block=r.block, lds_bytes=r.lds_bytes, vgprs=r.vgprs)
                 for r in rows[:n.value]]
 
+    def describe_workspace(self, batch: int, keep_all: bool = False):
+        """(tensors, rows) of the liveness-planned workspace: tensors = [{offset, bytes, first_row, last_row}], rows = per table row
+        {in_tensor, out_tensor, conv_tensor, res_tensor} (tf2_net_describe_workspace; no device needed)."""
+        import ctypes as C
+        nl = len(self.plan)
+        ts = (_lib.TensorInfo * 1024)()
+        rs = (_lib.RowTensors * nl)()
+        n = C.c_int(0)
+        _lib.check(_lib.lib().tf2_net_describe_workspace(self._h, batch, int(keep_all), ts, 1024, C.byref(n), rs, nl))
+        return ([dict(offset=t.offset, bytes=t.bytes, first_row=t.first_row, last_row=t.last_row) for t in ts[:n.value]],
+                [dict(in_tensor=r.in_tensor, out_tensor=r.out_tensor, conv_tensor=r.conv_tensor, res_tensor=r.res_tensor) for r in rs])
+
     def workspace_size(self, batch: int, keep_all: bool = False) -> int:
         return int(_lib.lib().tf2_net_workspace_size(self._h, batch, int(keep_all)))
 
