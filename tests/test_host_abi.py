@@ -256,20 +256,34 @@ def test_run_ex_rejects_bad_options_without_touching_the_device():
     assert L.tf2_net_run_ex(net._h, buf, 1, buf, 64, buf, None, None) == -1
 
 
-@pytest.mark.parametrize("batch", [5, 32, 40])
-def test_rows_that_share_a_launch_never_share_memory(golden_dir, batch):
+def _liveness_net(golden_dir, name):
+    if name == "resnet50":
+        t = cfg.resnet50_tables()
+        q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    elif name == "googlenet":                               # concat slices and independent pooling rows
+        import json
+        t = cfg.NetTables(json.load(open(os.path.join(golden_dir, "tables_googlenet.json"))))
+        t.setdefault("xConv1Rewrite", 1)
+        q = np.loadtxt(os.path.join(golden_dir, "googlenet_Q"), dtype=np.int32)
+    else:
+        t = cfg.squeezenet11_tables()
+        q = synth.synth_q_values(t, 21, spread=2)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
+    return net
+
+
+@pytest.mark.parametrize("name,batch", [("resnet50", 5), ("resnet50", 32), ("resnet50", 40), ("googlenet", 8), ("squeezenet", 32)])
+def test_rows_that_share_a_launch_never_share_memory(golden_dir, name, batch):
     """tf2_net_describe_workspace: (1) the first-fit planner never gives two tensors that are alive at the same table row overlapping
     bytes; (2) every launch that computes several rows -- conv_bneck pairs, pair launches, group launches and their chains of up
     to five bottlenecks, whose blocks are ordered by flags and cache scopes instead of kernel boundaries -- touches pairwise
     disjoint memory, and everything it touches is alive for the whole launch (Net::plan).  One batch at a time and the
     several-streams plan; no device needed."""
-    t = cfg.resnet50_tables()
-    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
-    net = network.NetWork(t)
-    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
+    net = _liveness_net(golden_dir, name)
     tensors, rows = net.describe_workspace(batch)
     nl = len(rows)
-    assert nl == 54 and all(0 <= x["offset"] and 0 < x["bytes"] and x["first_row"] <= x["last_row"] for x in tensors)
+    assert nl == len(net.plan) and all(0 <= x["offset"] and 0 < x["bytes"] and x["first_row"] <= x["last_row"] for x in tensors)
     assert max(x["offset"] + x["bytes"] for x in tensors) <= net.workspace_size(batch)
 
     def overlap(a, b):
@@ -292,4 +306,5 @@ def test_rows_that_share_a_launch_never_share_memory(golden_dir, batch):
                 assert tensors[a]["first_row"] <= l and tensors[a]["last_row"] >= min(end, nl), (l, end, a, tensors[a])
                 for b in ids[i + 1:]:
                     assert not overlap(tensors[a], tensors[b]), (l, end, a, b)
-    assert n_multi >= (10 if batch >= 12 else 2)                  # (small batches: few fused launches, by the library's own rules)
+    if name == "resnet50":
+        assert n_multi >= (10 if batch >= 12 else 2)              # (small batches: few fused launches, by the library's own rules)
