@@ -10,7 +10,7 @@ HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
                                      "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into", "w_share", "w_main_TM")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
-                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_perm", "off_unit")])
+                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_unit")])
 
 
 def parse(blob: np.ndarray):
@@ -44,23 +44,11 @@ def requant(acc, alpha, beta, relu):
     return v.astype(np.int8)
 
 
-def perm_of(blob, pl, n):
-    """PackLayer::off_perm: physical position of every logical output channel (identity when the layer has none)."""
-    if not int(pl["off_perm"]):
-        return np.arange(n)
-    p = i32(blob, int(pl["off_perm"]), n).astype(np.int64)
-    assert sorted(p.tolist()) == list(range(n))
-    return p
-
-
-def nhwc(x_nchw, Cp, signed_half=None, perm=None):
+def nhwc(x_nchw, Cp, signed_half=None):
     """[B,C,H,W] int8 -> [B,H,W,Cp]; with signed_half: [x | (int8)(-x)] halves."""
     B, C, H, W = x_nchw.shape
     t = np.zeros((B, H, W, Cp), np.int8)
-    if perm is None:
-        t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))
-    else:                                   # the producer stores logical channel c at physical position perm[c]
-        t[..., perm] = np.transpose(x_nchw, (0, 2, 3, 1))
+    t[..., :C] = np.transpose(x_nchw, (0, 2, 3, 1))
     if signed_half is not None:
         t[..., signed_half:signed_half + C] = (-t[..., :C].astype(np.int16)).astype(np.int8)
     return t
@@ -195,9 +183,6 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         acc = (bias[:, None] + acc) % 2 ** 32
     acc = ((acc + 2 ** 31) % 2 ** 32 - 2 ** 31)
     y = requant(acc[:N], alpha[:N, None], beta[:N, None], L.relu)          # [N, npix], PHYSICAL row order
-    if int(pl["off_perm"]):
-        # the layer writes its channels sorted by Q (weight_pack.cpp): logical channel n sits at physical row perm[n]
-        y = y[perm_of(blob, pl, N)]
     y = y.reshape(N, B, OH, OW).transpose(1, 0, 2, 3)
     if res is not None:
         s = np.clip(y.astype(np.int16) + res.astype(np.int16), -128, 127)
@@ -257,5 +242,4 @@ def conv_stem_from_packed(blob, pl, L, x_nchw):
     acc = (bias[:, None] + (acc << lo[:, None])) % 2 ** 32
     acc = ((acc + 2 ** 31) % 2 ** 32 - 2 ** 31)
     y = requant(acc[:N], alpha[:N, None], beta[:N, None], L.relu)
-    y = y[perm_of(blob, pl, N)]                      # physical rows -> logical channels
     return np.ascontiguousarray(y.reshape(N, B, OH, OW).transpose(1, 0, 2, 3))

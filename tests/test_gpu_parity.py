@@ -398,20 +398,6 @@ def test_doubled_channels_written_by_conv_stem_and_by_a_fused_expand(which, monk
     rig.check_all_layers(synth.synth_images(t, 4, 3))
 
 
-@pytest.mark.parametrize("conc", ["0", "1"])
-def test_fragment_prefetch_variant_of_the_ring_kernel(r50, monkeypatch, conc):
-    """conv_mfma2's PF instantiation (next step's fragments read during the current step's MFMAs, four ring stages; off by default,
-    TF2_AMD_PF_BLOCKS): the small-grid single-window layers of both launch plans, batch 32, against the oracle."""
-    monkeypatch.setenv("TF2_AMD_PF_BLOCKS", "256")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
-    rig = Rig(*r50, 0)
-    assert any("prefetch" in l["kernel"] for l in rig.net.describe_launches(32, int(conc)))
-    x = synth.synth_images(rig.t, 32, 21)
-    got = rig.run(x, keep_all=False)
-    np.testing.assert_array_equal(got[:3], rig.ref.logits(rig.ref.run(x[:3])))
-    np.testing.assert_array_equal(got[3:6], rig.run(x[3:6], keep_all=False))
-
-
 @pytest.mark.parametrize("chain", ["5", "2", "1"])
 def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     """TF2_AMD_BGROUP=1 (the default): the five identity bottlenecks of stage 4 (rows 28-42) and the two of stage 5 (rows 47-52, the
@@ -424,15 +410,13 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN7", "1")          # (by default batches below 12 keep the separate launches: measured equal or faster there)
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN14", "1")
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN28", "1")
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN56", "1")          # (off by default: measured equal)
     monkeypatch.setenv("TF2_AMD_BGROUP_MIN56F", "1")
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN14F", "1")
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
     stage45 = {"5": [28, 47], "2": [28, 34, 40, 47], "1": [28, 31, 34, 37, 40, 47, 50]}[chain]
     stage3 = [15, 18, 21] if chain == "1" else [15, 21]      # (rows 15-20 share a launch; row 21's 3x3 is a two-window layer: another instantiation)
-    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1, 5, 8] + stage3 + [24] + stage45
+    assert [r["layer"] for r in rows if "conv_bgroup" in r["kernel"]] == [1] + stage3 + stage45
     assert "dual reduce" in [r for r in rows if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in rows if r["layer"] == (50 if chain == "1" else 47)][0]["kernel"]
     rig.check_all_layers(synth.synth_images(rig.t, 2, 71))
     rig.check_all_layers(synth.synth_images(rig.t, 5, 72))
@@ -452,7 +436,7 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     (TF2_AMD_NOFAST), plain instead of doubled channels (TF2_AMD_NODBL: more two-window rows -- some bottlenecks then fall back to
     separate launches, by the library's own eligibility rules), no SEMI rows.  Every layer against the oracle, group launches on."""
     monkeypatch.setenv(pack_switch, "1")
-    for k in ("TF2_AMD_BGROUP_MIN7", "TF2_AMD_BGROUP_MIN14", "TF2_AMD_BGROUP_MIN28", "TF2_AMD_BGROUP_MIN56", "TF2_AMD_BGROUP_MIN56F", "TF2_AMD_BGROUP_MIN14F"):
+    for k in ("TF2_AMD_BGROUP_MIN7", "TF2_AMD_BGROUP_MIN14", "TF2_AMD_BGROUP_MIN28", "TF2_AMD_BGROUP_MIN56F"):
         monkeypatch.setenv(k, "1")
     monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
     rig = Rig(*r50, 0)
@@ -465,49 +449,3 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     np.testing.assert_array_equal(rig.run(x32, keep_all=False)[:2], rig.ref.logits(rig.ref.run(x32[:2])))
 
 
-@pytest.mark.parametrize("conc", ["0", "1"])
-def test_chain_launches_against_the_oracle(r50, monkeypatch, conc):
-    """TF2_AMD_CHAIN=1 (off by default): consecutive 128-row ring-kernel rows in ONE launch (conv_mfma2_chain_kernel), blocks ordered
-    only by per-pixel-tile completion counters, activations through agent-scope loads / stores, every tensor of a chain alive
-    to its end (Net::plan).  Every layer at batch 2 and 32 against the oracle (keep_all workspace), then the batch-32 logits of
-    repeated runs on a liveness-planned workspace (the memory layout the counters protect)."""
-    monkeypatch.setenv("TF2_AMD_CHAIN", "1")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
-    rig = Rig(*r50, 0)
-    launches = rig.net.describe_launches(32, int(conc))
-    chains = [l for l in launches if "chain" in l["kernel"]]
-    assert chains and (conc == "0" or len(launches) <= 22)
-    rig.check_all_layers(synth.synth_images(rig.t, 2, 51))
-    x = synth.synth_images(rig.t, 32, 52)
-    want3 = rig.ref.logits(rig.ref.run(x[:3]))
-    first = rig.run(x, keep_all=False).copy()
-    np.testing.assert_array_equal(first[:3], want3)
-    for _ in range(10):
-        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
-    monkeypatch.setenv("TF2_AMD_CHAIN", "0")
-    plain = Rig(*r50, 0)
-    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
-
-
-@pytest.mark.parametrize("off", ["TF2_AMD_NOPERM", "TF2_AMD_NOGROUP"])
-def test_q_sorted_tensors_and_channel_group_phases_on_and_off(r50, monkeypatch, off):
-    """TF2_AMD_GROUP=1: multi-Q tensors stored with their channels sorted by Q, their consumers packed with one Horner phase per
-    channel group (weight_pack.cpp) -- every layer against the oracle and the batch-32 logits; then each half switched off again
-    (identity channel order / exponent-window phases), every layer against the oracle."""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import emu_packed as emu
-    monkeypatch.setenv("TF2_AMD_GROUP", "1")          # the form is opt-in at pack time (weight_pack.cpp: measured +-0)
-    base = Rig(*r50, 0)
-    _, pls = emu.parse(base.net.packed_host())
-    assert sum(1 for p in pls if int(p["off_perm"])) >= 12 and sum(1 for p in pls if int(p["n_phases"]) == 3) >= 10
-    base.check_all_layers(synth.synth_images(base.t, 2, 34))
-    x32 = synth.synth_images(base.t, 32, 35)
-    np.testing.assert_array_equal(base.run(x32, keep_all=False)[:2], base.ref.logits(base.ref.run(x32[:2])))
-    monkeypatch.setenv(off, "1")
-    rig = Rig(*r50, 0)
-    _, pls = emu.parse(rig.net.packed_host())
-    assert all(int(p["n_phases"]) <= 2 for p in pls)
-    if off == "TF2_AMD_NOPERM":
-        assert not any(int(p["off_perm"]) for p in pls)
-    rig.check_all_layers(synth.synth_images(rig.t, 2, 33))

@@ -187,60 +187,6 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
         net.describe_launches(0, 0)
 
 
-def test_group_phase_packing_is_table_driven(golden_dir, monkeypatch):
-    """TF2_AMD_GROUP=1 (pack time): multi-Q tensors sorted by Q, their consumers packed with one Horner phase per channel group:
-    those launches read the header tables, and the packed image shrinks."""
-    t = cfg.resnet50_tables()
-    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
-    model = synth.synth_model(t, q, 0)
-    sizes = {}
-    for on in ("0", "1"):
-        monkeypatch.setenv("TF2_AMD_GROUP", on)
-        net = network.NetWork(t)
-        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
-        sizes[on] = net.packed_host().size
-        ring = [r for r in net.describe_launches(32, 0) if "conv_mfma" in r["kernel"]]
-        tabled = {r["layer"] for r in ring if "tables" in r["kernel"]}
-        assert tabled == (set() if on == "0" else {5, 8, 11, 15, 18, 21, 24, 47, 50, 53})
-    assert sizes["1"] < sizes["0"] < 40e6
-
-
-def test_chain_launches_are_opt_in_and_planned_with_their_own_liveness(golden_dir, monkeypatch):
-    """TF2_AMD_CHAIN=1: the several-streams plan of ResNet-50 carries stages 3 and 4 (rows 11..44, pairs as two segments) in ONE
-    chain launch; tensors of a chain do not share memory, so the workspace grows; off (default): no chain kernel, same workspace
-    as ever."""
-    t = cfg.resnet50_tables()
-    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
-    net = network.NetWork(t)
-    net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 0)); net.Pack(0)
-    L = _lib.lib()
-    def ws_bytes(b):
-        return int(L.tf2_net_workspace_size(net._h, b, 0))
-    plain = net.describe_launches(32, 1)
-    ws0 = ws_bytes(32)
-    assert not any("chain" in r["kernel"] for r in plain)
-    monkeypatch.setenv("TF2_AMD_CHAIN", "1")
-    net.reload_options()
-    rows = net.describe_launches(32, 1)
-    chains = [r for r in rows if "chain" in r["kernel"]]
-    assert len(chains) == 1 and chains[0]["layer"] == 11 and "34 layers, rows 11..44" in chains[0]["kernel"]
-    assert len(rows) == len(plain) - 31 + 1 and chains[0]["block"] == 512      # 31 launches (three of them pairs) become one
-    # grid = the segments' blocks, each segment starting on a multiple of 8
-    want = 0
-    for r in plain:
-        if 11 <= r["layer"] <= 44:
-            if "pair" in r["kernel"]:
-                a, b = r["kernel"].split("(")[1].split(" blocks")[0].split(" + ")
-                for n in (int(a), int(b)): want = (want + 7) // 8 * 8 + n
-            else:
-                want = (want + 7) // 8 * 8 + r["grid"]
-    assert chains[0]["grid"] == (want + 7) // 8 * 8
-    assert ws_bytes(32) > ws0
-    monkeypatch.setenv("TF2_AMD_CHAIN", "0")
-    net.reload_options()
-    assert ws_bytes(32) == ws0
-
-
 def test_run_ex_rejects_bad_options_without_touching_the_device():
     t = cfg.tiny_tables()
     q = synth.synth_q_values(t, 0)

@@ -44,7 +44,7 @@ def check_net(t, q, model, images, mode, layers=None):
             S = plan[L.src]
             if S.concat >= 0:
                 pytest.skip("concat sources are covered by the GPU tests")
-            x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16), perm=emu.perm_of(blob, pls[L.src], S.N))
+            x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
         else:
             cid = -(L.src + 2)
             members = [M for M in plan if M.concat == cid]
@@ -178,7 +178,7 @@ def test_resnet50_wide_tile_alternatives(golden_dir):
     for i in (wide[0], k3[0], k3[-1], [j for j in wide if not R.plan[j].endpool][-1], narrow[0], n3[0], n3[-1], narrow[-1]):
         L = R.plan[i]
         S = R.plan[L.src]
-        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16), perm=emu.perm_of(blob, pls[L.src], S.N))
+        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16))
         res = outs[L.add_src] if L.add_src >= 0 else None
         y = emu.conv_from_packed(blob, alts[i], L, x_t, res)
         np.testing.assert_array_equal(y, outs[i], err_msg=f"layer {i} wide-tile alternative")
@@ -201,35 +201,3 @@ def test_resnet50_doubled_channels(golden_dir):
     assert int(pls[28]["fast"]) == 2        # a producer off the FAST proof (SEMI form): the -128 rides in its rows' shift word
 
 
-def test_resnet50_group_phase_form_and_shared_tiles(golden_dir, monkeypatch):
-    """TF2_AMD_GROUP=1 at pack time: multi-Q tensors stored sorted by Q (PackLayer::off_perm), their consumers packed with one Horner
-    phase per input-channel group; TF2_AMD_SHARE=2: every alternative tile height reads the main entry's tiles.  The packed
-    consumers, producers and alternatives must still compute the oracle's layers."""
-    monkeypatch.setenv("TF2_AMD_GROUP", "1")
-    monkeypatch.setenv("TF2_AMD_SHARE", "2")
-    t = cfg.resnet50_tables()
-    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
-    model = synth.synth_model(t, q, 0)
-    x = synth.synth_images(t, 1, 0)
-    kinds, pls = check_net(t, q, model, x, 0, layers={0, 1, 2, 4, 5, 10, 11, 12, 14, 15, 24, 25, 27, 43, 46, 47, 52, 53})
-    assert sum(1 for p in pls if int(p["off_perm"])) >= 12
-    assert {i for i, p in enumerate(pls) if int(p["n_phases"]) == 3} == {5, 8, 11, 12, 15, 18, 21, 24, 25, 47, 50, 53}
-    # alternatives: all of them share, and compute the same layers
-    net = network.NetWork(t)
-    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
-    blob = net.packed_host()
-    _, pls = emu.parse(blob)
-    alts = emu.parse_alt(blob)
-    have = [i for i in range(len(alts)) if int(alts[i]["kind"]) == 1]
-    assert have and all(int(alts[i]["w_share"]) == 1 for i in have)
-    R = netref.RefNet(t, q, model)
-    outs = R.run(x)
-    for i in (11, 15, 24, 26, 45, 47, 52):
-        L = R.plan[i]
-        S = R.plan[L.src]
-        x_t = emu.nhwc(outs[L.src], _round_up(S.N, 16), perm=emu.perm_of(blob, pls[L.src], S.N))
-        res = outs[L.add_src] if L.add_src >= 0 else None
-        y = emu.conv_from_packed(blob, alts[i], L, x_t, res)
-        if L.endpool:
-            y = np.stack([O.global_avg(yi, L.endpool_mult) for yi in y]).reshape(y.shape[0], L.N, 1, 1)
-        np.testing.assert_array_equal(y, outs[i], err_msg=f"layer {i} alternative (shared tiles)")

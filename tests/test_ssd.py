@@ -67,8 +67,7 @@ def test_ssd300_small_width_oracle_vs_packed_emulation():
     for l in (15, 18, 20, 25, 28):                    # conv6 (dilated), stride-2 extras, head rows (25: on the L2Norm row)
         L = plan[l]
         xin = outs[L.src] if L.src >= 0 else x
-        perm = emu.perm_of(blob, pls[L.src], plan[L.src].N) if L.src >= 0 else None      # producers may store channels sorted by Q
-        got = emu.conv_from_packed(blob, pls[l], L, emu.nhwc(xin, int(pls[l]["Cp_in"]), perm=perm))
+        got = emu.conv_from_packed(blob, pls[l], L, emu.nhwc(xin, int(pls[l]["Cp_in"])))
         np.testing.assert_array_equal(got, outs[l], err_msg=f"layer {l}")
 
 

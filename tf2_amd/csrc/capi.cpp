@@ -146,8 +146,7 @@ tf2_status tf2_net_bind_device(tf2_net* net, const void* packed_dev, size_t n_by
 
 size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all) {
   if (!net || batch <= 0) return 0;
-  const WorkPlan* wp = net->impl.plan(batch, keep_all != 0);
-  return wp ? wp->total_bytes : 0;
+  return net->impl.workspace_size(batch, keep_all != 0);
 }
 
 size_t tf2_net_logits_size(const tf2_net* net, int batch) {

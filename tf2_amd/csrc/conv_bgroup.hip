@@ -430,295 +430,8 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
   }
 }
 
-// ---- the 56 x 56 maps (ResNet-50 stage 2: C = 256, M = 64) ---------------------------------------------------------------------
-// 3136 pixels per image and only 64 intermediate channels: the eight members are eight row bands of seven rows (392 pixels =
-// thirteen 32-pixel column tiles), each with ALL channels.  Reduce and 3x3: wave w owns column tiles w and w + 8 (two rounds) and
-// both 32-row tiles; the band's 3x3 output stays in LDS (the member needs nobody else's: ONE meeting per launch, after the
-// reduce, for the halo rows of the neighbouring bands).  Expand: wave w owns 32-row tile w of the 256 channels, weights in
-// registers (K = 64), thirteen column tiles.  Reduce and expand may be two-window layers (DUAL1 / DUAL3).
-template <bool DUAL1, bool DUAL3>
-__global__ __launch_bounds__(512, 2) void conv_bgroup56_kernel(BGroupArgs a) {
-  constexpr int HW = 56, C = 256, M = 64, PR = 7;
-  constexpr int NPX = HW * HW, NPB = PR * HW;            // 3136, 392
-  constexpr int NT = (NPB + 31) / 32;                    // 13 column tiles per band
-  constexpr int KS1 = C / 64;                            // 4
-  constexpr int NW1 = DUAL1 ? 2 : 1, NW3 = DUAL3 ? 2 : 1;
-  constexpr int HC = 64, HALO = (PR + 2) * HC * 64;      // 9 rows x 64 columns (58 used), one 64-channel slab: 36 KB
-  constexpr int kHdrSlots = 6;                           // reduce, 3x3, four 64-row m-tiles of the expand
-  constexpr int W_BYTES = 36 * 1024, R_BYTES = 64 * 1024;
-  static_assert(W_BYTES >= KS1 * NW1 * 4096 && W_BYTES >= 9 * 4096 && R_BYTES >= HALO + NT * 2048, "phase regions");
-  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  int8_t* const hdr_lds = lds;
-  int8_t* const wreg = lds + kHdrSlots * kBgHdrSlot;
-  int8_t* const work = wreg + W_BYTES;
-  int* const ctl = reinterpret_cast<int*>(work + R_BYTES);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
-  if (img >= a.B) return;
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const int drow = lane >> 2;
-  const size_t px_img = (size_t)img * NPX;
-  const size_t px_band = px_img + (size_t)m * NPB;
-  unsigned* const ctr = a.ctr + (size_t)img * 32;
-  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
-#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
-  BG_STAMP(0);
-  const int frow = lane & 31;
-  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
-  const i32x4 nores = {0, 0, 0, 0};
-
-  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {
-#pragma unroll
-    for (int g2 = 0; g2 < 2; g2++)
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
-  };
-  {
-    auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int slot) {
-      const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
-      for (int i = wave; i < kBgHdrSlot / 1024; i += 8)
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(hdr_lds + slot * kBgHdrSlot + i * 1024), 16, 0, 0);
-    };
-    hdr_dma(a.hdr1, a.hdr1_bytes, 0, 0);
-    hdr_dma(a.hdr2, a.hdr2_bytes, 0, 1);
-#pragma unroll
-    for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, q, 2 + q);
-    // the reduce's weights: [slab][window][two 32-row tiles]
-    for (int u = wave; u < KS1 * NW1 * 2; u += 8) {
-      const int s = u / (NW1 * 2), win = (u / 2) % NW1, ctq = u & 1;
-      w_dma(a.w1, ((size_t)s * NW1 + win) * 64 + 32 * ctq, wreg + u * 2048);
-    }
-    if (tid == 64 * 7) {
-      unsigned e;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-      ctl[0] = (int)e;
-    }
-  }
-  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-  const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
-  const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
-  unsigned tag = 0;
-  bool local0 = false;                                      // roll call: the whole group on this XCD
-
-  // =================================== phase A: reduce, 1x1 C -> M, two rounds of column tiles ===================================
-  {
-    int8_t* const ring = work + wave * (KS1 * 2048);        // all four slabs of a column tile in flight at once
-    auto issue_tile = [&](int t) {
-#pragma unroll
-      for (int s = 0; s < KS1; s++)
-#pragma unroll
-        for (int g2 = 0; g2 < 2; g2++) {
-          const int p = 32 * t + 16 * g2 + drow;
-          const int8_t* src = (t < NT && p < NPB) ? a.x + (px_band + p) * C + s * 64 + chunk * 16 : a.zero + chunk * 16;
-          __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + s * 2048 + g2 * 1024), 16, 0, 0);
-        }
-    };
-    issue_tile(wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // headers and the reduce's weights are in LDS
-    BG_STAMP(1);
-    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
-    bg_rollcall_post(ctr, m, tag, tid);
-    const int lo_b = a.relu1 ? 0 : -128;
-#pragma unroll
-    for (int rd = 0; rd < 2; rd++) {
-      const int t = wave + 8 * rd;
-      i32x16 acc[2], accl[DUAL1 ? 2 : 1];
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acc[q][r] = 0; if (DUAL1) accl[q][r] = 0; }
-      if (rd == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (round 0's stores and this round's pixels)
-#pragma unroll
-      for (int s = 0; s < KS1; s++) {
-        const int8_t* A = wreg + s * (NW1 * 4096);
-        const int8_t* B = ring + s * 2048;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-          const i32x4 b = *reinterpret_cast<const i32x4*>(B + (fr0 ^ (ks << 5)));
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const i32x4 ah = *reinterpret_cast<const i32x4*>(A + q * 2048 + (fr0 ^ (ks << 5)));
-            acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, b, acc[q], 0, 0, 0);
-            if (DUAL1) {
-              const i32x4 al = *reinterpret_cast<const i32x4*>(A + 4096 + q * 2048 + (fr0 ^ (ks << 5)));
-              accl[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, b, accl[q], 0, 0, 0);
-            }
-          }
-        }
-      }
-      asm volatile("" ::: "memory");
-      if (rd == 0) issue_tile(wave + 8);                   // next round's pixels fly behind this round's requantisation
-      if (DUAL1) {
-        const int* dsh = prm1 + (kPrmWordsPerRow + 1) * 64;
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-          for (int G = 0; G < 4; G++) {
-            const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 32 * q + 4 * half + 8 * G);
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
-          }
-      }
-      const int p = 32 * t + (lane & 31);
-      if (rd == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        int a16[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
-        i32x4 out;
-        if (a.fast1 == 1) out = requant_tile16<false, 0, true>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, false);
-        else out = requant_tile16<false, 0, false>(a16, prm1, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
-        if (t < NT && p < NPB) {
-          int8_t* dst = a.mid1 + (px_band + p) * M + 32 * q + 16 * half;
-          bg_store_x(dst, out, local0);
-        }
-      }
-    }
-  }
-  BG_STAMP(2);
-  bg_signal(ctr + 8, m, tag, tid);
-  BG_STAMP(3);
-  // the 3x3's weights: [tap][two 32-row tiles]
-  for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
-  BG_STAMP(4);
-
-  // =================================== phase B: 3x3 / pad 1, M -> M; the band's output stays in LDS ===================================
-  int8_t* const tiles = work + HALO;                       // [column tile][32 pixels][64]: B operand of the expand
-  {
-    int8_t* const halo = work;                             // [9 x 64 halo pixels][64], halo (r, c) = pixel (7 m - 1 + r, c - 1)
-    constexpr int NGRP = (PR + 2) * HC / 16;               // 36 groups of 16 halo pixels
-    for (int grp = wave; grp < NGRP; grp += 8) {
-      const int h = grp * 16 + drow;
-      const int row = m * PR - 1 + (h >> 6), col = (h & 63) - 1;
-      const bool ok = (unsigned)row < (unsigned)HW && (unsigned)col < (unsigned)HW;
-      const int8_t* src = ok ? a.mid1 + (px_img + row * HW + col) * M + chunk * 16 : a.zero2 + chunk * 16;
-      if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 1);
-      else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // halo and weights complete in every wave
-    BG_STAMP(5);
-    const int lo_b = a.relu2 ? 0 : -128;
-#pragma unroll
-    for (int rd = 0; rd < 2; rd++) {
-      const int t = wave + 8 * rd;
-      if (t < NT) {
-        int p = 32 * t + (lane & 31);
-        const bool ok = p < NPB;
-        if (!ok) p = 0;
-        const int oh = p / HW, ow = p - oh * HW;
-        const int h0 = oh * HC + ow;
-        i32x16 acc[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[q][r] = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-          const int8_t* A = wreg + tap * 4096;
-          const int h = h0 + (tap / 3) * HC + tap % 3;
-          const int ba = h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
-          const i32x4 b0 = *reinterpret_cast<const i32x4*>(halo + ba), b1 = *reinterpret_cast<const i32x4*>(halo + (ba ^ 32));
-          const i32x4 a00 = *reinterpret_cast<const i32x4*>(A + fr0), a01 = *reinterpret_cast<const i32x4*>(A + (fr0 ^ 32));
-          const i32x4 a10 = *reinterpret_cast<const i32x4*>(A + 2048 + fr0), a11 = *reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32));
-          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a00, b0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a10, b0, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a01, b1, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a11, b1, acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
-          i32x4 out;
-          if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, false);
-          else out = requant_tile16<false, 0, false>(a16, prm2, 64, 32 * q + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
-          const int row = lane & 31, c = 2 * q + half;    // B-operand layout of the expand: pixel row, 16-byte chunk c of its 64 channels
-          *reinterpret_cast<i32x4*>(tiles + t * 2048 + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;
-          if (ok) *reinterpret_cast<i32x4*>(a.mid2 + (px_band + 32 * t + row) * M + 32 * q + 16 * half) = out;      // (the row's own tensor: tf2_net_read_layer)
-        }
-      }
-    }
-  }
-  BG_STAMP(6);
-  // the expand's weights of this wave (32-row tile `wave` of the 256 channels): K = 64 -> two fragments per window, in registers
-  const int ch3 = 32 * wave;
-  const int mt3 = ch3 / 64, ro3 = ch3 % 64;
-  i32x4 wf[NW3][2];
-#pragma unroll
-  for (int win = 0; win < NW3; win++) {
-    const int8_t* p = a.w3 + (((size_t)mt3 * NW3 + win) * 64 + ro3 + frow) * 64 + half * 16;
-    wf[win][0] = *reinterpret_cast<const i32x4*>(p); wf[win][1] = *reinterpret_cast<const i32x4*>(p + 32);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                         // the band's 3x3 output is complete in LDS
-  BG_STAMP(7); BG_STAMP(8); BG_STAMP(9);
-
-  // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
-  {
-    const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
-    const int* pm = reinterpret_cast<const int*>(hdr_lds + (2 + mt3) * kBgHdrSlot);
-    auto load_res = [&](int tt) -> i32x4 {
-      const int p = 32 * tt + (lane & 31);
-      const int8_t* rp = (a.has_res && p < NPB) ? a.res + (px_band + p) * a.res_cp + a.res_off + ch3 + 16 * half : a.zero;
-      return *reinterpret_cast<const i32x4*>(rp);
-    };
-    i32x4 rnext = load_res(0);
-#pragma unroll 1
-    for (int tt = 0; tt < NT; tt++) {
-      const i32x4 rcur = rnext;
-      if (tt + 1 < NT) rnext = load_res(tt + 1);
-      const int8_t* B = tiles + tt * 2048;
-      const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
-      i32x16 acc, acc1, accl, accl1;
-#pragma unroll
-      for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; accl[r] = 0; accl1[r] = 0; }
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][0], b0, acc, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][1], b1, acc1, 0, 0, 0);
-      if (DUAL3) {
-        accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NW3 - 1][0], b0, accl, 0, 0, 0);
-        accl1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NW3 - 1][1], b1, accl1, 0, 0, 0);
-      }
-      int a16[16];
-      if (DUAL3) {
-        const int* dsh = pm + (kPrmWordsPerRow + 1) * 64;
-#pragma unroll
-        for (int G = 0; G < 4; G++) {
-          const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + ro3 + 4 * half + 8 * G);
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            a16[G * 4 + r] = (int)((((unsigned)acc[G * 4 + r] + (unsigned)acc1[G * 4 + r]) << (d[r] & 31)) + (unsigned)accl[G * 4 + r] + (unsigned)accl1[G * 4 + r]);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
-      }
-      i32x4 out;
-      if (a.fast3 == 1) {
-        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rcur, false, false);
-        else out = requant_tile16<false, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
-      } else {
-        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
-        else out = requant_tile16<false, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
-      }
-      const int p = 32 * tt + (lane & 31);
-      if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
-    }
-  }
-  BG_STAMP(10);
-#undef BG_STAMP
-}
-
 // ---- the FIRST bottleneck of the 56 x 56 stage (ResNet-50 rows 1-4: projection shortcut 64 -> 256 | reduce 64 -> 64, 3x3, expand + residual)
-// Same bands as conv_bgroup56_kernel, with C_in = 64: the band's input pixels (392 x 64 bytes) stay in LDS from the reduce on, and
+// Eight row bands of seven rows per image (one per member), C_in = 64: the band's input pixels (392 x 64 bytes) stay in LDS from the reduce on, and
 // the expand's wave computes the SHORTCUT tile it needs as residual itself (K = 64: two MFMAs per window on the resident input
 // tile, its own requantisation) -- the shortcut's 25.7 MB map is neither written nor read back (with keep_s it is written, for
 // tf2_net_read_layer).  DUAL: reduce, expand and shortcut are two-window layers (ResNet-50), else all single.
@@ -967,377 +680,6 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
       if (p < NPB) *reinterpret_cast<i32x4*>(a.y + (px_band + p) * a.y_cp + a.y_off + ch3 + 16 * half) = out;
     }
   }
-}
-
-// ---- the FIRST bottleneck of the 14 x 14 stage (ResNet-50 rows 24-27: projection shortcut 512 -> 1024 / stride 2 | reduce 512 -> 256 on
-// the 28 x 28 map, 3x3 / stride 2 / pad 1, expand 256 -> 1024 + residual) in one launch.  Members by channel as on the 14 x 14 maps:
-// 32 intermediate channels, 128 output channels each.  Phases:
-//   A  reduce on the 784 input pixels: wave w streams column tiles w, w + 8, ... (25 tiles) through its private ring, the member's
-//      32 weight rows (both windows) LDS-resident; the requantised tiles wait in registers and are stored behind the K stream;
-//   S  the shortcut, between "signal" and "wait" of the first meeting (it needs nobody else's data): 1x1 / stride 2 on the even
-//      pixels, two passes of two 32-row tiles (64 KB of weights per pass), its requantised output goes to the shortcut's own
-//      tensor and comes back in phase C as the residual;
-//   B  3x3 / stride 2: one 64-channel slab of the 28 x 28 intermediate at a time (30 rows x 32 columns, the columns split by parity so
-//      that a tap's 32 output pixels read consecutive LDS slots), 72 KB of weights resident;
-//   C  expand + residual, outputs and residual through an LDS image of the member's [196 pixels][128 channels].
-// DUAL: reduce and shortcut are two-window layers.
-template <bool DUAL>
-__global__ __launch_bounds__(512, 2) void conv_bgroup14f_kernel(BGroupArgs a) {
-  constexpr int HWI = 28, HWO = 14, CIN = 512, M = 256, COUT = 1024;
-  constexpr int NPI = HWI * HWI, NPO = HWO * HWO;        // 784, 196
-  constexpr int NTI = (NPI + 31) / 32, NTO = (NPO + 31) / 32;      // 25, 7
-  constexpr int KS1 = CIN / 64, KS2 = M / 64;            // 8, 4
-  constexpr int NWN = DUAL ? 2 : 1;
-  constexpr int S = 4;
-  constexpr int HROWS = HWI + 2, HSLAB = HROWS * 32 * 64;         // halo slab: 30 rows x 32 slots (parity-split columns): 60 KB
-  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-  int8_t* const hdr_lds = lds;                           // [reduce 4 KB][3x3 2 KB][pad 2 KB][expand 2 x 2 KB][shortcut 2 x 2 KB]
-  int8_t* const wreg = lds + 16 * 1024;                  // 72 KB
-  int8_t* const work = wreg + 72 * 1024;                 // 64 KB
-  int* const ctl = reinterpret_cast<int*>(work + 64 * 1024);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5;
-  const int img = a.img0 + ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 6), m = ((int)blockIdx.x >> 3) & 7;
-  if (img >= a.B) return;
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const int drow = lane >> 2;
-  const size_t pxi_img = (size_t)img * NPI, pxo_img = (size_t)img * NPO;
-  unsigned* const ctr = a.ctr + (size_t)img * 32;
-  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bgroup_timeline.py
-#define BG_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
-  BG_STAMP(0);
-  const int frow = lane & 31;
-  const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
-  const i32x4 nores = {0, 0, 0, 0};
-  const int c1 = 32 * m;                                 // first intermediate channel of this member
-  const int mt1 = c1 / a.tm1, ro1 = c1 % a.tm1;
-  const int mt2 = c1 / a.tm2, ro2 = c1 % a.tm2;
-  const int c3 = 128 * m;                                // first output channel (expand and shortcut)
-
-  auto w_dma = [&](const int8_t* w, size_t row0, int8_t* dst) {
-#pragma unroll
-    for (int g2 = 0; g2 < 2; g2++)
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(w + (row0 + 16 * g2 + drow) * 64 + chunk * 16), TF2_LDS_PTR(dst + g2 * 1024), 16, 0, 0);
-  };
-  auto hdr_dma = [&](const int32_t* hdr, int hdr_bytes, int mt, int tm, int nwords, int8_t* dst) {
-    const int used = (nwords * tm * 4 + 1023) & ~1023;
-    const int8_t* src = reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + lane * 16;
-    for (int i = wave; i * 1024 < used; i += 8)
-      __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src + i * 1024), TF2_LDS_PTR(dst + i * 1024), 16, 0, 0);
-  };
-  int8_t* const hdr1 = hdr_lds, * const hdr2 = hdr_lds + 4096, * const hdr3 = hdr_lds + 8192, * const hdrs = hdr_lds + 12288;
-  hdr_dma(a.hdr1, a.hdr1_bytes, mt1, a.tm1, kPrmWordsPerRow + 2, hdr1);
-  hdr_dma(a.hdr2, a.hdr2_bytes, mt2, a.tm2, kPrmWordsPerRow, hdr2);
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    hdr_dma(a.hdr3, a.hdr3_bytes, c3 / 64 + q, 64, kPrmWordsPerRow, hdr3 + q * 2048);
-    hdr_dma(a.hdrs, a.hdrs_bytes, c3 / 64 + q, 64, kPrmWordsPerRow + 2, hdrs + q * 2048);
-  }
-  // the reduce's weights: [slab][window][32 rows]
-  for (int u = wave; u < KS1 * NWN; u += 8) {
-    const int sl = u / NWN, win = u % NWN;
-    w_dma(a.w1, (((size_t)mt1 * KS1 + sl) * NWN + win) * a.tm1 + ro1, wreg + u * 2048);
-  }
-  if (tid == 64 * 7) {
-    unsigned e;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-    ctl[0] = (int)e;
-  }
-  const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-  const int* const prm1 = reinterpret_cast<const int*>(hdr1);
-  const int* const prm2 = reinterpret_cast<const int*>(hdr2);
-  int8_t* const ring = work + wave * (S * 2048);
-
-  auto combine = [&](i32x16& hi, const i32x16& lo, const int* prm, int tm, int row0) {     // (hi << dshift[1][row]) + lo
-    const int* dsh = prm + (kPrmWordsPerRow + 1) * tm;
-#pragma unroll
-    for (int G = 0; G < 4; G++) {
-      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + row0 + 4 * half + 8 * G);
-#pragma unroll
-      for (int r = 0; r < 4; r++) hi[G * 4 + r] = (int)(((unsigned)hi[G * 4 + r] << (d[r] & 31)) + (unsigned)lo[G * 4 + r]);
-    }
-  };
-
-  // =================================== phase A: reduce, 1x1 CIN -> M on the 28 x 28 map ===================================
-  unsigned tag = 0;
-  bool local0 = false;
-  {
-    const int ntl = (NTI - wave + 7) / 8;                  // column tiles of this wave: wave, wave + 8, ...
-    const int nstep = ntl * KS1;
-    auto issue = [&](int g, int slot) {
-      const int t = wave + 8 * (g / KS1), sl = g % KS1;
-#pragma unroll
-      for (int g2 = 0; g2 < 2; g2++) {
-        const int p = 32 * t + 16 * g2 + drow;
-        const int8_t* src = p < NPI ? a.x + (pxi_img + p) * CIN + sl * 64 + chunk * 16 : a.zero + chunk * 16;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * 2048 + g2 * 1024), 16, 0, 0);
-      }
-    };
-#pragma unroll
-    for (int g = 0; g < S - 1; g++) issue(g, g);          // (every wave has at least three tiles)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // headers and the reduce's weights are in LDS
-    BG_STAMP(1);
-    tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
-    bg_rollcall_post(ctr, m, tag, tid);
-    i32x4 outs[4];                                         // the requantised tiles of this wave, stored behind the K stream
-    i32x16 acc, accl;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
-    const int lo_b = a.relu1 ? 0 : -128;
-    int cs = 0, is = S - 1;
-    for (int g = 0; g < nstep; g++) {
-      if (g >= S - 1) { if (g + 2 < nstep) bg_wait_vmcnt<4>(); else if (g + 1 < nstep) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
-      const int sl = g % KS1;
-      const int8_t* A = wreg + sl * (NWN * 2048);
-      const int8_t* B = ring + cs * 2048;
-      const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + fr0), b1 = *reinterpret_cast<const i32x4*>(B + (fr0 ^ 32));
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), b0, acc, 0, 0, 0);
-      if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + fr0), b0, accl, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), b1, acc, 0, 0, 0);
-      if (DUAL) accl = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 2048 + (fr0 ^ 32)), b1, accl, 0, 0, 0);
-      if (g + S - 1 < nstep) { issue(g + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
-      cs = cs + 1 == S ? 0 : cs + 1;
-      if (sl == KS1 - 1) {
-        if (DUAL) combine(acc, accl, prm1, a.tm1, ro1);
-        int a16[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) a16[r] = acc[r];
-        i32x4 out;
-        if (a.fast1 == 1) out = requant_tile16<false, 0, true>(a16, prm1, a.tm1, ro1 + 4 * half, lo_b, -128, nores, a.dbl1 != 0, false);
-        else out = requant_tile16<false, 0, false>(a16, prm1, a.tm1, ro1 + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
-        const int ti = g / KS1;
-        if (ti == 0) outs[0] = out; else if (ti == 1) outs[1] = out; else if (ti == 2) outs[2] = out; else outs[3] = out;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acc[r] = 0; accl[r] = 0; }
-      }
-    }
-    BG_STAMP(2);
-    local0 = bg_rollcall_wave(ctr, tag, lane);
-#pragma unroll
-    for (int ti = 0; ti < 4; ti++) {
-      const int p = 32 * (wave + 8 * ti) + (lane & 31);
-      if (ti < ntl && p < NPI) bg_store_x(a.mid1 + (pxi_img + p) * M + c1 + 16 * half, outs[ti], local0);
-    }
-  }
-  bg_signal(ctr + 8, m, tag, tid);
-  BG_STAMP(3);
-
-  // =================================== phase S: the shortcut, 1x1 / stride 2 CIN -> COUT (this member: 128 channels) ===================================
-  {
-    const bool worker = wave < NTO;
-    const int t = wave;
-    // this lane's LDS-DMA rows: output pixel p -> input pixel (2 oh) * 28 + 2 ow
-    auto src_px = [&](int p) { const int oh = p / HWO, ow = p - oh * HWO; return (2 * oh) * HWI + 2 * ow; };
-    int srow[2];
-#pragma unroll
-    for (int g2 = 0; g2 < 2; g2++) { const int p = 32 * t + 16 * g2 + drow; srow[g2] = (worker && p < NPO) ? src_px(p) : -1; }
-    auto issue = [&](int sl, int slot) {
-#pragma unroll
-      for (int g2 = 0; g2 < 2; g2++) {
-        const int8_t* src = srow[g2] >= 0 ? a.x + (pxi_img + srow[g2]) * CIN + sl * 64 + chunk * 16 : a.zero + chunk * 16;
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(ring + slot * 2048 + g2 * 1024), 16, 0, 0);
-      }
-    };
-    const int lo_s = a.relu_s ? 0 : -128;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-      // weights of the pass: [slab][window][two 32-row tiles] of channels c3 + 64 pass ..
-      for (int u = wave; u < KS1 * NWN * 2; u += 8) {
-        const int sl = u / (NWN * 2), win = (u / 2) % NWN, q = u & 1;
-        const int ch = c3 + 64 * pass + 32 * q;
-        w_dma(a.ws, (((size_t)(ch / 64) * KS1 + sl) * NWN + win) * 64 + ch % 64, wreg + u * 2048);
-      }
-      if (worker) {
-#pragma unroll
-        for (int sl = 0; sl < S - 1; sl++) issue(sl, sl);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                     // the pass's weights are in LDS
-      if (worker) {
-        i32x16 acc[2], accl[DUAL ? 2 : 1];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) { acc[q][r] = 0; if (DUAL) accl[q][r] = 0; }
-        int cs = 0, is = S - 1;
-        for (int sl = 0; sl < KS1; sl++) {
-          if (sl >= S - 1) { if (sl + 2 < KS1) bg_wait_vmcnt<4>(); else if (sl + 1 < KS1) bg_wait_vmcnt<2>(); else bg_wait_vmcnt<0>(); }
-          const int8_t* A = wreg + sl * (NWN * 4096);
-          const int8_t* B = ring + cs * 2048;
-#pragma unroll
-          for (int ks = 0; ks < 2; ks++) {
-            const i32x4 b = *reinterpret_cast<const i32x4*>(B + (fr0 ^ (ks << 5)));
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-              acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + q * 2048 + (fr0 ^ (ks << 5))), b, acc[q], 0, 0, 0);
-              if (DUAL) accl[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + 4096 + q * 2048 + (fr0 ^ (ks << 5))), b, accl[q], 0, 0, 0);
-            }
-          }
-          if (sl + S - 1 < KS1) { issue(sl + S - 1, is); is = is + 1 == S ? 0 : is + 1; }
-          cs = cs + 1 == S ? 0 : cs + 1;
-        }
-        const int p = 32 * t + (lane & 31);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          const int ch = c3 + 64 * pass + 32 * q;
-          const int* ps = reinterpret_cast<const int*>(hdrs + pass * 2048);
-          if (DUAL) combine(acc[q], accl[q], ps, 64, 32 * q);
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
-          i32x4 rs;
-          if (a.fast_s == 1) rs = requant_tile16<false, 0, true>(a16, ps, 64, 32 * q + 4 * half, lo_s, -128, nores, false, false);
-          else rs = requant_tile16<false, 0, false>(a16, ps, 64, 32 * q + 4 * half, lo_s, -128, nores, false, a.fast_s == 2);
-          if (p < NPO) *reinterpret_cast<i32x4*>(a.ys + (pxo_img + p) * a.ys_cp + ch + 16 * half) = rs;
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();                                     // every wave is done with the pass's weights
-    }
-  }
-  BG_STAMP(4);
-  // the 3x3's weights: [step e = tap * KS2 + slab][32 rows]
-  for (int e = wave; e < 9 * KS2; e += 8) w_dma(a.w2, ((size_t)mt2 * 9 * KS2 + e) * a.tm2 + ro2, wreg + e * 2048);
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
-  BG_STAMP(5);
-
-  // =================================== phase B: 3x3 / stride 2 / pad 1, one input slab at a time ===================================
-  {
-    int8_t* const halo = work;                             // [30 rows][parity 2][16 columns][64]: halo (r, c) = pixel (r - 1, c - 1)
-    const bool worker = wave < NTO;
-    int p = 32 * wave + (lane & 31);
-    const bool p_ok = worker && p < NPO;
-    if (!p_ok) p = 0;
-    const int oh = p / HWO, ow = p - oh * HWO;
-    i32x16 acc, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc[r] = 0; acc1[r] = 0; }
-#pragma unroll 1
-    for (int sl = 0; sl < KS2; sl++) {
-      if (sl) __syncthreads();                             // every wave is done with the previous slab
-      for (int grp = wave; grp < HROWS * 2; grp += 8) {   // 60 groups of 16 slots
-        const int h = grp * 16 + drow;
-        const int hr = h >> 5, par = (h >> 4) & 1, j = h & 15;
-        const int row = hr - 1, col = 2 * j + par - 1;
-        const bool ok = (unsigned)row < (unsigned)HWI && (unsigned)col < (unsigned)HWI;
-        const int8_t* src = ok ? a.mid1 + (pxi_img + row * HWI + col) * M + sl * 64 + chunk * 16 : a.zero2 + sl * 64 + chunk * 16;
-        if (local1) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 1);
-        else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(halo + grp * 1024), 16, 0, 16);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                     // the slab (and, the first time, the weights) complete in every wave
-      if (worker) {
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-          const int dh = tap / 3, dw = tap % 3;
-          // input pixel (2 oh - 1 + dh, 2 ow - 1 + dw) -> halo (2 oh + dh, 2 ow + dw): parity dw & 1, slot ow + (dw >> 1)
-          const int h = (2 * oh + dh) * 32 + (dw & 1) * 16 + ow + (dw >> 1);
-          const int ba = h * 64 + ((half ^ ((h >> 2) & 3)) << 4);
-          const int8_t* A = wreg + (tap * KS2 + sl) * 2048;
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + fr0), *reinterpret_cast<const i32x4*>(halo + ba), acc, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A + (fr0 ^ 32)), *reinterpret_cast<const i32x4*>(halo + (ba ^ 32)), acc1, 0, 0, 0);
-        }
-      }
-    }
-    if (worker) {
-      int a16[16];
-#pragma unroll
-      for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
-      const int lo_b = a.relu2 ? 0 : -128;
-      i32x4 out;
-      if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm2, a.tm2, ro2 + 4 * half, lo_b, -128, nores, a.dbl2 != 0, false);
-      else out = requant_tile16<false, 0, false>(a16, prm2, a.tm2, ro2 + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
-      if (p_ok) bg_store_x(a.mid2 + (pxo_img + p) * M + c1 + 16 * half, out, local0);
-    }
-  }
-  BG_STAMP(6);
-  bg_signal(ctr + 16, m, tag, tid);
-  BG_STAMP(7);
-  // the expand's weights: [32-row tile][slab]; the shortcut's output of this member comes back as the residual, through an LDS image
-  // [196 pixels][128 channels] (row px keeps its eight 16-byte pieces XOR-swizzled with px & 7), which then takes the outputs
-  for (int u = wave; u < 4 * KS2; u += 8) {
-    const int ch = c3 + 32 * (u / KS2);
-    w_dma(a.w3, ((size_t)(ch / 64) * KS2 + u % KS2) * 64 + ch % 64, wreg + u * 2048);
-  }
-  int8_t* const stage = wreg + 4 * KS2 * 2048;             // 32 KB of weights, then 25 KB of staging
-  constexpr int NCHUNK = (NPO * 128 + 1023) / 1024;        // 1 KiB = eight pixel rows of 128 bytes
-  for (int ci = wave; ci < NCHUNK; ci += 8) {
-    const int px = 8 * ci + (lane >> 3), q = (lane & 7) ^ (px & 7);
-    const int8_t* src = px < NPO ? a.ys + (pxo_img + px) * a.ys_cp + c3 + q * 16 : a.zero;
-    __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(stage + ci * 1024), 16, 0, 0);
-  }
-  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
-  BG_STAMP(8);
-
-  // =================================== phase C: expand, 1x1 M -> COUT, + residual ===================================
-  {
-    const bool worker = wave < NTO;
-    const int t = wave;
-    int8_t* const tile = work + wave * (KS2 * 2048);
-    if (worker) {
-#pragma unroll
-      for (int sl = 0; sl < KS2; sl++)
-#pragma unroll
-        for (int g2 = 0; g2 < 2; g2++) {
-          const int p = 32 * t + 16 * g2 + drow;
-          const int8_t* src = p < NPO ? a.mid2 + (pxo_img + p) * M + sl * 64 + chunk * 16 : a.zero + chunk * 16;
-          if (local2) __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tile + sl * 2048 + g2 * 1024), 16, 0, 1);
-          else __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(tile + sl * 2048 + g2 * 1024), 16, 0, 16);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // expand weights, residual image (fetched by every wave), this wave's tile
-    BG_STAMP(9);
-    if (worker) {
-      const int lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
-      const int pxl = 32 * t + (lane & 31);
-#pragma unroll
-      for (int pair = 0; pair < 2; pair++) {
-        i32x16 acc[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[q][r] = 0;
-#pragma unroll
-        for (int sl = 0; sl < KS2; sl++) {
-          const i32x4 b0 = *reinterpret_cast<const i32x4*>(tile + sl * 2048 + fr0), b1 = *reinterpret_cast<const i32x4*>(tile + sl * 2048 + (fr0 ^ 32));
-          const int8_t* A0 = wreg + ((2 * pair + 0) * KS2 + sl) * 2048;
-          const int8_t* A1 = wreg + ((2 * pair + 1) * KS2 + sl) * 2048;
-          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A0 + fr0), b0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A1 + fr0), b0, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A0 + (fr0 ^ 32)), b1, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(A1 + (fr0 ^ 32)), b1, acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          const int ctq = 2 * pair + q;
-          const int* pm = reinterpret_cast<const int*>(hdr3 + (ctq >> 1) * 2048);
-          int8_t* const slot = stage + pxl * 128 + ((((2 * ctq + half) ^ (pxl & 7))) << 4);
-          const i32x4 rcur = *reinterpret_cast<const i32x4*>(slot);
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
-          i32x4 out;
-          if (a.fast3 == 1) out = requant_tile16<true, 0, true>(a16, pm, 64, 32 * (ctq & 1) + 4 * half, lo_b, rlo, rcur, false, false);
-          else out = requant_tile16<true, 0, false>(a16, pm, 64, 32 * (ctq & 1) + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
-          *reinterpret_cast<i32x4*>(slot) = out;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                       // the member's outputs are complete in LDS
-    for (int ci = wave; ci < NCHUNK; ci += 8) {
-      const int px = 8 * ci + (lane >> 3), q = (lane & 7) ^ (px & 7);
-      const i32x4 v = *reinterpret_cast<const i32x4*>(stage + ci * 1024 + lane * 16);
-      if (px < NPO) *reinterpret_cast<i32x4*>(a.y + (pxo_img + px) * a.y_cp + a.y_off + c3 + q * 16) = v;
-    }
-  }
-  BG_STAMP(10);
-#undef BG_STAMP
 }
 
 // ---- the 28 x 28 maps (ResNet-50 stage 3: C = 512, M = 128) --------------------------------------------------------------------
@@ -2078,39 +1420,17 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
 size_t conv_bgroup_lds_bytes(int HW, int C, int M) {
   if (HW == 7) return 6 * (size_t)kBgHdrSlot + 96 * 1024 + 48 * 1024 + 64;
   if (HW == 28) return 4 * 4096 + 72 * 1024 + 7 * 5 * 2048 + 64;
-  if (HW == 56) return 6 * (size_t)kBgHdrSlot + 36 * 1024 + 64 * 1024 + 64;
   const int KS2 = M / 64;
   return 4 * (size_t)kBgHdrSlot + (size_t)9 * KS2 * 2048 + (size_t)KS2 * 256 * 64 + 64 + 64;     // + the control words behind the work region
 }
 
 bool conv_bgroup_shape_ok(int HW, int C, int M) {
-  return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128) ||
-         (HW == 56 && C == 256 && M == 64);
+  return (HW == 14 && C == 1024 && M == 256) || (HW == 7 && C == 2048 && M == 512) || (HW == 28 && C == 512 && M == 128);
 }
 
-// the first bottleneck of the 14 x 14 stage (rows: shortcut / 2, reduce on 28 x 28, 3x3 / 2, expand): conv_bgroup14f_kernel
-static int launch_conv_bgroup_first14(const BGroupArgs& a, hipStream_t s) {
-  const size_t lds = 16 * 1024 + 72 * 1024 + 64 * 1024 + 64;
-  const void* fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup14f_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup14f_kernel<false>);
-  if (!lds_attr_once(fn)) return -1;
-  for (int i0 = 0; i0 < a.B; i0 += 32) {
-    BGroupArgs b = a;
-    b.img0 = i0;
-    const int n = std::min(32, a.B - i0);
-    const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    TF2_LAUNCH_NAME("conv_bgroup14f_kernel<shortcut 512->1024 /2 | 512->256 on 28x28, 3x3 /2, ->1024%s> (8 blocks per image, images %d..%d)", a.dual1 ? ",dual" : "", i0, i0 + n - 1);
-    if (a.dual1) TF2_LAUNCH((conv_bgroup14f_kernel<true>), grid, dim3(512), lds, s, b);
-    else TF2_LAUNCH((conv_bgroup14f_kernel<false>), grid, dim3(512), lds, s, b);
-    if (!launch_ok()) return -1;
-  }
-  return 0;
-}
-
-// the first bottleneck of the 56 x 56 stage (rows: shortcut, reduce, 3x3, expand): conv_bgroup56f_kernel; a.first_shape == 14: the
-// 14 x 14 stage's
+// the first bottleneck of the 56 x 56 stage (rows: shortcut, reduce, 3x3, expand): conv_bgroup56f_kernel
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.first_shape == 14) return launch_conv_bgroup_first14(a, s);
   const size_t lds = 10 * (size_t)kBgHdrSlot + 36 * 1024 + 36 * 1024 + 2 * 13 * 2048 + 64;
   const void* fn = a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56f_kernel<true>) : reinterpret_cast<const void*>(conv_bgroup56f_kernel<false>);
   if (!lds_attr_once(fn)) return -1;
@@ -2131,7 +1451,7 @@ int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bgroup_shape_ok(HW, C, M)) return 1;
-  if (n_chain < 1 || n_chain > kBgMaxChain || (n_chain > 1 && HW == 56)) return 1;
+  if (n_chain < 1 || n_chain > kBgMaxChain) return 1;
   const BGroupArgs& a = chain[0];
   const BGroupArgs& z = chain[n_chain - 1];            // (7 x 7: the LAST bottleneck of a chain may end in the global average)
   for (int k = 1; k < n_chain; k++)
@@ -2139,8 +1459,6 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
   const size_t lds = conv_bgroup_lds_bytes(HW, C, M);
   const void* fn = nullptr;
   if (HW == 14) fn = reinterpret_cast<const void*>(conv_bgroup_kernel<14, 1024, 256>);
-  else if (HW == 56) fn = a.dual3 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup56_kernel<false, true>))
-                                  : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup56_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup56_kernel<false, false>));
   else if (HW == 28) fn = a.dual2 ? (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, true>))
                                   : (a.dual1 ? reinterpret_cast<const void*>(conv_bgroup28_kernel<true, false>) : reinterpret_cast<const void*>(conv_bgroup28_kernel<false, false>));
   else if (a.dual1) fn = z.avg_mult ? reinterpret_cast<const void*>(conv_bgroup7_kernel<true, true>) : reinterpret_cast<const void*>(conv_bgroup7_kernel<true, false>);
@@ -2156,17 +1474,13 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
     if (n_chain > 1) TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> x %d bottlenecks (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
                                      (HW != 14 && a.dual1) ? ",dual reduce" : "", a.dual2 ? ",dual 3x3" : "", z.avg_mult ? ",global average" : "", n_chain, i0, i0 + n - 1);
-    else TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : HW == 56 ? "56" : "", HW, HW, C, M,
+    else TF2_LAUNCH_NAME("conv_bgroup%s_kernel<%dx%d,C%d,M%d%s%s%s> (8 blocks per image, images %d..%d)", HW == 7 ? "7" : HW == 28 ? "28" : "", HW, HW, C, M,
                     (HW != 14 && a.dual1) ? (a.dual2 ? ",dual reduce,dual 3x3" : ",dual reduce") : (a.dual2 ? ",dual 3x3" : ""), a.dual3 ? ",dual expand" : "",
                     a.avg_mult ? ",global average" : "", i0, i0 + n - 1);
     BGroupChain c;
     c.n = n_chain;
     for (int k = 0; k < n_chain; k++) { c.b[k] = chain[k]; c.b[k].img0 = i0; }
     if (HW == 14) TF2_LAUNCH((conv_bgroup_kernel<14, 1024, 256>), grid, dim3(512), lds, s, c);
-    else if (HW == 56 && a.dual1 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<true, true>), grid, dim3(512), lds, s, b);
-    else if (HW == 56 && a.dual3) TF2_LAUNCH((conv_bgroup56_kernel<false, true>), grid, dim3(512), lds, s, b);
-    else if (HW == 56 && a.dual1) TF2_LAUNCH((conv_bgroup56_kernel<true, false>), grid, dim3(512), lds, s, b);
-    else if (HW == 56) TF2_LAUNCH((conv_bgroup56_kernel<false, false>), grid, dim3(512), lds, s, b);
     else if (HW == 28 && a.dual2 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, true>), grid, dim3(512), lds, s, c);
     else if (HW == 28 && a.dual2) TF2_LAUNCH((conv_bgroup28_kernel<false, true>), grid, dim3(512), lds, s, c);
     else if (HW == 28 && a.dual1) TF2_LAUNCH((conv_bgroup28_kernel<true, false>), grid, dim3(512), lds, s, c);

@@ -74,31 +74,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DENSE (ConvArgs::dense): the gather words of a step come from its index (tf2_device.h dense_gather) instead of the header's
 // goff / ghw tables and the m-tile's entry range is mtile * nslab .. + nslab: nothing in front of the first DMAs but the
 // kernel arguments (one dependent scalar-load round trip and the LDS table reads of every step less).
-// PF (single-window DENSE layers on small grids, S >= 4): the fragments of step it + 1 are read from LDS while the MFMAs of
-// step it run -- the wait + barrier for stage it + 1 moves in front of step it, so one ring stage of DMA slack is spent on
-// covering the LDS read latency.  With one block per CU (the 98-block 14x14 layers of the several-streams plan) a step was
-// wait -> barrier -> 6 ds_read_b128 -> 4 MFMAs strictly in sequence, two waves per SIMD and nobody to fill the gaps.
 // The body is a device function of (argument block, block index, grid size) so that ONE launch can carry two independent layers
 // (conv_mfma2_pair_kernel below: a stage's shortcut convolution next to the first 1x1 of its first bottleneck -- same input, no
 // dependence, same instantiation): blocks [0, n0) work on the first argument block, the rest on the second.
-// COH (chain launches, conv_mfma2_chain_kernel below): the block is one of a segment of a multi-layer launch.  It waits for the
-// pixel tiles it reads (ChainSeg, tf2_internal.h) after its header and before its first activation access, reads activations and
-// the residual with agent-scope (sc1) loads, writes its outputs with sc1 stores and counts itself finished once they are acknowledged:
-// inside one kernel the L2 of an XCD is not coherent with the other XCDs' (MI355X_MICROARCH.md), sc1 accesses go to the memory
-// side.  Weights and headers are constant for the whole launch and keep using the L2.
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false, bool COH = false>
-__device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk_x, const int nblk_x, const ChainSeg* seg = nullptr,
-                                                unsigned* ctr = nullptr, const int seg_index = 0) {
-  static_assert(!PF || (!DUAL && DENSE && S >= 4), "fragment prefetch: single-window dense layers, four ring stages");
-  static_assert(!COH || (DENSE && !PF), "chain segments: dense layers, plain loop");
-#ifndef TF2_CHAIN_SLEEP
-#define TF2_CHAIN_SLEEP 2
-#endif
-#ifndef TF2_CHAIN_VAR
-#define TF2_CHAIN_VAR 0      // timing experiments only (tools/chain_variants.sh): 1 plain loads, 2 plain stores, 4 no wait, 8 no completion count
-#endif
-  constexpr bool COH_LD = COH && !(TF2_CHAIN_VAR & 1), COH_ST = COH && !(TF2_CHAIN_VAR & 2), COH_WAIT = COH && !(TF2_CHAIN_VAR & 4), COH_SIG = COH && !(TF2_CHAIN_VAR & 8);
-  constexpr int kActAux = COH_LD ? 16 : 0;     // cache policy of activation LDS-DMAs: sc1 = agent scope
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
+__device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk_x, const int nblk_x) {
   constexpr int NW = WM * WN;                  // waves per block
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int NTM = WTM / 32, NTN = WTN / 32;   // 32x32 MFMA tiles per wave (rows, columns)
@@ -202,44 +182,6 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     for (int i = wave; i * 1024 < a_hdr_bytes; i += NW)
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(hsrc + i * 1024), TF2_LDS_PTR(hdst + i * 1024), 16, 0, 0);
   };
-  if constexpr (COH) {
-    // header first (constant data), then wait for the producing segments: everything after this point may read their outputs
-    issue_header();
-    if (COH_WAIT) {
-      // the producing segment's pixel tiles that cover this block's input pixels, one polling lane per tile; lane 0 of wave 1:
-      // this block's own tile of the residual's producer
-      const int p_first = px0, p_last = (px0 + TN < g.n_pix ? px0 + TN : g.n_pix) - 1;
-      int in_lo = p_first, in_hi = p_last;                 // 1x1 / stride 1: the same pixels
-      if (a_k != 1 || g.stride != 1) {
-        const int b0 = fast_div(p_first, g.ohw_m, g.ohw_s), b1 = fast_div(p_last, g.ohw_m, g.ohw_s);
-        const int oh0 = fast_div(p_first - b0 * g.OHW, g.ow_m, g.ow_s), oh1 = fast_div(p_last - b1 * g.OHW, g.ow_m, g.ow_s);
-        int ih_lo = oh0 * g.stride - g.pad_h, ih_hi = oh1 * g.stride - g.pad_h + (a_k - 1) * a_dil;
-        ih_lo = ih_lo < 0 ? 0 : ih_lo; ih_hi = ih_hi > g.H - 1 ? g.H - 1 : ih_hi;
-        in_lo = (b0 * g.H + ih_lo) * g.W; in_hi = (b1 * g.H + ih_hi) * g.W + g.W - 1;
-      }
-      const int t_lo = in_lo >> 7, t_hi = in_hi >> 7;
-      const int sc = seg->src_ctr, rc = seg->res_ctr;
-      const unsigned* cp = nullptr; unsigned need = 0;
-      if (wave == 0 && sc >= 0 && t_lo + lane <= t_hi) { cp = ctr + (size_t)(sc + t_lo + lane) * kChainCtrStride; need = (unsigned)seg->src_need; }
-      if (tid == 64 && rc >= 0) { cp = ctr + (size_t)(rc + ntile) * kChainCtrStride; need = (unsigned)seg->res_need; }
-      if (cp) {
-        int polls = 0;
-        while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-          __builtin_amdgcn_s_sleep(TF2_CHAIN_SLEEP);
-          if (++polls > (1 << 24)) __builtin_trap();        // never in a correct launch (ascending dispatch order): fail, do not hang
-        }
-      }
-      if (wave == 0 && sc >= 0)
-        for (int t = t_lo + 64 + lane; t <= t_hi; t += 64) {    // (more than 64 producer tiles: strided convolutions at odd shapes)
-          int polls = 0;
-          while (__hip_atomic_load(ctr + (size_t)(sc + t) * kChainCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)seg->src_need) {
-            __builtin_amdgcn_s_sleep(TF2_CHAIN_SLEEP);
-            if (++polls > (1 << 24)) __builtin_trap();
-          }
-        }
-    }
-    __syncthreads();
-  }
   // residual tile prefetch FIRST (ordinary loads, the oldest entries of this wave's VMEM queue: every counted
   // wait below covers them; first use is in the epilogue)
   const int half = lane >> 5;
@@ -253,15 +195,8 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
       const int px = px0 + wn * WTN + j * 32 + (lane & 31);
       const int chl = mtile * TM + wm * WTM + i * 32 + 16 * half;
       const bool ok = g.has_res && px < g.n_pix && chl + 16 <= g.y_nvalid;
-      if constexpr (COH_LD) {
-        // agent-scope buffer load; masked lanes point past the range and get zeros
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(ares ? ares : azero), 0, 0x7fffff00, 0x00020000);
-        const int voff = ok ? (int)((size_t)px * g.res_cp + g.res_off + chl) : 0x7fffff00;
-        resv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 16);
-      } else {
-        const int8_t* rp = ok ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
-        resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
-      }
+      const int8_t* rp = ok ? ares + (size_t)px * g.res_cp + g.res_off + chl : azero;
+      resv[i][j] = *reinterpret_cast<const i32x4*>(rp);
     }
   asm volatile("" ::: "memory");           // keep the residual loads OLDER than every DMA below
 
@@ -319,14 +254,14 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
           ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         }
         const int8_t* src = ok ? brow_ptr[j] + off : azero + pc;      // out of range: the stored form of x = 0 (weight_pack.cpp off_pad)
-        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + gi * 1024), 16, 0, kActAux);
+        __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(slot + gi * 1024), 16, 0, 0);
       }
     }
   };
 
   // ---- block start: header, then the first S-1 stages, all by LDS-DMA and all in flight together ----
   // VMEM queue of a wave: [residual, header, stage 0 .. stage S-2, then one stage per loop iteration]
-  if constexpr (!COH) issue_header();
+  issue_header();
 #pragma unroll
   for (int s = 0; s < S - 1; s++)
     if (s < n_ent) issue_stage(e_begin + s, pro_off[s], pro_hw[s], s);
@@ -450,62 +385,6 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     cslot = cslot + 1 == S ? 0 : cslot + 1;
   };
 
-  if constexpr (PF) {
-    // ---- K loop with the next step's fragments in flight -------------------------------------------------------------
-    struct Frag { i32x4 a[2][NTM], b[2][NTN]; };
-    auto read_frag = [&](Frag& f, int slot) {
-      const int8_t* A = lds + slot * STAGE;
-      const int8_t* B = A + A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < NTM; i++) {
-          const int row = wm * WTM + i * 32 + (lane & 31);
-          f.a[ks][i] = *reinterpret_cast<const i32x4*>(A + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < NTN; j++) {
-          const int row = wn * WTN + j * 32 + (lane & 31);
-          f.b[ks][j] = *reinterpret_cast<const i32x4*>(B + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-        }
-      }
-    };
-    auto mma = [&](const Frag& f) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-        for (int i = 0; i < NTM; i++)
-#pragma unroll
-          for (int j = 0; j < NTN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
-    };
-    Frag f0, f1;
-    read_frag(f0, 0);                        // stage 0 landed (wait + barrier above)
-    int rslot = 1;                           // ring slot of stage it + 1
-    // one step: stage it + 1 complete for everybody -> issue stage it + S - 1 into the slot of stage it - 1 -> read it + 1 -> MFMAs of it
-    auto pf_step = [&](int it_, const Frag& cur, Frag& nxt) {
-      if (it_ + 1 < n_ent) {
-        // stages it + 2 .. it + S - 2 may still fly -- while that many have been issued; in the tail everything must have landed
-        if (it_ + S - 2 < n_ent) { if (ni_hi) wait_vmcnt<(S - 3) * NI_HI>(); else wait_vmcnt<(S - 3) * NI_LO>(); }
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (it_ + S - 1 < n_ent) {
-          issue_stage(e_begin + it_ + S - 1, off_nx, hw_nx, islot);
-          islot = islot + 1 == S ? 0 : islot + 1;
-          gather_of(it_ + S, off_nx, hw_nx);
-        }
-        read_frag(nxt, rslot);
-        rslot = rslot + 1 == S ? 0 : rslot + 1;
-      }
-      mma(cur);
-    };
-    for (int it_ = 0; it_ < n_ent; it_ += 2) {
-      pf_step(it_, f0, f1);
-      if (it_ + 1 < n_ent) pf_step(it_ + 1, f1, f0);
-    }
-  } else {
   int it = 0;
   long long t_wait = 0, t_bar = 0, t_body = 0;     // dbg (tools/layer_times.py --stamps): cycles of block 0 / wave 0 in the vmcnt wait, the barrier, the step body
   for (; it < n_main; it++) {
@@ -531,7 +410,6 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     }
     body(it, false);
   }
-  }   // !PF
   if (DUAL) {
     // combine the two windows: (hi << dshift[1][row]) + lo   (Z/2^32, as the Horner form)
 #pragma unroll
@@ -576,20 +454,13 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
         const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j], g.dbl_out != 0, g.fast == 2);
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl);
-          if constexpr (COH_ST) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(out) : "memory");
-          else *dst = out;
+          *dst = out;
         }
       }
     }
   };
   if (g.fast == 1) { if (g.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
-  if constexpr (COH_SIG) {
-    // every store of every wave acknowledged at agent scope, then this block counts as finished
-    wait_vmcnt<0>();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ctr + (size_t)(seg->ctr_off + ntile) * kChainCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TF2_STAMP(6); }
   if (adbg2 && tid == 0) {
     long long* d = adbg2 + (size_t)blk_x * 8;
@@ -601,48 +472,29 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
 #undef TF2_STAMP
 }
 
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_kernel(ConvArgs a) {
-  conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, PF>(a, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // two independent layers of the same instantiation in one launch
 template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC) / 4) void conv_mfma2_pair_kernel(ConvArgs a0, ConvArgs a1, int n0) {
   const int b = (int)blockIdx.x;
-  if (b < n0) conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, false>(a0, b, n0);
-  else conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, false>(a1, b - n0, (int)gridDim.x - n0);
+  if (b < n0) conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>(a0, b, n0);
+  else conv_mfma2_body<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>(a1, b - n0, (int)gridDim.x - n0);
 }
 
-// consecutive layers in one launch (ChainSeg / ChainArgs, tf2_internal.h): the 8-wave 128 x 128 dense shape, every window /
-// padding form; a block finds its segment by its index, runs the ring-kernel body on that segment's argument block
-template <int S>
-__global__ __launch_bounds__(512, 4) void conv_mfma2_chain_kernel(ChainArgs c) {
-  const int b = (int)blockIdx.x;
-  int si = 0;
-  for (int i = 1; i < c.n_segs; i++) si += b >= c.seg_first[i] ? 1 : 0;
-  const ChainSeg* const sg = c.segs + si;
-  const int lb = b - sg->first_block;
-  const int nb = sg->n_blocks;
-  if (lb >= nb) return;                      // alignment filler between two segments
-  switch (sg->variant & 3) {
-    case 0: conv_mfma2_body<4, 2, 32, 64, S, 2, false, false, true, false, true>(sg->a, lb, nb, sg, c.ctr, si); break;
-    case 1: conv_mfma2_body<4, 2, 32, 64, S, 2, true, false, true, false, true>(sg->a, lb, nb, sg, c.ctr, si); break;
-    case 2: conv_mfma2_body<4, 2, 32, 64, S, 2, false, true, true, false, true>(sg->a, lb, nb, sg, c.ctr, si); break;
-    default: conv_mfma2_body<4, 2, 32, 64, S, 2, true, true, true, false, true>(sg->a, lb, nb, sg, c.ctr, si); break;
-  }
-}
-
-template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE, bool PF = false>
+template <int WM, int WN, int WTM, int WTN, int S, int OCC, bool PADCHK, bool DUAL, bool DENSE>
 static int launch_cfg3(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = WM * WTM, TN = WN * WTN;
   constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
   const size_t lds = (size_t)S * STAGE + (size_t)a.hdr_bytes + 64;
-  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE, PF>;
+  auto fn = conv_mfma2_kernel<WM, WN, WTM, WTN, S, OCC, PADCHK, DUAL, DENSE>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
   if (lds > 160 * 1024) return -3;
   const int ntiles = (a.g.n_pix + TN - 1) / TN;
-  TF2_LAUNCH_NAME("conv_mfma2_kernel<%dx%d waves of %dx%d,S%d,%s%s%s%s>", WM, WN, WTM, WTN, S, PADCHK ? "pad," : "", DUAL ? "dual," : "", DENSE ? "dense" : "tables", PF ? ",prefetch" : "");
+  TF2_LAUNCH_NAME("conv_mfma2_kernel<%dx%d waves of %dx%d,S%d,%s%s%s>", WM, WN, WTM, WTN, S, PADCHK ? "pad," : "", DUAL ? "dual," : "", DENSE ? "dense" : "tables");
   TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles), dim3(WM * WN * 64), lds, s, a);
   return launch_ok() ? 0 : -1;
 }
@@ -678,12 +530,6 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
     return -1;
   }
   if (TM == 128) {
-    // small grids with a long slab list (the 14x14 / 7x7 layers of the several-streams plan): fragment prefetch, four ring stages
-    // (ConvGeom::flags bit 12, set by net.hip from TF2_AMD_PF_BLOCKS; measured: no gain, profiles/r03_experiments.txt -- off by default)
-    if (!w4 && !w16 && a.dense && (a.g.flags & 0x1000) && a.nslab >= 8) {
-      return (a.g.pad_h | a.g.pad_w) ? launch_cfg3<4, 2, 32, 64, 4, 2, true, false, true, true>(a, s)
-                                      : launch_cfg3<4, 2, 32, 64, 4, 2, false, false, true, true>(a, s);
-    }
     return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   }
   if (TM == 64) {
@@ -711,30 +557,8 @@ static int launch_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
   if (TM0 != 128 || TM1 != 128 || a0.dense != a1.dense || a0.dual != a1.dual) return false;
   if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
-  if ((a0.g.flags | a1.g.flags) & (2 | 4 | 0x1000)) return false;            // A/B block shapes, prefetch variant: single launches only
+  if ((a0.g.flags | a1.g.flags) & (2 | 4)) return false;            // A/B block shapes: single launches only
   return true;
-}
-
-// ---- chain launch -------------------------------------------------------------------------------------------------------
-bool conv_mfma2_chain_eligible(const ConvArgs& a, int TM) {
-  return TM == 128 && a.dense && !(a.g.flags & (2 | 4 | 0x1000)) && a.dbg == nullptr && a.dbg2 == nullptr;
-}
-
-int launch_conv_mfma2_chain(const ChainArgs& c, const ChainSeg* hs, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  constexpr int S = 3;
-  size_t lds = 0;
-  for (int i = 0; i < c.n_segs; i++) {
-    const bool dual = (hs[i].variant & 2) != 0;
-    lds = std::max(lds, (size_t)S * ((dual ? 2 : 1) * 128 + 128) * 64 + (size_t)hs[i].a.hdr_bytes + 64);
-  }
-  auto fn = conv_mfma2_chain_kernel<S>;
-  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
-  if (lds > 160 * 1024) return -3;
-  const int grid = c.seg_first[c.n_segs];
-  TF2_LAUNCH_NAME("conv_mfma2_chain_kernel<4x2 waves of 32x64,S3,dense> (%d layers, rows %d..%d)", c.n_segs, hs[0].layer, hs[c.n_segs - 1].layer);
-  TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, c);
-  return launch_ok() ? 0 : -1;
 }
 
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream) {

@@ -31,8 +31,19 @@ __device__ __forceinline__ int quant_input(float x, float trans) {
 }
 
 // side job of the step's first kernel: advance the workspace's step counter (conv_bgroup.hip: the value a set group flag carries)
+// and clear every flag word of the step's group launches.  Done EVERY step: the control area sits behind the tensors, and a caller
+// that re-uses the buffer for another batch size (or an allocator that hands the same address out again) leaves arbitrary bytes
+// there -- the counter may then start anywhere (its low 24 bits just must not be 0, the value of a cleared flag), the flags may not.
 __device__ __forceinline__ void prep_zero_ctrl(const PrepArgs& a) {
-  if (a.epoch_ptr && blockIdx.x == 0 && threadIdx.x == 0) a.epoch_ptr[0] = a.epoch_ptr[0] + 1u;
+  if (a.epoch_ptr && blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      unsigned e = a.epoch_ptr[0] + 1u;
+      if ((e & 0xffffffu) == 0) e++;
+      a.epoch_ptr[0] = e;
+    }
+    unsigned* const flags = a.epoch_ptr + 64;
+    for (int i = threadIdx.x; i < a.n_flag_words; i += blockDim.x) flags[i] = 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "tf2_net.h"
 #include "tf2_device.h"
 
@@ -174,7 +176,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // reads stays live to its last row, what it writes exists from its first
   if (packed_valid && opts.bgroup_mode)
     for (int l = 0; l + 2 < nl; l++) {
-      if (bgroup_first_at(l) || bgroup_first14_at(l)) {
+      if (bgroup_first_at(l)) {
         TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
         tin.last_use = std::max(tin.last_use, l + 3);
         TensorPlan& tm1 = wp.tensors[wp.exec[l + 1].out_tensor];
@@ -201,7 +203,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // shares memory (the exchange inside a launch is ordered by flags and cache scopes, not by kernel boundaries)
   if (packed_valid && opts.bgroup_mode && opts.bgroup_chain > 1)
     for (int l = 0; l + 2 < nl;) {
-      if (!bgroup_at(l) || layers[l].H == 56) { l++; continue; }
+      if (!bgroup_at(l)) { l++; continue; }
       int e = l + 2;
       while (e + 3 < nl && bgroup_at(e + 1) && layers[e + 1].H == layers[l].H) e += 3;
       if (e > l + 2)
@@ -211,27 +213,6 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
         }
       l = e + 1;
     }
-  // Chain launches (conv_mfma2_chain_kernel, TF2_AMD_CHAIN): blocks of consecutive rows run concurrently, ordered only by the
-  // data they read -- so nothing a chain touches may share memory: every tensor whose life ends inside a run of chainable rows
-  // lives until the run's last row.  (Which rows actually share a launch is decided per launch plan; always inside these runs.)
-  wp.chain_end.assign(nl, -1);
-  if (packed_valid && opts.chain_mode) {
-    size_t tiles = 0;
-    for (int l = 0; l < nl;) {
-      if (!chain_row(l)) { l++; continue; }
-      int e = l;
-      while (e + 1 < nl && chain_row(e + 1)) e++;
-      for (int k = l; k <= e; k++) {
-        wp.chain_end[k] = e;
-        tiles += ((size_t)batch * layers[k].OH * layers[k].OW + 127) / 128;
-      }
-      if (e > l)
-        for (TensorPlan& t : wp.tensors)
-          if (t.last_use >= l && t.last_use < e) t.last_use = e;
-      l = e + 1;
-    }
-    wp.chain_ctr_bytes = (tiles * kChainCtrStride * 4 + 255) / 256 * 256;
-  }
   // ---- offsets ----
   struct Seg { size_t off, len; };
   std::vector<Seg> free_list;           // sorted by offset
@@ -280,8 +261,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   }
   wp.ctrl_off = (top + 255) / 256 * 256 + 256;
   wp.ctrl_bytes = (wp.ctrl_bytes + 255) / 256 * 256;
-  wp.chain_off = wp.ctrl_off + wp.ctrl_bytes;
-  wp.total_bytes = wp.chain_off + (wp.chain_ctr_bytes ? kChainTablesBytes + 2 * wp.chain_ctr_bytes : 0);
+  wp.total_bytes = wp.ctrl_off + wp.ctrl_bytes;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
@@ -326,32 +306,6 @@ bool Net::bgroup_first_at(int l) const {
   return n_dual == 0 || n_dual == 3;
 }
 
-// Rows l .. l + 3 = projection shortcut (1x1 / stride 2, 512 -> 1024) and reduce (1x1, 512 -> 256) of the same 28 x 28 input, 3x3 /
-// stride 2 / pad 1, expand + residual from the shortcut: conv_bgroup14f_kernel.  Shortcut and reduce both two-window or both not.
-bool Net::bgroup_first14_at(int l) const {
-  if (l < 1 || l + 3 >= nd.n_layers) return false;
-  const tf2_layer_desc& S = layers[l]; const tf2_layer_desc& A = layers[l + 1]; const tf2_layer_desc& B = layers[l + 2]; const tf2_layer_desc& E = layers[l + 3];
-  for (const tf2_layer_desc* L : {&S, &A, &B, &E})
-    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->dil != 1) return false;
-  if (S.src < 0 || S.src != A.src || layers[S.src].concat >= 0 || S.add_src >= 0 || A.add_src >= 0 || B.add_src >= 0) return false;
-  if (S.k != 1 || S.stride != 2 || S.pad_h || S.H != 28 || S.W != 28 || S.OH != 14 || S.OW != 14 || S.C != 512 || S.N != 1024) return false;
-  if (A.k != 1 || A.stride != 1 || A.pad_h || A.H != 28 || A.W != 28 || A.C != 512 || A.N != 256) return false;
-  if (B.src != l + 1 || B.k != 3 || B.stride != 2 || B.pad_h != 1 || B.pad_w != 1 || B.H != 28 || B.OH != 14 || B.OW != 14 || B.C != 256 || B.N != 256) return false;
-  if (E.src != l + 2 || E.k != 1 || E.stride != 1 || E.pad_h || E.H != 14 || E.add_src != l || E.C != 256 || E.N != 1024) return false;
-  int duals = 0;
-  for (int k = l; k <= l + 3; k++) {
-    const PackLayer* pl = pack_layer(k);
-    if (!pl || pl->kind != KIND_MFMA || pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
-    if (pl->fuse_next > 0 || pl->fused_into >= 0) return false;
-    if (k == l + 1 ? (pl->TM != 64 && pl->TM != 128) : pl->TM != 64) return false;
-    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
-    if (k >= l + 2) { if (!one_window) return false; }
-    else { if (!one_window && !dual) return false; duals += dual ? 1 : 0; }
-    if (k == l && pl->off_dbl) return false;
-  }
-  return duals == 0 || duals == 2;
-}
-
 // Rows l, l + 1, l + 2 = 1x1 reduce, 3x3 / 1 / pad 1, 1x1 expand + residual from the reduce's input, of a shape conv_bgroup.hip
 // is instantiated for, every row single-window in 64- or 128-row dense tiles.
 bool Net::bgroup_at(int l) const {
@@ -375,27 +329,12 @@ bool Net::bgroup_at(int l) const {
       // may be a two-window layer; rows packed for a conv_bneck pair qualify (the pair's own entries are one dense m-tile)
       if ((pl->TM != 64 && pl->TM != 128) || (k == l + 2 && pl->TM != 128)) return false;
       if (!(one_window || (k <= l + 1 && dual))) return false;
-    } else if (A.H == 56) {
-      // the 56 x 56 kernel: 64-row tiles; reduce and expand may be two-window layers; conv_bneck pairs qualify
-      if (pl->TM != 64) return false;
-      if (!(one_window || (k != l + 1 && dual))) return false;
     } else {
       if (pl->fuse_next > 0 || pl->fused_into >= 0 || pl->TM != 64) return false;      // (2 KiB header slots: 64-row m-tiles)
       if (!(one_window || (k == l && A.H == 7 && dual))) return false;                 // the 7 x 7 kernel's reduce may be two-window
     }
   }
   return true;
-}
-
-// Row l could be a segment of a chain launch: a plain convolution row whose packed form (or wide-tile alternative) has 128-row
-// tiles for the ring kernel.  Static (tables + packed image); the launch plan decides per batch and concurrency.
-bool Net::chain_row(int l) const {
-  const tf2_layer_desc& L = layers[l];
-  if (l < 1 || L.ipool || L.pool_en || L.endpool || L.concat >= 0 || L.src < 0) return false;
-  if (L.add_src >= 0 && layers[L.add_src].concat >= 0) return false;
-  const PackLayer* pl = pack_layer(l); const PackLayer* pa = pack_layer_alt(l);
-  if (!pl || pl->kind != KIND_MFMA) return false;
-  return pl->TM == 128 || (pa && pa->TM == 128);
 }
 
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
@@ -418,16 +357,12 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_PF_BLOCKS")) o.pf_blocks = atol(e);   // largest 128 x 128 grid that takes conv_mfma2's fragment-prefetch variant (default 0: never)
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN56")) o.bgroup_min56 = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN14F")) o.bgroup_min14f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_CHAIN")) o.bgroup_chain = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
-  if (const char* e = getenv("TF2_AMD_CHAIN")) o.chain_mode = atoi(e);        // 1: consecutive 128-row ring-kernel layers in one launch (conv_mfma2_chain_kernel)
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
@@ -450,30 +385,47 @@ void Net::load_options() {
   for (const auto& k : keys) (void)plan(k.first, k.second != 0);
 }
 
-// Group launches (conv_bgroup.hip) keep eight blocks per image resident together, one block per CU: they need a device (or
-// device partition) of at least 64 CUs.  No device (describing a plan on the CPU): assume the full chip.
+// Group launches (conv_bgroup.hip) keep eight blocks per image resident together, one block per CU: they need a device of at
+// least 64 CUs -- and a STREAM that may use at least 64 of them (stream_cu_count below; Net::run asks per call).  No device
+// (describing a plan on the CPU): assume the full chip.
 static bool device_fits_group_launches() {
-  static int n_cu = -1;
-  if (n_cu < 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    else n_cu = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  static std::mutex mu;
+  static std::map<int, int> n_cu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = n_cu.find(dev);
+  if (it == n_cu.end()) {
+    hipDeviceProp_t prop;
+    const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    it = n_cu.emplace(dev, n).first;
   }
-  return n_cu >= 64;
+  return it->second >= 64;
+}
+
+// CUs the stream's launches may use (hipExtStreamCreateWithCUMask: tf2_amd/streams.py); an unmasked stream reports the device's.
+static int stream_cu_count(hipStream_t s) {
+  uint32_t mask[16] = {0};
+  if (hipExtStreamGetCUMask(s, 16, mask) != hipSuccess) { (void)hipGetLastError(); return 1 << 20; }
+  int n = 0;
+  for (uint32_t w : mask) n += __builtin_popcount(w);
+  return n > 0 ? n : 1 << 20;
 }
 
 // ---- launch plan: every kernel argument block of one step, resolved once per (batch, workspace, packed image) ----
 // Net::run used to rebuild ~60 argument structs, scan the packed directory and read a dozen environment variables
 // per call; at batch 1 (57 launches of a few microseconds) that host work was the step.  Now a step is a loop over
 // prepared launches; only the image and logits pointers change between calls.
-const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent) {
+const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent, bool allow_groups) {
+  if (concurrent) allow_groups = false;
   for (const LaunchPlan& lp : launch_plans)
-    if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0)) return &lp;
+    if (lp.batch == batch && lp.wp == wp && lp.ws == ws && lp.packed_dev == packed_dev && lp.concurrent == (concurrent ? 1 : 0) &&
+        lp.groups == (allow_groups ? 1 : 0)) return &lp;
   if (launch_plans.size() >= 64)                       // evict the oldest plan nobody is walking
     for (auto it = launch_plans.begin(); it != launch_plans.end(); ++it)
       if (it->walkers == 0) { launch_plans.erase(it); break; }
   LaunchPlan lp;
-  lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0;
+  lp.batch = batch; lp.wp = wp; lp.ws = ws; lp.packed_dev = packed_dev; lp.concurrent = concurrent ? 1 : 0; lp.groups = allow_groups ? 1 : 0;
   int8_t* base = (int8_t*)ws;
   const int nl = nd.n_layers;
   auto T = [&](int id) -> const TensorPlan& { return wp->tensors[id]; };
@@ -586,7 +538,6 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       ca.res = base + tr.offset; g.res_cp = tr.Cp; g.res_off = E.res_off;
     }
     g.flags = opts.flags;
-    if (pl->TM == 128 && ((long)batch * L.OH * L.OW + 127) / 128 * pl->n_mtiles <= opts.pf_blocks) g.flags |= 0x1000;   // conv_mfma2 fragment-prefetch variant
     st.TM = pl->TM; st.signed_in = pl->signed_in; st.mul24 = pl->max_shift <= 22;
     if (pl->kind == KIND_MFMA) {
       // small grid + long slab list: the four (or eight) waves of a block split K (conv_mfma_sk.hip)
@@ -612,7 +563,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   };
   std::vector<char> fused_done(nl, 0), pair_done(nl, 0);
   int bg_used = 0;                                           // group launches so far (each has its own counters)
-  const bool groups_fit = device_fits_group_launches();
+  const bool groups_fit = allow_groups && device_fits_group_launches();
   bool stem_pool_fused = false;
   const bool profiling_pairs_off = false;
   for (int l = 0; l < nl; l++) {
@@ -638,8 +589,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
     // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
-    const bool first14 = opts.bgroup_mode && bgroup_first14_at(l) && batch >= opts.bgroup_min14f;
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && (first14 || (bgroup_first_at(l) && batch >= opts.bgroup_min56f)) &&
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
         256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch ss, s0, s1, s2;
       if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
@@ -662,9 +612,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
         f.ws = cs.w; f.hdrs = cs.hdr; f.hdrs_bytes = cs.hdr_bytes; f.tms = ss.TM; f.relu_s = cs.g.relu; f.fast_s = cs.g.fast;
         f.ys = cs.y; f.ys_cp = cs.g.y_cp; f.keep_s = wp->keep_all ? 1 : 0;
-        f.first_shape = first14 ? 14 : 56;
         f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
+        lp.steps[0].prep.n_flag_words = (int32_t)((wp->ctrl_bytes - 256) / 4);
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
         lp.steps.push_back(st);
@@ -673,7 +623,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
-    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : L.H == 56 ? opts.bgroup_min56 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
+    if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch s0, s1, s2;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
       if (s0.conv.dense && s1.conv.dense && s2.conv.dense && (!layers[l + 2].endpool || s2.avg_fused)) {
@@ -697,11 +647,12 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         st.bg_hw = L.H; st.bg_c = L.C; st.bg_m = L.N;
         // the step's first kernel (input preparation) advances the step counter
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
+        lp.steps[0].prep.n_flag_words = (int32_t)((wp->ctrl_bytes - 256) / 4);
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1;
         // the 14 x 14 stage's identity bottlenecks follow one another: the groups of the previous launch carry on with this one
         // (its roll-call row doubles as the meeting "input complete")
-        if (opts.bgroup_chain > 1 && L.H != 56 && !lp.steps.empty() && !f.dbg) {
+        if (opts.bgroup_chain > 1 && !lp.steps.empty() && !f.dbg) {
           Launch& pv = lp.steps.back();
           const int pn = pv.bg_chain.empty() ? 1 : (int)pv.bg_chain.size();
           if (pv.kind == Launch::CONV && pv.sel == Launch::SEL_BGROUP && pv.bg_hw == L.H && pv.layer + 3 * pn == l && f.dual1 == pv.bgroup.dual1 && f.dual2 == pv.bgroup.dual2 && !pv.bg_chain_last().avg_mult && pn < std::min(kBgMaxChain, opts.bgroup_chain) &&
@@ -818,77 +769,6 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       lp.steps.push_back(sa);
     }
   }
-  // ---- chain launches: runs of consecutive ring-kernel steps of the 8-wave 128 x 128 dense shape become ONE launch each ----
-  // (conv_mfma2_chain_kernel: a block of a later layer waits in place for the pixel tiles it reads instead of for a kernel
-  //  boundary -- no launch, no drain, no empty chip between the layers, and layers overlap wherever the data allows)
-  if (opts.chain_mode && wp->chain_ctr_bytes) {
-    auto chainable = [&](const Launch& st) {
-      if (st.kind != Launch::CONV || (lp.logits_direct >= 0 && &st == &lp.steps[lp.logits_direct])) return false;
-      if (wp->chain_end[st.layer] < 0) return false;
-      if (st.sel == Launch::SEL_MFMA2) return conv_mfma2_chain_eligible(st.conv, st.TM);
-      if (st.sel == Launch::SEL_PAIR) return wp->chain_end[st.layer + 1] >= 0 && conv_mfma2_chain_eligible(st.conv, 128) && conv_mfma2_chain_eligible(st.conv2, 128);
-      return false;
-    };
-    std::vector<Launch> out;
-    size_t table_used = 0, ctr_used = 0;          // segments / counters handed out so far
-    const size_t table_base = wp->chain_off + (concurrent ? kChainTableSegs * kChainSegStride : 0);
-    const size_t ctr_base = wp->chain_off + kChainTablesBytes + (concurrent ? wp->chain_ctr_bytes : 0);
-    for (size_t i = 0; i < lp.steps.size();) {
-      size_t j = i; int nseg = 0;
-      while (j < lp.steps.size() && chainable(lp.steps[j]) && wp->chain_end[lp.steps[j].layer] == wp->chain_end[lp.steps[i].layer]) {
-        const int add = lp.steps[j].sel == Launch::SEL_PAIR ? 2 : 1;
-        if (nseg + add > kChainMaxSegs || table_used + nseg + add > kChainTableSegs) break;
-        nseg += add; j++;
-      }
-      if (j - i < 2) { out.push_back(lp.steps[i]); i++; continue; }
-      Launch ch; ch.kind = Launch::CONV; ch.sel = Launch::SEL_CHAIN; ch.layer = lp.steps[i].layer;
-      int next_block = 0;
-      const size_t ctr0 = ctr_used;
-      std::map<int, int> seg_of_layer;
-      auto add_seg = [&](const ConvArgs& ca, int layer) {
-        const tf2_layer_desc& L = layers[layer];
-        ChainSeg sg{};
-        sg.a = ca; sg.layer = layer;
-        const int ntiles = (ca.g.n_pix + 127) / 128;
-        sg.first_block = next_block;
-        sg.n_blocks = ntiles * ca.n_mtiles;
-        sg.variant = ((ca.g.pad_h | ca.g.pad_w) ? 1 : 0) | (ca.dual ? 2 : 0);
-        sg.ctr_off = (int)(ctr_used - ctr0); ctr_used += (size_t)ntiles;
-        sg.src_ctr = sg.res_ctr = -1;
-        auto ps = seg_of_layer.find(L.src);
-        if (ps != seg_of_layer.end()) { sg.src_ctr = ch.chain_segs[ps->second].ctr_off; sg.src_need = ch.chain_segs[ps->second].a.n_mtiles; }
-        auto pr = L.add_src >= 0 ? seg_of_layer.find(L.add_src) : seg_of_layer.end();
-        if (pr != seg_of_layer.end()) { sg.res_ctr = ch.chain_segs[pr->second].ctr_off; sg.res_need = ch.chain_segs[pr->second].a.n_mtiles; }
-        ch.chain.seg_first[ch.chain_segs.size()] = next_block;
-        next_block = (next_block + sg.n_blocks + 7) / 8 * 8;
-        seg_of_layer[layer] = (int)ch.chain_segs.size();
-        ch.chain_segs.push_back(sg);
-      };
-      for (size_t k = i; k < j; k++) {
-        const Launch& st = lp.steps[k];
-        add_seg(st.conv, st.layer);
-        if (st.sel == Launch::SEL_PAIR) add_seg(st.conv2, st.layer + 1);
-      }
-      ch.chain.n_segs = (int)ch.chain_segs.size();
-      for (int k = ch.chain.n_segs; k <= kChainMaxSegs; k++) ch.chain.seg_first[k] = next_block;
-      ch.chain_table_off = table_base + table_used * kChainSegStride;
-      ch.chain.segs = reinterpret_cast<const ChainSeg*>(base + ch.chain_table_off);
-      ch.chain.ctr = reinterpret_cast<unsigned*>(base + ctr_base + ctr0 * kChainCtrStride * 4);
-      ch.chain_ctr_bytes = (ctr_used - ctr0) * kChainCtrStride * 4;
-      table_used += ch.chain_segs.size();
-      out.push_back(std::move(ch));
-      lp.n_chains++;
-      i = j;
-    }
-    if (ctr_used * kChainCtrStride * 4 > wp->chain_ctr_bytes) return fail("chain counters outgrew the workspace plan");
-    if (lp.n_chains) {
-      if (lp.logits_direct >= 0) {          // (the direct-logits step is never part of a chain; find it again)
-        const int layer = lp.steps[lp.logits_direct].layer;
-        for (size_t k = 0; k < out.size(); k++) if (out[k].layer == layer && out[k].sel == Launch::SEL_SK) lp.logits_direct = (int)k;
-      }
-      lp.steps = std::move(out);
-    }
-  }
   launch_plans.push_back(std::move(lp));
   return &launch_plans.back();
 }
@@ -922,9 +802,6 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_BGROUP:
           if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);
           return launch_conv_bgroup(&st.bgroup, 1, st.bg_hw, st.bg_c, st.bg_m, stream);
-        case Launch::SEL_CHAIN:
-          if (!launch_recorder() && hipMemsetAsync(st.chain.ctr, 0, st.chain_ctr_bytes, (hipStream_t)stream) != hipSuccess) return -1;
-          return launch_conv_mfma2_chain(st.chain, st.chain_segs.data(), stream);
         case Launch::SEL_STEM: return launch_conv_stem(st.stem, st.shape, stream);
         default: return launch_conv_shift(st.conv, st.signed_in, st.mul24, st.shape, stream);
       }
@@ -939,10 +816,16 @@ tf2_status Net::describe_launches(int batch, bool concurrent, std::vector<std::p
   if (!packed_valid) { set_error("tf2_net_describe_launches: no packed image"); return TF2_ERR_STATE; }
   if (batch <= 0) { set_error("tf2_net_describe_launches: batch must be positive"); return TF2_ERR_ARG; }
   const WorkPlan* wp = plan(batch, false);
+  // the description's plan is built beside the cache (never evicts or replaces a run plan) and dropped again
   const uint8_t* saved = packed_dev;
   if (!packed_dev) packed_dev = packed.data();               // addresses are only formatted into argument blocks nobody launches
   static char fake_ws[16];
-  const LaunchPlan* lp = launch_plan(batch, wp, fake_ws, concurrent);
+  std::list<LaunchPlan> keep;
+  keep.swap(launch_plans);
+  const LaunchPlan* lp = launch_plan(batch, wp, fake_ws, concurrent, true);
+  std::list<LaunchPlan> mine;
+  mine.swap(launch_plans);
+  launch_plans.swap(keep);
   packed_dev = saved;
   if (!lp) return TF2_ERR_ARG;
   LaunchRecorder rec; rec.name[0] = 0;
@@ -955,8 +838,6 @@ tf2_status Net::describe_launches(int batch, bool concurrent, std::vector<std::p
     for (size_t i = before; i < rec.rows.size(); i++) out->emplace_back(st.layer, rec.rows[i]);
   }
   g_recorder = nullptr;
-  for (auto it = launch_plans.begin(); it != launch_plans.end(); ++it)       // the description's plan is not a run plan
-    if (&*it == lp) { launch_plans.erase(it); break; }
   if (rc) { set_error("tf2_net_describe_launches: " + std::string(device_last_error())); return TF2_ERR_HIP; }
   return TF2_OK;
 }
@@ -972,6 +853,12 @@ tf2_status Net::describe_workspace(int batch, bool keep_all, std::vector<TensorP
   *tensors = wp->tensors;
   *rows = wp->exec;
   return TF2_OK;
+}
+
+size_t Net::workspace_size(int batch, bool keep_all) {
+  std::lock_guard<std::mutex> lock(run_mutex);
+  const WorkPlan* wp = plan(batch, keep_all);
+  return wp ? wp->total_bytes : 0;
 }
 
 size_t Net::logits_bytes(int batch) const {
@@ -1003,9 +890,12 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   if (concurrency >= 0 && opts.alt_conc_mode == 2) concurrent = concurrency != 0;        // the caller's own statement (tf2_net_run_ex)
   else if (opts.alt_conc_mode == 2)
     for (int i = 0; i < 8 && !concurrent; i++) concurrent = recent_streams[i] != nullptr && recent_streams[i] != tag;
-  const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent);
-  if (!lp) return TF2_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  // group launches spin until the eight members of an image are resident together, one block per CU: never on a stream whose CU
+  // mask leaves fewer than 64 CUs (asked per call: the handle does not know what the caller's next stream looks like)
+  const bool allow_groups = !concurrent && opts.bgroup_mode && stream_cu_count(s) >= 64;
+  const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent, allow_groups);
+  if (!lp) return TF2_ERR_ARG;
   const int nl = nd.n_layers;
   // The enqueue itself runs outside the handle's mutex, under the plan's own (tf2_amd.h threading note): host threads that
   // feed different streams issue their ~40 launches per step side by side.  (Profiling runs keep the handle's mutex: the
@@ -1035,20 +925,6 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
     }
     return TF2_OK;
   };
-  if (lp->n_groups && !lp->ctrl_zeroed) {
-    // first step of this plan on this workspace: the control words (step counter, group flags) start from zero -- whatever the
-    // memory held before must not look like a set flag
-    HIP_OK(hipMemsetAsync((int8_t*)ws + wp->ctrl_off, 0, wp->ctrl_bytes, s));
-    const_cast<LaunchPlan*>(lp)->ctrl_zeroed = true;
-  }
-  if (lp->n_chains && !lp->chain_uploaded) {
-    // the segment tables of the chain launches go into the workspace once per (workspace, plan); stream order covers the launches
-    for (const Launch& st : lp->steps)
-      if (st.sel == Launch::SEL_CHAIN && st.kind == Launch::CONV)
-        for (size_t k = 0; k < st.chain_segs.size(); k++)
-          HIP_OK(hipMemcpyAsync((int8_t*)ws + st.chain_table_off + k * sizeof(ChainSeg), &st.chain_segs[k], sizeof(ChainSeg), hipMemcpyHostToDevice, s));
-    const_cast<LaunchPlan*>(lp)->chain_uploaded = true;
-  }
   bool mark_pending = mark_event != nullptr;
 #ifdef TF2_PROBES
   // tools/probe_run.py: leave out the launches of a layer range (results are then wrong; only durations are read)
@@ -1117,8 +993,10 @@ void Net::drain_profile() {
 tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, size_t cap, void* stream) {
   // the keep_all plan of this batch (planning is deterministic: rebuilt if tf2_net_reload_options dropped it since the run)
   if (batch <= 0) { set_error("tf2_net_read_layer: batch must be positive"); return TF2_ERR_ARG; }
-  const WorkPlan& wp = *plan(batch, true);
   if (layer < -1 || layer >= nd.n_layers) { set_error("tf2_net_read_layer: bad layer"); return TF2_ERR_ARG; }
+  const WorkPlan* wpp;
+  { std::lock_guard<std::mutex> lock(run_mutex); wpp = plan(batch, true); }        // (std::map nodes are stable: the plan outlives the lock)
+  const WorkPlan& wp = *wpp;
   int tid, off, C;
   if (layer == -1) { tid = wp.input_tensor; off = 0; C = layers[0].C; }
   else { tid = wp.exec[layer].out_tensor; off = wp.exec[layer].out_off; C = layers[layer].N; }
@@ -1133,12 +1011,10 @@ tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, si
   // doubled channels are stored as 2y - 128 (weight_pack.cpp): hand back y
   const PackLayer* pl = layer >= 0 ? pack_layer(layer) : nullptr;
   const uint8_t* dblf = (pl && pl->off_dbl) ? packed.data() + pl->off_dbl : nullptr;
-  // channels of a multi-Q tensor are stored sorted by Q (PackLayer::off_perm): hand back logical order
-  const int32_t* permf = (pl && pl->off_perm) ? reinterpret_cast<const int32_t*>(packed.data() + pl->off_perm) : nullptr;
   for (int b = 0; b < batch; b++)
     for (int c = 0; c < C; c++)
       for (size_t p = 0; p < HW; p++) {
-        int8_t v = tmp[((size_t)b * HW + p) * Cp + off + (permf ? permf[c] : c)];
+        int8_t v = tmp[((size_t)b * HW + p) * Cp + off + c];
         if (dblf && dblf[c]) v = (int8_t)(((int)v + 128) >> 1);
         dst[((size_t)b * C + c) * HW + p] = v;
       }

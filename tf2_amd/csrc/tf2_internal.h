@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 29;
+constexpr uint32_t kPackVersion = 30;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -58,8 +58,6 @@ struct PackLayer {
   uint64_t off_dbl;      // uint8[Np]: 1 = this layer stores output channel n as 2y - 128 (0: no such channel)
   uint64_t off_pad;      // uint8[Cp_in + 16]: what an out-of-range tap reads (the stored form of x = 0: -128 on doubled input
                          // channels), 0: the zero page
-  uint64_t off_perm;     // int32[N]: physical position of logical output channel n in this layer's output tensor (0: identity).  Tensors
-                         // with several Q values are stored sorted by Q so that their consumers' K slabs are Q-uniform (weight_pack.cpp)
   uint64_t off_unit;     // conv_stem only, != 0: the layer's LOW exponent window is nothing but unit taps (+x << 0, the conv1
                          // rewrite's memset rows, model_loader.cpp:244-257), the same (tap, channel) set in every output row:
                          // int8[9][32] 0/1 mask; off_w2 then holds the HIGH window alone and the kernel adds the per-pixel sum
@@ -146,34 +144,6 @@ struct ConvArgs {
   ConvGeom g;
 };
 
-// conv_mfma2_chain_kernel (conv_mfma2.hip): consecutive table rows in ONE launch.  Segment i owns the hardware blocks
-// [first_block, first_block + n_blocks) of the grid (first_block a multiple of 8: the XCD-aware block remap of the ring kernel
-// keeps working); blocks are dispatched in ascending order, so a block that waits for earlier segments never occupies a slot
-// that a block it waits for still needs (chain launches).  Dependencies are per PIXEL TILE (128 output
-// pixels): every block adds 1 to its segment's counter of its pixel tile when its stores are acknowledged, and a block starts
-// its first activation load when the tiles of the producing segment that cover its input pixels hold n_mtiles(producer) each
-// (and its own tile of the residual's producer likewise).  Counters are zeroed by the host before every launch.  Activations
-// written and read inside a chain bypass the XCD-private L2s (sc1 loads / stores): within a kernel the L2 of one XCD is not
-// coherent with another's.  The workspace planner keeps every tensor a chain touches alive until the chain's last row
-// (Net::plan), so the only ordering a segment needs is on the data it reads.
-struct ChainSeg {
-  ConvArgs a;
-  int32_t first_block, n_blocks;
-  int32_t variant;           // bit 0: padded taps (PADCHK), bit 1: dual-window tiles
-  int32_t ctr_off;           // this segment's counters: ctr[(ctr_off + pixel tile) * kChainCtrStride]
-  int32_t src_ctr, src_need; // producer of the input tensor inside the chain: its ctr_off (-1: none) and n_mtiles
-  int32_t res_ctr, res_need; // the same for the residual tensor
-  int32_t layer;             // table row (diagnostics)
-};
-constexpr int kChainMaxSegs = 48;
-constexpr int kChainCtrStride = 8;         // counters sit 32 bytes apart (in 32-bit words)
-struct ChainArgs {
-  const ChainSeg* segs;      // device copy of the segment table
-  unsigned* ctr;             // completion counters, kChainCtrStride words apart
-  int32_t n_segs;
-  int32_t seg_first[kChainMaxSegs + 1];
-};
-
 // conv_bneck.hip: layer C (3x3 / stride 1 / pad 1, C -> C channels, C = 64 / 128 / 256) followed by its only consumer E
 // (1x1, C -> 4C, + residual): one launch per R x W pixel band of an image.
 struct BneckArgs {
@@ -227,7 +197,6 @@ struct BGroupArgs {
   const int8_t* ws; const int32_t* hdrs;     // its dense weight tiles and header images
   int8_t* ys;                                // its own output tensor (written only with keep_s)
   int32_t hdrs_bytes, tms, relu_s, fast_s, keep_s, ys_cp;      // tms: rows per m-tile of the shortcut (64 or 128)
-  int32_t first_shape;       // 56: conv_bgroup56f_kernel; 14: conv_bgroup14f_kernel (stride-2 first bottleneck whose output map is 14 x 14)
 };
 
 // consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
@@ -290,15 +259,14 @@ struct PrepArgs {
   int32_t src_is_q;           // 1: source already int8
   int32_t xonly;              // 1 (rewrite form only): 32 bytes of x per pixel, no xneg half (conv_stem.hip)
   unsigned* epoch_ptr;        // side job of the step's first kernel: the workspace's step counter += 1 (the value the flags of the
-                              // step's conv_bgroup launches carry), or null
+                              // step's conv_bgroup launches carry) and its n_flag_words flag words (256 bytes behind it) cleared, or null
+  int32_t n_flag_words;
 };
 
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
-bool conv_mfma2_chain_eligible(const ConvArgs& a, int TM);                                  // the 8-wave 128 x 128 dense shape
-int launch_conv_mfma2_chain(const ChainArgs& c, const ChainSeg* host_segs, void* stream);   // host_segs: the same table on the host (grid, LDS size, description)
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);

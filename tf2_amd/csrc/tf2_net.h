@@ -38,33 +38,19 @@ struct WorkPlan {
   int input_tensor = -1;
   int final_tensor = -1;
   size_t ctrl_off = 0, ctrl_bytes = 0;   // group counters of conv_bgroup launches (two words per image and launch)
-  size_t chain_off = 0;     // end of the workspace: segment tables (kChainTablesBytes), then the counters of chain launches
-  size_t chain_ctr_bytes = 0;   // counters of ONE plan (one batch at a time / several in flight): one per pixel tile of every chainable row
-  std::vector<int> chain_end;   // per row: last row of the chainable run it belongs to (-1: not chainable); see Net::plan
   size_t total_bytes = 0;
 };
-
-// chain area of a workspace: two segment tables (one batch at a time / several in flight: both plans may exist for one
-// workspace) of kChainTableSegs entries each, then their counters
-constexpr size_t kChainTableSegs = 64;
-constexpr size_t kChainSegStride = 512;
-constexpr size_t kChainTablesBytes = 2 * kChainTableSegs * kChainSegStride;
-static_assert(sizeof(ChainSeg) <= kChainSegStride, "ChainSeg outgrew its table slot");
 
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_CHAIN, SEL_BGROUP, SEL_BGROUPF } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
   ConvArgs conv{};
   ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
-  std::vector<ChainSeg> chain_segs;   // SEL_CHAIN: the launch's segments (host copy of the device table)
-  ChainArgs chain{};
-  size_t chain_table_off = 0;         // where the device table sits in the workspace
-  size_t chain_ctr_bytes = 0;         // counters of this launch (zeroed before every launch)
   BneckArgs bneck{};
   BGroupArgs bgroup{};       // SEL_BGROUP: rows layer .. layer + 2 (an identity bottleneck) in one launch
   int bg_hw = 0, bg_c = 0, bg_m = 0;
@@ -83,12 +69,10 @@ struct LaunchPlan {
   void* ws = nullptr;
   const uint8_t* packed_dev = nullptr;
   int concurrent = 0;               // built for several batches in flight (wide-tile alternatives from a smaller grid on)
+  int groups = 0;                   // group launches (conv_bgroup.hip) allowed: one batch at a time on a stream of >= 64 CUs
   std::vector<Launch> steps;
   int logits_direct = -1;           // index of the conv step that writes the dense logits itself (its y is patched per call), else -1
-  bool chain_uploaded = false;      // the chain launches' segment tables are in the workspace (copied by the first run)
-  int n_chains = 0;
   int n_groups = 0;                 // group launches (conv_bgroup.hip) in the plan
-  bool ctrl_zeroed = false;         // the workspace's control words were zeroed for this plan (first run)
   // Net::run walks a plan OUTSIDE the handle's mutex (several host threads, one stream and workspace each, enqueue at the same
   // time): `enqueue` serialises walks of this plan (one workspace = one step at a time anyway), `walkers` (under the handle's
   // mutex) keeps the plan from being evicted while somebody walks it
@@ -106,13 +90,9 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_max_slabs = 17;   // TF2_AMD_DENSE_MAX: layers with more K slabs than this on grids of more than one round keep the header tables
   int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
-  long pf_blocks = 0;      // TF2_AMD_PF_BLOCKS
   int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
   int bgroup_chain = 5;             // consecutive identity bottlenecks of the 28 x 28 / 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
-  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56 = 1 << 30, bgroup_min56f = 12, bgroup_min14f = 1 << 30;   // (14f: measured equal to its three launches -- every member streams the whole 28 x 28 input: off unless asked for)
-    // (56 x 56: measured equal to reduce + conv_bneck -- that stage is bound by its 16-byte-granular memory traffic, not by launches: off unless asked for)
-     // TF2_AMD_BGROUP_MIN7 / _MIN14: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
-  int chain_mode = 0;      // TF2_AMD_CHAIN: consecutive ring-kernel layers in one launch (conv_mfma2_chain_kernel): 0 never, 1 where eligible
+  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // TF2_AMD_BGROUP_MIN7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
   int stem_pool = 1;       // TF2_AMD_STEM_POOL: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
@@ -169,12 +149,11 @@ struct Net {
   bool pair_candidate(int l) const;        // rows l and l + 1 are independent plain conv rows (one launch may compute both)
   uint64_t tables_hash() const;
   const WorkPlan* plan(int batch, bool keep_all);
-  const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent);
+  const LaunchPlan* launch_plan(int batch, const WorkPlan* wp, void* ws, bool concurrent, bool allow_groups);
+  size_t workspace_size(int batch, bool keep_all);      // plan(...)->total_bytes under the handle's mutex
   tf2_status describe_workspace(int batch, bool keep_all, std::vector<TensorPlan>* tensors, std::vector<LayerExec>* rows);
-  bool bgroup_first14_at(int l) const;     // rows l .. l + 3 = the stride-2 first bottleneck whose output map is 14 x 14 (conv_bgroup14f_kernel)
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
-  bool chain_row(int l) const;             // row l could be a segment of a chain launch (plain conv row with a 128-row ring-kernel form)
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
   int recent_pos = 0;
   void load_options();

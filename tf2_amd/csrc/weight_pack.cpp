@@ -189,58 +189,6 @@ tf2_status Net::pack(int mode) {
       if (ok) dbl[p] = f;
     }
   }
-  // ---- channel order of internal tensors.  A tensor whose channels carry three Q values (ResNet-50's stage outputs; the shift of a
-  // code is 15 + Q_in[c] - Q_out[n] - i) costs every consumer a second exponent window.  Stored with its channels SORTED BY Q,
-  // the channels of one Q value fill whole 64-byte K slabs of the consumer (up to one mixed slab per boundary), and the consumer
-  // is packed with one Horner phase per channel GROUP instead of per exponent window: every group needs only seven exponents, the
-  // phases hold disjoint slab sets, and the layer walks ~nslab entries of ONE weight tile instead of nslab entries of two.
-  // perm[p][n] = physical position of logical output channel n of layer p (empty: identity).  A permuted tensor is read only by
-  // MFMA convolutions (as input or residual -- residual partners carry the same Q vector, hence the same order);
-  // tf2_net_read_layer hands back logical order (PackLayer::off_perm).
-  // Measured on ResNet-50 (profiles/r03_experiments.txt): 12 layers walk 6 / 10 / 34 weight tiles per m-tile instead of 8 / 16 / 64 and
-  // the packed image loses 7 MB, but those layers leave the arithmetic-gather (DENSE) prologue for the table-driven one: four batches
-  // in flight +1 %, one batch at a time +-0, batch-1 latency +2.5 %.  Hence OFF by default; TF2_AMD_GROUP=1 at pack time turns
-  // both halves on (sorted tensors + group phases), TF2_AMD_NOPERM / TF2_AMD_NOGROUP then switch the halves off individually.
-  const bool group_on = getenv("TF2_AMD_GROUP") != nullptr && atoi(getenv("TF2_AMD_GROUP")) != 0;
-  std::vector<std::vector<int>> perm(nl);
-  if (mode == 0 && group_on && getenv("TF2_AMD_NOPERM") == nullptr) {
-    const int M = nd.max_out_channel;
-    std::vector<char> cand(nl, 0);
-    auto qrow_eq = [&](int a, int b) { return layers[a].N == layers[b].N && std::memcmp(q.data() + (size_t)(a + 1) * M, q.data() + (size_t)(b + 1) * M, layers[a].N) == 0; };
-    for (int p = 0; p + 1 < nl; p++) {
-      const tf2_layer_desc& P_ = layers[p];
-      if (P_.ipool || P_.concat >= 0 || !dbl[p].empty()) continue;
-      const int8_t* qo = q.data() + (size_t)(p + 1) * M;
-      bool multi = false;
-      for (int n = 1; n < P_.N && !multi; n++) multi = qo[n] != qo[0];
-      if (!multi) continue;
-      bool ok = true; int n_cons = 0, n_res = 0;
-      for (int j = 0; j < nl && ok; j++) {
-        if (layers[j].src == p) { n_cons++; if (layers[j].ipool || layers[j].C != P_.N) ok = false; }
-        if (layers[j].add_src == p) n_res++;
-      }
-      if (n_cons > 0 && out_signed[p]) ok = false;        // a signed mid-network tensor is read by the shift kernel (no permuted form)
-      cand[p] = ok && (n_cons > 0 || n_res > 0);          // (a shortcut convolution is read as a residual only)
-    }
-    for (bool changed = true; changed;) {          // residual partners: both permuted (same Q vector) or neither
-      changed = false;
-      for (int j = 0; j < nl; j++) {
-        const int r = layers[j].add_src;
-        if (r < 0) continue;
-        const bool both = cand[j] && cand[r] && qrow_eq(j, r);
-        if (!both && (cand[j] || cand[r])) { cand[j] = cand[r] = 0; changed = true; }
-      }
-    }
-    for (int p = 0; p < nl; p++) {
-      if (!cand[p]) continue;
-      const int8_t* qo = q.data() + (size_t)(p + 1) * M;
-      std::vector<int> order(layers[p].N);
-      for (int n = 0; n < layers[p].N; n++) order[n] = n;
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return qo[a] > qo[b]; });   // runtime q = -Q: lowest file Q (largest shifts) first
-      perm[p].assign(layers[p].N, 0);
-      for (int i = 0; i < layers[p].N; i++) perm[p][order[i]] = i;
-    }
-  }
   for (int attempt = 0; attempt < 8; attempt++) {
   decide_fusion();
   packed.clear();
@@ -302,25 +250,8 @@ tf2_status Net::pack(int mode) {
     // doubled input channels: weights one exponent lower, 64 * sum(w) into the bias (Z/2^32 like the accumulator)
     const std::vector<uint8_t>* in_dbl = (L.src >= 0 && !dbl[L.src].empty()) ? &dbl[L.src] : nullptr;
     LayerModel mm;
-    const std::vector<int>* perm_out = (mode == 0 && !perm[l].empty()) ? &perm[l] : nullptr;
-    const std::vector<int>* perm_in = (mode == 0 && L.src >= 0 && !perm[L.src].empty()) ? &perm[L.src] : nullptr;
-    if (perm_out || perm_in) {
-      // the layer in PHYSICAL channel order: rows (codes, BiasBn) by perm_out, filter columns by perm_in -- everything below
-      // (windows, tiles, headers, range proofs) is then order-agnostic
-      const LayerModel& src_m = models[l];
-      mm = src_m;
-      const int tp = L.k * L.k;
-      for (int n = 0; n < L.N; n++) {
-        const int rn = perm_out ? (*perm_out)[n] : n;
-        mm.bias[rn] = src_m.bias[n]; mm.alpha[rn] = src_m.alpha[n]; mm.beta[rn] = src_m.beta[n];
-        for (int c = 0; c < L.C; c++) {
-          const int rc = perm_in ? (*perm_in)[c] : c;
-          std::memcpy(&mm.codes[((size_t)rn * L.C + rc) * tp], &src_m.codes[((size_t)n * L.C + c) * tp], tp);
-        }
-      }
-    }
     if (in_dbl) {
-      if (!(perm_out || perm_in)) mm = models[l];
+      mm = models[l];
       const int tp = L.k * L.k;
       for (int n = 0; n < L.N; n++)
         for (int c = 0; c < L.C; c++) {
@@ -335,8 +266,7 @@ tf2_status Net::pack(int mode) {
           }
         }
     }
-    if (in_dbl && perm_in) { set_error("layer " + std::to_string(l) + ": internal error, doubled and permuted input"); return TF2_ERR_STATE; }
-    const LayerModel& m = (in_dbl || perm_out || perm_in) ? mm : models[l];
+    const LayerModel& m = in_dbl ? mm : models[l];
     const int N = L.N, C = L.C, k = L.k, taps = k * k;
     const InLayout& il = in_layout[l];
     const bool in_signed = src_signed(L.src) != 0;
@@ -386,77 +316,12 @@ tf2_status Net::pack(int mode) {
         }
         P = std::max(P, (int)row_lo[n].size());
       }
-      // ---- phases by input-channel GROUP instead of by exponent window (see the channel-order note above) ----
-      // group of a (physical) input channel = rank of its Q among the input tensor's distinct Q values, highest shift first; per
-      // row and group one 7-exponent window [glo, glo + 6] must hold every code of the group, and the bases must not rise from
-      // one group to the next (Horner shifts are left shifts).  Taken when it walks fewer weight tiles than the window form.
-      std::vector<int> gid(C, 0);
-      int G = 1;
-      bool grp = false;
-      std::vector<int32_t> glo;
-      if (mode == 0 && group_on && P >= 2 && L.src >= 0 && layers[L.src].concat < 0 && !is_image && !in_dbl && getenv("TF2_AMD_NOGROUP") == nullptr) {
-        const int M = nd.max_out_channel;
-        const int8_t* q_in = q.data() + (size_t)L.q_in_row * M;
-        std::vector<int> vals;
-        for (int c = 0; c < C; c++) if (std::find(vals.begin(), vals.end(), (int)q_in[c]) == vals.end()) vals.push_back((int)q_in[c]);
-        std::sort(vals.begin(), vals.end(), [](int a, int b) { return a > b; });   // runtime q = -Q descending: the lowest file Q first --
-                                                             // the shift of a code is 15 - Q_in + Q_out - i, so these are the largest shifts
-        G = (int)vals.size();
-        if (G >= 2 && G <= 4) {
-          for (int c = 0; c < C; c++) {
-            const int g = (int)(std::find(vals.begin(), vals.end(), (int)q_in[c]) - vals.begin());
-            gid[perm_in ? (*perm_in)[c] : c] = g;
-          }
-          glo.assign((size_t)G * Np, 0);
-          grp = true;
-          for (int n = 0; n < N && grp; n++) {
-            int top[4] = {-1, -1, -1, -1}, bot[4] = {99, 99, 99, 99};
-            for (int c = 0; c < C; c++)
-              for (int t = 0; t < taps; t++) {
-                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
-                if (code_zero(code)) continue;
-                const int s = code_shift(code), g = gid[c];
-                top[g] = std::max(top[g], s); bot[g] = std::min(bot[g], s);
-              }
-            // a group's base b must satisfy top - 6 <= b <= bot (its window [b, b + 6] holds every code), and the bases must not
-            // rise from one group to the next (Horner shifts are left shifts): from the last group backwards, the smallest base
-            // that is allowed and not below its successor's
-            int cur = -1;
-            for (int g = G - 1; g >= 0 && grp; g--) {
-              int b = -1;
-              if (top[g] >= 0) {
-                if (top[g] - bot[g] > 6) { grp = false; break; }            // more than seven exponents inside one group
-                b = std::max(std::max(top[g] - 6, 0), cur);
-                if (b > bot[g]) { grp = false; break; }                     // would need a rising base
-                cur = b;
-              }
-              glo[(size_t)g * Np + n] = b;
-            }
-            // empty groups: the base of the nearest non-empty group behind them (shift 0), trailing ones the last base
-            int fill = 0;
-            for (int g = G - 1; g >= 0; g--) if (glo[(size_t)g * Np + n] >= 0) fill = glo[(size_t)g * Np + n];
-            for (int g = 0; g < G; g++) { if (glo[(size_t)g * Np + n] < 0) glo[(size_t)g * Np + n] = fill; else fill = glo[(size_t)g * Np + n]; }
-          }
-          if (grp) {
-            // weight tiles walked per m-tile: one per slab a group touches, against nslab entries of P windows
-            long cost_g = 0;
-            for (int g = 0; g < G; g++) {
-              std::vector<char> touched(nslab, 0);
-              for (int c = 0; c < C; c++) if (gid[c] == g) for (int t = 0; t < taps; t++) touched[(t * il.Cp_in + c) / 64] = 1;
-              for (int sl = 0; sl < nslab; sl++) cost_g += touched[sl];
-            }
-            if (getenv("TF2_AMD_PACKDBG")) fprintf(stderr, "layer %d: group scheme feasible, G %d, %ld tiles against %d x %d\n", l, G, cost_g, P, nslab);
-            if (cost_g >= (long)P * nslab) grp = false;
-          } else if (getenv("TF2_AMD_PACKDBG")) fprintf(stderr, "layer %d: group scheme infeasible (G %d)\n", l, G);
-        } else G = 1;
-      }
-      if (grp) P = G;
       // lo[p][n]; rows with fewer windows repeat their last one (Horner shift 0)
       std::vector<int32_t> lo((size_t)P * Np, 0);
       for (int n = 0; n < N; n++)
         for (int p = 0; p < P; p++) {
           const auto& r = row_lo[n];
-          lo[(size_t)p * Np + n] = grp ? glo[(size_t)p * Np + n] : (r.empty() ? 0 : r[std::min<size_t>(p, r.size() - 1)]);
+          lo[(size_t)p * Np + n] = r.empty() ? 0 : r[std::min<size_t>(p, r.size() - 1)];
         }
       // ---- dense per-phase int8 matrices ----
       std::vector<int8_t> W((size_t)P * Np * Kp, 0);
@@ -468,9 +333,8 @@ tf2_status Net::pack(int mode) {
             if (code_zero(code)) continue;
             const int s = code_shift(code);
             int p = 0;
-            if (grp) p = gid[c];
-            else while (p + 1 < (int)r.size() && s < r[p]) p++;
-            const int rel = grp ? s - glo[(size_t)p * Np + n] : s - r[p];
+            while (p + 1 < (int)r.size() && s < r[p]) p++;
+            const int rel = s - r[p];
             int kk = t * il.Cp_in + c;
             int val = 1 << rel;
             if (code_neg(code)) {
@@ -485,7 +349,7 @@ tf2_status Net::pack(int mode) {
       // slab that is non-zero in either window, holding [hi window TM x 64][lo window TM x 64].  The kernels then
       // fetch each activation slab once, keep two accumulators and combine them once at the end,
       // (hi << dshift[1]) + lo -- exact in Z/2^32 like the Horner form -- which halves the K steps.
-      const bool dual = P == 2 && !grp && getenv("TF2_AMD_NODUAL") == nullptr;
+      const bool dual = P == 2 && getenv("TF2_AMD_NODUAL") == nullptr;
       pl.dual = dual ? 1 : 0;
       std::vector<int32_t> dir((size_t)n_mtiles * (P + 1), 0);
       std::vector<int32_t> entries;
@@ -670,10 +534,6 @@ tf2_status Net::pack(int mode) {
         std::copy(dbl[l].begin(), dbl[l].end(), f.begin());
         pl.off_dbl = blob.alloc(Np);
         std::memcpy(blob.at<uint8_t>(pl.off_dbl), f.data(), Np);
-      }
-      if (perm_out) {
-        pl.off_perm = blob.alloc((size_t)N * 4);
-        std::memcpy(blob.at<uint8_t>(pl.off_perm), perm_out->data(), (size_t)N * 4);
       }
       if (in_dbl) {
         std::vector<int8_t> pad(il.Cp_in + 16, 0);

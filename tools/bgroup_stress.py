@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14F"] = "1"      # every batch size takes the group launches here
+os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1";      # every batch size takes the group launches here
 import torch
 from tf2_amd import config as cfg, network, synth
 t = cfg.resnet50_tables()

@@ -4,7 +4,7 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TF2_AMD_BGROUP"] = "1"; os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14F"] = "1"
+os.environ["TF2_AMD_BGROUP"] = "1"; os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1";
 import torch
 from tf2_amd import config as cfg, network, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=31)
