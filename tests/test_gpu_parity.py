@@ -449,3 +449,32 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     np.testing.assert_array_equal(rig.run(x32, keep_all=False)[:2], rig.ref.logits(rig.ref.run(x32[:2])))
 
 
+
+
+@pytest.mark.parametrize("rows,conc", [("7", "1"), ("4", "1"), ("2", "0")])
+def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc):
+    """conv_bband.hip: stage 4's identity bottlenecks (rows 28-42) as ONE launch each of independent row bands -- a block owns
+    `rows` output rows of one image and all channels, recomputes the reduce for its halo rows, keeps both intermediates in LDS; no
+    exchange between blocks.  The default with batches in flight (7 rows), TF2_AMD_BBAND=2 one batch at a time as well.  Every
+    layer against the oracle at batch 2 and 5 (keep_all: the intermediates are written out too), then batch-32 logits of repeated
+    runs on the liveness-planned workspace, and against the plain launches."""
+    monkeypatch.setenv("TF2_AMD_BBAND", "2" if conc == "0" else "1")
+    monkeypatch.setenv("TF2_AMD_BBAND_ROWS", rows)
+    monkeypatch.setenv("TF2_AMD_BBAND_ROWS_ALONE", rows)
+    monkeypatch.setenv("TF2_AMD_BBAND_MIN", "1")
+    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    rig = Rig(*r50, 0)
+    launches = rig.net.describe_launches(32, int(conc))
+    assert [r["layer"] for r in launches if "conv_bband" in r["kernel"]] == [28, 31, 34, 37, 40]
+    assert not any(r["layer"] in (29, 30, 32, 33) for r in launches)
+    rig.check_all_layers(synth.synth_images(rig.t, 2, 91))
+    rig.check_all_layers(synth.synth_images(rig.t, 5, 92))
+    x = synth.synth_images(rig.t, 32, 93)
+    first = rig.run(x, keep_all=False).copy()
+    np.testing.assert_array_equal(first[:3], rig.ref.logits(rig.ref.run(x[:3])))
+    for _ in range(5):
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
+    monkeypatch.setenv("TF2_AMD_BBAND", "0")
+    plain = Rig(*r50, 0)
+    assert not any("conv_bband" in r["kernel"] for r in plain.net.describe_launches(32, int(conc)))
+    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)

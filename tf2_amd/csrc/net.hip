@@ -174,9 +174,9 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
     }
   // Group launches (conv_bgroup.hip: rows l .. l + 2 in one launch, images at different layers at the same time): what the launch
   // reads stays live to its last row, what it writes exists from its first
-  if (packed_valid && opts.bgroup_mode)
+  if (packed_valid && (opts.bgroup_mode || opts.bband_mode))
     for (int l = 0; l + 2 < nl; l++) {
-      if (bgroup_first_at(l)) {
+      if (opts.bgroup_mode && bgroup_first_at(l)) {
         TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
         tin.last_use = std::max(tin.last_use, l + 3);
         TensorPlan& tm1 = wp.tensors[wp.exec[l + 1].out_tensor];
@@ -188,15 +188,18 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
         l += 3;
         continue;
       }
-      if (!bgroup_at(l)) continue;
+      const bool grp = opts.bgroup_mode && bgroup_at(l);
+      if (!grp && !(opts.bband_mode && (bband_at(l, opts.bband_rows) || bband_at(l, opts.bband_rows_alone)))) continue;
       TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
       tin.last_use = std::max(tin.last_use, l + 2);
       TensorPlan& tm1 = wp.tensors[wp.exec[l].out_tensor];
       tm1.last_use = std::max(tm1.last_use, l + 2);
       for (size_t t = 0; t < wp.tensors.size(); t++)
         if (born[t] == l + 1 || born[t] == l + 2) born[t] = l;
-      if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;                         // the step counter
-      wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;            // three rows of eight flag words per image (roll call, two meetings)
+      if (grp) {
+        if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;                       // the step counter
+        wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;          // three rows of eight flag words per image (roll call, two meetings)
+      }
       l += 2;
     }
   // ... and consecutive identity bottlenecks of the 14 x 14 maps may share a launch (bgroup_chain): nothing such a run touches
@@ -337,6 +340,27 @@ bool Net::bgroup_at(int l) const {
   return true;
 }
 
+// Rows l, l + 1, l + 2 = an identity bottleneck (as bgroup_at) of a shape conv_bband.hip is instantiated for, every row a dense
+// single-window layer.
+bool Net::bband_at(int l, int rows) const {
+  if (l < 1 || l + 2 >= nd.n_layers) return false;
+  const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1]; const tf2_layer_desc& E = layers[l + 2];
+  for (const tf2_layer_desc* L : {&A, &B, &E})
+    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->stride != 1 || L->dil != 1) return false;
+  if (A.src < 0 || A.k != 1 || A.pad_h || A.pad_w || A.add_src >= 0) return false;
+  if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
+  if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
+  if (layers[A.src].concat >= 0 || !conv_bband_shape_ok(A.H, A.W, A.C, A.N, std::min(rows, A.H))) return false;
+  if (out_Cp[A.src] != A.C) return false;                  // the input tensor holds exactly C bytes per pixel
+  for (int k = l; k <= l + 2; k++) {
+    const PackLayer* pl = pack_layer(k);
+    if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128)) return false;
+    if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
+    if (pl->n_phases != 1 || pl->dual || pl->w_share) return false;
+  }
+  return true;
+}
+
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
 // space-to-depth prep applies; the input tensor then carries 32 bytes per pixel in the same allocation.
 bool Net::stem_selected(int batch) const {
@@ -363,6 +387,10 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_CHAIN")) o.bgroup_chain = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
+  if (const char* e = getenv("TF2_AMD_BBAND")) o.bband_mode = atoi(e);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
+  if (const char* e = getenv("TF2_AMD_BBAND_ROWS")) o.bband_rows = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BBAND_ROWS_ALONE")) o.bband_rows_alone = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BBAND_MIN")) o.bband_min = atoi(e);
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
@@ -621,6 +649,36 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         continue;
       }
     }
+    // an identity bottleneck as ONE launch of independent row bands (conv_bband.hip): no exchange between blocks, so it may share
+    // the chip with anything -- the form for batches in flight (TF2_AMD_BBAND=2: one batch at a time as well, instead of the groups)
+    {
+      const int band_rows = concurrent ? opts.bband_rows : opts.bband_rows_alone;
+      if (opts.bband_mode && (concurrent || opts.bband_mode == 2) && batch >= opts.bband_min && bband_at(l, band_rows)) {
+        Launch s0, s1, s2;
+        if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
+        if (s0.conv.dense && s1.conv.dense && s2.conv.dense) {
+          Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BBAND; st.layer = l;
+          BBandArgs& f = st.bband;
+          const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
+          f.x = c0.x; f.mid1 = c0.y; f.mid2 = c1.y; f.y = c2.y; f.res = c2.res;
+          f.w1 = c0.w; f.w2 = c1.w; f.w3 = c2.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr3 = c2.hdr;
+          f.hdr1_bytes = c0.hdr_bytes; f.hdr2_bytes = c1.hdr_bytes; f.hdr3_bytes = c2.hdr_bytes;
+          f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
+          f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
+          f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
+          f.B = batch; f.H = L.H; f.W = L.W; f.R = std::min(band_rows, L.H); f.tiles_per_img = (L.H + f.R - 1) / f.R;
+          f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
+          f.keep_mid = wp->keep_all ? 1 : 0;
+          f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
+          f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
+          f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
+          st.bg_c = L.C; st.bg_m = L.N;
+          pair_done[l + 1] = 1; pair_done[l + 2] = 1;
+          lp.steps.push_back(st);
+          continue;
+        }
+      }
+    }
     // an identity bottleneck of a small map as ONE launch, eight blocks per image (one batch at a time: two such kernels
     // sharing CUs could hold each other's slots while their groups wait)
     if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_at(l) && batch >= (L.H == 7 ? opts.bgroup_min7 : L.H == 28 ? opts.bgroup_min28 : opts.bgroup_min14) && 256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
@@ -798,6 +856,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:
           if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);

@@ -92,13 +92,14 @@ inline bool launch_ok() { return launch_recorder() != nullptr || hipGetLastError
 
 // hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB for a kernel, once per (function, device): a process driving
 // several GPUs must set it on each of them.
-inline bool lds_attr_once(const void* fn) {
+// (max_dynamic: a kernel with static __shared__ arrays may only ask for the rest of the 160 KiB)
+inline bool lds_attr_once(const void* fn, int max_dynamic = 160 * 1024) {
   if (launch_recorder()) return true;            // describing, not launching (works without a device)
   static thread_local const void* seen_fn[64]; static thread_local int seen_dev[64]; static thread_local int n_seen = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   for (int i = 0; i < n_seen; i++) if (seen_fn[i] == fn && seen_dev[i] == dev) return true;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_dynamic) != hipSuccess) return false;
   if (n_seen < 64) { seen_fn[n_seen] = fn; seen_dev[n_seen] = dev; n_seen++; }
   return true;
 }

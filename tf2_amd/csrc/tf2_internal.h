@@ -199,6 +199,28 @@ struct BGroupArgs {
   int32_t hdrs_bytes, tms, relu_s, fast_s, keep_s, ys_cp;      // tms: rows per m-tile of the shortcut (64 or 128)
 };
 
+// conv_bband.hip: the same three rows (identity bottleneck) in one launch WITHOUT any exchange between blocks: a block owns R output
+// rows x the full width of one image and all channels, recomputes the reduce for its halo rows, keeps both intermediates in LDS
+struct BBandArgs {
+  const int8_t* x;           // the bottleneck's input [B][H*W][C], exactly C bytes per pixel
+  int8_t* mid1;              // reduce output  [B][H*W][M]  (written only with keep_mid)
+  int8_t* mid2;              // 3x3 output     [B][H*W][M]  (written only with keep_mid)
+  int8_t* y;                 // expand output
+  const int8_t* res;
+  const int8_t* w1; const int8_t* w2; const int8_t* w3;        // dense single-window weight tiles [m-tile * nslab + slab][tm rows][64]
+  const int32_t* hdr1; const int32_t* hdr2; const int32_t* hdr3;
+  const int8_t* zero;        // zero page
+  const int8_t* zero2;       // the 3x3's pad row (the stored form of x = 0 of its input tensor)
+  long long* dbg;            // optional: 16 wall-clock stamps per block (tools/bband_timeline.py), else null
+  int32_t hdr1_bytes, hdr2_bytes, hdr3_bytes;
+  int32_t tm1, tm2, tm3;     // rows per m-tile of the three layers (64 or 128)
+  int32_t B, H, W, R, tiles_per_img;     // R output rows per block, ceil(H / R) blocks per image
+  int32_t relu1, relu2, relu3, add_relu, has_res, keep_mid;
+  int32_t fast1, fast2, fast3;     // PackLayer::fast
+  int32_t dbl1, dbl2, dbl3;        // the layer's output tensor has doubled channels
+  int32_t res_cp, res_off, y_cp, y_off;
+};
+
 // consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
 // conv_bgroup7_kernel: the groups run them back to back)
 constexpr int kBgMaxChain = 5;
@@ -275,6 +297,8 @@ size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream);     // n_chain > 1: 14 x 14 only
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
+bool conv_bband_shape_ok(int H, int W, int C, int M, int R);
+int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream);        // 1: shape not instantiated / does not fit
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
 int launch_conv_stem(const StemArgs& a, int nwin, void* stream);              // 1: does not fit

@@ -17,6 +17,7 @@ ap.add_argument("--conc", type=int, default=0, help="launch plan: 0 one batch at
 ap.add_argument("--spinup-ms", type=float, default=600.0,
                 help="keep the device busy this long with torch matrix products first (other kernel names: they do not enter the tf2 rows "
                      "of the profile): an idle MI355X needs ~0.4 s of load to reach its engine clock (tools/clock_sample.py)")
+ap.add_argument("--partition", type=int, default=0, help="N > 0: run on ONE stream restricted to 8 / N XCDs (tf2_amd.streams): what one of N in-flight batches sees")
 ap.add_argument("--meta", default=None, help="write {batch, steps, launches} here")
 a = ap.parse_args()
 t = cfg.resnet50_tables()
@@ -33,8 +34,15 @@ if a.spinup_ms > 0:
             m2 = m @ m
         torch.cuda.synchronize()
     del m, m2
-for _ in range(a.warmup + a.steps):
-    r.run_batch(x, concurrency=a.conc)
+if a.partition > 0:
+    from tf2_amd import streams
+    st = streams.partitioned_streams(a.partition, "cuda:0")[0]
+    with torch.cuda.stream(st):
+        for _ in range(a.warmup + a.steps):
+            r.run_batch(x, concurrency=a.conc)
+else:
+    for _ in range(a.warmup + a.steps):
+        r.run_batch(x, concurrency=a.conc)
 torch.cuda.synchronize()
 if a.meta:
     json.dump(dict(batch=a.batch, steps=a.warmup + a.steps, conc=a.conc, launches=net.describe_launches(a.batch, a.conc)), open(a.meta, "w"), indent=0)
