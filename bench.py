@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py -- ResNet50 INT4w/INT8a images/s on N MI355X (BASELINE.json metric).
+"""bench.py -- ResNet50 INT4w/INT8a images/s on N MI355X (BASELINE.json metric); `--net` runs the other BASELINE configurations
+(SqueezeNet 1.1, VGG16, SSD300-VGG: synthetic Q values and weights) through the same measurement and prints the same JSON line.
 
 One process per GPU (torchrun contract), batches sharded with no data-path collective (weak
 scaling: every rank runs `--batch` images per step); the packed weights are broadcast once
@@ -70,6 +71,7 @@ def spawn_check(args):
     """The launch path alone: process group of --gpus ranks (RCCL on GPUs, gloo on CPU), rank -> device pinning, the ONE
     collective of the data path (broadcast of the packed weights) on a small network, and a CRC agreement check."""
     import zlib
+    import numpy as np
     import torch
     import torch.distributed as dist
     from tf2_amd import config as cfg, dist as tdist, network, synth
@@ -98,9 +100,27 @@ def spawn_check(args):
         dist.all_gather(got, tt)
         crcs = [int(g.item()) for g in got]
     lo, hi = tdist.shard_range(args.batch * world, rank, world)
+    # one sharded step per rank (GPU only: the product has no CPU path): every rank runs its contiguous shard of ONE global batch
+    # plus image 0 of the global batch, and the ranks compare the CRC of image 0's logits -- the same image must give the same
+    # bytes on every GPU, whatever shard it rides with
+    step_ok = None
+    if on_gpu:
+        per = max(1, min(args.batch, 4))
+        gx = synth.synth_images(t, per * world, 11)
+        mine = np.concatenate([gx[:1], gx[rank * per:(rank + 1) * per]])
+        out = network.Runner(None, net).run_batch(torch.from_numpy(np.ascontiguousarray(mine)).to(device)).cpu().numpy()
+        c0 = zlib.crc32(out[0].tobytes()) & 0xFFFFFFFF
+        c0s = [c0]
+        if world > 1:
+            tt = torch.tensor([c0], dtype=torch.int64, device=device)
+            got = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(got, tt)
+            c0s = [int(g.item()) for g in got]
+        step_ok = len(set(c0s)) == 1
     if rank == 0:
         print(json.dumps(dict(spawn_check=True, n_gpus=world, backend=(dist.get_backend() if world > 1 else None),
                               device=str(device) if on_gpu else "cpu", packed_crc_all_ranks_equal=len(set(crcs)) == 1,
+                              sharded_step_same_logits_all_ranks=step_ok,
                               rank0_shard=[lo, hi], global_batch=args.batch * world)))
     if world > 1:
         dist.barrier()
@@ -114,6 +134,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300"],
+                    help="network: resnet50 (the headline: shipped resnet50_Q, seeded INQ weights) or another BASELINE.json configuration "
+                         "(synthetic Q values and weights); e.g. BASELINE config 4 is `--gpus 8 --net vgg16 --batch 32`")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (MFMA), 1 north-star split, 2 shift only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -131,9 +154,11 @@ def main():
                     help="1: replay every step from a captured HIP graph (each leg captured with its own launch plan); 0 (default): launch; "
                          "-1: graphs for the batches-in-flight leg only.  Measured equal within noise on a warm device: 87.3-88.6 k against "
                          "86.6-87.8 k img/s at 20 steps in flight, 60.8-60.9 k against 61.2-61.4 k one batch at a time")
-    ap.add_argument("--partition", type=int, default=1,
-                    help="1: every in-flight stream gets its own XCDs (hipExtStreamCreateWithCUMask, tf2_amd/streams.py) when the number of "
-                         "batches in flight divides 8; 0: plain streams")
+    ap.add_argument("--partition", type=int, default=0,
+                    help="1: the in-flight streams are created with hipExtStreamCreateWithCUMask (tf2_amd/streams.py) when the number of batches "
+                         "in flight divides 8; 0 (default): plain streams.  Round 4 measured that the interleaved masks of streams.py are IGNORED by "
+                         "the hardware (every block still runs on all 256 CUs: tools/ubench/cumask_probe.hip, profiles/r04_ubench_cumask_probe.txt), "
+                         "so rounds 2-3's 'XCD partitions' were plain streams under another name")
     ap.add_argument("--stagger-layer", type=int, default=-1,
                     help=">= 0: stage-interlocked pipelining of the batches in flight -- step k+1's stream waits (hipStreamWaitEvent) for an "
                          "event that step k's run records once its layers 0..L are enqueued (tf2_net_run_ex mark_event), so a batch "
@@ -175,13 +200,21 @@ def main():
     import torch.distributed as dist
     assert world == args.gpus and (world == 1 or dist.get_world_size() == args.gpus), "process group size != --gpus"
 
-    tables = cfg.resnet50_tables()
+    if args.net == "resnet50":
+        tables = cfg.resnet50_tables()
+        qv = np.loadtxt(os.path.join(ROOT, "tests", "golden", "resnet50_Q"), dtype=np.int32)
+        net_name, net_note, seed_m = "ResNet50", "54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights", 0
+    else:
+        tables, net_name, seed_m = {"squeezenet": (cfg.squeezenet11_tables(), "SqueezeNet 1.1", 6), "vgg16": (cfg.vgg16_tables(), "VGG16", 1),
+                                    "ssd300": (cfg.ssd300_tables(), "SSD300-VGG", 3)}[args.net]
+        qv = synth.synth_q_values(tables, seed_m, spread=1)
+        net_note = "TF2 table program built by tf2_amd.config, synthetic per-channel Q values and seeded INQ weights"
     plan = cfg.build_plan(tables)
-    qfile = os.path.join(ROOT, "tests", "golden", "resnet50_Q")
-    qv = np.loadtxt(qfile, dtype=np.int32)
-    model = synth.synth_model(tables, qv, seed=0) if rank == 0 else None
+    qtext = synth.q_text(qv)
+    model = synth.synth_model(tables, qv, seed=seed_m) if rank == 0 else None
     net = network.NetWork(tables)
-    tdist.broadcast_network(net, model, qfile, device, pack_mode=args.mode)
+    tdist.broadcast_network(net, model, qtext, device, pack_mode=args.mode)
+    img_c, img_h, img_w = int(tables["INPUT_IMAGE_C"]), int(tables["INPUT_IMAGE_H"]), int(tables["INPUT_IMAGE_W"])
     runner = network.Runner(None, net)
 
     feeder = [None]
@@ -259,7 +292,7 @@ def main():
         if n_inflight > 1 and not serial[0]:   # set-up, not a step: every in-flight runner allocates its workspace
             for st, rn in zip(fl_streams, fl_runners):
                 with torch.cuda.stream(st):
-                    one(rn, x)
+                    one(rn, x, concurrency=1)
         torch.cuda.synchronize(device)
         if args.spinup_ms > 0 and spin:        # bring the device out of its idle power state (set-up, not a step)
             t_end = time.perf_counter() + args.spinup_ms * 1e-3
@@ -323,7 +356,7 @@ def main():
             with torch.cuda.stream(fl_streams[i]):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(fl_streams[i])
-                one(fl_runners[i], x)
+                one(fl_runners[i], x, concurrency=1)
                 e1.record(fl_streams[i])
             evs.append((e0, e1))
         torch.cuda.synchronize(device)
@@ -367,93 +400,134 @@ def main():
             res[name] = round((time.perf_counter() - t0) / n_lat * 1e6, 1)
         lat = dict(us_per_image=min(res.values()), by_path=res, note="batch 1, one image at a time, host-synchronised after each")
 
-    # ---- roofline: live per-layer HIP-event timing on the launch stream (C-side hook) ----
+    # ---- roofline: live per-layer HIP-event timing on the launch stream (C-side hook), for BOTH launch plans ----
     lo = layer_ops(plan)
-    prof_steps = 5
-    for _ in range(8):                       # settle the library's one-stream / several-streams choice (see above)
-        runner.run_batch(x)
-    _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
-    for _ in range(prof_steps):
-        runner.run_batch(x)
-    torch.cuda.synchronize(device)
-    ms = np.zeros(len(plan), np.float32); nl = np.zeros(len(plan), np.int32); kinds = np.zeros(len(plan), np.int32)
-    _lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kinds.ctypes.data, len(plan)))
-    # one event pair around the whole layer loop: what the per-layer pairs add by themselves (each record is a
-    # marker the command processor handles between kernels) is removed by rescaling the per-layer sum to it
-    _lib.check(_lib.lib().tf2_net_profile(net._h, 2))
-    for _ in range(prof_steps):
-        runner.run_batch(x)
-    torch.cuda.synchronize(device)
-    loop_ms, loop_n = C.c_float(0), C.c_int32(0)
-    _lib.check(_lib.lib().tf2_net_profile_loop_read(net._h, C.byref(loop_ms), C.byref(loop_n)))
-    _lib.check(_lib.lib().tf2_net_profile(net._h, 0))
-    per_layer_ms = ms / np.maximum(nl, 1)
-    event_scale = 1.0
-    if loop_n.value > 0 and per_layer_ms.sum() > 0:
-        event_scale = min(1.0, (loop_ms.value / loop_n.value) / float(per_layer_ms.sum()))
-    per_layer_ms = per_layer_ms * event_scale
-    # classes by LAUNCH: a launch that computes several table rows (conv_bneck: 3x3 + expand; pair launches; group launches: a
-    # whole bottleneck) is its own class, named after the rows it covers -- its time cannot be split between them
-    classes = {}
-    for name, g in launch_groups([r["cls"] for r in lo], nl, kinds):
-        c = classes.setdefault(name, dict(ops=0, bytes=0, ms=0.0, kernel=set(), launches=0))
-        c["launches"] += 1
-        for i in g:
-            c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
-            c["ms"] += float(per_layer_ms[i]); c["kernel"].add({0: "none", 1: "conv_mfma", 2: "conv_shift", 3: "l2norm"}.get(int(kinds[i]), "?"))
     PEAK_I8 = 5000.0    # TOP/s dense int8 MFMA (MI355X_MICROARCH.md: ~2x the 2.5 PF bf16 dense peak)
     PEAK_HBM = 8000.0   # GB/s
-    per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), launches=v["launches"], ms=round(v["ms"], 4),
-                         tops=round(v["ops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
-                         frac_int8_peak=round(v["ops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_I8, 4) if v["ms"] > 0 else None,
-                         gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,
-                         frac_hbm_peak=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4) if v["ms"] > 0 else None)
-                 for k, v in classes.items()}
-    # dominant kernel family = the convolution kernels: all their launches of one step.  SURVEY.md 8(d): the binding
-    # roofline of the layer-by-layer int8 streaming is HBM; the int8 MFMA fraction is reported beside it.
-    cv = [i for i in range(len(plan)) if kinds[i] in (1, 2)]
+    prof_steps = 5
+
+    def profile_plan(conc):
+        """One batch at a time on one stream with the launch plan of `conc` (0: the one-batch-at-a-time plan, 1: the plan the
+        timed region runs with batches in flight): per-launch HIP-event times, classes by launch, kernel names from the
+        library's own launch list."""
+        for _ in range(3):
+            runner.run_batch(x, concurrency=conc)
+        _lib.check(_lib.lib().tf2_net_profile(net._h, 1))
+        for _ in range(prof_steps):
+            runner.run_batch(x, concurrency=conc)
+        torch.cuda.synchronize(device)
+        ms = np.zeros(len(plan), np.float32); nl = np.zeros(len(plan), np.int32); kinds = np.zeros(len(plan), np.int32)
+        _lib.check(_lib.lib().tf2_net_profile_read(net._h, ms.ctypes.data, nl.ctypes.data, kinds.ctypes.data, len(plan)))
+        # one event pair around the whole layer loop: what the per-layer pairs add by themselves (each record is a
+        # marker the command processor handles between kernels) is removed by rescaling the per-layer sum to it
+        _lib.check(_lib.lib().tf2_net_profile(net._h, 2))
+        for _ in range(prof_steps):
+            runner.run_batch(x, concurrency=conc)
+        torch.cuda.synchronize(device)
+        loop_ms, loop_n = C.c_float(0), C.c_int32(0)
+        _lib.check(_lib.lib().tf2_net_profile_loop_read(net._h, C.byref(loop_ms), C.byref(loop_n)))
+        _lib.check(_lib.lib().tf2_net_profile(net._h, 0))
+        per_layer_ms = ms / np.maximum(nl, 1)
+        event_scale = 1.0
+        if loop_n.value > 0 and per_layer_ms.sum() > 0:
+            event_scale = min(1.0, (loop_ms.value / loop_n.value) / float(per_layer_ms.sum()))
+        per_layer_ms = per_layer_ms * event_scale
+        launches = net.describe_launches(args.batch, conc)
+        kern_of = {}
+        for l in launches:
+            if l["layer"] >= 0:
+                kern_of.setdefault(l["layer"], []).append(l["kernel"].split("<")[0].split(" ")[0])
+        # classes by LAUNCH: a launch that computes several table rows (conv_bneck: 3x3 + expand; pair launches; group / band launches:
+        # a whole bottleneck, or several) is its own class, named after the rows it covers -- its time cannot be split between them
+        classes = {}
+        for name, g in launch_groups([r["cls"] for r in lo], nl, kinds):
+            c = classes.setdefault(name, dict(ops=0, bytes=0, ms=0.0, kernel=set(), launches=0))
+            c["launches"] += 1
+            c["kernel"].update(kern_of.get(g[0], ["none"]))
+            for i in g:
+                c["ops"] += lo[i]["ops"] * args.batch; c["bytes"] += lo[i]["bytes"] * args.batch
+                c["ms"] += float(per_layer_ms[i])
+        per_class = {k: dict(kernel="+".join(sorted(v["kernel"])), launches=v["launches"], ms=round(v["ms"], 4),
+                             tops=round(v["ops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                             frac_int8_peak=round(v["ops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_I8, 4) if v["ms"] > 0 else None,
+                             gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,
+                             frac_hbm_peak=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4) if v["ms"] > 0 else None)
+                     for k, v in classes.items()}
+        cv = [i for i in range(len(plan)) if kinds[i] in (1, 2)]
+        n_launch = max(1, sum(1 for i in cv if nl[i] > 0))
+        dom_ms = float(sum(per_layer_ms[i] for i in cv))
+        # the launch that takes the most time: the plan's dominant kernel
+        top = max((i for i in cv if nl[i] > 0), key=lambda i: per_layer_ms[i], default=None)
+        top_kernel = None
+        if top is not None:
+            full = [l["kernel"] for l in launches if l["layer"] == top]
+            top_kernel = dict(kernel=full[0] if full else None, first_row=int(top), us=round(float(per_layer_ms[top]) * 1e3, 2))
+        return dict(per_layer_ms=per_layer_ms, nl=nl, kinds=kinds, cv=cv, n_launch=n_launch, dom_ms=dom_ms, event_scale=event_scale,
+                    per_class=per_class, top_kernel=top_kernel, kernels=sorted({k for v in kern_of.values() for k in v if k.startswith("conv")}))
+
+    def committed(name):
+        """a profile of THIS round committed under profiles/ for this network / batch / kernel mode (tools/round_evidence.sh)"""
+        pj = os.path.join(ROOT, "profiles", name)
+        return pj if (os.path.exists(pj) and args.mode == 0 and args.net == "resnet50") else None
+
+    P0 = profile_plan(0)
+    P1 = profile_plan(1) if n_inflight > 1 else None
+    cv = P0["cv"]
     dom_ops = sum(lo[i]["ops"] for i in cv) * args.batch
     alg_bytes = sum(lo[i]["bytes"] for i in cv) * args.batch
-    dom_ms = float(sum(per_layer_ms[i] for i in cv))
-    traffic, traffic_note = None, "no PMC pass committed for this batch size and kernel mode"
-    for rnd in ("r03", "r02", "r01"):
-        pj = os.path.join(ROOT, "profiles", f"{rnd}_pmc_conv_b{args.batch}.json")
-        if os.path.exists(pj) and args.mode == 0:
-            pm = json.load(open(pj))
-            if len(pm.get("layers", [])) == len(plan):
-                tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in cv)
-                traffic = round(tb / max(1, sum(1 for i in cv if nl[i] > 0)))
-                traffic_note = (f"mean HBM bytes per launch over the step's {sum(1 for i in cv if nl[i] > 0)} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)"
-                                f"+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
-                break
-    # the committed rocprofv3 --kernel-trace --stats summary of the same workload (tools/round_evidence.sh: ONLY batch-N steps one at
-    # a time in the profiled process): the conv kernels' time per step as the profiler sees it, next to the live HIP-event figure
-    rocprof_us, rocprof_src = None, None
-    for rnd in ("r03",):
-        pj = os.path.join(ROOT, "profiles", f"{rnd}_rocprof_b{args.batch}_summary.json")
-        if os.path.exists(pj) and args.mode == 0:
-            rs = json.load(open(pj))
-            rocprof_us, rocprof_src = round(rs["conv_us_per_step"], 1), os.path.basename(pj)
-    n_launch = max(1, sum(1 for i in cv if nl[i] > 0))      # a conv_bneck launch computes two table rows
-    gbps = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    tops = dom_ops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    kname = {0: "conv_mfma2_kernel (+ conv_mfma_sk / conv_pw / conv_bneck / conv_stem: every conv launch of the step)", 1: "conv_shift_kernel (k>1) + MFMA kernels (1x1)",
-             2: "conv_shift_kernel"}[args.mode]
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
+    traffic, traffic_note = None, "no PMC pass committed for this network / batch size / kernel mode"
+    pj = committed(f"r04_pmc_conv_b{args.batch}.json")
+    if pj:
+        pm = json.load(open(pj))
+        if len(pm.get("layers", [])) == len(plan):
+            tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in cv)
+            traffic = round(tb / P0["n_launch"])
+            traffic_note = (f"mean HBM bytes per launch over the step's {P0['n_launch']} conv launches (one batch at a time), rocprofv3 "
+                            f"FETCH_SIZE(x2, gfx950)+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
+    # the committed rocprofv3 --kernel-trace summaries of the same workload (tools/round_evidence.sh: ONLY batch-N steps in the
+    # profiled process, one per launch plan): the conv kernels' time per step as the profiler sees it, next to the live figure
+    def rocprof_of(name):
+        pj = committed(name)
+        if not pj:
+            return None, None
+        rs = json.load(open(pj))
+        return round(rs["conv_us_per_step"], 1), os.path.basename(pj)
+    rocprof_us, rocprof_src = rocprof_of(f"r04_rocprof_b{args.batch}_summary.json")
+    gbps = alg_bytes / (P0["dom_ms"] * 1e-3) / 1e9 if P0["dom_ms"] > 0 else 0.0
+    tops = dom_ops / (P0["dom_ms"] * 1e-3) / 1e12 if P0["dom_ms"] > 0 else 0.0
+    n_launch = P0["n_launch"]
+    roofline = dict(bound="hbm", kernel=P0["top_kernel"], kernels=P0["kernels"], achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
                     traffic=traffic, traffic_note=traffic_note,
                     algorithmic_bytes_per_launch=round(alg_bytes / n_launch), launches_per_step=n_launch,
-                    avg_launch_us=round(dom_ms / n_launch * 1e3, 2), event_pair_scale=round(event_scale, 4),
-                    kernel_us_per_step=round(dom_ms * 1e3, 1), kernel_us_per_step_rocprof=rocprof_us, rocprof_summary=rocprof_src,
+                    avg_launch_us=round(P0["dom_ms"] / n_launch * 1e3, 2), event_pair_scale=round(P0["event_scale"], 4),
+                    kernel_us_per_step=round(P0["dom_ms"] * 1e3, 1), kernel_us_per_step_rocprof=rocprof_us, rocprof_summary=rocprof_src,
                     mfma_side=dict(achieved_tops=round(tops, 1), peak_tops=PEAK_I8, frac=round(tops / PEAK_I8, 4),
                                    algorithmic_ops_per_launch=round(dom_ops / n_launch)),
-                    note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d): 26.9 MB per image) of "
-                         "the step's conv launches / sum of their HIP-event durations on the launch stream, one batch at a time; "
-                         "per-layer event times rescaled by event_pair_scale = (one event pair around the whole layer loop) / (their sum)")
+                    note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d)) of the step's conv launches "
+                         "/ sum of their HIP-event durations on the launch stream, ONE BATCH AT A TIME with that plan's launches (`kernel` = the "
+                         "launch that takes the most time, named by tf2_net_describe_launches); per-layer event times rescaled by event_pair_scale "
+                         "= (one event pair around the whole layer loop) / (their sum).  The plan the TIMED region runs is `in_flight`.")
     total_bytes = sum(r["bytes"] for r in lo) * args.batch
     hbm_gbps = total_bytes / (ms_per_step * 1e-3) / 1e9
-    # the same algorithmic bytes against the TIMED region (batches in flight): the rate the whole pipeline sustains
-    roofline["in_flight"] = dict(achieved=round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1), frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM, 4),
-                                 note="conv launches' algorithmic bytes per step / ms_per_step of the timed region")
+    # the plan the timed region runs (batches in flight): its launches timed one batch at a time on one stream (live events + the
+    # committed rocprofv3 summary of the same), and the same algorithmic bytes against the TIMED region = the rate the pipeline sustains
+    fl = dict(achieved=round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1), frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM, 4),
+              mfma_frac=round(dom_ops / (ms_per_step * 1e-3) / 1e12 / PEAK_I8, 4),
+              note="conv launches' algorithmic bytes (ops) per step / ms_per_step of the timed region; kernel_us_per_step*: the SAME launches run "
+                   "one batch at a time on one stream (the profiler serialises streams, so their overlap cannot be traced: pipeline_evidence)")
+    if P1 is not None:
+        r1_us, r1_src = rocprof_of(f"r04_rocprof_b{args.batch}_conc1_summary.json")
+        fl.update(launches_per_step=P1["n_launch"], kernel_us_per_step=round(P1["dom_ms"] * 1e3, 1), kernel_us_per_step_rocprof=r1_us,
+                  rocprof_summary=r1_src, kernel=P1["top_kernel"], kernels=P1["kernels"], event_pair_scale=round(P1["event_scale"], 4),
+                  overlap_factor=round(P1["dom_ms"] / ms_per_step, 2) if ms_per_step > 0 else None)
+    roofline["in_flight"] = fl
+    per_class = P0["per_class"]
+    # the per-class fractions of the REPORTED number: the in-flight plan's classes, each with its share of that plan's kernel time;
+    # a class's sustained rate in the timed region = its one-at-a-time rate x overlap_factor (kernel time / step time)
+    per_class_in_flight = None
+    if P1 is not None:
+        tot1 = sum(v["ms"] for v in P1["per_class"].values()) or 1.0
+        per_class_in_flight = {k: dict(v, share_of_kernel_time=round(v["ms"] / tot1, 4)) for k, v in P1["per_class"].items()}
 
     # ---- CPU baseline: the oracle (restated reference CPU path) on the host cores, rank 0, N=1 ----
     cpu = None
@@ -461,10 +535,10 @@ def main():
         from oracle import netref, oracle as O
         ref = netref.RefNet(tables, qv, model)
         n_done, t_cpu = 0, 0.0
-        imgs = synth.synth_images(tables, 64, seed=100)
+        imgs = synth.synth_images(tables, 64 if args.net == "resnet50" else 16, seed=100)
         chunk = max(1, min(16, O.num_threads()))          # tf2o_layer parallelises over (image, output channel): every thread busy
         first_logits = None
-        while t_cpu < args.cpu_seconds and n_done + chunk <= 64:
+        while t_cpu < args.cpu_seconds and n_done + chunk <= len(imgs):
             t0 = time.perf_counter()
             outs = ref.run(imgs[n_done:n_done + chunk])
             t_cpu += time.perf_counter() - t0
@@ -475,21 +549,21 @@ def main():
         got = runner.run_batch(torch.from_numpy(imgs[:first_logits.shape[0]]).to(device)).cpu().numpy()
         parity = bool((got == first_logits).all())
         cpu = dict(value=round(n_done / t_cpu, 3), unit="images/s", cores=O.num_threads(), kind="port",
-                   sample=f"{n_done} synthetic 224x224 images, same ResNet50 weights/Q, oracle/tf2_oracle.c (OpenMP over image x output "
+                   sample=f"{n_done} synthetic {img_h}x{img_w} images, same {net_name} weights/Q, oracle/tf2_oracle.c (OpenMP over image x output "
                           f"channel, {O.num_threads()} threads = the CPUs this process may use: affinity {len(os.sched_getaffinity(0))}, "
                           f"cgroup quota applied; {os.cpu_count()} logical CPUs visible) in {t_cpu:.1f} s",
                    parity_with_gpu_logits=parity)
 
     if rank == 0:
-        line = dict(metric="images/sec ResNet50 INT4w/INT8a", value=round(value, 1), unit="images/s", n_gpus=world,
+        line = dict(metric=f"images/sec {net_name} INT4w/INT8a", value=round(value, 1), unit="images/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4), higher_is_better=True,
                     scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
-                    config=dict(workload=f"ResNet50 INT4w/INT8a (54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights), "
-                                         f"batch {args.batch}/GPU, 3x224x224 float images resident in HBM",
+                    config=dict(workload=f"{net_name} INT4w/INT8a ({net_note}), "
+                                         f"batch {args.batch}/GPU, {img_c}x{img_h}x{img_w} float images resident in HBM",
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
                                 sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=dict(in_flight_leg=bool(graph_inflight), one_batch_at_a_time_leg=bool(graph_serial)),
                                 stage_interlock_layer=(args.stagger_layer if stagger else None),
-                                xcd_partitions=(n_inflight if partitioned else None),
+                                cu_masked_streams=(n_inflight if partitioned else None),
                                 host_feeder_threads=(n_inflight if feeder[0] is not None else 1),
                                 spinup_ms=args.spinup_ms,
                                 spinup_note="untimed steps for spinup_ms before the W warm-up steps of every timed leg: an idle MI355X sits "
@@ -498,7 +572,7 @@ def main():
                     cold_start=cold, roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
-                    per_layer_class=per_class, images_per_s_by_batch=sweep,
+                    per_layer_class=per_class, per_layer_class_in_flight=per_class_in_flight, images_per_s_by_batch=sweep,
                     images_per_s_one_batch_at_a_time=serial_value, latency_batch1=lat, pipeline_evidence=pipe)
         print(json.dumps(line))
     if world > 1:

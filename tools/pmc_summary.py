@@ -5,8 +5,9 @@ KiB units; FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes for wide c
 gfx950 -- validated here against layers whose byte count is known), wave cycles and instruction mix."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_pmc_conv_b32.json")
+src = os.path.join(ROOT, "gpurun_out", os.environ.get("PMC_DIR", "pmc"))
+CONC = int(os.environ.get("PMC_CONC", "0"))      # which launch plan the profiled process ran (tools/pmc_run.sh <batch> <conc> <dir>)
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_pmc_conv_b32.json")
 
 def table(d):
     f = glob.glob(f"{src}/{d}/runc/*_counter_collection.csv")[0]
@@ -27,7 +28,7 @@ _q = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 _net = network.NetWork(_t); _net.Quantization(synth.q_text(_q)); _net.LoadModel(synth.synth_model(_t, _q, 0)); _net.Pack(0)
 B = int(os.environ.get("PMC_BATCH", "32"))
 _plan = cfg.build_plan(_t)
-_launches = [l for l in _net.describe_launches(B, 0) if "conv_" in l["kernel"]]
+_launches = [l for l in _net.describe_launches(B, CONC) if "conv_" in l["kernel"]]
 launch_layers = [l["layer"] for l in _launches]
 fused_into = {}
 for k, l in enumerate(_launches):          # a launch that computes several table rows (conv_bneck pair, conv_mfma2 pair launch)
@@ -44,7 +45,7 @@ for k, l in enumerate(_launches):          # the profiler's rows are the launch 
 assert "conv_stem" in sq1[0]["kernel"]
 rows = [None] * len(_plan)
 for i in fused_into:
-    rows[i] = dict(layer=i, kernel="(computed by the conv_bneck launch of layer %d)" % fused_into[i], fused_into=fused_into[i], grid_threads=0, vgpr=0,
+    rows[i] = dict(layer=i, kernel="(computed by the launch of layer %d)" % fused_into[i], fused_into=fused_into[i], grid_threads=0, vgpr=0,
                    fetch_bytes=0.0, fetch_bytes_raw_counter=0.0, write_bytes=0.0, waves=0.0, wave_cycles_quad=0.0, wait_any=0.0, wait_inst_any=0.0,
                    active_inst_any=0.0, insts_valu=0.0, insts_salu=0.0, insts_lds=0.0, insts_vmem=0.0, insts_mfma=0.0, mfma_busy_cycles=0.0, lds_bank_conflict=0.0)
 for k, i in enumerate(launch_layers):
@@ -57,6 +58,6 @@ for k, i in enumerate(launch_layers):
                      insts_vmem=b["SQ_INSTS_VMEM"], insts_mfma=b["SQ_INSTS_MFMA"], mfma_busy_cycles=b["SQ_VALU_MFMA_BUSY_CYCLES"],
                      lds_bank_conflict=b["SQ_LDS_BANK_CONFLICT"])
 tot = dict(fetch_bytes=sum(r["fetch_bytes"] for r in rows), write_bytes=sum(r["write_bytes"] for r in rows))
-json.dump(dict(note="rocprofv3 --pmc passes (separate runs: SQ x2, FETCH_SIZE+GRBM, WRITE_SIZE), ResNet50 batch 32, one step (a conv_bneck launch covers two table rows: counters on the first); "
+json.dump(dict(note="rocprofv3 --pmc passes (separate runs: SQ x2, FETCH_SIZE+GRBM, WRITE_SIZE), ResNet50 batch %d, one step of the %s launch plan (a launch that covers several table rows: counters on the first); " % (B, "batches-in-flight" if CONC else "one-batch-at-a-time") +
                     "fetch_bytes = 2 x FETCH_SIZE KiB (gfx950 correction)", total=tot, layers=rows), open(out, "w"), indent=1)
 print("wrote", out, {k: round(v / 1e6, 1) for k, v in tot.items()}, "MB per step")

@@ -17,7 +17,8 @@ for r in rows:
                      us_per_step=float(r["TotalDurationNs"]) / 1e3 / steps))
 conv = [k for k in kern if "conv_" in k["kernel"]]
 n_conv_plan = sum(1 for l in meta["launches"] if "conv_" in l["kernel"])
-out = dict(note="rocprofv3 --kernel-trace --stats of tools/steps_only.py: ResNet50, batch %d, %d steps one batch at a time, nothing else in the process but a clock spin-up of torch matrix products before them (tools/steps_only.py --spinup-ms)" % (meta["batch"], steps),
+out = dict(note="rocprofv3 --kernel-trace --stats of tools/steps_only.py: ResNet50, batch %d, %d steps one batch at a time on one stream with the %s launch plan, nothing else in the process but a clock spin-up of torch matrix products before them (tools/steps_only.py --spinup-ms)" % (meta["batch"], steps, "batches-in-flight (--conc 1: what bench.py's timed region launches)" if meta.get("conc") else "one-batch-at-a-time"),
+           conc=meta.get("conc", 0),
            batch=meta["batch"], steps=steps,
            conv_launches_per_step=sum(k["calls_per_step"] for k in conv), conv_launches_per_step_launch_plan=n_conv_plan,
            conv_us_per_step=sum(k["us_per_step"] for k in conv), all_kernels_us_per_step=sum(k["us_per_step"] for k in kern),
