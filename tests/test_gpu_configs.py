@@ -187,7 +187,7 @@ def test_four_batches_in_flight_as_bench_times_them(r50, graph):
     torch = _torch()
     assert os.environ.get("GPU_MAX_HW_QUEUES") == "8"
     rig = Rig(*r50, 0)
-    n_fl, n_in, n_steps = 4, 8, 16
+    n_fl, n_in, n_steps = 4, 8, 32
     xs = [synth.synth_images(rig.t, 32, 300 + i) for i in range(n_in)]
     xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
     serial = [rig.run(x, keep_all=False).copy() for x in xs]          # one stream, one batch at a time

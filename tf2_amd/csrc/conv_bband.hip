@@ -38,8 +38,9 @@ using i32x16 = int __attribute__((ext_vector_type(16)));
 
 template <int N>
 __device__ __forceinline__ void bb_wait_vmcnt() {
-  static_assert(N == 4 || N == 8, "prepared immediates");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  static_assert(N == 2 || N == 4 || N == 8, "prepared immediates");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
@@ -62,7 +63,10 @@ __device__ __forceinline__ void bb_dma16(const int8_t* src, int8_t* lds_dst) {
 // ((R + 2) * W <= 32 NT0) and of the band itself (R * W <= 32 NT1); SC: channel slabs per chunk of the input stream
 // NW: waves per block (8: two per SIMD, up to 256 registers; 16: four per SIMD, 128 registers -- the requantisation phases are VALU
 // work that one or two waves per SIMD cannot issue at rate)
-template <int M, int NW, int WN, int NT0, int NT1, int SC>
+// DUAL1 / DUAL2: the reduce / the 3x3 is a two-window layer (weight_pack.cpp: entries [hi rows | lo rows]).  The reduce keeps two
+// accumulator sets over the one input stream and combines them once, (hi << dshift[1]) + lo; the 3x3 sweeps its LDS-resident halo
+// tile window by window into ONE set with the Horner shift in between (conv_bneck's scheme) -- both exact in Z/2^32.
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a) {
   constexpr int C = 4 * M;
   constexpr int WM = NW / WN, MT = M / (32 * WM);
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   constexpr int LEAN = NW == 16 ? 2 : 0;                 // requant_epilogue.h: header rows read two ahead instead of all sixteen at once (128-register budget)
   constexpr int KS1 = C / 64, KS2 = M / 64, NE = 9 * KS2;
   constexpr int NP0 = 32 * NT0, NP1 = 32 * NT1;
-  static_assert(KS1 % SC == 0, "whole chunks");
+  static_assert(KS1 % SC == 0 && SC >= 2, "whole chunks; a chunk's DMAs are told from its fragment loads by a counted wait (below)");
   constexpr int NCH = KS1 / SC;                          // chunks of the input stream
   constexpr int CHUNK = SC * NP0 * 64;
   constexpr int MID2 = KS2 * NP1 * 64;
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   const int slabb = n_grp_h * 1024;                      // bytes of one 64-channel slab of the halo tile
   int8_t* const mid1 = dyn;
   const int tms1 = a.tm1 == 128 ? 7 : 6, tms2 = a.tm2 == 128 ? 7 : 6, tms3 = a.tm3 == 128 ? 7 : 6;
-  const int hst1 = 20 << tms1, hst2 = 20 << tms2, hst3 = 20 << tms3;      // bytes of one m-tile's rows | lo image
+  // bytes of one m-tile's header image: rows {bias, alpha, addend64} | lo | dshift[P] (the Horner shifts: two-window layers only)
+  const int hst1 = (DUAL1 ? 28 : 20) << tms1, hst2 = (DUAL2 ? 28 : 20) << tms2, hst3 = 20 << tms3;
   int8_t* const hdr1 = mid1 + KS2 * slabb;
   int8_t* const hdr2 = hdr1 + (M >> tms1) * hst1;
   int8_t* const hdr3 = hdr2 + (M >> tms2) * hst2;
@@ -142,41 +147,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   if (NCH > 1) issue_chunk(1, ring1);
   // (3) header images (rows {bias | dbl, alpha, addend64} | lo per m-tile) by ordinary loads: 20 * tm bytes per m-tile, packed
   {
-    auto hdr_copy = [&](const int32_t* hdr, int hdr_bytes, int tms, int n_mt, int8_t* dst) {
-      const int per = 5 << (tms - 2);                      // 16-byte pieces per m-tile
+    auto hdr_copy = [&](const int32_t* hdr, int hdr_bytes, int tms, int n_mt, int8_t* dst, int words_per_row) {
+      const int per = words_per_row << (tms - 2);          // 16-byte pieces per m-tile
       for (int i = tid; i < n_mt * per; i += NW * 64) {
         const int mt = i / per, k = i - mt * per;
         const i32x4 v = *reinterpret_cast<const i32x4*>(reinterpret_cast<const int8_t*>(hdr) + (size_t)mt * hdr_bytes + k * 16);
         *reinterpret_cast<i32x4*>(dst + (size_t)mt * (per * 16) + k * 16) = v;
       }
     };
-    hdr_copy(a.hdr1, a.hdr1_bytes, tms1, M >> tms1, hdr1);
-    hdr_copy(a.hdr2, a.hdr2_bytes, tms2, M >> tms2, hdr2);
-    hdr_copy(a.hdr3, a.hdr3_bytes, tms3, C >> tms3, hdr3);
+    hdr_copy(a.hdr1, a.hdr1_bytes, tms1, M >> tms1, hdr1, DUAL1 ? 7 : 5);
+    hdr_copy(a.hdr2, a.hdr2_bytes, tms2, M >> tms2, hdr2, DUAL2 ? 7 : 5);
+    hdr_copy(a.hdr3, a.hdr3_bytes, tms3, C >> tms3, hdr3, 5);
   }
 
   // weight fragments: a lane's MFMA A fragment is 16 contiguous bytes of its row in the packed tile [tm rows][64]
   struct Afr { i32x4 k[MT][2]; };
   const int cb_w = wm * (MT * 32);                       // this wave's first channel inside an M-channel pass
-  auto load_a = [&](Afr& f, const int8_t* w, int tms, int nslab, int cb, int slab) {
+  // (wins: windows per entry of the layer's packed tiles, win: the one to fetch)
+  auto load_a = [&](Afr& f, const int8_t* w, int tms, int nslab, int cb, int slab, int wins = 1, int win = 0) {
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int ch = cb + i * 32;
       const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
-      const int8_t* p = w + ((((size_t)mt * nslab + slab) << tms) + ro + (lane & 31)) * 64 + half * 16;
+      const int8_t* p = w + (((((size_t)mt * nslab + slab) * wins + win) << tms) + ro + (lane & 31)) * 64 + half * 16;
       f.k[i][0] = *reinterpret_cast<const i32x4*>(p);
       f.k[i][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
   };
+  // fragments of global step v (phase 0: slab v of the reduce's high window; phase 1: (window, tap, slab) of the 3x3; phase 2 loads its own)
+  constexpr int N1 = (DUAL2 ? 2 : 1) * NE;               // steps of phase 1
+  auto load_step = [&](Afr& f, auto v_c) {
+    constexpr int v = decltype(v_c)::value;
+    if constexpr (v < KS1) load_a(f, a.w1, tms1, KS1, cb_w, v, DUAL1 ? 2 : 1, 0);
+    else if constexpr (v < KS1 + N1) load_a(f, a.w2, tms2, NE, cb_w, (v - KS1) % NE, DUAL2 ? 2 : 1, (v - KS1) / NE);
+    else load_a(f, a.w3, tms3, KS2, cb_w, v - KS1 - N1);                                     // the expand's first fragments (pass 0)
+  };
+  Afr g0, g1, g2, g3;                                    // DUAL1: the reduce's LOW window fragments, rotating like f0..f3
+#define BB_BUFL(v) ((v) % 4 == 0 ? g0 : (v) % 4 == 1 ? g1 : (v) % 4 == 2 ? g2 : g3)
   // four rotating buffers (PF = 2 would need three; four divides the step count of every phase, so that the pass loop of phase 2 can
   // be a run-time loop with the same buffer assignment in every iteration)
   Afr f0, f1, f2, f3;
   static_assert(kBbPF == 2 && (2 * KS2) % 4 == 0, "buffer rotation: one pass pair advances the step count by a multiple of four");
 #define BB_BUF(v) ((v) % 4 == 0 ? f0 : (v) % 4 == 1 ? f1 : (v) % 4 == 2 ? f2 : f3)
-  load_a(f0, a.w1, tms1, KS1, cb_w, 0);
-  load_a(f1, a.w1, tms1, KS1, cb_w, 1);
+  load_step(f0, std::integral_constant<int, 0>{});
+  load_step(f1, std::integral_constant<int, 1>{});
+  if constexpr (DUAL1) { load_a(g0, a.w1, tms1, KS1, cb_w, 0, 2, 1); load_a(g1, a.w1, tms1, KS1, cb_w, 1, 2, 1); }
 
   i32x16 acc[MT][J0 > J1 ? J0 : J1];
+  i32x16 acc2[DUAL1 ? MT : 1][DUAL1 ? J0 : 1];           // DUAL1: the reduce's low window
   auto zero_acc = [&](int nj) {
 #pragma unroll
     for (int i = 0; i < MT; i++)
@@ -187,6 +205,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
           for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
   };
   zero_acc(J0);
+  if constexpr (DUAL1) {
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < J0; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc2[i][j][r] = 0;
+  }
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // pad fill, chunks 0 and 1, headers: complete in every wave
@@ -206,14 +232,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     Afr& cur = BB_BUF(v);
     Afr& nxt = BB_BUF(v + 2);
     if constexpr (sl == 0 && ch > 0) {
-      // chunk ch landed in every wave and nobody reads buffer (ch + 1) & 1 any more.  This wave's DMAs of chunk ch were issued one
-      // chunk ago; younger than them are only weight fragments, of which the last two steps' (4 MT loads) may still fly.
-      bb_wait_vmcnt<4 * MT>();
+      // chunk ch landed in every wave and nobody reads buffer (ch + 1) & 1 any more.  This wave's DMAs of chunk ch were issued at
+      // the first step of chunk ch - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
+      // other SC - 1 steps, (DUAL1 ? 4 : 2) MT each, of which at most the last two steps' still fly -- so "no more than
+      // min(2, SC - 1) steps' loads outstanding" means every DMA of the chunk has landed.  (SC = 2 with the bound for two steps
+      // let DMAs fly on: wrong logits with batches in flight, round 4.)
+      bb_wait_vmcnt<(SC - 1 < 2 ? SC - 1 : 2) * (DUAL1 ? 4 : 2) * MT>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    if constexpr (v + 2 < KS1) load_a(nxt, a.w1, tms1, KS1, cb_w, v + 2);
-    else if constexpr (v + 2 - KS1 < NE) load_a(nxt, a.w2, tms2, NE, cb_w, v + 2 - KS1);      // the 3x3's first fragments
+    load_step(nxt, std::integral_constant<int, v + 2>{});
+    if constexpr (DUAL1 && v + 2 < KS1) load_a(BB_BUFL(v + 2), a.w1, tms1, KS1, cb_w, v + 2, 2, 1);
     if constexpr (sl == 0 && ch > 0 && ch + 1 < NCH) {
       // (behind this step's fragment loads: the compiler's counted wait for the NEXT step's fragments then still lets these fly)
       asm volatile("" ::: "memory");
@@ -228,11 +257,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
 #pragma unroll
       for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int j = 0; j < J0; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < J0; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
+          if constexpr (DUAL1) acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(BB_BUFL(v).k[i][ks], bf[j], acc2[i][j], 0, 0, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   bb_static_for<0, KS1>(step0);
+  // Horner step of a two-window layer: acc = (acc << dshift[1][row]) [+ the low window's sums]; dshift sits behind rows | lo
+  auto window_combine = [&](const int8_t* hdr, int tms, int hst, int nj, bool add_low) {
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int ch = cb_w + i * 32;
+      const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
+      const int* dsh = reinterpret_cast<const int*>(hdr + mt * hst) + (6 << tms) + ro + 4 * half;       // dshift[1]
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int j = 0; j < (J0 > J1 ? J0 : J1); j++)
+            if (j < nj) {
+              unsigned vv = (unsigned)acc[i][j][G * 4 + r] << (d[r] & 31);
+              if constexpr (DUAL1) { if (add_low) vv += (unsigned)acc2[i][j < J0 ? j : 0][G * 4 + r]; }
+              acc[i][j][G * 4 + r] = (int)vv;
+            }
+      }
+    }
+  };
+  if constexpr (DUAL1) window_combine(hdr1, tms1, hst1, J0, true);
   BB_STAMP(2);
 
   // hand-over: requantise (pe.cl:185-203, relu.cl:54) into the halo tile; pixels of rows outside the image keep the pad value
@@ -284,13 +339,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     h0[j] = r * Wp + (p - r * W);
   }
   auto step1 = [&](auto e_c) {
-    constexpr int e = decltype(e_c)::value;
-    constexpr int v = KS1 + e;                             // global step index: the fragment buffers keep rotating
-    constexpr int t = e / KS2, s = e % KS2;
+    constexpr int ew = decltype(e_c)::value;               // (window, tap, slab)
+    constexpr int v = KS1 + ew;                            // global step index: the fragment buffers keep rotating
+    constexpr int e = ew % NE, t = e / KS2, s = e % KS2;
     Afr& cur = BB_BUF(v);
     Afr& nxt = BB_BUF(v + 2);
-    if constexpr (e + 2 < NE) load_a(nxt, a.w2, tms2, NE, cb_w, e + 2);
-    else load_a(nxt, a.w3, tms3, KS2, cb_w, e + 2 - NE);                                   // the expand's first fragments (pass 0)
+    load_step(nxt, std::integral_constant<int, v + 2>{});
+    if constexpr (DUAL2 && ew == NE) window_combine(hdr2, tms2, hst2, J1, false);        // between the windows
     const int8_t* B = mid1 + s * slabb;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -307,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  bb_static_for<0, NE>(step1);
+  bb_static_for<0, N1>(step1);
   BB_STAMP(4);
 
   // residual tiles of pass q (16 contiguous NHWC bytes per lane and column tile), loaded one pass ahead
@@ -380,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   for (int qq = 0; qq < NPASS; qq += 2) {
     auto step2 = [&](auto u_c) {
       constexpr int u = decltype(u_c)::value;                // step inside the pair
-      constexpr int v = KS1 + NE + u;
+      constexpr int v = KS1 + N1 + u;
       constexpr int ql = u / KS2, s = u % KS2;
       Afr& cur = BB_BUF(v);
       Afr& nxt = BB_BUF(v + 2);
@@ -442,45 +497,67 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   BB_STAMP(6);
 #undef BB_STAMP
 #undef BB_BUF
+#undef BB_BUFL
 }
 
 // dynamic LDS of a launch: the halo tile + the three layers' header images (the chunk buffers are static)
-static size_t bband_dyn_lds(int M, int R, int W, int tm1, int tm2, int tm3) {
+static size_t bband_dyn_lds(int M, int R, int W, bool dual1, bool dual2) {
   const int n_h = (R + 2) * (W + 2);
-  return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)20 * (M + M + 4 * M) + 64;
-  (void)tm1; (void)tm2; (void)tm3;
+  return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * 20) * M + 64;
 }
 
-template <int M, int NW, int WN, int NT0, int NT1, int SC>
-static int launch_bband(const BBandArgs& a, hipStream_t s) {
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
+static int launch_bband2(const BBandArgs& a, hipStream_t s) {
   constexpr int C = 4 * M;
   constexpr int CHUNK = SC * 32 * NT0 * 64, MID2 = (M / 64) * 32 * NT1 * 64;
-  const size_t dyn = bband_dyn_lds(M, a.R, a.W, a.tm1, a.tm2, a.tm3);
+  const size_t dyn = bband_dyn_lds(M, a.R, a.W, DUAL1, DUAL2);
   const size_t stat = (size_t)(CHUNK > MID2 ? CHUNK : MID2) + CHUNK;
   if (dyn + stat > 160 * 1024) return 1;
-  auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC>;
+  auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
-  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d,tiles %d/%d,%d waves> (%d bands per image)", a.H, a.W, C, M, a.R, NT0, NT1, NW, a.tiles_per_img);
+  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d,tiles %d/%d,%d waves%s%s> (%d bands per image)", a.H, a.W, C, M, a.R, NT0, NT1, NW,
+                  DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", a.tiles_per_img);
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img), dim3(NW * 64), dyn, s, a);
   return launch_ok() ? 0 : -1;
 }
 
-// Shapes instantiated (ResNet-50 stage 4: 14 x 14, C = 1024, M = 256): R rows per band -> column tiles of the halo band / the band.
-// Returns 1 for anything else (the caller then launches the three rows separately).
+// Shapes instantiated: ResNet-50 stage 4 (14 x 14, C = 1024, M = 256: every row single-window with the shipped Q) and stage 3
+// (28 x 28, C = 512, M = 128: two-window reduce, the last bottleneck's 3x3 two-window as well), R rows per band -> column tiles of the
+// halo band / the band.  16 waves per block measured SLOWER than 8 (profiles/r04_bband_timeline_r7_w16.txt: the requantisation phases
+// are bound by the SIMDs' VALU throughput, not by issue latency, and the 3x3 loop loses: 40 against 34 us per block).
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R) {
   if (C != 4 * M || H != W || R < 1 || R > H) return false;
   if (M == 256 && W == 14) return R == 7 || R == 4 || R == 2;
+  if (M == 128 && W == 28) return R == 7 || R == 4;
   return false;
+}
+bool conv_bband_windows_ok(int M, int dual1, int dual2) {
+  if (M == 256) return !dual1 && !dual2;
+  if (M == 128) return dual1 || !dual2;                   // (single, single), (dual, single), (dual, dual)
+  return false;
+}
+
+template <int M, int NW, int WN, int NT0, int NT1, int SC>
+static int launch_bband(const BBandArgs& a, hipStream_t s) {
+  if constexpr (M == 256) return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
+  else {
+    if (a.dual1 && a.dual2) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, true>(a, s);
+    if (a.dual1) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, false>(a, s);
+    return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
+  }
 }
 
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R)) return 1;
+  if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R) || !conv_bband_windows_ok(M, a.dual1, a.dual2)) return 1;
   if (M == 256 && a.W == 14) {
-    static const int nw = getenv("TF2_AMD_BBAND_WAVES") ? atoi(getenv("TF2_AMD_BBAND_WAVES")) : 16;      // A/B: 8 or 16 waves per block
-    if (a.R == 7) return nw == 8 ? launch_bband<256, 8, 1, 4, 4, 4>(a, s) : launch_bband<256, 16, 2, 4, 4, 4>(a, s);      // 126 / 98 pixels
+    if (a.R == 7) return launch_bband<256, 8, 1, 4, 4, 4>(a, s);      // 126 / 98 pixels
     if (a.R == 4) return launch_bband<256, 8, 1, 3, 2, 4>(a, s);      // 84 / 56
     if (a.R == 2) return launch_bband<256, 8, 1, 2, 1, 4>(a, s);      // 56 / 28
+  }
+  if (M == 128 && a.W == 28) {
+    if (a.R == 7) return launch_bband<128, 8, 2, 8, 8, 2>(a, s);      // 252 / 196 pixels
+    if (a.R == 4) return launch_bband<128, 8, 2, 6, 4, 2>(a, s);      // 168 / 112
   }
   return 1;
 }

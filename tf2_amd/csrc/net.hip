@@ -356,9 +356,11 @@ bool Net::bband_at(int l, int rows) const {
     const PackLayer* pl = pack_layer(k);
     if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128)) return false;
     if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
-    if (pl->n_phases != 1 || pl->dual || pl->w_share) return false;
+    if (pl->w_share) return false;
+    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+    if (!one_window && !(dual && k < l + 2)) return false;                                                // (the expand: single-window only)
   }
-  return true;
+  return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual);
 }
 
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
@@ -671,6 +673,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
           f.keep_mid = wp->keep_all ? 1 : 0;
           f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
           f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
+          f.dual1 = c0.dual; f.dual2 = c1.dual;
           f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
           st.bg_c = L.C; st.bg_m = L.N;
           pair_done[l + 1] = 1; pair_done[l + 2] = 1;
