@@ -483,32 +483,3 @@ def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc)
     plain = Rig(*r50, 0)
     assert not any("conv_bband" in r["kernel"] for r in plain.net.describe_launches(32, int(conc)))
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
-
-
-@pytest.mark.parametrize("rows,conc", [("4", "1"), ("2", "0"), ("4", "0")])
-def test_band_launches_of_the_first_bottlenecks(r50, monkeypatch, rows, conc):
-    """conv_bfirst.hip: the first bottleneck of stage 3 (rows 11-14) and of stage 4 (rows 24-27) -- projection shortcut / 2 | reduce on
-    the 2H x 2W input, 3x3 / 2, expand + residual from the shortcut -- as ONE launch each of independent row bands (two-window
-    shortcut and reduce; the shortcut's map is materialised only for keep_all).  Every layer against the oracle at batch 2 and 5 --
-    rows 11 / 24 are the shortcut's own output, 12 / 25 the reduce's at full resolution --, then batch-32 logits of repeated runs on
-    the liveness-planned workspace, and against the separate launches."""
-    monkeypatch.setenv("TF2_AMD_BFIRST", "2")
-    monkeypatch.setenv("TF2_AMD_BFIRST_ROWS", rows)
-    monkeypatch.setenv("TF2_AMD_BFIRST_ROWS_ALONE", rows)
-    monkeypatch.setenv("TF2_AMD_BBAND_MIN", "1")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
-    rig = Rig(*r50, 0)
-    launches = rig.net.describe_launches(32, int(conc))
-    assert [r["layer"] for r in launches if "conv_bfirst" in r["kernel"]] == [11, 24]
-    assert not any(r["layer"] in (12, 13, 14, 25, 26, 27) for r in launches)
-    rig.check_all_layers(synth.synth_images(rig.t, 2, 95))
-    rig.check_all_layers(synth.synth_images(rig.t, 5, 96))
-    x = synth.synth_images(rig.t, 32, 97)
-    first = rig.run(x, keep_all=False).copy()
-    np.testing.assert_array_equal(first[:3], rig.ref.logits(rig.ref.run(x[:3])))
-    for _ in range(5):
-        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
-    monkeypatch.setenv("TF2_AMD_BFIRST", "0")
-    plain = Rig(*r50, 0)
-    assert not any("conv_bfirst" in r["kernel"] for r in plain.net.describe_launches(32, int(conc)))
-    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)

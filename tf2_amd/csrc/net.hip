@@ -174,21 +174,8 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
     }
   // Group launches (conv_bgroup.hip: rows l .. l + 2 in one launch, images at different layers at the same time): what the launch
   // reads stays live to its last row, what it writes exists from its first
-  if (packed_valid && (opts.bgroup_mode || opts.bband_mode || opts.bfirst_mode))
+  if (packed_valid && (opts.bgroup_mode || opts.bband_mode))
     for (int l = 0; l + 2 < nl; l++) {
-      if (opts.bfirst_mode && (bfirst_at(l, opts.bfirst_rows) || bfirst_at(l, opts.bfirst_rows_alone))) {
-        // rows l .. l + 3 in one launch: what it reads stays live to its last row, what it writes exists from its first
-        TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
-        tin.last_use = std::max(tin.last_use, l + 3);
-        for (size_t t = 0; t < wp.tensors.size(); t++)
-          if (born[t] > l && born[t] <= l + 3) born[t] = l;
-        for (int k = l; k <= l + 2; k++) {
-          TensorPlan& to = wp.tensors[wp.exec[k].out_tensor];
-          to.last_use = std::max(to.last_use, l + 3);
-        }
-        l += 3;
-        continue;
-      }
       if (opts.bgroup_mode && bgroup_first_at(l)) {
         TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
         tin.last_use = std::max(tin.last_use, l + 3);
@@ -353,39 +340,6 @@ bool Net::bgroup_at(int l) const {
   return true;
 }
 
-// Rows l .. l + 3 = projection shortcut S (1x1 / stride 2, Cin -> 4 M) and reduce A (1x1, Cin -> M) of the same input, 3x3 / stride 2 /
-// pad 1 (M -> M), expand (1x1, M -> 4 M) + residual from S, Cin = 2 M, of a shape conv_bfirst.hip is instantiated for; every row dense,
-// B and E single-window, S and A both two-window or both single.
-bool Net::bfirst_at(int l, int rows) const {
-  if (l < 1 || l + 3 >= nd.n_layers) return false;
-  const tf2_layer_desc& S = layers[l]; const tf2_layer_desc& A = layers[l + 1]; const tf2_layer_desc& B = layers[l + 2]; const tf2_layer_desc& E = layers[l + 3];
-  for (const tf2_layer_desc* L : {&S, &A, &B, &E})
-    if (L->ipool || L->pool_en || L->endpool || L->concat >= 0 || L->dil != 1) return false;
-  if (S.src < 0 || S.src != A.src || layers[S.src].concat >= 0 || S.add_src >= 0 || A.add_src >= 0 || B.add_src >= 0) return false;
-  const int M = A.N, Hin = A.H, Win = A.W, H = S.OH, W = S.OW;
-  if (Hin != 2 * H || Win != 2 * W || H != W) return false;
-  if (S.k != 1 || S.stride != 2 || S.pad_h || S.pad_w || S.H != Hin || S.W != Win || S.C != 2 * M || S.N != 4 * M) return false;
-  if (A.k != 1 || A.stride != 1 || A.pad_h || A.pad_w || A.C != 2 * M) return false;
-  if (B.src != l + 1 || B.k != 3 || B.stride != 2 || B.pad_h != 1 || B.pad_w != 1 || B.H != Hin || B.W != Win || B.OH != H || B.OW != W || B.C != M || B.N != M) return false;
-  if (E.src != l + 2 || E.k != 1 || E.stride != 1 || E.pad_h || E.pad_w || E.H != H || E.W != W || E.add_src != l || E.C != M || E.N != 4 * M) return false;
-  if (out_Cp[S.src] != 2 * M) return false;
-  for (int j = 0; j < nd.n_layers; j++)                     // S's map is never materialised: nothing but E's residual may read it
-    if (j != l + 3 && (layers[j].src == l || layers[j].add_src == l)) return false;
-  int duals = 0;
-  for (int k = l; k <= l + 3; k++) {
-    const PackLayer* pl = pack_layer(k);
-    if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128) || pl->w_share) return false;
-    if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
-    if (pl->fuse_next > 0 || pl->fused_into >= 0) return false;
-    const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
-    if (k >= l + 2) { if (!one_window) return false; }
-    else { if (!one_window && !dual) return false; duals += dual ? 1 : 0; }
-    if (k == l && pl->off_dbl) return false;                // (the shortcut's output is only ever a residual)
-  }
-  if (duals != 0 && duals != 2) return false;
-  return conv_bfirst_shape_ok(H, W, M, std::min(rows, H), duals == 2);
-}
-
 // Rows l, l + 1, l + 2 = an identity bottleneck (as bgroup_at) of a shape conv_bband.hip is instantiated for, every row a dense
 // single-window layer.
 bool Net::bband_at(int l, int rows) const {
@@ -435,9 +389,6 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_CHAIN")) o.bgroup_chain = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
-  if (const char* e = getenv("TF2_AMD_BFIRST")) o.bfirst_mode = atoi(e);      // a stage's first bottleneck as one band launch (conv_bfirst.hip): 0 never, 1 with batches in flight, 2 always
-  if (const char* e = getenv("TF2_AMD_BFIRST_ROWS")) o.bfirst_rows = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BFIRST_ROWS_ALONE")) o.bfirst_rows_alone = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND")) o.bband_mode = atoi(e);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS")) o.bband_rows = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS_ALONE")) o.bband_rows_alone = atoi(e);
@@ -700,35 +651,6 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         continue;
       }
     }
-    // a stage's first bottleneck (shortcut / 2 | reduce, 3x3 / 2, expand + residual) as ONE launch of independent row bands (conv_bfirst.hip)
-    {
-      const int band_rows = concurrent ? opts.bfirst_rows : opts.bfirst_rows_alone;
-      if (opts.bfirst_mode && (concurrent || opts.bfirst_mode == 2) && batch >= opts.bband_min && bfirst_at(l, band_rows)) {
-        Launch ss, s0, s1, s2;
-        if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
-        if (ss.conv.dense && s0.conv.dense && s1.conv.dense && s2.conv.dense) {
-          Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BFIRST; st.layer = l;
-          BFirstArgs& f = st.bfirst;
-          const ConvArgs& cs = ss.conv; const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
-          f.x = c0.x; f.ys = cs.y; f.mid1 = c0.y; f.mid2 = c1.y; f.y = c2.y;
-          f.ws = cs.w; f.w1 = c0.w; f.w2 = c1.w; f.w3 = c2.w; f.hdrs = cs.hdr; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr3 = c2.hdr;
-          f.hdrs_bytes = cs.hdr_bytes; f.hdr1_bytes = c0.hdr_bytes; f.hdr2_bytes = c1.hdr_bytes; f.hdr3_bytes = c2.hdr_bytes;
-          f.tms = ss.TM; f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
-          f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
-          f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
-          f.B = batch; f.H = L.OH; f.W = L.OW; f.R = std::min(band_rows, L.OH); f.tiles_per_img = (L.OH + f.R - 1) / f.R;
-          f.relu_s = cs.g.relu; f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu;
-          f.keep_mid = wp->keep_all ? 1 : 0;
-          f.fast_s = cs.g.fast; f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
-          f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dual = c0.dual;
-          f.ys_cp = cs.g.y_cp; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
-          st.bg_m = layers[l + 1].N;
-          pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
-          lp.steps.push_back(st);
-          continue;
-        }
-      }
-    }
     // an identity bottleneck as ONE launch of independent row bands (conv_bband.hip): no exchange between blocks, so it may share
     // the chip with anything -- the form for batches in flight (TF2_AMD_BBAND=2: one batch at a time as well, instead of the groups)
     {
@@ -937,7 +859,6 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
-        case Launch::SEL_BFIRST: return launch_conv_bfirst(st.bfirst, st.bg_m, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:

@@ -222,29 +222,6 @@ struct BBandArgs {
   int32_t res_cp, res_off, y_cp, y_off;
 };
 
-// conv_bfirst.hip: the FIRST bottleneck of a stage -- projection shortcut S (1x1 / stride 2) | reduce A (1x1) of the same 2H x 2W input,
-// 3x3 / stride 2 / pad 1, expand + residual from S -- four table rows in one launch of independent row bands (Cin = 2 M, Cout = 4 M)
-struct BFirstArgs {
-  const int8_t* x;           // the stage input [B][2H*2W][Cin], exactly Cin bytes per pixel
-  int8_t* ys;                // S's own output tensor [B][H*W][ys_cp]  (written only with keep_mid)
-  int8_t* mid1;              // reduce output  [B][2H*2W][M]           (written only with keep_mid)
-  int8_t* mid2;              // 3x3 output     [B][H*W][M]             (written only with keep_mid)
-  int8_t* y;                 // expand output
-  const int8_t* ws; const int8_t* w1; const int8_t* w2; const int8_t* w3;      // dense weight tiles of S, A, B, E
-  const int32_t* hdrs; const int32_t* hdr1; const int32_t* hdr2; const int32_t* hdr3;
-  const int8_t* zero;        // zero page
-  const int8_t* zero2;       // the 3x3's pad row
-  long long* dbg;            // optional: 16 wall-clock stamps per block, else null
-  int32_t hdrs_bytes, hdr1_bytes, hdr2_bytes, hdr3_bytes;
-  int32_t tms, tm1, tm2, tm3;            // rows per m-tile (64 or 128)
-  int32_t B, H, W, R, tiles_per_img;     // OUTPUT map, R output rows per block
-  int32_t relu_s, relu1, relu2, relu3, add_relu, keep_mid;
-  int32_t fast_s, fast1, fast2, fast3;
-  int32_t dbl1, dbl2;        // the reduce's / the 3x3's output tensor has doubled channels
-  int32_t dual;              // S and A are two-window layers
-  int32_t ys_cp, y_cp, y_off;
-};
-
 // consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
 // conv_bgroup7_kernel: the groups run them back to back)
 constexpr int kBgMaxChain = 5;
@@ -321,8 +298,6 @@ size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream);     // n_chain > 1: 14 x 14 only
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
-bool conv_bfirst_shape_ok(int H, int W, int M, int R, int dual);       // instantiated and fits the LDS
-int launch_conv_bfirst(const BFirstArgs& a, int M, void* stream);             // 1: shape not instantiated / does not fit
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R);
 bool conv_bband_windows_ok(int M, int dual1, int dual2);     // the instantiated (reduce, 3x3) window forms
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream);        // 1: shape not instantiated / does not fit

@@ -44,7 +44,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_BFIRST } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -52,7 +52,6 @@ struct Launch {
   ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
   BneckArgs bneck{};
-  BFirstArgs bfirst{};       // SEL_BFIRST: rows layer .. layer + 3 (a stage's first bottleneck: shortcut | reduce, 3x3 / 2, expand) in one launch
   BBandArgs bband{};         // SEL_BBAND: rows layer .. layer + 2 (an identity bottleneck) in one launch, no exchange between blocks
   BGroupArgs bgroup{};       // SEL_BGROUP: rows layer .. layer + 2 (an identity bottleneck) in one launch
   int bg_hw = 0, bg_c = 0, bg_m = 0;
@@ -97,8 +96,6 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // TF2_AMD_BGROUP_MIN7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int bband_mode = 1;      // TF2_AMD_BBAND: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
   int bband_rows = 7, bband_rows_alone = 2;   // TF2_AMD_BBAND_ROWS / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
-  int bfirst_mode = 2;     // TF2_AMD_BFIRST: a stage's first bottleneck (shortcut | reduce, 3x3 / 2, expand) as ONE band launch (conv_bfirst.hip): 0 never, 1 with batches in flight, 2 (default) always
-  int bfirst_rows = 4, bfirst_rows_alone = 2;   // TF2_AMD_BFIRST_ROWS / _ROWS_ALONE: output rows per block
   int bband_min = 8;       // TF2_AMD_BBAND_MIN: smallest batch that takes them
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
@@ -160,7 +157,6 @@ struct Net {
   size_t workspace_size(int batch, bool keep_all);      // plan(...)->total_bytes under the handle's mutex
   tf2_status describe_workspace(int batch, bool keep_all, std::vector<TensorPlan>* tensors, std::vector<LayerExec>* rows);
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
-  bool bfirst_at(int l, int rows) const;   // rows l .. l + 3 = shortcut / 2 | reduce, 3x3 / 2, expand + residual of a shape conv_bfirst.hip takes
   bool bband_at(int l, int rows) const;    // rows l, l + 1, l + 2 are an identity bottleneck conv_bband.hip can take with `rows` output rows per block
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=31)
 ap.add_argument("--rows", type=int, default=7); ap.add_argument("--conc", type=int, default=1)
 a = ap.parse_args()
-os.environ["TF2_AMD_BBAND"] = "2"; os.environ["TF2_AMD_BFIRST"] = "2"; os.environ["TF2_AMD_BFIRST_ROWS"] = str(a.rows); os.environ["TF2_AMD_BFIRST_ROWS_ALONE"] = str(a.rows); os.environ["TF2_AMD_BBAND_ROWS"] = str(a.rows); os.environ["TF2_AMD_BBAND_ROWS_ALONE"] = str(a.rows); os.environ["TF2_AMD_BBAND_MIN"] = "1"
+os.environ["TF2_AMD_BBAND"] = "2"; os.environ["TF2_AMD_BBAND_ROWS"] = str(a.rows); os.environ["TF2_AMD_BBAND_ROWS_ALONE"] = str(a.rows); os.environ["TF2_AMD_BBAND_MIN"] = "1"
 import torch
 from tf2_amd import config as cfg, network, synth
 t = cfg.resnet50_tables()
@@ -26,7 +26,6 @@ torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 16)[:, :7].astype(np.float64)
 t0 = d[:, 0].min()
 names = ["start", "prologue landed", "reduce loop end", "halo tile done", "3x3 loop end", "B tile done", "expand end"]
-if a.layer in (11, 24, 43): names = ["start", "prologue landed", "reduce done (halo tile)", "3x3 loop end", "B tile written", "passes end", "-"]
 print("blocks", len(d), "first start -> last end %.2f us; block starts spread over %.2f us" % ((d[:, 6].max() - t0) / 100, (d[:, 0].max() - t0) / 100))
 for i, n in enumerate(names):
     print(f"  {n:18s} {np.median(d[:, i] - d[:, 0]) / 100:7.2f}   {('+%.2f' % (np.median(d[:, i] - d[:, i - 1]) / 100)) if i else ''}")
