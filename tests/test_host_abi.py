@@ -173,9 +173,13 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     assert "x 5 bottlenecks" in [r for r in groups if r["layer"] == 28][0]["kernel"]
     assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in groups if r["layer"] == 47][0]["kernel"]
     assert not any("conv_bgroup" in r["kernel"] for r in many)
-    # seven groups of three rows one batch at a time (14 launches fewer), two more that replace a reduce + conv_bneck pair where the
-    # several-streams plan runs three launches (4 fewer), row 22's pair fused only one batch at a time, three pairs against two
-    assert len(many) == len(one) + 14 + 6 + 2 - 1 + 4 + 1 + 1  # (+ the first bottleneck of stage 2: one launch instead of three; + the chains of stages 3, 4 and 5)
+    # with batches in flight the identity bottlenecks of stages 3 and 4 are ONE band launch each (conv_bband.hip: no exchange between
+    # blocks -- two-window reduce on stage 3, the last one's 3x3 two-window as well and in 4-row bands), stage 5 keeps its separate launches
+    bands = [r for r in many if "conv_bband" in r["kernel"]]
+    assert [r["layer"] for r in bands] == [15, 18, 21, 28, 31, 34, 37, 40] and not any("conv_bband" in r["kernel"] for r in one)
+    assert [r["grid"] for r in bands] == [128, 128, 224, 64, 64, 64, 64, 64] and all(r["block"] == 512 and r["lds_bytes"] + 65536 <= 160 * 1024 for r in bands)
+    assert "dual reduce" in bands[0]["kernel"] and "dual reduce,dual 3x3" in bands[2]["kernel"] and "dual" not in bands[3]["kernel"]
+    assert len(many) == 33 and len(one) == 22
     assert [r["grid"] for r in net.describe_launches(40, 0) if r["layer"] == 28] == [256, 64]     # at most 32 images per launch
     # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation (single-window and dual layers are dense)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]

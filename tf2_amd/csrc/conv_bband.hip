@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   constexpr int WM = NW / WN, MT = M / (32 * WM);
   static_assert(WM * WN == NW && MT * 32 * WM == M && NT0 % WN == 0 && NT1 % WN == 0, "wave grid");
   constexpr int J0 = NT0 / WN, J1 = NT1 / WN;            // column tiles per wave
-  constexpr int LEAN = NW == 16 ? 2 : 0;                 // requant_epilogue.h: header rows read two ahead instead of all sixteen at once (128-register budget)
+  constexpr int LEAN = (NW == 16 || (DUAL1 && J0 >= 4)) ? 2 : 0;                 // requant_epilogue.h: header rows read two ahead instead of all sixteen at once (128-register budget)
   constexpr int KS1 = C / 64, KS2 = M / 64, NE = 9 * KS2;
   constexpr int NP0 = 32 * NT0, NP1 = 32 * NT1;
   static_assert(KS1 % SC == 0 && SC >= 2, "whole chunks; a chunk's DMAs are told from its fragment loads by a counted wait (below)");
@@ -193,9 +193,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   load_step(f1, std::integral_constant<int, 1>{});
   if constexpr (DUAL1) { load_a(g0, a.w1, tms1, KS1, cb_w, 0, 2, 1); load_a(g1, a.w1, tms1, KS1, cb_w, 1, 2, 1); }
 
+  // (every lambda that touches the accumulators is always_inline: a call would take the arrays by reference, i.e. put them in scratch)
   i32x16 acc[MT][J0 > J1 ? J0 : J1];
   i32x16 acc2[DUAL1 ? MT : 1][DUAL1 ? J0 : 1];           // DUAL1: the reduce's low window
-  auto zero_acc = [&](int nj) {
+  auto zero_acc = [&](int nj) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   };
   bb_static_for<0, KS1>(step0);
   // Horner step of a two-window layer: acc = (acc << dshift[1][row]) [+ the low window's sums]; dshift sits behind rows | lo
-  auto window_combine = [&](const int8_t* hdr, int tms, int hst, int nj, bool add_low) {
+  auto window_combine = [&](const int8_t* hdr, int tms, int hst, int nj, bool add_low) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int ch = cb_w + i * 32;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   {
     const int lo_b = a.relu1 ? 0 : -128;
     const i32x4 nores = {0, 0, 0, 0};
-    auto to_mid1 = [&](auto fast_c) {
+    auto to_mid1 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
       for (int i = 0; i < MT; i++) {
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   BB_STAMP(4);
 
   // residual tiles of pass q (16 contiguous NHWC bytes per lane and column tile), loaded one pass ahead
-  auto load_res = [&](i32x4 (&rv)[MT][J1], int q) {
+  auto load_res = [&](i32x4 (&rv)[MT][J1], int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   {
     const int lo_b = a.relu2 ? 0 : -128;
     const i32x4 nores = {0, 0, 0, 0};
-    auto to_mid2 = [&](auto fast_c) {
+    auto to_mid2 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
       for (int i = 0; i < MT; i++) {
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       if constexpr (s == KS2 - 1) {
         i32x4 (&rv)[MT][J1] = (RESDB && (ql & 1)) ? res1 : res0;
         const int q = qq + ql;
-        auto epilogue = [&](auto fast_c) {
+        auto epilogue = [&](auto fast_c) __attribute__((always_inline)) {
           constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
           for (int i = 0; i < MT; i++) {
@@ -515,7 +516,7 @@ static int launch_bband2(const BBandArgs& a, hipStream_t s) {
   if (dyn + stat > 160 * 1024) return 1;
   auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
-  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d,tiles %d/%d,%d waves%s%s> (%d bands per image)", a.H, a.W, C, M, a.R, NT0, NT1, NW,
+  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d%s%s> (%d bands per image)", a.H, a.W, C, M, a.R,
                   DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", a.tiles_per_img);
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img), dim3(NW * 64), dyn, s, a);
   return launch_ok() ? 0 : -1;
@@ -537,11 +538,19 @@ bool conv_bband_windows_ok(int M, int dual1, int dual2) {
   return false;
 }
 
+// rows per band actually used for `wanted`: the 7-row form of the 28 x 28 kernel with BOTH reduce and 3x3 two-window would need more
+// than 256 registers (23 spilled) -- that bottleneck takes 4-row bands
+int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted) {
+  if (M == 128 && W == 28 && wanted == 7 && dual1 && dual2) return 4;
+  return wanted;
+}
+
 template <int M, int NW, int WN, int NT0, int NT1, int SC>
 static int launch_bband(const BBandArgs& a, hipStream_t s) {
+  if constexpr (M == 128 && NT0 == 8) { if (a.dual1 && a.dual2) return 1; }
   if constexpr (M == 256) return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
   else {
-    if (a.dual1 && a.dual2) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, true>(a, s);
+    if constexpr (NT0 != 8) { if (a.dual1 && a.dual2) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, true>(a, s); }
     if (a.dual1) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, false>(a, s);
     return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
   }

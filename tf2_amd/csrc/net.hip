@@ -350,7 +350,12 @@ bool Net::bband_at(int l, int rows) const {
   if (A.src < 0 || A.k != 1 || A.pad_h || A.pad_w || A.add_src >= 0) return false;
   if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
   if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
-  if (layers[A.src].concat >= 0 || !conv_bband_shape_ok(A.H, A.W, A.C, A.N, std::min(rows, A.H))) return false;
+  if (layers[A.src].concat >= 0) return false;
+  {
+    const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1);
+    if (!p0 || !p1) return false;
+    if (!conv_bband_shape_ok(A.H, A.W, A.C, A.N, std::min(conv_bband_pick_rows(A.W, A.N, p0->dual, p1->dual, rows), A.H))) return false;
+  }
   if (out_Cp[A.src] != A.C) return false;                  // the input tensor holds exactly C bytes per pixel
   for (int k = l; k <= l + 2; k++) {
     const PackLayer* pl = pack_layer(k);
@@ -668,7 +673,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
           f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
           f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
           f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
-          f.B = batch; f.H = L.H; f.W = L.W; f.R = std::min(band_rows, L.H); f.tiles_per_img = (L.H + f.R - 1) / f.R;
+          f.B = batch; f.H = L.H; f.W = L.W; f.R = std::min(conv_bband_pick_rows(L.W, L.N, c0.dual, c1.dual, band_rows), L.H);
+          f.tiles_per_img = (L.H + f.R - 1) / f.R;
           f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
           f.keep_mid = wp->keep_all ? 1 : 0;
           f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
