@@ -59,27 +59,24 @@ __device__ __forceinline__ void bb_dma16(const int8_t* src, int8_t* lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(l) : "memory", "m0");
 }
 
-// M: channels of the intermediates; WN: pixel-tile columns of the wave grid; the halo band's (R + 2) * W pixels are reduced in NG
-// groups of TG 32-pixel column tiles (one group's accumulators at a time: a 56 x 56 band has 500 pixels; the input streams through
-// the chunk ring exactly once, the reduce's weights are fetched again per group); NT1: column tiles of the band itself
-// (R * W <= 32 NT1); SC: channel slabs per chunk of the input stream
+// M: channels of the intermediates; WN: pixel-tile columns of the wave grid; NT0 / NT1: 32-pixel column tiles of the halo band
+// ((R + 2) * W <= 32 NT0) and of the band itself (R * W <= 32 NT1); SC: channel slabs per chunk of the input stream
 // NW: waves per block (8: two per SIMD, up to 256 registers; 16: four per SIMD, 128 registers -- the requantisation phases are VALU
 // work that one or two waves per SIMD cannot issue at rate)
 // DUAL1 / DUAL2: the reduce / the 3x3 is a two-window layer (weight_pack.cpp: entries [hi rows | lo rows]).  The reduce keeps two
 // accumulator sets over the one input stream and combines them once, (hi << dshift[1]) + lo; the 3x3 sweeps its LDS-resident halo
-// tile window by window into ONE set with the Horner shift in between (conv_bneck's scheme) -- both exact in Z/2^32.  DUAL3: the
-// expand is a two-window layer, swept like the 3x3.
-template <int M, int NW, int WN, int TG, int NG, int NT1, int SC, bool DUAL1, bool DUAL2, bool DUAL3>
+// tile window by window into ONE set with the Horner shift in between (conv_bneck's scheme) -- both exact in Z/2^32.
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a) {
   constexpr int C = 4 * M;
   constexpr int WM = NW / WN, MT = M / (32 * WM);
-  static_assert(WM * WN == NW && MT * 32 * WM == M && TG % WN == 0 && NT1 % WN == 0, "wave grid");
-  constexpr int J0 = TG / WN, J1 = NT1 / WN;             // column tiles per wave
+  static_assert(WM * WN == NW && MT * 32 * WM == M && NT0 % WN == 0 && NT1 % WN == 0, "wave grid");
+  constexpr int J0 = NT0 / WN, J1 = NT1 / WN;            // column tiles per wave
   constexpr int LEAN = (NW == 16 || (DUAL1 && J0 >= 4)) ? 2 : 0;                 // requant_epilogue.h: header rows read two ahead instead of all sixteen at once (128-register budget)
   constexpr int KS1 = C / 64, KS2 = M / 64, NE = 9 * KS2;
-  constexpr int NP0 = 32 * TG, NP1 = 32 * NT1;           // pixels of a reduce group / of the band
+  constexpr int NP0 = 32 * NT0, NP1 = 32 * NT1;
   static_assert(KS1 % SC == 0 && SC >= 2, "whole chunks; a chunk's DMAs are told from its fragment loads by a counted wait (below)");
-  constexpr int NCH = KS1 / SC;                          // chunks of the input stream per group
+  constexpr int NCH = KS1 / SC;                          // chunks of the input stream
   constexpr int CHUNK = SC * NP0 * 64;
   constexpr int MID2 = KS2 * NP1 * 64;
   constexpr int RING = CHUNK > MID2 ? CHUNK : MID2;
@@ -102,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   int8_t* const mid1 = dyn;
   const int tms1 = a.tm1 == 128 ? 7 : 6, tms2 = a.tm2 == 128 ? 7 : 6, tms3 = a.tm3 == 128 ? 7 : 6;
   // bytes of one m-tile's header image: rows {bias, alpha, addend64} | lo | dshift[P] (the Horner shifts: two-window layers only)
-  const int hst1 = (DUAL1 ? 28 : 20) << tms1, hst2 = (DUAL2 ? 28 : 20) << tms2, hst3 = (DUAL3 ? 28 : 20) << tms3;
+  const int hst1 = (DUAL1 ? 28 : 20) << tms1, hst2 = (DUAL2 ? 28 : 20) << tms2, hst3 = 20 << tms3;
   int8_t* const hdr1 = mid1 + KS2 * slabb;
   int8_t* const hdr2 = hdr1 + (M >> tms1) * hst1;
   int8_t* const hdr3 = hdr2 + (M >> tms2) * hst2;
@@ -136,12 +133,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     bb_dma16(a.zero2 + s * 64 + chunk * 16, mid1 + s * slabb + grp * 1024);
   }
   // (2) the input stream: chunk c = channel slabs [c * SC, (c + 1) * SC) of the NP0 halo-band pixels -> [slab][pixel][64] swizzled
-  // chunk item ci = (group g, chunk c), buffer ci & 1
-  auto issue_chunk = [&](int ci, int8_t* buf) {
-    const int g = ci / NCH, c = ci - g * NCH;
+  auto issue_chunk = [&](int c, int8_t* buf) {
     for (int gi = wave; gi < SC * (NP0 / 16); gi += NW) {
       const int sl = gi / (NP0 / 16), grp = gi - sl * (NP0 / 16);
-      const int p = g * NP0 + grp * 16 + drow;
+      const int p = grp * 16 + drow;
       const int row = r0 - 1 + p / W;
       const bool ok = p < n_p0 && (unsigned)row < (unsigned)H;
       const int8_t* src = ok ? a.x + (size_t)(pix0 + p) * C + (c * SC + sl) * 64 + chunk * 16 : a.zero + chunk * 16;
@@ -149,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     }
   };
   issue_chunk(0, ring0);
-  if (NG * NCH > 1) issue_chunk(1, ring1);
+  if (NCH > 1) issue_chunk(1, ring1);
   // (3) header images (rows {bias | dbl, alpha, addend64} | lo per m-tile) by ordinary loads: 20 * tm bytes per m-tile, packed
   {
     auto hdr_copy = [&](const int32_t* hdr, int hdr_bytes, int tms, int n_mt, int8_t* dst, int words_per_row) {
@@ -162,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     };
     hdr_copy(a.hdr1, a.hdr1_bytes, tms1, M >> tms1, hdr1, DUAL1 ? 7 : 5);
     hdr_copy(a.hdr2, a.hdr2_bytes, tms2, M >> tms2, hdr2, DUAL2 ? 7 : 5);
-    hdr_copy(a.hdr3, a.hdr3_bytes, tms3, C >> tms3, hdr3, DUAL3 ? 7 : 5);
+    hdr_copy(a.hdr3, a.hdr3_bytes, tms3, C >> tms3, hdr3, 5);
   }
 
   // weight fragments: a lane's MFMA A fragment is 16 contiguous bytes of its row in the packed tile [tm rows][64]
@@ -180,25 +175,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     }
   };
   // fragments of global step v (phase 0: slab v of the reduce's high window; phase 1: (window, tap, slab) of the 3x3; phase 2 loads its own)
-  constexpr int N0 = NG * KS1;                           // steps of phase 0 (group-major)
   constexpr int N1 = (DUAL2 ? 2 : 1) * NE;               // steps of phase 1
-  constexpr int W3 = DUAL3 ? 2 : 1, NS2 = W3 * KS2;      // windows of the expand, steps of one pass of phase 2
   auto load_step = [&](Afr& f, auto v_c) {
     constexpr int v = decltype(v_c)::value;
-    if constexpr (v < N0) load_a(f, a.w1, tms1, KS1, cb_w, v % KS1, DUAL1 ? 2 : 1, 0);
-    else if constexpr (v < N0 + N1) load_a(f, a.w2, tms2, NE, cb_w, (v - N0) % NE, DUAL2 ? 2 : 1, (v - N0) / NE);
-    else load_a(f, a.w3, tms3, KS2, cb_w, (v - N0 - N1) % KS2, W3, (v - N0 - N1) / KS2);     // the expand's first fragments (pass 0)
+    if constexpr (v < KS1) load_a(f, a.w1, tms1, KS1, cb_w, v, DUAL1 ? 2 : 1, 0);
+    else if constexpr (v < KS1 + N1) load_a(f, a.w2, tms2, NE, cb_w, (v - KS1) % NE, DUAL2 ? 2 : 1, (v - KS1) / NE);
+    else load_a(f, a.w3, tms3, KS2, cb_w, v - KS1 - N1);                                     // the expand's first fragments (pass 0)
   };
   Afr g0, g1, g2, g3;                                    // DUAL1: the reduce's LOW window fragments, rotating like f0..f3
 #define BB_BUFL(v) ((v) % 4 == 0 ? g0 : (v) % 4 == 1 ? g1 : (v) % 4 == 2 ? g2 : g3)
   // four rotating buffers (PF = 2 would need three; four divides the step count of every phase, so that the pass loop of phase 2 can
   // be a run-time loop with the same buffer assignment in every iteration)
   Afr f0, f1, f2, f3;
-  static_assert(kBbPF == 2, "four rotating fragment buffers");
+  static_assert(kBbPF == 2 && (2 * KS2) % 4 == 0, "buffer rotation: one pass pair advances the step count by a multiple of four");
 #define BB_BUF(v) ((v) % 4 == 0 ? f0 : (v) % 4 == 1 ? f1 : (v) % 4 == 2 ? f2 : f3)
   load_step(f0, std::integral_constant<int, 0>{});
   load_step(f1, std::integral_constant<int, 1>{});
-  if constexpr (DUAL1) { load_a(g0, a.w1, tms1, KS1, cb_w, 0, 2, 1); load_a(g1, a.w1, tms1, KS1, cb_w, 1 % KS1, 2, 1); }
+  if constexpr (DUAL1) { load_a(g0, a.w1, tms1, KS1, cb_w, 0, 2, 1); load_a(g1, a.w1, tms1, KS1, cb_w, 1, 2, 1); }
 
   // (every lambda that touches the accumulators is always_inline: a call would take the arrays by reference, i.e. put them in scratch)
   i32x16 acc[MT][J0 > J1 ? J0 : J1];
@@ -234,12 +227,50 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     const int row = (wn + j * WN) * 32 + (lane & 31);
     bm0[j] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
   }
-  // Horner step of a two-window layer: acc = (acc << dshift[1][row]) [+ the low window's sums]; dshift sits behind rows | lo.
-  // cb: first channel of the wave's rows inside the layer
-  auto window_combine = [&](const int8_t* hdr, int tms, int hst, int cb, int nj, bool add_low) __attribute__((always_inline)) {
+  auto step0 = [&](auto v_c) {
+    constexpr int v = decltype(v_c)::value;                // slab index
+    constexpr int ch = v / SC, sl = v % SC;
+    Afr& cur = BB_BUF(v);
+    Afr& nxt = BB_BUF(v + 2);
+    if constexpr (sl == 0 && ch > 0) {
+      // chunk ch landed in every wave and nobody reads buffer (ch + 1) & 1 any more.  This wave's DMAs of chunk ch were issued at
+      // the first step of chunk ch - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
+      // other SC - 1 steps, (DUAL1 ? 4 : 2) MT each, of which at most the last two steps' still fly -- so "no more than
+      // min(2, SC - 1) steps' loads outstanding" means every DMA of the chunk has landed.  (SC = 2 with the bound for two steps
+      // let DMAs fly on: wrong logits with batches in flight, round 4.)
+      bb_wait_vmcnt<(SC - 1 < 2 ? SC - 1 : 2) * (DUAL1 ? 4 : 2) * MT>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    load_step(nxt, std::integral_constant<int, v + 2>{});
+    if constexpr (DUAL1 && v + 2 < KS1) load_a(BB_BUFL(v + 2), a.w1, tms1, KS1, cb_w, v + 2, 2, 1);
+    if constexpr (sl == 0 && ch > 0 && ch + 1 < NCH) {
+      // (behind this step's fragment loads: the compiler's counted wait for the NEXT step's fragments then still lets these fly)
+      asm volatile("" ::: "memory");
+      issue_chunk(ch + 1, ((ch + 1) & 1) ? ring1 : ring0);
+    }
+    const int8_t* B = ((ch & 1) ? ring1 : ring0) + sl * (NP0 * 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      i32x4 bf[J0];
+#pragma unroll
+      for (int j = 0; j < J0; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm0[j] ^ (ks << 5)));
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < J0; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
+          if constexpr (DUAL1) acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(BB_BUFL(v).k[i][ks], bf[j], acc2[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  bb_static_for<0, KS1>(step0);
+  // Horner step of a two-window layer: acc = (acc << dshift[1][row]) [+ the low window's sums]; dshift sits behind rows | lo
+  auto window_combine = [&](const int8_t* hdr, int tms, int hst, int nj, bool add_low) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; i++) {
-      const int ch = cb + i * 32;
+      const int ch = cb_w + i * 32;
       const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
       const int* dsh = reinterpret_cast<const int*>(hdr + mt * hst) + (6 << tms) + ro + 4 * half;       // dshift[1]
 #pragma unroll
@@ -257,11 +288,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       }
     }
   };
-  // a group's hand-over: requantise (pe.cl:185-203, relu.cl:54) into the halo tile; pixels of rows outside the image keep the pad value
-  const i32x4 nores = {0, 0, 0, 0};
-  auto group_out = [&](int g) __attribute__((always_inline)) {
-    if constexpr (DUAL1) window_combine(hdr1, tms1, hst1, cb_w, J0, true);
+  if constexpr (DUAL1) window_combine(hdr1, tms1, hst1, J0, true);
+  BB_STAMP(2);
+
+  // hand-over: requantise (pe.cl:185-203, relu.cl:54) into the halo tile; pixels of rows outside the image keep the pad value
+  {
     const int lo_b = a.relu1 ? 0 : -128;
+    const i32x4 nores = {0, 0, 0, 0};
     auto to_mid1 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
@@ -276,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
 #pragma unroll
           for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
           const i32x4 out = requant_tile16<false, LEAN, FAST>(a16, prm, 1 << tms1, ro + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
-          const int p = g * NP0 + (wn + j * WN) * 32 + (lane & 31);
+          const int p = (wn + j * WN) * 32 + (lane & 31);
           const int hr = p / W, col = p - hr * W;
           const int row = r0 - 1 + hr;
           if (p < n_p0 && (unsigned)row < (unsigned)H) {
@@ -290,63 +323,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       }
     };
     if (a.fast1 == 1) to_mid1(std::true_type{}); else to_mid1(std::false_type{});
-    if constexpr (NG > 1) {
-      // (keep_all only: the stores above sit in the same counter as the chunk DMAs the next groups wait for by count)
-      if (a.keep_mid) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      zero_acc(J0);
-      if constexpr (DUAL1) {
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-          for (int j = 0; j < J0; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc2[i][j][r] = 0;
-      }
-    }
-  };
-  auto step0 = [&](auto v_c) {
-    constexpr int v = decltype(v_c)::value;                // group-major slab index
-    constexpr int g = v / KS1, s0 = v % KS1, ci = v / SC, sl = v % SC;
-    Afr& cur = BB_BUF(v);
-    Afr& nxt = BB_BUF(v + 2);
-    if constexpr (sl == 0 && ci > 0) {
-      // chunk item ci landed in every wave and nobody reads buffer (ci + 1) & 1 any more.  This wave's DMAs of it were issued at
-      // the first step of item ci - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that item's
-      // other SC - 1 steps, (DUAL1 ? 4 : 2) MT each, of which at most the last two steps' still fly -- so "no more than
-      // min(2, SC - 1) steps' loads outstanding" means every DMA of the item has landed.  (SC = 2 with the bound for two steps
-      // let DMAs fly on: wrong logits with batches in flight, round 4.)
-      bb_wait_vmcnt<(SC - 1 < 2 ? SC - 1 : 2) * (DUAL1 ? 4 : 2) * MT>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    load_step(nxt, std::integral_constant<int, v + 2>{});
-    if constexpr (DUAL1 && v + 2 < N0) load_a(BB_BUFL(v + 2), a.w1, tms1, KS1, cb_w, (v + 2) % KS1, 2, 1);
-    if constexpr (sl == 0 && ci > 0 && ci + 1 < NG * NCH) {
-      // (behind this step's fragment loads: the compiler's counted wait for the NEXT step's fragments then still lets these fly)
-      asm volatile("" ::: "memory");
-      issue_chunk(ci + 1, ((ci + 1) & 1) ? ring1 : ring0);
-    }
-    const int8_t* B = ((ci & 1) ? ring1 : ring0) + sl * (NP0 * 64);
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      i32x4 bf[J0];
-#pragma unroll
-      for (int j = 0; j < J0; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm0[j] ^ (ks << 5)));
-#pragma unroll
-      for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < J0; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
-          if constexpr (DUAL1) acc2[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(BB_BUFL(v).k[i][ks], bf[j], acc2[i][j], 0, 0, 0);
-        }
-    }
-    if constexpr (s0 == KS1 - 1) {
-      if constexpr (g == NG - 1) BB_STAMP(2);
-      group_out(g);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  bb_static_for<0, N0>(step0);
+  }
   zero_acc(J1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // the halo tile is complete
@@ -364,12 +341,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   }
   auto step1 = [&](auto e_c) {
     constexpr int ew = decltype(e_c)::value;               // (window, tap, slab)
-    constexpr int v = N0 + ew;                             // global step index: the fragment buffers keep rotating
+    constexpr int v = KS1 + ew;                            // global step index: the fragment buffers keep rotating
     constexpr int e = ew % NE, t = e / KS2, s = e % KS2;
     Afr& cur = BB_BUF(v);
     Afr& nxt = BB_BUF(v + 2);
     load_step(nxt, std::integral_constant<int, v + 2>{});
-    if constexpr (DUAL2 && ew == NE) window_combine(hdr2, tms2, hst2, cb_w, J1, false);   // between the windows
+    if constexpr (DUAL2 && ew == NE) window_combine(hdr2, tms2, hst2, J1, false);        // between the windows
     const int8_t* B = mid1 + s * slabb;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -410,6 +387,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // hand-over: requantise the 3x3 into the expand's B tile [slab][pixel][64]
   {
     const int lo_b = a.relu2 ? 0 : -128;
+    const i32x4 nores = {0, 0, 0, 0};
     auto to_mid2 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
@@ -450,28 +428,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   const int lo_b3 = a.relu3 ? 0 : -128;
   const int rlo = a.add_relu ? 0 : -128;
   constexpr int NPASS = C / M;
-  constexpr int PP = (2 * NS2) % 4 == 0 ? 2 : 4;         // passes per iteration of the run-time loop: its steps a multiple of four
-  static_assert(NPASS % PP == 0 && (PP * NS2) % 4 == 0, "an iteration advances the step count by a multiple of four (fragment buffer rotation)");
-  // The passes run in PAIRS (in fours where a pass is a single step) inside a run-time loop (the body is statically unrolled: the
-  // residual buffers alternate and the fragment buffers rotate the same way in every iteration): less code than four unrolled passes.  An identity
+  static_assert(NPASS % 2 == 0, "passes run in pairs");
+  // The passes run in PAIRS inside a run-time loop (the body is two passes, statically unrolled: the residual buffers alternate and
+  // the fragment buffers rotate the same way in every iteration): a quarter of the code of four unrolled passes.  An identity
   // bottleneck always has its residual (Net::bband_at).
 #pragma unroll 1
-  for (int qq = 0; qq < NPASS; qq += PP) {
+  for (int qq = 0; qq < NPASS; qq += 2) {
     auto step2 = [&](auto u_c) {
       constexpr int u = decltype(u_c)::value;                // step inside the pair
-      constexpr int v = N0 + N1 + u;
-      constexpr int ql = u / NS2, t = u % NS2, s = t % KS2;   // pass inside the pair, (window, slab) step inside the pass
+      constexpr int v = KS1 + N1 + u;
+      constexpr int ql = u / KS2, s = u % KS2;
       Afr& cur = BB_BUF(v);
       Afr& nxt = BB_BUF(v + 2);
       {
         // fragments of step u + 2 (the next pair's first two steps at the end: loaded past the last pass they read valid memory of
         // pass NPASS - 1 again and are never used)
-        constexpr int u2 = (u + 2) % (PP * NS2), t2 = u2 % NS2;
-        const int q2 = qq + (u + 2) / NS2;
-        load_a(nxt, a.w3, tms3, KS2, (q2 < NPASS ? q2 : NPASS - 1) * M + cb_w, t2 % KS2, W3, t2 / KS2);
+        constexpr int u2 = (u + 2) % (2 * KS2);
+        const int q2 = qq + (u + 2) / KS2;
+        load_a(nxt, a.w3, tms3, KS2, (q2 < NPASS ? q2 : NPASS - 1) * M + cb_w, u2 % KS2);
       }
-      if constexpr (DUAL3 && t == KS2) window_combine(hdr3, tms3, hst3, (qq + ql) * M + cb_w, J1, false);      // between the expand's windows
-      if constexpr (t == 0) {
+      if constexpr (s == 0) {
         if constexpr (RESDB) {
           const int qn = qq + ql + 1 < NPASS ? qq + ql + 1 : NPASS - 1;
           if constexpr (ql & 1) load_res(res0, qn); else load_res(res1, qn);
@@ -490,7 +466,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
 #pragma unroll
           for (int j = 0; j < J1; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
       }
-      if constexpr (t == NS2 - 1) {
+      if constexpr (s == KS2 - 1) {
         i32x4 (&rv)[MT][J1] = (RESDB && (ql & 1)) ? res1 : res0;
         const int q = qq + ql;
         auto epilogue = [&](auto fast_c) __attribute__((always_inline)) {
@@ -517,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    bb_static_for<0, PP * NS2>(step2);
+    bb_static_for<0, 2 * KS2>(step2);
   }
   BB_STAMP(6);
 #undef BB_STAMP
@@ -526,47 +502,42 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
 }
 
 // dynamic LDS of a launch: the halo tile + the three layers' header images (the chunk buffers are static)
-static size_t bband_dyn_lds(int M, int R, int W, bool dual1, bool dual2, bool dual3) {
+static size_t bband_dyn_lds(int M, int R, int W, bool dual1, bool dual2) {
   const int n_h = (R + 2) * (W + 2);
-  return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * (dual3 ? 28 : 20)) * M + 64;
+  return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * 20) * M + 64;
 }
 
-template <int M, int NW, int WN, int TG, int NG, int NT1, int SC, bool DUAL1, bool DUAL2, bool DUAL3>
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 static int launch_bband2(const BBandArgs& a, hipStream_t s) {
   constexpr int C = 4 * M;
-  constexpr int CHUNK = SC * 32 * TG * 64, MID2 = (M / 64) * 32 * NT1 * 64;
-  const size_t dyn = bband_dyn_lds(M, a.R, a.W, DUAL1, DUAL2, DUAL3);
+  constexpr int CHUNK = SC * 32 * NT0 * 64, MID2 = (M / 64) * 32 * NT1 * 64;
+  const size_t dyn = bband_dyn_lds(M, a.R, a.W, DUAL1, DUAL2);
   const size_t stat = (size_t)(CHUNK > MID2 ? CHUNK : MID2) + CHUNK;
-  if (dyn + stat > 160 * 1024 || (a.R + 2) * a.W > 32 * TG * NG || a.R * a.W > 32 * NT1) return 1;
-  auto fn = conv_bband_kernel<M, NW, WN, TG, NG, NT1, SC, DUAL1, DUAL2, DUAL3>;
+  if (dyn + stat > 160 * 1024) return 1;
+  auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
-  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d%s%s%s> (%d bands per image)", a.H, a.W, C, M, a.R,
-                  DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", DUAL3 ? ",dual expand" : "", a.tiles_per_img);
+  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d%s%s> (%d bands per image)", a.H, a.W, C, M, a.R,
+                  DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", a.tiles_per_img);
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img), dim3(NW * 64), dyn, s, a);
   return launch_ok() ? 0 : -1;
 }
 
-// Shapes instantiated: ResNet-50 stage 4 (14 x 14, C = 1024, M = 256: every row single-window with the shipped Q), stage 3 (28 x 28,
-// C = 512, M = 128: two-window reduce, the last bottleneck's 3x3 two-window as well) and stage 2 (56 x 56, C = 256, M = 64: two-window
-// reduce, the last bottleneck's expand two-window); R rows per band -> reduce groups x column tiles of the halo band / tiles of the band:
-//   14 x 14: R 7: 126 px = 1 x 4 tiles, 98 = 4 | R 4: 84 = 1 x 3, 56 = 2 | R 2: 56 = 1 x 2, 28 = 1
-//   28 x 28: R 7: 252 px = 1 x 8, 196 = 8 | R 4: 168 = 1 x 6, 112 = 4
-//   56 x 56: R 7: 504 px = 2 x 8, 392 = 16 (13 used) | R 4: 336 = 3 x 4, 224 = 8
-// 16 waves per block measured SLOWER than 8 (profiles/r04_bband_timeline_r7_w16.txt: the requantisation phases are bound by the SIMDs'
-// VALU throughput, not by issue latency, and the 3x3 loop loses: 40 against 34 us per block).
+// Shapes instantiated: ResNet-50 stage 4 (14 x 14, C = 1024, M = 256: every row single-window with the shipped Q) and stage 3
+// (28 x 28, C = 512, M = 128: two-window reduce, the last bottleneck's 3x3 two-window as well), R rows per band -> column tiles of the
+// halo band / the band.  16 waves per block measured SLOWER than 8 (profiles/r04_bband_timeline_r7_w16.txt: the requantisation phases
+// are bound by the SIMDs' VALU throughput, not by issue latency, and the 3x3 loop loses: 40 against 34 us per block).
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R) {
   if (C != 4 * M || H != W || R < 1 || R > H) return false;
   if (M == 256 && W == 14) return R == 7 || R == 4 || R == 2;
   if (M == 128 && W == 28) return R == 7 || R == 4;
-  if (M == 64 && W == 56) return R == 7 || R == 4;
   return false;
 }
-bool conv_bband_windows_ok(int M, int dual1, int dual2, int dual3) {
-  if (M == 256) return !dual1 && !dual2 && !dual3;
-  if (M == 128) return !dual3 && (dual1 || !dual2);       // (single, single), (dual, single), (dual, dual) reduce / 3x3
-  if (M == 64) return !dual2 && (dual1 || !dual3);        // (single, single), (dual, single), (dual, dual) reduce / expand
+bool conv_bband_windows_ok(int M, int dual1, int dual2) {
+  if (M == 256) return !dual1 && !dual2;
+  if (M == 128) return dual1 || !dual2;                   // (single, single), (dual, single), (dual, dual)
   return false;
 }
+
 // rows per band actually used for `wanted`: the 7-row form of the 28 x 28 kernel with BOTH reduce and 3x3 two-window would need more
 // than 256 registers (23 spilled) -- that bottleneck takes 4-row bands
 int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted) {
@@ -574,36 +545,28 @@ int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted) {
   return wanted;
 }
 
-template <int M, int NW, int WN, int TG, int NG, int NT1, int SC>
+template <int M, int NW, int WN, int NT0, int NT1, int SC>
 static int launch_bband(const BBandArgs& a, hipStream_t s) {
-  if constexpr (M == 256) return launch_bband2<M, NW, WN, TG, NG, NT1, SC, false, false, false>(a, s);
-  else if constexpr (M == 128) {
-    if constexpr (TG != 8) { if (a.dual1 && a.dual2) return launch_bband2<M, NW, WN, TG, NG, NT1, SC, true, true, false>(a, s); }
-    if (a.dual1 && a.dual2) return 1;
-    if (a.dual1) return launch_bband2<M, NW, WN, TG, NG, NT1, SC, true, false, false>(a, s);
-    return launch_bband2<M, NW, WN, TG, NG, NT1, SC, false, false, false>(a, s);
-  } else {
-    if (a.dual1 && a.dual3) return launch_bband2<M, NW, WN, TG, NG, NT1, SC, true, false, true>(a, s);
-    if (a.dual1) return launch_bband2<M, NW, WN, TG, NG, NT1, SC, true, false, false>(a, s);
-    return launch_bband2<M, NW, WN, TG, NG, NT1, SC, false, false, false>(a, s);
+  if constexpr (M == 128 && NT0 == 8) { if (a.dual1 && a.dual2) return 1; }
+  if constexpr (M == 256) return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
+  else {
+    if constexpr (NT0 != 8) { if (a.dual1 && a.dual2) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, true>(a, s); }
+    if (a.dual1) return launch_bband2<M, NW, WN, NT0, NT1, SC, true, false>(a, s);
+    return launch_bband2<M, NW, WN, NT0, NT1, SC, false, false>(a, s);
   }
 }
 
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R) || !conv_bband_windows_ok(M, a.dual1, a.dual2, a.dual3)) return 1;
+  if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R) || !conv_bband_windows_ok(M, a.dual1, a.dual2)) return 1;
   if (M == 256 && a.W == 14) {
-    if (a.R == 7) return launch_bband<256, 8, 1, 4, 1, 4, 4>(a, s);
-    if (a.R == 4) return launch_bband<256, 8, 1, 3, 1, 2, 4>(a, s);
-    if (a.R == 2) return launch_bband<256, 8, 1, 2, 1, 1, 4>(a, s);
+    if (a.R == 7) return launch_bband<256, 8, 1, 4, 4, 4>(a, s);      // 126 / 98 pixels
+    if (a.R == 4) return launch_bband<256, 8, 1, 3, 2, 4>(a, s);      // 84 / 56
+    if (a.R == 2) return launch_bband<256, 8, 1, 2, 1, 4>(a, s);      // 56 / 28
   }
   if (M == 128 && a.W == 28) {
-    if (a.R == 7) return launch_bband<128, 8, 2, 8, 1, 8, 2>(a, s);
-    if (a.R == 4) return launch_bband<128, 8, 2, 6, 1, 4, 2>(a, s);
-  }
-  if (M == 64 && a.W == 56) {
-    if (a.R == 7) return launch_bband<64, 8, 4, 8, 2, 16, 2>(a, s);
-    if (a.R == 4) return launch_bband<64, 8, 4, 4, 3, 8, 2>(a, s);
+    if (a.R == 7) return launch_bband<128, 8, 2, 8, 8, 2>(a, s);      // 252 / 196 pixels
+    if (a.R == 4) return launch_bband<128, 8, 2, 6, 4, 2>(a, s);      // 168 / 112
   }
   return 1;
 }

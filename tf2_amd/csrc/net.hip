@@ -350,7 +350,7 @@ bool Net::bband_at(int l, int rows) const {
   if (A.src < 0 || A.k != 1 || A.pad_h || A.pad_w || A.add_src >= 0) return false;
   if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
   if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
-  if (layers[A.src].concat >= 0 || !(opts.bband_maps & (A.H >= 56 ? 1 : A.H >= 28 ? 2 : 4))) return false;
+  if (layers[A.src].concat >= 0) return false;
   {
     const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1);
     if (!p0 || !p1) return false;
@@ -363,9 +363,9 @@ bool Net::bband_at(int l, int rows) const {
     if (pl->Cp_in % 64 != 0 || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;      // dense tiles
     if (pl->w_share) return false;
     const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
-    if (!one_window && !dual) return false;
+    if (!one_window && !(dual && k < l + 2)) return false;                                                // (the expand: single-window only)
   }
-  return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual, pack_layer(l + 2)->dual);
+  return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual);
 }
 
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
@@ -398,7 +398,6 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS")) o.bband_rows = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS_ALONE")) o.bband_rows_alone = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND_MIN")) o.bband_min = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BBAND_MAPS")) o.bband_maps = atoi(e);
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
@@ -680,7 +679,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
           f.keep_mid = wp->keep_all ? 1 : 0;
           f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
           f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
-          f.dual1 = c0.dual; f.dual2 = c1.dual; f.dual3 = c2.dual;
+          f.dual1 = c0.dual; f.dual2 = c1.dual;
           f.res_cp = c2.g.res_cp; f.res_off = c2.g.res_off; f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
           st.bg_c = L.C; st.bg_m = L.N;
           pair_done[l + 1] = 1; pair_done[l + 2] = 1;

@@ -218,7 +218,7 @@ struct BBandArgs {
   int32_t relu1, relu2, relu3, add_relu, has_res, keep_mid;
   int32_t fast1, fast2, fast3;     // PackLayer::fast
   int32_t dbl1, dbl2, dbl3;        // the layer's output tensor has doubled channels
-  int32_t dual1, dual2, dual3;     // the reduce / the 3x3 / the expand is a two-window layer (entries [hi rows | lo rows])
+  int32_t dual1, dual2;            // the reduce / the 3x3 is a two-window layer (entries [hi rows | lo rows])
   int32_t res_cp, res_off, y_cp, y_off;
 };
 
@@ -300,7 +300,7 @@ int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int 
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R);
 int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted);     // rows per band used when `wanted` are asked for
-bool conv_bband_windows_ok(int M, int dual1, int dual2, int dual3);     // the instantiated (reduce, 3x3, expand) window forms
+bool conv_bband_windows_ok(int M, int dual1, int dual2);     // the instantiated (reduce, 3x3) window forms
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream);        // 1: shape not instantiated / does not fit
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used);
