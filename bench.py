@@ -150,10 +150,11 @@ def main():
     ap.add_argument("--feeder", type=int, default=0,
                     help="1: one host thread per in-flight stream enqueues that stream's steps (tf2_amd/feeder.py); 0: one thread feeds all "
                          "(measured equal at 20 steps: the streams then start together, and steps that run in lock-step take longer)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1: replay every step from a captured HIP graph (each leg captured with its own launch plan); 0 (default): launch; "
-                         "-1: graphs for the batches-in-flight leg only.  Measured equal within noise on a warm device: 87.3-88.6 k against "
-                         "86.6-87.8 k img/s at 20 steps in flight, 60.8-60.9 k against 61.2-61.4 k one batch at a time")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="-1 (default): the batches-in-flight leg replays every step from a captured HIP graph (one per stream and input buffer, "
+                         "captured with that leg's launch plan during the untimed steps), the one-batch-at-a-time leg launches; 1: both legs "
+                         "replay graphs; 0: both launch.  Round 4, three alternating runs at 20 steps: 90.5-91.0 k (in-flight leg replayed) against "
+                         "89.1-90.3 k img/s (launched); one batch at a time 60.7 k replayed against 61.2 k launched (profiles/r04_experiments.txt)")
     ap.add_argument("--partition", type=int, default=0,
                     help="1: the in-flight streams are created with hipExtStreamCreateWithCUMask (tf2_amd/streams.py) when the number of batches "
                          "in flight divides 8; 0 (default): plain streams.  Round 4 measured that the interleaved masks of streams.py are IGNORED by "

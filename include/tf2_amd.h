@@ -153,7 +153,8 @@ tf2_status tf2_net_run_q(tf2_net* net, const int8_t* images_q_dev, int batch, vo
  * on an internal mutex only while they look up / build the launch plan, the enqueue of the step's launches runs side by side
  * (calls that share a workspace serialise for the whole enqueue; kernel execution is asynchronous as always).  Everything
  * else on a handle (create / set_q / load / pack / bind / reload_options / profile / destroy) must not run concurrently
- * with a run on the same handle.  tf2_last_error is per thread.                                                          */
+ * with a run on the same handle; workspace_size / read_layer / describe_* / run_stats take the handle's mutex and may.  tf2_last_error
+ * is per thread.                                                          */
 typedef struct tf2_run_opts {
   uint32_t size;              /* sizeof(tf2_run_opts), for forward compatibility */
   int32_t images_are_q;
@@ -163,6 +164,19 @@ typedef struct tf2_run_opts {
 } tf2_run_opts;
 tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void* workspace_dev, size_t workspace_bytes,
                           int8_t* logits_dev, void* hip_stream, const tf2_run_opts* opts);
+/* Group launches (conv_bgroup.hip: the one-batch-at-a-time plan keeps the eight blocks of an image resident together, one block per
+ * CU, and lets them meet inside the kernel) have PRECONDITIONS the library checks where it can and the caller owns where it cannot:
+ *  - at least 64 CUs for the stream: checked per call (hipExtStreamGetCUMask); a stream masked to fewer runs the step without them.
+ *  - one batch at a time: selected only for concurrency == 0, stated or inferred.  A caller that STATES concurrency = 0 on more than
+ *    four streams of one device at once (or drives more than four handles that way) breaks the contract: each XCD has 32
+ *    one-block slots, four concurrent group kernels always leave room for one complete group, a fifth need not -- a meeting
+ *    that does not complete within 2^24 polls traps (the context is lost, as after any GPU fault) instead of hanging.  With
+ *    concurrency = -1 (tf2_net_run) the library sees the several streams in its call history and never selects them there.
+ *  - the workspace bytes behind the tensors (step counter, flags) are the library's; they are re-initialised by every step.
+ * The batches-in-flight plan (concurrency = 1) has none of this: its fused launches (conv_bband.hip) exchange nothing between blocks.
+ * tf2_net_run_stats: out4 = {steps run, steps whose plan had group launches, steps run with the in-flight plan, steps on a stream
+ * of fewer than 64 CUs} since tf2_net_create -- what a test or a server asserts its deployment against.                          */
+tf2_status tf2_net_run_stats(tf2_net* net, int64_t* out4);
 /* Introspection: the kernel launches one step of `batch` images consists of, in issue order, as the library's own launch
  * plan selects them (concurrency as in tf2_run_opts: 0 or 1).  Needs a packed image, no device.  rows[i].layer = the table
  * row the launch belongs to (-1: input preparation; a fused launch carries its first row).  Returns the number of launches

@@ -271,3 +271,58 @@ def test_cli_on_the_shipped_image(r50, golden_dir, tmp_path, capsys):
     # a missing verify file is reported, not fatal (the reference prints the open error and goes on, network_helper.cpp:77-83)
     assert cli.main([str(mf), os.path.join(golden_dir, "resnet50_Q"), img, str(tmp_path / "nope.bin"), "1"]) == 0
     assert "verify file not readable" in capsys.readouterr().out
+
+
+def test_group_launch_preconditions_are_checked_per_call(r50):
+    """include/tf2_amd.h, group launches: (1) a stream whose CU mask leaves fewer than 64 CUs never takes them, even when the caller
+    states concurrency = 0 -- the step runs with separate launches and the same logits; (2) five host threads, one stream and
+    workspace each, calling tf2_net_run on ONE handle: the library sees the several streams in its call history and selects the
+    in-flight plan -- no group launch is ever enqueued there (tf2_net_run_stats), and every thread gets the logits of a serial run."""
+    torch = _torch()
+    import threading
+    from tf2_amd import streams as tstreams
+    rig = Rig(*r50, 0)
+    x = torch.from_numpy(synth.synth_images(rig.t, 32, 411)).to("cuda:0")
+    want = rig.runner.run_batch(x, concurrency=0).clone()
+    torch.cuda.synchronize()
+    s0 = rig.net.run_stats()
+    assert s0["group_steps"] >= 1 and s0["small_mask_steps"] == 0          # the full-chip stream took the group launches
+    # (1) a 32-CU stream (contiguous mask bits: honoured by the hardware), concurrency = 0 stated
+    small = tstreams.masked_stream(range(32), "cuda:0")
+    r_small = network.Runner(None, rig.net)
+    with torch.cuda.stream(small):
+        for _ in range(3):
+            got = r_small.run_batch(x, concurrency=0)
+    torch.cuda.synchronize()
+    s1 = rig.net.run_stats()
+    assert s1["small_mask_steps"] - s0["small_mask_steps"] == 3 and s1["group_steps"] == s0["group_steps"]
+    assert bool((got == want).all())
+    # (2) five threads / streams / workspaces, the library left to infer the concurrency
+    n_thr, n_steps = 5, 12
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_thr)]
+    runners = [network.Runner(None, rig.net) for _ in range(n_thr)]
+    for st, rn in zip(streams, runners):                    # workspaces allocated up front (set-up, on the main thread)
+        with torch.cuda.stream(st):
+            rn.run_batch(x, concurrency=1)
+    torch.cuda.synchronize()
+    s2 = rig.net.run_stats()
+    errs = []
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(streams[i]):
+                for _ in range(n_steps):
+                    runners[i].run_batch(x)                 # tf2_net_run: concurrency decided by the library
+        except Exception as e:                              # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    s3 = rig.net.run_stats()
+    assert s3["steps"] - s2["steps"] == n_thr * n_steps
+    # the very first call of the burst may still see a one-stream history; from the second stream on every step is an in-flight step
+    assert s3["group_steps"] - s2["group_steps"] <= 1 and s3["inflight_steps"] - s2["inflight_steps"] >= n_thr * n_steps - 1
+    for rn in runners:
+        assert bool((rn._logits == want).all())

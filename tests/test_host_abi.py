@@ -258,3 +258,29 @@ def test_rows_that_share_a_launch_never_share_memory(golden_dir, name, batch):
                     assert not overlap(tensors[a], tensors[b]), (l, end, a, b)
     if name == "resnet50":
         assert n_multi >= (10 if batch >= 12 else 2)              # (small batches: few fused launches, by the library's own rules)
+
+
+def test_feeder_reports_every_error_and_never_hangs(monkeypatch):
+    """tf2_amd/feeder.py without a GPU: a thread whose set-up fails (no device here: torch.cuda.set_device raises) must not leave
+    drain() waiting for ever, and errors of several threads are all reported."""
+    from tf2_amd.feeder import StreamFeeder
+    import contextlib, types, sys as _sys
+    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(set_device=lambda d: None, stream=lambda s: contextlib.nullcontext()))
+    monkeypatch.setitem(_sys.modules, "torch", fake)
+    f = StreamFeeder([object(), object()], ["r0", "r1"], "cpu")
+    seen = []
+    f.submit(0, lambda rn: seen.append(rn))
+    f.submit(1, lambda rn: (_ for _ in ()).throw(ValueError("boom 1")))
+    f.submit(0, lambda rn: (_ for _ in ()).throw(ValueError("boom 0")))
+    with pytest.raises(RuntimeError, match="2 errors"):
+        f.drain()
+    assert seen == ["r0"]
+    f.drain()                                    # errors are reported once
+    f.close()
+    # a thread that dies in its set-up releases drain()
+    fake.cuda.set_device = lambda d: (_ for _ in ()).throw(RuntimeError("no device"))
+    g = StreamFeeder([object()], ["r"], "cpu")
+    g.submit(0, lambda rn: None)
+    with pytest.raises(RuntimeError, match="no device"):
+        g.drain()
+    g.close()

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -15,7 +16,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # null stream's), so a fourth in-flight batch would queue behind another (-15 %, profiles/r02_inflight_hwqueues.txt).  The runtime
 # reads the variable when it initialises, i.e. it only takes effect if tf2_amd is imported before the first HIP call of the
 # process; a deployment that embeds the C library directly exports it itself (INTEGRATION.md "Deployment preconditions").
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    _torch_mod = sys.modules.get("torch")
+    if _torch_mod is not None and getattr(getattr(_torch_mod, "cuda", None), "is_initialized", lambda: False)():
+        import warnings
+        warnings.warn("tf2_amd: HIP was initialised before tf2_amd was imported, GPU_MAX_HW_QUEUES=8 cannot take effect any more: a fourth "
+                      "batch in flight will share a hardware queue (export GPU_MAX_HW_QUEUES=8 before starting the process)", RuntimeWarning)
 # TF2_AMD_LIB: another build of the same sources (tools/probe_run.py loads the -DTF2_PROBES library); never a fallback
 LIB_PATH = os.environ.get("TF2_AMD_LIB") or os.path.join(_HERE, "libtf2amd.so")
 
@@ -114,6 +121,7 @@ def lib() -> C.CDLL:
     L.tf2_net_run.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_ex.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp, C.POINTER(RunOpts)]
+    L.tf2_net_run_stats.argtypes = [vp, vp]
     L.tf2_net_describe_launches.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LaunchInfo), C.c_int, C.POINTER(C.c_int)]
     L.tf2_net_describe_workspace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TensorInfo), C.c_int, C.POINTER(C.c_int), C.POINTER(RowTensors), C.c_int]
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
@@ -130,7 +138,7 @@ EXPORTED = [
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
-    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
+    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_run_stats", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
 def check(status: int) -> None:

@@ -182,6 +182,14 @@ tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void*
   return net->impl.run(images_dev, o->images_are_q != 0, batch, ws, ws_bytes, logits_dev, hip_stream, o->concurrency, o->mark_event, o->mark_after_layer);
 }
 
+tf2_status tf2_net_run_stats(tf2_net* net, int64_t* out4) {
+  CHECK_NET(net);
+  if (!out4) { set_error("tf2_net_run_stats: null argument"); return TF2_ERR_ARG; }
+  std::lock_guard<std::mutex> lock(net->impl.run_mutex);
+  out4[0] = net->impl.stat_steps; out4[1] = net->impl.stat_group_steps; out4[2] = net->impl.stat_inflight_steps; out4[3] = net->impl.stat_small_mask_steps;
+  return TF2_OK;
+}
+
 tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, tf2_launch_info* rows, int capacity, int* n) {
   CHECK_NET(net);
   if (!n || (capacity > 0 && !rows)) { set_error("tf2_net_describe_launches: null argument"); return TF2_ERR_ARG; }

@@ -961,9 +961,11 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   hipStream_t s = (hipStream_t)stream;
   // group launches spin until the eight members of an image are resident together, one block per CU: never on a stream whose CU
   // mask leaves fewer than 64 CUs (asked per call: the handle does not know what the caller's next stream looks like)
-  const bool allow_groups = !concurrent && opts.bgroup_mode && stream_cu_count(s) >= 64;
+  const bool wide_stream = stream_cu_count(s) >= 64;
+  const bool allow_groups = !concurrent && opts.bgroup_mode && wide_stream;
   const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent, allow_groups);
   if (!lp) return TF2_ERR_ARG;
+  stat_steps++; stat_group_steps += lp->n_groups ? 1 : 0; stat_inflight_steps += concurrent ? 1 : 0; stat_small_mask_steps += wide_stream ? 0 : 1;
   const int nl = nd.n_layers;
   // The enqueue itself runs outside the handle's mutex, under the plan's own (tf2_amd.h threading note): host threads that
   // feed different streams issue their ~40 launches per step side by side.  (Profiling runs keep the handle's mutex: the

@@ -159,6 +159,7 @@ struct Net {
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bband_at(int l, int rows) const;    // rows l, l + 1, l + 2 are an identity bottleneck conv_bband.hip can take with `rows` output rows per block
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
+  long long stat_steps = 0, stat_group_steps = 0, stat_inflight_steps = 0, stat_small_mask_steps = 0;   // tf2_net_run_stats
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
   int recent_pos = 0;
   void load_options();

@@ -16,7 +16,9 @@ class StreamFeeder:
         assert len(streams) == len(runners)
         self.device = device
         self._qs = [queue.SimpleQueue() for _ in streams]
-        self._err = None
+        self._errs = []                              # (thread, exception), appended under _lock
+        self._lock = threading.Lock()
+        self._dead = [False] * len(streams)          # thread i left its loop (error in set-up, or close())
         self._threads = [threading.Thread(target=self._loop, args=(i, st, rn), daemon=True, name=f"tf2-feeder-{i}")
                          for i, (st, rn) in enumerate(zip(streams, runners))]
         for t in self._threads:
@@ -26,20 +28,34 @@ class StreamFeeder:
         return len(self._qs)
 
     def _loop(self, i, stream, runner):
-        import torch
-        torch.cuda.set_device(self.device)
-        with torch.cuda.stream(stream):            # the current stream is per thread
-            while True:
-                item = self._qs[i].get()
-                if item is None:
-                    return
+        try:
+            import torch
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(stream):        # the current stream is per thread
+                while True:
+                    item = self._qs[i].get()
+                    if item is None:
+                        return
+                    if isinstance(item, threading.Event):
+                        item.set()
+                        continue
+                    try:
+                        item(runner)
+                    except BaseException as e:     # reported by drain() in the submitting thread
+                        with self._lock:
+                            self._errs.append((i, e))
+        except BaseException as e:                 # set-up failed (set_device / stream): nobody will ever serve this queue
+            with self._lock:
+                self._errs.append((i, e))
+        finally:
+            self._dead[i] = True
+            while True:                            # release every drain() that is (or will be) waiting on this thread
+                try:
+                    item = self._qs[i].get_nowait()
+                except queue.Empty:
+                    break
                 if isinstance(item, threading.Event):
                     item.set()
-                    continue
-                try:
-                    item(runner)
-                except BaseException as e:         # reported by drain() in the submitting thread
-                    self._err = e
 
     def submit(self, i, fn):
         """fn(runner) is called on feeder thread i with stream i current; returns at once."""
@@ -52,14 +68,24 @@ class StreamFeeder:
             e = threading.Event()
             q.put(e)
             evs.append(e)
-        for e in evs:
-            e.wait()
-        if self._err is not None:
-            err, self._err = self._err, None
-            raise err
+        for i, e in enumerate(evs):
+            while not e.wait(0.5):
+                if self._dead[i]:                  # the thread died after we queued the event and before it drained its queue
+                    break
+        self._raise_collected()
+
+    def _raise_collected(self):
+        with self._lock:
+            errs, self._errs = self._errs, []
+        if errs:
+            i, first = errs[0]
+            if len(errs) > 1:
+                raise RuntimeError(f"{len(errs)} errors on feeder threads; first on thread {i}: {first!r}") from first
+            raise first
 
     def close(self):
         for q in self._qs:
             q.put(None)
         for t in self._threads:
             t.join()
+        self._raise_collected()                      # errors nobody drained are not lost

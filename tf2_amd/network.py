@@ -181,6 +181,13 @@ class NetWork:
         return [dict(layer=r.layer, kernel=r.kernel.decode(), grid=r.grid, block=r.block, lds_bytes=r.lds_bytes, vgprs=r.vgprs)
                 for r in rows[:n.value]]
 
+    def run_stats(self):
+        """{steps, group_steps, inflight_steps, small_mask_steps} since the handle was created (tf2_net_run_stats)."""
+        import numpy as _np
+        out = _np.zeros(4, _np.int64)
+        _lib.check(_lib.lib().tf2_net_run_stats(self._h, out.ctypes.data))
+        return dict(steps=int(out[0]), group_steps=int(out[1]), inflight_steps=int(out[2]), small_mask_steps=int(out[3]))
+
     def describe_workspace(self, batch: int, keep_all: bool = False):
         """(tensors, rows) of the liveness-planned workspace: tensors = [{offset, bytes, first_row, last_row}], rows = per table row
         {in_tensor, out_tensor, conv_tensor, res_tensor} (tf2_net_describe_workspace; no device needed)."""

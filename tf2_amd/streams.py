@@ -1,11 +1,13 @@
-"""HIP streams restricted to whole XCDs (hipExtStreamCreateWithCUMask).
+"""HIP streams created with hipExtStreamCreateWithCUMask.
 
-MI355X has 8 XCDs of 32 CUs, each with its own L2.  A server that keeps N independent batches in flight can give every
-batch its own set of XCDs: the kernels of one batch then never wait for CU slots behind another batch's kernels, and a batch's
-activations stay in its XCDs' L2.  On this part bit i of the CU mask is CU i / 8 of XCD i % 8 (measured: masks built that way
-and masks of consecutive-bit groups of 8 XCD-interleaved CUs behave alike, contiguous quarters of the bit range do not), so a
-partition of k XCDs is the bits with (i % 8) in a set of k residues.  bench.py uses four partitions of two XCDs by default
-(+7 % at 20 timed steps, +2 % at 100 against plain streams, profiles/r03_cumask.txt)."""
+Rounds 2-3 built "XCD partitions" with this: every in-flight batch on its own pair of XCDs, mask bits chosen as (i % 8) in a set of
+XCD residues.  Round 4 measured what such a stream really uses (tools/ubench/cumask_probe.hip, profiles/r04_ubench_cumask_probe.txt:
+every block records its XCC id and hardware id): the INTERLEAVED masks are ignored -- a stream masked to the bits i % 8 in {0, 1}
+(or i % 8 == 0, or i % 4 == 0) runs on all 256 CUs of all 8 XCDs at a plain stream's speed -- and only CONTIGUOUS bit ranges restrict:
+[0, 64) gives 64 CUs, eight on EVERY XCD.  So partitioned_streams() below never partitioned anything (its +2...7 % in round 3 was run-to-run
+noise), real CU partitions lose badly (round 3, experiment 30), and bench.py uses plain streams now.  The functions stay for the
+tests and tools that create masked streams (the library asks a stream for its CU count before it selects group launches:
+Net::run, conv_bgroup.hip)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -36,6 +38,24 @@ def xcd_mask_bits(part: int, n_parts: int, n_cu: int, n_xcd: int = 8) -> List[in
         raise ValueError(f"{n_parts} partitions do not divide {n_xcd} XCDs")
     per = n_xcd // n_parts
     return [i for i in range(n_cu) if (i % n_xcd) // per == part]
+
+
+def masked_stream(bits, device="cuda:0"):
+    """One torch stream whose CU mask has exactly `bits` set (contiguous ranges are what the hardware honours: [0, 32) = 32 CUs,
+    four on every XCD)."""
+    import torch
+    dev = torch.device(device)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (n_cu + 31) // 32
+    arr = (C.c_uint32 * words)()
+    for b in bits:
+        arr[b // 32] |= 1 << (b % 32)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        rc = _hiplib().hipExtStreamCreateWithCUMask(C.byref(h), words, arr)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(h.value, device=dev)
 
 
 def partitioned_streams(n_parts: int, device="cuda:0"):
