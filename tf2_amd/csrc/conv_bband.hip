@@ -66,11 +66,7 @@ __device__ __forceinline__ void bb_dma16(const int8_t* src, int8_t* lds_dst) {
 // DUAL1 / DUAL2: the reduce / the 3x3 is a two-window layer (weight_pack.cpp: entries [hi rows | lo rows]).  The reduce keeps two
 // accumulator sets over the one input stream and combines them once, (hi << dshift[1]) + lo; the 3x3 sweeps its LDS-resident halo
 // tile window by window into ONE set with the Horner shift in between (conv_bneck's scheme) -- both exact in Z/2^32.
-// PIPE2: phase 2 software-pipelined by column-tile HALVES -- while the MFMAs of one half of the pass's tiles run, the other half's
-// finished tiles are requantised four rows at a time (rq_group): the expand's passes are VALU-bound (8 us of requantisation against
-// 3.4 us of matrix pipe per 14 x 14 block), so the matrix work hides behind it; a pass's weight fragments are loaded once, a whole
-// pass ahead, and serve both halves.
-template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2, bool PIPE2>
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a) {
   constexpr int C = 4 * M;
   constexpr int WM = NW / WN, MT = M / (32 * WM);
@@ -184,7 +180,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     constexpr int v = decltype(v_c)::value;
     if constexpr (v < KS1) load_a(f, a.w1, tms1, KS1, cb_w, v, DUAL1 ? 2 : 1, 0);
     else if constexpr (v < KS1 + N1) load_a(f, a.w2, tms2, NE, cb_w, (v - KS1) % NE, DUAL2 ? 2 : 1, (v - KS1) / NE);
-    else if constexpr (!PIPE2) load_a(f, a.w3, tms3, KS2, cb_w, v - KS1 - N1);               // the expand's first fragments (pass 0)
+    else load_a(f, a.w3, tms3, KS2, cb_w, v - KS1 - N1);                                     // the expand's first fragments (pass 0)
   };
   Afr g0, g1, g2, g3;                                    // DUAL1: the reduce's LOW window fragments, rotating like f0..f3
 #define BB_BUFL(v) ((v) % 4 == 0 ? g0 : (v) % 4 == 1 ? g1 : (v) % 4 == 2 ? g2 : g3)
@@ -386,20 +382,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // (two buffers, loaded one pass ahead, where the register budget allows; else one, loaded at the start of its pass)
   constexpr bool RESDB = NW != 16;
   i32x4 res0[MT][J1], res1[MT][J1];
-  if constexpr (RESDB && !PIPE2) load_res(res0, 0);
-  // PIPE2: the weight fragments of a whole pass per parity (pass q in pf[q & 1], loaded while pass q - 1 runs); pass 0's now, so that
-  // they fly during the hand-over below
-  Afr pf[PIPE2 ? 2 : 1][PIPE2 ? KS2 : 1];
-  auto load_pass = [&](int par, int q) __attribute__((always_inline)) {
-    if constexpr (PIPE2) {
-#pragma unroll
-      for (int s2 = 0; s2 < KS2; s2++) {
-        if (par) load_a(pf[PIPE2 ? 1 : 0][s2], a.w3, tms3, KS2, q * M + cb_w, s2);
-        else load_a(pf[0][s2], a.w3, tms3, KS2, q * M + cb_w, s2);
-      }
-    }
-  };
-  if constexpr (PIPE2) load_pass(0, 0);
+  if constexpr (RESDB) load_res(res0, 0);
 
   // hand-over: requantise the 3x3 into the expand's B tile [slab][pixel][64]
   {
@@ -449,7 +432,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // The passes run in PAIRS inside a run-time loop (the body is two passes, statically unrolled: the residual buffers alternate and
   // the fragment buffers rotate the same way in every iteration): a quarter of the code of four unrolled passes.  An identity
   // bottleneck always has its residual (Net::bband_at).
-  if constexpr (!PIPE2) {
 #pragma unroll 1
   for (int qq = 0; qq < NPASS; qq += 2) {
     auto step2 = [&](auto u_c) {
@@ -513,113 +495,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     };
     bb_static_for<0, 2 * KS2>(step2);
   }
-  } else {
-    static_assert(J1 % 2 == 0 && 4 % KS2 == 0, "two halves of column tiles; the four row groups of a tile spread over the pass's steps");
-    constexpr int JH = J1 / 2, GPS = 4 / KS2;              // tiles per half, row groups requantised per step
-    RqTile rq[MT][JH];
-    // one half of one pass: MFMAs of tiles [JH * hm, JH * hm + JH) with fragments pf[par], interleaved with the requantisation of the
-    // OTHER half's tiles [JH * (1 - hm), ...) whose sums were finished one half earlier (pass qr, residual buffer parity rpar)
-    auto half_pass = [&](auto hm_c, auto par_c, auto rpar_c, int qr, bool do_rq, auto mode_c) __attribute__((always_inline)) {
-      constexpr int hm = decltype(hm_c)::value, par = decltype(par_c)::value, rpar = decltype(rpar_c)::value, MODE = decltype(mode_c)::value;
-      constexpr int j0m = JH * hm, j0r = JH * (1 - hm);
-      i32x4 (&rv)[MT][J1] = rpar ? res1 : res0;
-      if (do_rq) {
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-          for (int j = 0; j < JH; j++) rq_begin<true>(rq[i][j], rv[i][j0r + j]);
-      }
-      auto st = [&](auto s_c) __attribute__((always_inline)) {
-        constexpr int s2 = decltype(s_c)::value;
-        const int8_t* B = mid2 + s2 * (NP1 * 64);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-          i32x4 bf[JH];
-#pragma unroll
-          for (int j = 0; j < JH; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm1[j0m + j] ^ (ks << 5)));
-#pragma unroll
-          for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int j = 0; j < JH; j++)
-              acc[i][j0m + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(pf[par][s2].k[i][ks], bf[j], acc[i][j0m + j], 0, 0, 0);
-        }
-        if (do_rq) {
-#pragma unroll
-          for (int i = 0; i < MT; i++) {
-            const int ch = qr * M + cb_w + i * 32;
-            const int mt = ch >> tms3, ro = ch & ((1 << tms3) - 1);
-            const int* prm = reinterpret_cast<const int*>(hdr3 + mt * hst3);
-#pragma unroll
-            for (int j = 0; j < JH; j++) {
-              auto grp = [&](auto g_c) __attribute__((always_inline)) {
-                constexpr int G = GPS * s2 + decltype(g_c)::value;
-                rq_group<true, MODE, G>(rq[i][j], acc[i][j0r + j], prm, 1 << tms3, ro + 4 * half, lo_b3, rlo);
-              };
-              bb_static_for<0, GPS>(grp);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      bb_static_for<0, KS2>(st);
-      if (do_rq) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-          const int chl = qr * M + cb_w + i * 32 + 16 * half;
-#pragma unroll
-          for (int j = 0; j < JH; j++) {
-            const i32x4 out = rq_finish(rq[i][j]);
-            const int p = (wn + (j0r + j) * WN) * 32 + (lane & 31);
-            if (p < n_px) *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j0r + j][r] = 0;
-          }
-        }
-      }
-    };
-    auto run2 = [&](auto mode_c) __attribute__((always_inline)) {
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-#pragma unroll 1
-      for (int qq = 0; qq < NPASS; qq += 2) {
-        // pass qq (even parity): next pass's fragments and this pass's residual tiles on their way, then first half (tiles A) against
-        // the previous pass's second half (tiles B), second half against this pass's first
-        load_pass(1, qq + 1);
-        load_res(res0, qq);
-        half_pass(I0{}, I0{}, I1{}, qq - 1, qq > 0, mode_c);
-        half_pass(I1{}, I0{}, I0{}, qq, true, mode_c);
-        // pass qq + 1 (odd parity)
-        load_pass(0, qq + 2 < NPASS ? qq + 2 : NPASS - 1);
-        load_res(res1, qq + 1);
-        half_pass(I0{}, I1{}, I0{}, qq, true, mode_c);
-        half_pass(I1{}, I1{}, I1{}, qq + 1, true, mode_c);
-      }
-      // the last pass's second half: requantisation alone
-      {
-        i32x4 (&rv)[MT][J1] = res1;
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-          const int ch = (NPASS - 1) * M + cb_w + i * 32;
-          const int mt = ch >> tms3, ro = ch & ((1 << tms3) - 1);
-          const int* prm = reinterpret_cast<const int*>(hdr3 + mt * hst3);
-          const int chl = ch + 16 * half;
-#pragma unroll
-          for (int j = 0; j < JH; j++) {
-            rq_begin<true>(rq[i][j], rv[i][JH + j]);
-            rq_group<true, decltype(mode_c)::value, 0>(rq[i][j], acc[i][JH + j], prm, 1 << tms3, ro + 4 * half, lo_b3, rlo);
-            rq_group<true, decltype(mode_c)::value, 1>(rq[i][j], acc[i][JH + j], prm, 1 << tms3, ro + 4 * half, lo_b3, rlo);
-            rq_group<true, decltype(mode_c)::value, 2>(rq[i][j], acc[i][JH + j], prm, 1 << tms3, ro + 4 * half, lo_b3, rlo);
-            rq_group<true, decltype(mode_c)::value, 3>(rq[i][j], acc[i][JH + j], prm, 1 << tms3, ro + 4 * half, lo_b3, rlo);
-            const i32x4 out = rq_finish(rq[i][j]);
-            const int p = (wn + (JH + j) * WN) * 32 + (lane & 31);
-            if (p < n_px) *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
-          }
-        }
-      }
-    };
-    if (a.fast3 == 1) run2(std::integral_constant<int, 1>{});
-    else if (a.fast3 == 2) run2(std::integral_constant<int, 2>{});
-    else run2(std::integral_constant<int, 0>{});
-  }
   BB_STAMP(6);
 #undef BB_STAMP
 #undef BB_BUF
@@ -632,27 +507,19 @@ static size_t bband_dyn_lds(int M, int R, int W, bool dual1, bool dual2) {
   return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * 20) * M + 64;
 }
 
-template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2, bool PIPE2>
-static int launch_bband3(const BBandArgs& a, hipStream_t s) {
+template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
+static int launch_bband2(const BBandArgs& a, hipStream_t s) {
   constexpr int C = 4 * M;
   constexpr int CHUNK = SC * 32 * NT0 * 64, MID2 = (M / 64) * 32 * NT1 * 64;
   const size_t dyn = bband_dyn_lds(M, a.R, a.W, DUAL1, DUAL2);
   const size_t stat = (size_t)(CHUNK > MID2 ? CHUNK : MID2) + CHUNK;
   if (dyn + stat > 160 * 1024) return 1;
-  auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2, PIPE2>;
+  auto fn = conv_bband_kernel<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
-  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d%s%s%s> (%d bands per image)", a.H, a.W, C, M, a.R,
-                  DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", PIPE2 ? ",pipelined expand" : "", a.tiles_per_img);
+  TF2_LAUNCH_NAME("conv_bband_kernel<%dx%d,C%d,M%d,R%d%s%s> (%d bands per image)", a.H, a.W, C, M, a.R,
+                  DUAL1 ? ",dual reduce" : "", DUAL2 ? ",dual 3x3" : "", a.tiles_per_img);
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img), dim3(NW * 64), dyn, s, a);
   return launch_ok() ? 0 : -1;
-}
-
-template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
-static int launch_bband2(const BBandArgs& a, hipStream_t s) {
-  // A/B switch (TF2_AMD_BBAND_PIPE, default 1): phase 2 pipelined by tile halves where the shape has an even tile count per wave
-  static const int pipe = getenv("TF2_AMD_BBAND_PIPE") ? atoi(getenv("TF2_AMD_BBAND_PIPE")) : 1;
-  if constexpr ((NT1 / WN) % 2 == 0 && NW == 8) { if (pipe) return launch_bband3<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2, true>(a, s); }
-  return launch_bband3<M, NW, WN, NT0, NT1, SC, DUAL1, DUAL2, false>(a, s);
 }
 
 // Shapes instantiated: ResNet-50 stage 4 (14 x 14, C = 1024, M = 256: every row single-window with the shipped Q) and stage 3

@@ -116,58 +116,6 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
   return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
 }
 
-// The same requantisation in PIECES, for kernels that interleave it with another tile's MFMAs (conv_bband.hip phase 2): rq_begin
-// (the residual's swaps), rq_group for G = 0..3 (four output rows each: rows row0 + 8 G + {0..3}), rq_finish (the 16 NHWC bytes).
-// MODE: 1 = FAST rows, 2 = SEMI, 0 = generic (PackLayer::fast); no doubled channels (a residual layer never has them).
-struct RqTile { unsigned d[4]; unsigned rd[4]; };
-template <bool HAS_RES>
-__device__ __forceinline__ void rq_begin(RqTile& t, const rq_i32x4& resv) {
-  if (HAS_RES) {
-    auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[0], (unsigned)resv[1], false, false);
-    auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[2], (unsigned)resv[3], false, false);
-    t.rd[0] = r02[0]; t.rd[2] = r02[1]; t.rd[1] = r13[0]; t.rd[3] = r13[1];
-  }
-}
-template <bool HAS_RES, int MODE, int G, class ACC>
-__device__ __forceinline__ void rq_group(RqTile& t, const ACC& acc, const int* prm, int TM, int row0, int lo_bound, int rlo) {
-  const rq_i32x4* rowp = reinterpret_cast<const rq_i32x4*>(prm) + row0;
-  rq_i32x4 lo4 = {0, 0, 0, 0};
-  if (MODE != 1) lo4 = *reinterpret_cast<const rq_i32x4*>(prm + 4 * TM + row0 + 8 * G);
-  int q[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const rq_i32x4 pr = rowp[8 * G + r];
-    const long long b64 = (long long)(((unsigned long long)(unsigned)pr[3] << 32) | (unsigned)pr[2]);
-    const int av = acc[G * 4 + r];
-    int y;
-    if (MODE == 1) {
-      const long long p = (long long)av * (long long)pr[1] + b64;
-      y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
-    } else {
-      const int v = (int)((unsigned)pr[0] + ((unsigned)av << (lo4[r] & 31)));
-      const long long p = (long long)v * (long long)pr[1] + b64;
-      if (MODE == 2) y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
-      else { const int x = (int)(p >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
-    }
-    int c;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
-    if (HAS_RES) {
-      const int rr = (int)(signed char)((t.rd[G] >> (8 * r)) & 0xff);
-      const int sres = c + rr;
-      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
-    }
-    q[r] = c;
-  }
-  const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
-  const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
-  t.d[G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-}
-__device__ __forceinline__ rq_i32x4 rq_finish(const RqTile& t) {
-  auto s02 = __builtin_amdgcn_permlane32_swap(t.d[0], t.d[2], false, false);
-  auto s13 = __builtin_amdgcn_permlane32_swap(t.d[1], t.d[3], false, false);
-  return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
-}
-
 // FAST = the layer's PackLayer::fast == 1; semi (wave-uniform, only read when !FAST) = PackLayer::fast == 2
 template <bool HAS_RES, int LEAN = 0, bool FAST = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0, int lo_bound, int rlo, const rq_i32x4& resv,
