@@ -92,7 +92,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5;
-  const int W = a.W, Wp = a.W + 2, R = a.R, H = a.H;
+  // the map side is the template's (square maps: 14 for M = 256, 28 for M = 128; the launcher checks): every p / W below is then a
+  // multiply-high instead of the ~35-instruction division by a run-time value -- two dozen per lane and block, a fifth of the block's
+  // VALU work before (round 4)
+  constexpr int W = M == 256 ? 14 : M == 128 ? 28 : 56, Wp = W + 2, H = W;
+  const int R = a.R;
   const int n_h = (R + 2) * Wp;
   const int n_grp_h = (n_h + 15) >> 4;
   const int slabb = n_grp_h * 1024;                      // bytes of one 64-channel slab of the halo tile
@@ -559,6 +563,7 @@ static int launch_bband(const BBandArgs& a, hipStream_t s) {
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R) || !conv_bband_windows_ok(M, a.dual1, a.dual2)) return 1;
+  if (a.H != a.W || a.W != (M == 256 ? 14 : M == 128 ? 28 : 56)) return 1;        // (the kernel's compile-time map side)
   if (M == 256 && a.W == 14) {
     if (a.R == 7) return launch_bband<256, 8, 1, 4, 4, 4>(a, s);      // 126 / 98 pixels
     if (a.R == 4) return launch_bband<256, 8, 1, 3, 2, 4>(a, s);      // 84 / 56

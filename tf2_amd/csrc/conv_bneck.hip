@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     for (int gi = wave; gi < n_grp * NSL; gi += 8) {
       const int s = gi / n_grp, grp = gi - s * n_grp;
       const int h = grp * 16 + (lane >> 2);
-      const int hr = h / Wp, hc = h - hr * Wp;
+      const int hr = fast_div(h, a.wp_m, a.wp_s), hc = h - hr * Wp;
       const int row = r0 - 1 + hr, col = hc - 1;
       const bool ok = h < n_h && (unsigned)row < (unsigned)a.H && (unsigned)col < (unsigned)W;
       const int8_t* src = ok ? a.x + (((long long)img * a.H + row) * W + col) * TM + s * 64 + chunk * 16
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   for (int j = 0; j < NTN; j++) {
     int p = wn * WTN + j * 32 + (lane & 31);
     if (p >= n_px) p = 0;                               // lanes beyond the tile compute on pixel 0 and are never stored
-    const int r = p / W;
+    const int r = fast_div(p, a.w_m, a.w_s);
     h0[j] = r * Wp + (p - r * W);
   }
   auto baddr = [&](int t, int j) {

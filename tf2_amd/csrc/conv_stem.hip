@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_kernel(StemArgs a) {
       for (int j = 0; j < 2; j++) {
         int p = tile * 64 + j * 32 + (lane & 31);
         if (p >= n_px) p = 0;                                // computed on pixel 0, never stored
-        const int r = p / OW;
+        const int r = fast_div(p, a.ow_m, a.ow_s);
         b0[j] = b_plane + (r * W + (p - r * OW)) * 16;
       }
       i32x16 acc[2][2];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pipe_kernel(StemArgs a) {
       for (int j = 0; j < 2; j++) {
         const int p_raw = tile * 64 + j * 32 + (lane & 31);
         const int p = p_raw < n_px ? p_raw : 0;                 // computed on pixel 0, never stored
-        const int r = p / OW;
+        const int r = fast_div(p, a.ow_m, a.ow_s);
         const int8_t* const b0 = b_plane + (r * W + (p - r * OW)) * 16;
         // S = the unit taps' sum of this pixel column tile: gathered with v_dot4c on the B fragments of the rt = 0 sweep (this
         // lane's K half), both halves added once that sweep is over; the rt = 1 sweep reads the fragments again (LDS has the
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
     for (int blk = wave; blk < n_blk; blk += 8) {
       const int p_raw = blk * 32 + (lane & 31);
       const int p = p_raw < n_px ? p_raw : 0;
-      const int r = p / OW;
+      const int r = fast_div(p, a.ow_m, a.ow_s);
       const int8_t* const b0 = b_plane + (r * W + (p - r * OW)) * 16;
       i32x16 acc = zero16;
       int us = 0;
@@ -681,8 +681,8 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
   const int n_items = a.pk * a.PW * 2;                         // (pooled row, pooled column, 16-channel group)
   for (int it = tid; it < n_items; it += 512) {
     const int g = it & 1;
-    const int pi = (it >> 1) % a.PW;
-    const int pjl = (it >> 1) / a.PW;
+    const int pjl = fast_div(it >> 1, a.pw_m, a.pw_s);
+    const int pi = (it >> 1) - pjl * a.PW;
     const int pj = pj0 + pjl;
     if (pj >= a.PH) continue;
     int m[16];

@@ -760,6 +760,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
       f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0; f.dbl_out = pb->off_dbl != 0;
       f.B = batch; f.H = L.H; f.W = L.W; f.probe = opts.flags;
+      set_fast_div((uint32_t)L.W, &f.w_m, &f.w_s); set_fast_div((uint32_t)(L.W + 2), &f.wp_m, &f.wp_s);
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
       f.R = std::min(TN / L.W, L.H);
       f.tiles_per_img = (L.H + f.R - 1) / f.R;
@@ -781,6 +782,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.unit = pl->off_unit ? (const int8_t*)(pk + pl->off_unit) : nullptr;
       f.hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
       f.B = batch; f.H = L.H; f.W = L.W; f.OH = L.OH; f.OW = L.OW;
+      set_fast_div((uint32_t)L.OW, &f.ow_m, &f.ow_s); set_fast_div((uint32_t)std::max(1, L.PW), &f.pw_m, &f.pw_s);
       f.relu = ca.g.relu; f.fast = ca.g.fast; f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid; f.dbl_out = ca.g.dbl_out; f.probe = opts.flags; f.dbg2 = (opts.dbg2 && opts.dbg_layer == 0) ? opts.dbg2 : nullptr;
       // rows per block: the fewest rounds of (two blocks per CU) x rows; two blocks must share a CU's 160 KiB
       long best = -1;

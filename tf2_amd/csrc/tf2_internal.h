@@ -163,6 +163,7 @@ struct BneckArgs {
   int32_t dbl_out;           // the expand's output has doubled channels (only without a residual: weight_pack.cpp)
   int32_t probe;             // timing probes (ConvGeom::flags of the pair; read by -DTF2_PROBES builds only)
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
+  uint32_t w_m, wp_m; int32_t w_s, wp_s;     // set_fast_div(W), set_fast_div(W + 2): the pixel decodes without a run-time division
 };
 
 // conv_bgroup.hip: an identity bottleneck of a small map (1x1 reduce C -> M, 3x3 / 1 / pad 1 M -> M, 1x1 expand M -> C + residual)
@@ -250,6 +251,7 @@ struct StemArgs {
   int8_t* yp;                // pooled output tensor [B][PH][PW][yp_cp], or null (y then gets the conv map)
   int32_t PH, PW, yp_cp, yp_off;
   int32_t pk;                // pooled rows per block (2 * pk + 1 conv rows)
+  uint32_t ow_m, pw_m; int32_t ow_s, pw_s;     // set_fast_div(OW), set_fast_div(PW)
 };
 
 struct PoolArgs {
