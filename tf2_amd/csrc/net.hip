@@ -398,6 +398,8 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS")) o.bband_rows = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND_ROWS_ALONE")) o.bband_rows_alone = atoi(e);
   if (const char* e = getenv("TF2_AMD_BBAND_MIN")) o.bband_min = atoi(e);
+  if (const char* e = getenv("TF2_AMD_BBAND_ALONE_MAPS")) o.bband_alone_maps = atoi(e);
+  if (o.bband_mode == 2) o.bband_alone_maps = 6;
   if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
   if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
   if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
@@ -660,7 +662,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     // the chip with anything -- the form for batches in flight (TF2_AMD_BBAND=2: one batch at a time as well, instead of the groups)
     {
       const int band_rows = concurrent ? opts.bband_rows : opts.bband_rows_alone;
-      if (opts.bband_mode && (concurrent || opts.bband_mode == 2) && batch >= opts.bband_min && bband_at(l, band_rows)) {
+      if (opts.bband_mode && (concurrent || (opts.bband_alone_maps & (L.H >= 28 ? 2 : 4))) && batch >= opts.bband_min && bband_at(l, band_rows)) {
         Launch s0, s1, s2;
         if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false) || !make_conv(l + 2, s2, false)) return nullptr;
         if (s0.conv.dense && s1.conv.dense && s2.conv.dense) {

@@ -96,6 +96,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // TF2_AMD_BGROUP_MIN7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int bband_mode = 1;      // TF2_AMD_BBAND: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
   int bband_rows = 7, bband_rows_alone = 2;   // TF2_AMD_BBAND_ROWS / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
+  int bband_alone_maps = 0;   // TF2_AMD_BBAND_ALONE_MAPS: maps that take band launches one batch at a time too, instead of the group launches (bit 1: 28 x 28, bit 2: 14 x 14; TF2_AMD_BBAND=2 = both)
   int bband_min = 8;       // TF2_AMD_BBAND_MIN: smallest batch that takes them
   int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
   int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
