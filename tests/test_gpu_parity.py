@@ -175,14 +175,6 @@ def test_split_k_kernel_forced_and_disabled(sk, monkeypatch):
     Rig(t, q, model, 0).check_all_layers(synth.synth_images(t, 3, 8))
 
 
-@pytest.mark.parametrize("wshape", ["0", "2", "4"])
-def test_mfma2_wave_shapes(r50, monkeypatch, wshape):
-    """conv_mfma2.hip block shapes: 8-wave (default, 32x64 wave tiles), 4-wave (64x64) and 16-wave (32x32) blocks."""
-    monkeypatch.setenv("TF2_AMD_EXP", wshape)
-    rig = Rig(*r50, 0)
-    rig.check_all_layers(synth.synth_images(rig.t, 2, 17), layers={0, 1, 2, 3, 4, 11, 12, 13, 14, 24, 25, 53})
-
-
 def test_generic_requant_forced(r50, monkeypatch):
     """TF2_AMD_NOFAST=1 at pack time: every layer takes the 6-instruction wrap-exact requantisation instead of the
     range-proven 3-instruction one (most synthetic ResNet-50 layers qualify for the latter); same bits."""

@@ -516,12 +516,10 @@ static int launch_dual(const ConvArgs& a, hipStream_t s) {
 }
 
 // TM is fixed by the packed image (64 or 128); the pixel-tile shape is picked per launch so
-// that small grids still spread over the 256 CUs.  Default: 8-wave blocks with 32x64 wave tiles (measured best);
-// a.g.flags bit 1 / bit 2: the 4-wave (64x64 tiles) / 16-wave (32x32) shapes (A/B switches, single-window layers).
+// that small grids still spread over the 256 CUs: 8-wave blocks with 32x64 wave tiles (measured best: 4 waves of 64x64 tiles were
+// equal, 16 waves of 32x32 6-9 % slower -- profiles/r03_experiments.txt item 18; both shapes left the tree in round 4).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const bool w4 = (a.g.flags & 2) != 0;
-  const bool w16 = (a.g.flags & 4) != 0;
   static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
   const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
   if (a.dual) {
@@ -530,10 +528,10 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
     return -1;
   }
   if (TM == 128) {
-    return w4 ? launch_cfg<2, 2, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<4, 4, 32, 32, 3, 2>(a, s) : launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
+    return launch_cfg<4, 2, 32, 64, 3, 2>(a, s);
   }
   if (TM == 64) {
-    if (blocks256 >= t256) return w4 ? launch_cfg<1, 4, 64, 64, 3, 3>(a, s) : w16 ? launch_cfg<2, 8, 32, 32, 3, 2>(a, s) : launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
+    if (blocks256 >= t256) return launch_cfg<2, 4, 32, 64, 3, 2>(a, s);
     return launch_cfg<2, 2, 32, 32, 4, 4>(a, s);
   }
   return -1;
@@ -557,8 +555,7 @@ static int launch_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
   if (TM0 != 128 || TM1 != 128 || a0.dense != a1.dense || a0.dual != a1.dual) return false;
   if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
-  if ((a0.g.flags | a1.g.flags) & (2 | 4)) return false;            // A/B block shapes: single launches only
-  return true;
+    return true;
 }
 
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream) {

@@ -382,7 +382,7 @@ bool Net::stem_selected(int batch) const {
 // ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
 void Net::load_options() {
   RunOpts o;
-  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 0xffe;    // conv_mfma2 block shape A/B switch: 2 = 4-wave, 4 = 16-wave
+  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 0xff8;    // timing-probe bits of the -DTF2_PROBES build (tf2_device.h kProbe*, tools/probe_run.py); nothing in the product reads them
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);

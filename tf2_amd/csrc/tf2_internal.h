@@ -87,7 +87,7 @@ struct ConvGeom {
   int32_t res_cp, res_off;   // residual tensor bytes per pixel and channel offset
   int32_t relu, add_relu, has_res;
   int32_t fast;              // PackLayer::fast: header rows hold {0, alpha << lo, B'} (requant_epilogue.h)
-  int32_t flags;             // bits 1,2: conv_mfma2 block-shape A/B switches (TF2_AMD_EXP)
+  int32_t flags;             // timing-probe bits (TF2_AMD_EXP, read by -DTF2_PROBES builds only)
   int32_t dbl_out;           // the output tensor has doubled channels (PackLayer::off_dbl): header word 0 of a row = -128 or 0
   int32_t avg_mult;          // conv_mfma_sk AVG: != 0 -> the layer's global average (full_size_pool.cl) is computed in the launch:
                              // y / y_cp / y_off then describe the AVERAGED tensor [batch][y_cp], one pixel tile = one image
