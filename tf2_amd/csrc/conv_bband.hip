@@ -1,10 +1,10 @@
 // conv_bband.hip -- a whole identity bottleneck (1x1 reduce C -> M, 3x3 / stride 1 / pad 1 M -> M, 1x1 expand M -> C + residual +
 // ReLU; pe.cl:144-203 three times, feature_writer.cl:119-122 once) in ONE launch with NO exchange between blocks (gfx950).
 //
-// Why (round 4): with several batches in flight the step is bound by resident-block time -- 48 launches whose blocks spend a
-// quarter of their life in a latency-bound prologue and whose grids (98 / 196 / 392 blocks) fill 0.77 of their last round on a
-// 64-CU partition -- and the group launches of conv_bgroup.hip, which remove two thirds of the launches,
-// cannot be used there: their eight blocks per image MEET, so they want every CU's LDS and co-residency guarantees.  This
+// Why (round 4): with several batches in flight the step is the serialised sum of the chip's pipes -- VALU first: the ring kernels
+// spend 11-23 VALU instructions per output on their 1x1 / 3x3 layers where the requantisation itself needs ~7 (profiles/
+// r04_pmc_conv_b32_conc1.json) -- and the group launches of conv_bgroup.hip, which remove two thirds of the launches, cannot be
+// used there: their eight blocks per image MEET, so they want every CU's LDS and co-residency guarantees.  This
 // kernel fuses the same three rows without any meeting: a block owns R output rows x the full width of ONE image and ALL
 // channels; it recomputes the reduce for its two halo rows (a 1x1 layer: (R + 2) / R of that layer's work) and keeps both
 // intermediates in LDS.  Nothing a block reads is written by another block of the launch, so any number of such launches may
