@@ -74,6 +74,26 @@ def test_squeezenet_concat(mode):
     Rig(t, q, model, mode).check_all_layers(x)
 
 
+@pytest.mark.parametrize("nofast", ["0", "1"])
+def test_shift_kernel_wave_split_fc(nofast, monkeypatch):
+    """conv_shift_fc_kernel (a 1x1 layer on a handful of pixels with a long channel walk: sixteen waves take every sixteenth
+    16-channel chunk, partial sums added through LDS) against the oracle -- unsigned input with 4-bit-packed and int32 filters
+    (mode 2: every layer on the shift kernels), and the signed input of SqueezeNet's classifier (default mode)."""
+    monkeypatch.setenv("TF2_AMD_NOFAST", nofast)
+    t = cfg.tiny_tables(hw=12, widths=(32, 512), classes=100)
+    q = synth.synth_q_values(t, 9, spread=2)
+    model = synth.synth_model(t, q, 9)
+    rig = Rig(t, q, model, 2)
+    names = [r["kernel"] for r in rig.net.describe_launches(3, 0)]
+    assert names[-1] == "conv_shift_fc_kernel", names
+    rig.check_all_layers(synth.synth_images(t, 3, 9))
+    t = cfg.squeezenet11_tables(image_hw=67)
+    q = synth.synth_q_values(t, 6, spread=2)
+    rig = Rig(t, q, synth.synth_model(t, q, 6), 0)
+    assert rig.net.describe_launches(5, 0)[-1]["kernel"] == "conv_shift_fc_kernel"
+    rig.check_all_layers(synth.synth_images(t, 5, 6))
+
+
 def test_vgg_small_bias_and_2x2_pools():
     t = cfg.vgg16_tables(32, 10)
     q = synth.synth_q_values(t, 7)

@@ -187,6 +187,129 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
   *reinterpret_cast<int2*>(a.y + (size_t)px * g.y_cp + g.y_off + n0) = out;
 }
 
+
+// ---- few pixels, many channels (a fully connected layer behind a global average: SqueezeNet 1.1's 1000 -> 128 on 32 pixels) ----
+// conv_shift_kernel walks the channel chunks one after the other behind two barriers each: with one block of pixels that is a chain
+// of n_cchunk memory latencies on four blocks (157 us for 63 chunks, measured).  Here one block owns 8 output channels and its
+// sixteen waves take every sixteenth chunk each -- lane = pixel reads its 16 input bytes straight from HBM (one tap: nothing to
+// gather) -- and the sixteen partial sums are added through LDS.  The sum is in Z/2^32, so the order does not matter: same bits.
+template <bool SIGNED_IN, bool MUL24, bool PACKED4>
+__global__ __launch_bounds__(1024) void conv_shift_fc_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds_raw[];      // [16 waves][8][64] int32 partial sums | PACKED4: [wave][2 signs][128] int32
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * 8;
+  const int p = blockIdx.x * 64 + lane;
+  int* const red = reinterpret_cast<int*>(lds_raw);
+  int* const wl = red + 16 * 8 * 64 + wave * 256;
+  const int8_t* xsrc = nullptr;
+  if (p < g.n_pix) {
+    const int b = fast_div(p, g.ohw_m, g.ohw_s);
+    const int rem = p - b * g.OHW;
+    const int oh = fast_div(rem, g.ow_m, g.ow_s), ow = rem - oh * g.OW;
+    xsrc = a.x + (size_t)(b * g.H * g.W + oh * g.stride * g.W + ow * g.stride) * g.Cp_in;     // k = 1, no padding (checked by the launcher)
+  }
+  int acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) acc[r] = 0;
+  for (int cc = wave; cc < a.n_cchunk; cc += 16) {
+    i32x4 xv = {0, 0, 0, 0};
+    if (xsrc) xv = *reinterpret_cast<const i32x4*>(xsrc + cc * 16);
+    if (PACKED4) {
+      // 128 codes of this (n8 tile, chunk) = 16 dwords; lanes 0..15 expand one dword (8 channels of one (half, r)) each
+      const unsigned* nb = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(a.w) + (((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128) / 2);
+      const int8_t* ab = a.w2;
+      if (lane < 16) {
+        const int r = lane & 7, h = (lane >> 3) & 1;
+        const int An = (int)ab[n0 + r];
+        const int2 bw = *reinterpret_cast<const int2*>(ab + a.Np + cc * 16 + h * 8);
+        const unsigned word = nb[lane];
+        int wv[8], wn[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int S = An + (int)(signed char)(((c < 4 ? bw.x : bw.y) >> (8 * (c & 3))) & 0xff);
+          const unsigned v = (word >> (4 * c)) & 15u;
+          const int e = (int)(v & 7u);
+          const int mag = e == 7 ? 0 : (int)(1u << ((S - e) & 31));
+          if (SIGNED_IN) { wv[c] = (v & 8u) ? 0 : mag; wn[c] = (v & 8u) ? mag : 0; }
+          else { wv[c] = (v & 8u) ? (int)(0u - (unsigned)mag) : mag; wn[c] = 0; }
+        }
+        i32x4* d = reinterpret_cast<i32x4*>(wl + lane * 8);
+        d[0] = i32x4{wv[0], wv[1], wv[2], wv[3]}; d[1] = i32x4{wv[4], wv[5], wv[6], wv[7]};
+        if (SIGNED_IN) {
+          i32x4* d2 = reinterpret_cast<i32x4*>(wl + 128 + lane * 8);
+          d2[0] = i32x4{wn[0], wn[1], wn[2], wn[3]}; d2[1] = i32x4{wn[4], wn[5], wn[6], wn[7]};
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const int* wbase = reinterpret_cast<const int*>(a.w) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128;
+    const int* w2base = SIGNED_IN ? reinterpret_cast<const int*>(a.w2) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128 : nullptr;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int xs[8], xn[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int word = xv[h * 2 + (c >> 2)];
+        xs[c] = (int)(signed char)((word >> (8 * (c & 3))) & 0xff);
+        xn[c] = SIGNED_IN ? (int)(signed char)(-xs[c]) : 0;       // int8 negate: -(-128) == -128 (pe.cl:32-37)
+      }
+      const int* wp = PACKED4 ? wl + h * 64 : wbase + h * 64;
+      const int* wq = SIGNED_IN ? (PACKED4 ? wl + 128 + h * 64 : w2base + h * 64) : nullptr;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const int w = wp[r * 8 + c];
+          if (MUL24) acc[r] += __mul24(xs[c], w);
+          else acc[r] = (int)((unsigned)acc[r] + (unsigned)xs[c] * (unsigned)w);
+          if (SIGNED_IN) {
+            const int w2 = wq[r * 8 + c];
+            if (MUL24) acc[r] += __mul24(xn[c], w2);
+            else acc[r] = (int)((unsigned)acc[r] + (unsigned)xn[c] * (unsigned)w2);
+          }
+        }
+      }
+    }
+    if (PACKED4) __builtin_amdgcn_wave_barrier();                  // the next chunk's expansion overwrites wl
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) red[(wave * 8 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave != 0 || p >= g.n_pix || n0 + 8 > g.y_nvalid) return;
+  int q[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    unsigned v = (unsigned)a.bias[n0 + r];
+#pragma unroll
+    for (int w = 0; w < 16; w++) v += (unsigned)red[(w * 8 + r) * 64 + lane];
+    q[r] = requant_i8s((int)v, a.alpha[n0 + r], a.beta[n0 + r], g.relu);
+  }
+  if (g.has_res) {
+    const int2 rv = *reinterpret_cast<const int2*>(a.res + (size_t)p * g.res_cp + g.res_off + n0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int word = r < 4 ? rv.x : rv.y;
+      int s = q[r] + (int)(signed char)((word >> (8 * (r & 3))) & 0xff);
+      s = s > 127 ? 127 : (s < -128 ? -128 : s);
+      if (g.add_relu) s = s > 0 ? s : 0;
+      q[r] = s;
+    }
+  }
+  int2 out;
+  out.x = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((q[3] & 0xff) << 24);
+  out.y = (q[4] & 0xff) | ((q[5] & 0xff) << 8) | ((q[6] & 0xff) << 16) | ((q[7] & 0xff) << 24);
+  *reinterpret_cast<int2*>(a.y + (size_t)p * g.y_cp + g.y_off + n0) = out;
+}
+
+// the wave-split form pays when the pixel blocks cannot fill the chip and the chunk walk is long
+static bool shift_fc_form(const ConvArgs& a) {
+  return a.k == 1 && a.g.pad_h == 0 && a.g.pad_w == 0 && a.n_cchunk >= 16 && (a.g.n_pix + 63) / 64 * ((a.Np / 8 + 3) / 4) < 64;
+}
+
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4) {
   return (size_t)taps * 64 * 16 + (packed4 ? (size_t)4 * taps * 128 * 4 * (signed_in ? 2 : 1) : 0);
 }
@@ -195,6 +318,20 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, 
   hipStream_t s = (hipStream_t)stream;
   const int taps = a.k * a.k;
   if (taps > kMaxTaps) return -2;
+  if (shift_fc_form(a)) {
+    dim3 fgrid((a.g.n_pix + 63) / 64, a.Np / 8);
+    const size_t flds = (size_t)16 * 8 * 64 * 4 + (packed4 ? (size_t)16 * 256 * 4 : 0);
+#define TF2_SHF(S, M, P) do { TF2_LAUNCH_NAME("conv_shift_fc_kernel"); TF2_LAUNCH((conv_shift_fc_kernel<S, M, P>), fgrid, dim3(1024), flds, s, a); } while (0)
+    if (packed4) {
+      if (signed_in) { if (mul24) TF2_SHF(true, true, true); else TF2_SHF(true, false, true); }
+      else { if (mul24) TF2_SHF(false, true, true); else TF2_SHF(false, false, true); }
+    } else {
+      if (signed_in) { if (mul24) TF2_SHF(true, true, false); else TF2_SHF(true, false, false); }
+      else { if (mul24) TF2_SHF(false, true, false); else TF2_SHF(false, false, false); }
+    }
+#undef TF2_SHF
+    return launch_ok() ? 0 : -1;
+  }
   dim3 grid((a.g.n_pix + 63) / 64, (a.Np / 8 + 3) / 4);
   const size_t lds = conv_shift_lds_bytes(taps, signed_in, packed4);
   if (lds > 160 * 1024) return -3;
