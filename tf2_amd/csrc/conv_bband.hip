@@ -66,6 +66,9 @@ __device__ __forceinline__ void bb_dma16(const int8_t* src, int8_t* lds_dst) {
 // DUAL1 / DUAL2: the reduce / the 3x3 is a two-window layer (weight_pack.cpp: entries [hi rows | lo rows]).  The reduce keeps two
 // accumulator sets over the one input stream and combines them once, (hi << dshift[1]) + lo; the 3x3 sweeps its LDS-resident halo
 // tile window by window into ONE set with the Horner shift in between (conv_bneck's scheme) -- both exact in Z/2^32.
+// rows per band of an instantiation: (map side, column tiles of the halo band) <-> R (launch_conv_bband's table)
+__host__ __device__ constexpr int bband_rows_of(int M, int NT0) { return M == 256 ? (NT0 == 4 ? 7 : NT0 == 3 ? 4 : 2) : (NT0 == 8 ? 7 : 4); }
+
 template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a) {
   constexpr int C = 4 * M;
@@ -96,10 +99,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // multiply-high instead of the ~35-instruction division by a run-time value -- two dozen per lane and block, a fifth of the block's
   // VALU work before (round 4)
   constexpr int W = M == 256 ? 14 : M == 128 ? 28 : 56, Wp = W + 2, H = W;
-  const int R = a.R;
-  const int n_h = (R + 2) * Wp;
-  const int n_grp_h = (n_h + 15) >> 4;
-  const int slabb = n_grp_h * 1024;                      // bytes of one 64-channel slab of the halo tile
+  // rows per band: the instantiation's (the launcher checks a.R), so that every offset into the halo tile is an immediate
+  constexpr int R = bband_rows_of(M, NT0);
+  constexpr int n_h = (R + 2) * Wp;
+  // the halo tile, per 64-channel slab: four PLANES of 16 bytes per pixel (plane k = K bytes 16 k .. 16 k + 15 of every pixel), each
+  // padded to whole 1 KiB DMA groups.  A lane's MFMA fragment of pixel h is 16 bytes at plane[half + 2 ks] + 16 h: the sixteen lanes
+  // a ds_read_b128 services together read 256 contiguous bytes whatever the tap -- no bank conflict without a swizzle, and tap,
+  // slab and K half are an immediate offset (the swizzled [pixel][64] form cost one address add per fragment read: 288 per wave)
+  constexpr int n_grp_h = ((n_h + 63) >> 6) * 4;
+  constexpr int slabb = n_grp_h * 1024;                  // bytes of one 64-channel slab of the halo tile
+  constexpr int planeb = slabb / 4;
   int8_t* const mid1 = dyn;
   const int tms1 = a.tm1 == 128 ? 7 : 6, tms2 = a.tm2 == 128 ? 7 : 6, tms3 = a.tm3 == 128 ? 7 : 6;
   // bytes of one m-tile's header image: rows {bias, alpha, addend64} | lo | dshift[P] (the Horner shifts: two-window layers only)
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // (1) the halo tile filled with the stored form of x = 0 (the 3x3's pad row): borders and rows outside the image stay that way
   for (int gi = wave; gi < n_grp_h * KS2; gi += NW) {
     const int s = gi / n_grp_h, grp = gi - s * n_grp_h;
-    bb_dma16(a.zero2 + s * 64 + chunk * 16, mid1 + s * slabb + grp * 1024);
+    bb_dma16(a.zero2 + s * 64 + (grp / (n_grp_h / 4)) * 16, mid1 + s * slabb + grp * 1024);
   }
   // (2) the input stream: chunk c = channel slabs [c * SC, (c + 1) * SC) of the NP0 halo-band pixels -> [slab][pixel][64] swizzled
   auto issue_chunk = [&](int c, int8_t* buf) {
@@ -168,14 +177,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   struct Afr { i32x4 k[MT][2]; };
   const int cb_w = wm * (MT * 32);                       // this wave's first channel inside an M-channel pass
   // (wins: windows per entry of the layer's packed tiles, win: the one to fetch)
+  const unsigned a_lane_off = (unsigned)((lane & 31) * 64 + half * 16);
   auto load_a = [&](Afr& f, const int8_t* w, int tms, int nslab, int cb, int slab, int wins = 1, int win = 0) {
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int ch = cb + i * 32;
       const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
-      const int8_t* p = w + (((((size_t)mt * nslab + slab) * wins + win) << tms) + ro + (lane & 31)) * 64 + half * 16;
-      f.k[i][0] = *reinterpret_cast<const i32x4*>(p);
-      f.k[i][1] = *reinterpret_cast<const i32x4*>(p + 32);
+      // (wave-uniform base + a 32-bit lane offset: the scalar-base form of global_load, no 64-bit address arithmetic per lane)
+      const int8_t* pu = w + (((((size_t)mt * nslab + slab) * wins + win) << tms) + ro) * 64;
+      f.k[i][0] = *reinterpret_cast<const i32x4*>(pu + a_lane_off);
+      f.k[i][1] = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
     }
   };
   // fragments of global step v (phase 0: slab v of the reduce's high window; phase 1: (window, tap, slab) of the 3x3; phase 2 loads its own)
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
           if (p < n_p0 && (unsigned)row < (unsigned)H) {
             const int h = hr * Wp + col + 1;
             const int c = (chl & 63) >> 4;
-            *reinterpret_cast<i32x4*>(mid1 + (chl >> 6) * slabb + h * 64 + ((c ^ ((h >> 2) & 3)) << 4)) = out;
+            *reinterpret_cast<i32x4*>(mid1 + (chl >> 6) * slabb + c * planeb + h * 16) = out;
             if (a.keep_mid && hr >= 1 && hr <= rows)
               *reinterpret_cast<i32x4*>(a.mid1 + (size_t)(pix0 + p) * M + chl) = out;
           }
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     int p = (wn + j * WN) * 32 + (lane & 31);
     if (p >= n_px) p = 0;                                 // lanes beyond the band compute on pixel 0 and are never stored
     const int r = p / W;
-    h0[j] = r * Wp + (p - r * W);
+    h0[j] = (r * Wp + (p - r * W)) * 16 + half * planeb;  // byte offset of the lane's fragment of tap (0, 0), K half 0
   }
   auto step1 = [&](auto e_c) {
     constexpr int ew = decltype(e_c)::value;               // (window, tap, slab)
@@ -356,10 +367,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     for (int ks = 0; ks < 2; ks++) {
       i32x4 bf[J1];
 #pragma unroll
-      for (int j = 0; j < J1; j++) {
-        const int h = h0[j] + (t / 3) * Wp + t % 3;
-        bf[j] = *reinterpret_cast<const i32x4*>(B + ((h * 64 + ((half ^ ((h >> 2) & 3)) << 4)) ^ (ks << 5)));
-      }
+      for (int j = 0; j < J1; j++)
+        bf[j] = *reinterpret_cast<const i32x4*>(B + h0[j] + (((t / 3) * Wp + t % 3) * 16 + 2 * ks * planeb));
 #pragma unroll
       for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -508,13 +517,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
 // dynamic LDS of a launch: the halo tile + the three layers' header images (the chunk buffers are static)
 static size_t bband_dyn_lds(int M, int R, int W, bool dual1, bool dual2) {
   const int n_h = (R + 2) * (W + 2);
-  return (size_t)(M / 64) * (((n_h + 15) >> 4) * 1024) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * 20) * M + 64;
+  return (size_t)(M / 64) * (((n_h + 63) >> 6) * 4096) + (size_t)((dual1 ? 28 : 20) + (dual2 ? 28 : 20) + 4 * 20) * M + 64;
 }
 
 template <int M, int NW, int WN, int NT0, int NT1, int SC, bool DUAL1, bool DUAL2>
 static int launch_bband2(const BBandArgs& a, hipStream_t s) {
   constexpr int C = 4 * M;
   constexpr int CHUNK = SC * 32 * NT0 * 64, MID2 = (M / 64) * 32 * NT1 * 64;
+  if (a.R != bband_rows_of(M, NT0)) return 1;
   const size_t dyn = bband_dyn_lds(M, a.R, a.W, DUAL1, DUAL2);
   const size_t stat = (size_t)(CHUNK > MID2 ? CHUNK : MID2) + CHUNK;
   if (dyn + stat > 160 * 1024) return 1;
