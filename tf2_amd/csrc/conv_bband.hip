@@ -318,12 +318,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
         const int mt = ch >> tms1, ro = ch & ((1 << tms1) - 1);
         const int* prm = reinterpret_cast<const int*>(hdr1 + mt * hst1);
         const int chl = ch + 16 * half;
+        // (the sixteen row-parameter reads once for the J0 column tiles, requant_epilogue.h RqRows: re-read per tile they are 16 KiB of
+        //  LDS return traffic per tile and wave, more than the tile's VALU work)
+        i32x4 outs[J0];
+        int a16s[J0][16];
+#pragma unroll
+        for (int j = 0; j < J0; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16s[j][r] = acc[i][j][r];
+        requant_tiles16_rows<J0, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms1, ro + 4 * half, lo_b,
+                                       a.dbl1 != 0, a.fast1 == 2);
 #pragma unroll
         for (int j = 0; j < J0; j++) {
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-          const i32x4 out = requant_tile16<false, LEAN, FAST>(a16, prm, 1 << tms1, ro + 4 * half, lo_b, -128, nores, a.dbl1 != 0, a.fast1 == 2);
+          const i32x4 out = outs[j];
           const int p = (wn + j * WN) * 32 + (lane & 31);
           const int hr = p / W, col = p - hr * W;
           const int row = r0 - 1 + hr;
@@ -409,12 +416,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
         const int mt = ch >> tms2, ro = ch & ((1 << tms2) - 1);
         const int* prm = reinterpret_cast<const int*>(hdr2 + mt * hst2);
         const int chl = ch + 16 * half;
+        i32x4 outs[J1];                                      // (as in the first hand-over: requantise, then write)
+        int a16s[J1][16];
+#pragma unroll
+        for (int j = 0; j < J1; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16s[j][r] = acc[i][j][r];
+        requant_tiles16_rows<J1, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms2, ro + 4 * half, lo_b,
+                                       a.dbl2 != 0, a.fast2 == 2);
 #pragma unroll
         for (int j = 0; j < J1; j++) {
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-          const i32x4 out = requant_tile16<false, LEAN, FAST>(a16, prm, 1 << tms2, ro + 4 * half, lo_b, -128, nores, a.dbl2 != 0, a.fast2 == 2);
+          const i32x4 out = outs[j];
           const int row = (wn + j * WN) * 32 + (lane & 31);
           const int c = (chl & 63) >> 4;
           *reinterpret_cast<i32x4*>(mid2 + (chl >> 6) * (NP1 * 64) + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;

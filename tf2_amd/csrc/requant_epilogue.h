@@ -23,6 +23,7 @@
 // addend needs no register moves.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "tf2_internal.h"
 
 namespace tf2 {
@@ -114,6 +115,83 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
   auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
   auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
   return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+}
+
+// ---- the same arithmetic with the rows' parameters held in registers across column tiles ------------------------------------------
+// A wave that requantises several column tiles of ONE row tile (conv_bband's hand-overs: four tiles per wave) reads the same
+// sixteen 16-byte parameter rows for each of them; with an LDS write between two tiles the compiler cannot keep them, and the reads
+// (1 KiB of LDS return traffic each, eight cycles of the CU's LDS pipe) outweigh the tile's VALU work.  Here the rows are read
+// once per row tile, eight at a time (32 registers + 8 for the shift words of rows that are not FAST; all sixteen at once spilled
+// in the 7-row band kernels), and every column tile's two packed words of those eight rows are built before the next eight.
+template <bool FAST, bool DBL, bool SEMI>
+__device__ __forceinline__ unsigned rq_rows4(const int (&a16)[16], int G, const rq_i32x4 (&pr4)[4], const rq_i32x4& lo4, int lo_bound) {
+  int q[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const rq_i32x4 pr = pr4[r];
+    const int acc = a16[G * 4 + r];
+    const long long b64 = (long long)(((unsigned long long)(unsigned)pr[3] << 32) | (unsigned)pr[2]);
+    int y, lo = 0;
+    if (FAST) {
+      const long long p = (long long)acc * (long long)pr[1] + b64;
+      y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+    } else {
+      lo = lo4[r];
+      const int v = (int)((unsigned)pr[0] + ((unsigned)acc << (lo & 31)));
+      const long long p = (long long)v * (long long)pr[1] + b64;
+      if (SEMI) y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+      else { const int x = (int)(p >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
+    }
+    int c;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+    if (DBL) {
+      const int kd = FAST ? pr[0] : (lo >> 8);
+      c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
+    }
+    q[r] = c;
+  }
+  const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[1], (unsigned)q[0], 0x0c0c0400u);
+  const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[3], (unsigned)q[2], 0x0c0c0400u);
+  return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// NJ column tiles of one row tile, no residual (acc_of(j) returns tile j's sixteen accumulators by reference; out[j] = its 16 bytes)
+template <int NJ, bool FAST, class AccOf>
+__device__ __forceinline__ void requant_tiles16_rows(AccOf acc_of, rq_i32x4 (&out)[NJ], const int* prm, int TM, int row0, int lo_bound,
+                                                     bool dbl /* wave-uniform */, bool semi /* wave-uniform, read when !FAST */) {
+  const rq_i32x4* rowp = reinterpret_cast<const rq_i32x4*>(prm) + row0;
+  const int* lop = prm + 4 * TM + row0;
+  auto run = [&](auto dbl_c, auto semi_c) __attribute__((always_inline)) {
+    constexpr bool DBL = decltype(dbl_c)::value, SEMI = decltype(semi_c)::value;
+    unsigned d[NJ][4];
+#pragma unroll
+    for (int gp = 0; gp < 2; gp++) {
+      rq_i32x4 pr[2][4], lo4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) pr[g][r] = rowp[8 * (2 * gp + g) + r];
+        if (!FAST) lo4[g] = *reinterpret_cast<const rq_i32x4*>(lop + 8 * (2 * gp + g));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) d[j][2 * gp + g] = rq_rows4<FAST, DBL, SEMI>(acc_of(j), 2 * gp + g, pr[g], lo4[g], lo_bound);
+      __builtin_amdgcn_sched_barrier(0);                 // (keeps the second eight rows' reads behind the first eight's use)
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      auto s02 = __builtin_amdgcn_permlane32_swap(d[j][0], d[j][2], false, false);
+      auto s13 = __builtin_amdgcn_permlane32_swap(d[j][1], d[j][3], false, false);
+      out[j] = rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+    }
+  };
+  if constexpr (FAST) {
+    if (dbl) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{});
+  } else {
+    if (semi) { if (dbl) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
+    else { if (dbl) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
+  }
 }
 
 // FAST = the layer's PackLayer::fast == 1; semi (wave-uniform, only read when !FAST) = PackLayer::fast == 2
