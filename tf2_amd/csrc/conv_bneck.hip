@@ -224,12 +224,19 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     const int chl = wm * 32 + 16 * half;                  // this lane's 16 channels of the intermediate
     auto to_mid = [&](auto fast_c) {
       constexpr bool FAST = decltype(fast_c)::value;
+      // (the wave's NTN column tiles row by row: each parameter row read once -- requant_epilogue.h requant_tiles16)
+      int a16s[NTN][16];
+      i32x4 outs[NTN], nores_j[NTN];
 #pragma unroll
       for (int j = 0; j < NTN; j++) {
-        int a16[16];
+        nores_j[j] = nores;
 #pragma unroll
-        for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-        const i32x4 out = requant_tile16<false, 2, FAST>(a16, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores, a.dbl_mid != 0, a.fast1 == 2);
+        for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
+      }
+      requant_tiles16<NTN, false, 1, FAST>(a16s, outs, prm1, TM, wm * 32 + 4 * half, lo_bound, -128, nores_j, a.dbl_mid != 0, a.fast1 == 2);
+#pragma unroll
+      for (int j = 0; j < NTN; j++) {
+        const i32x4 out = outs[j];
         const int row = wn * WTN + j * 32 + (lane & 31);
         const int c = (chl & 63) >> 4;
         *reinterpret_cast<i32x4*>(mid2 + (chl >> 6) * (TN * 64) + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = out;
@@ -284,12 +291,16 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
       auto epilogue = [&](auto has_res_c, auto fast_c) {
         constexpr bool HAS_RES = decltype(has_res_c)::value;
         constexpr bool FAST = decltype(fast_c)::value;
+        int a16s[NTN][16];
+        i32x4 outs[NTN];
+#pragma unroll
+        for (int j = 0; j < NTN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
+        requant_tiles16<NTN, HAS_RES, 1, FAST>(a16s, outs, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv, a.dbl_out != 0, a.fast2 == 2);
 #pragma unroll
         for (int j = 0; j < NTN; j++) {
-          int a16[16];
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16[r] = acc[j][r];
-          const i32x4 out = requant_tile16<HAS_RES, 2, FAST>(a16, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv[j], a.dbl_out != 0, a.fast2 == 2);
+          const i32x4 out = outs[j];
           const int p = wn * WTN + j * 32 + (lane & 31);
           if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
           if (p < n_px && chl + 16 <= a.y_nvalid)

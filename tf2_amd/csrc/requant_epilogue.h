@@ -117,6 +117,98 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
   return rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
 }
 
+// ---- NJ column tiles of one row tile in lockstep: every parameter row is read ONCE and applied to all NJ tiles ------------------
+// (conv_bneck: two tiles per wave at 128 registers -- the row-by-row order of LEAN costs no register beyond the tiles' own
+// packed words, and halves the parameter reads, which were two thirds of that kernel's LDS instructions)
+template <int NJ, bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI>
+__device__ __forceinline__ void requant_tiles16_impl(const int (&a16)[NJ][16], rq_i32x4 (&out)[NJ], const int* prm, int TM, int row0,
+                                                     int lo_bound, int rlo, const rq_i32x4 (&resv)[NJ]) {
+  static_assert(LEAN >= 1, "row-ordered form");
+  unsigned rd[NJ][4], d[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    if (HAS_RES) {
+      auto r02 = __builtin_amdgcn_permlane32_swap((unsigned)resv[j][0], (unsigned)resv[j][1], false, false);
+      auto r13 = __builtin_amdgcn_permlane32_swap((unsigned)resv[j][2], (unsigned)resv[j][3], false, false);
+      rd[j][0] = r02[0]; rd[j][2] = r02[1]; rd[j][1] = r13[0]; rd[j][3] = r13[1];
+    } else { rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0; }
+  }
+  const rq_i32x4* rowp = reinterpret_cast<const rq_i32x4*>(prm) + row0;
+  const int* lop = prm + 4 * TM + row0;
+  rq_i32x4 pq[3];
+  pq[0] = rowp[0]; if (LEAN > 1) pq[1] = rowp[1];
+#pragma unroll
+  for (int G = 0; G < 4; G++) {
+    rq_i32x4 lo4 = {0, 0, 0, 0};
+    if (!FAST) lo4 = *reinterpret_cast<const rq_i32x4*>(lop + 8 * G);
+    int q[NJ][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int k = G * 4 + r;
+      constexpr int NB = LEAN + 1;
+      if (k + LEAN < 16) pq[(k + LEAN) % NB] = rowp[8 * ((k + LEAN) / 4) + (k + LEAN) % 4];
+      __builtin_amdgcn_sched_barrier(0);
+      const rq_i32x4 pr = pq[k % NB];
+      const long long b64 = (long long)(((unsigned long long)(unsigned)pr[3] << 32) | (unsigned)pr[2]);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        int y;
+        if (FAST) {
+          const long long p = (long long)a16[j][k] * (long long)pr[1] + b64;
+          y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+        } else {
+          const int v = (int)((unsigned)pr[0] + ((unsigned)a16[j][k] << (lo4[r] & 31)));
+          const long long p = (long long)v * (long long)pr[1] + b64;
+          if (SEMI) y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+          else { const int x = (int)(p >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
+        }
+        int c;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+        if (DBL) {
+          const int kd = FAST ? pr[0] : (lo4[r] >> 8);
+          c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
+        }
+        if (HAS_RES) {
+          const int rr = (int)(signed char)((rd[j][G] >> (8 * r)) & 0xff);
+          const int sres = c + rr;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(sres), "s"(rlo), "v"(127));
+        }
+        q[j][r] = c;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const unsigned p01 = __builtin_amdgcn_perm((unsigned)q[j][1], (unsigned)q[j][0], 0x0c0c0400u);
+      const unsigned p23 = __builtin_amdgcn_perm((unsigned)q[j][3], (unsigned)q[j][2], 0x0c0c0400u);
+      d[j][G] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    auto s02 = __builtin_amdgcn_permlane32_swap(d[j][0], d[j][2], false, false);
+    auto s13 = __builtin_amdgcn_permlane32_swap(d[j][1], d[j][3], false, false);
+    out[j] = rq_i32x4{(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+  }
+}
+
+// (same dispatch as requant_tile16: dbl only without a residual, semi only read when !FAST)
+template <int NJ, bool HAS_RES, int LEAN, bool FAST>
+__device__ __forceinline__ void requant_tiles16(const int (&a16)[NJ][16], rq_i32x4 (&out)[NJ], const int* prm, int TM, int row0, int lo_bound, int rlo,
+                                                const rq_i32x4 (&resv)[NJ], bool dbl = false /* wave-uniform */, bool semi = false) {
+  if constexpr (!FAST) {
+    if (semi) {
+      if constexpr (!HAS_RES) {
+        if (dbl) return requant_tiles16_impl<NJ, false, LEAN, false, true, true>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+      }
+      return requant_tiles16_impl<NJ, HAS_RES, LEAN, false, false, true>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+    }
+  }
+  if constexpr (!HAS_RES) {
+    if (dbl) return requant_tiles16_impl<NJ, false, LEAN, FAST, true, false>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+  }
+  return requant_tiles16_impl<NJ, HAS_RES, LEAN, FAST, false, false>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+}
+
 // ---- the same arithmetic with the rows' parameters held in registers across column tiles ------------------------------------------
 // A wave that requantises several column tiles of ONE row tile (conv_bband's hand-overs: four tiles per wave) reads the same
 // sixteen 16-byte parameter rows for each of them; with an LDS write between two tiles the compiler cannot keep them, and the reads
