@@ -445,13 +445,18 @@ __device__ __forceinline__ void conv_mfma2_body(const ConvArgs& a, const int blk
     for (int i = 0; i < NTM; i++) {
       const int rb = wm * WTM + i * 32;                        // tile row base inside the block tile
       const int chl = mtile * TM + rb + 16 * half;
+      // the NTN column tiles of this row tile row by row in lockstep: every parameter row is read once (requant_epilogue.h)
+      int a16s[NTN][16];
+      i32x4 outs[NTN];
+#pragma unroll
+      for (int j = 0; j < NTN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16s[j][r] = acc[i][j][r];
+      requant_tiles16<NTN, HAS_RES, 1, FAST>(a16s, outs, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i], g.dbl_out != 0, g.fast == 2);
 #pragma unroll
       for (int j = 0; j < NTN; j++) {
         const int px = px0 + wn * WTN + j * 32 + (lane & 31);
-        int a16[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-        const i32x4 out = requant_tile16<HAS_RES, 0, FAST>(a16, prm, TM, rb + 4 * half, lo_bound, rlo, resv[i][j], g.dbl_out != 0, g.fast == 2);
+        const i32x4 out = outs[j];
         if (px < g.n_pix && chl + 16 <= g.y_nvalid) {
           i32x4* dst = reinterpret_cast<i32x4*>(ay + (size_t)px * g.y_cp + g.y_off + chl);
           *dst = out;
