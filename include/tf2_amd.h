@@ -200,9 +200,9 @@ tf2_status tf2_net_describe_workspace(tf2_net* net, int batch, int keep_all, tf2
  * [batch][N][PH][PW] (or [batch][N] after an end pool).  layer == -1: the quantised,
  * transformed network input [batch][C0][H0][W0].  Synchronises the stream.
  * This is the ONLY way to look at an intermediate map: inside the workspace a tensor may be
- * stored in an engine-private form (x alone instead of [x | xneg] for the image, 2x - 128 on
- * the "doubled" channels of internal post-ReLU tensors); read_layer hands back the
- * reference's int8 values.                                                               */
+ * stored in an engine-private form (x alone instead of [x | xneg] for the image, the im2col
+ * image of a 3x3 first layer on 3 channels, 2x - 128 on the "doubled" channels of internal
+ * post-ReLU tensors); read_layer hands back the reference's int8 values.                   */
 tf2_status tf2_net_read_layer(tf2_net* net, int layer, int batch, const void* workspace_dev,
                               int8_t* host_dst, size_t capacity, void* hip_stream);
 /* Per-kernel timing hook for bench.py: records HIP events around every conv launch of

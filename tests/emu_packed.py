@@ -54,6 +54,25 @@ def nhwc(x_nchw, Cp, signed_half=None):
     return t
 
 
+def first_layer_executed(L, img_q):
+    """The library's executed form of a 3x3 first layer on a 3-channel image (net.hip Net::init, PrepArgs::rewrite == 2): a POINTWISE
+    layer over the im2col image -- per output pixel the 27 values x[c][oh * s - pad + fh][ow * s - pad + fw] in the order c * 9 + fh * 3 + fw
+    (zero outside the image) as [x | xneg], 64 bytes.  Returns (LayerSpec of the executed layer, its input tensor [B, OH, OW, 64])."""
+    import dataclasses
+    B = img_q.shape[0]
+    xp = np.zeros((B, 3, L.H + 2 * L.pad_h + 2, L.W + 2 * L.pad_w + 2), np.int8)
+    xp[:, :, L.pad_h:L.pad_h + L.H, L.pad_w:L.pad_w + L.W] = img_q
+    t = np.zeros((B, L.OH, L.OW, 64), np.int8)
+    for c in range(3):
+        for fh in range(3):
+            for fw in range(3):
+                v = xp[:, c, fh:fh + L.stride * L.OH:L.stride, fw:fw + L.stride * L.OW:L.stride][:, :L.OH, :L.OW]
+                t[..., c * 9 + fh * 3 + fw] = v
+    t[..., 32:59] = (-t[..., :27].astype(np.int16)).astype(np.int8)
+    Le = dataclasses.replace(L, C=27, k=1, stride=1, pad_h=0, pad_w=0, H=L.OH, W=L.OW)
+    return Le, t
+
+
 def conv_from_packed(blob, pl, L, x_t, res=None):
     """L: LayerSpec.  x_t: input tensor [B,H,W,Cp_in] int8.  Returns conv-stage output NCHW
     [B,N,OH,OW] after requant/relu/residual (before pool / global average)."""

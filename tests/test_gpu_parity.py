@@ -94,6 +94,25 @@ def test_shift_kernel_wave_split_fc(nofast, monkeypatch):
     rig.check_all_layers(synth.synth_images(t, 5, 6))
 
 
+def test_first_3x3_layer_plain_form(monkeypatch):
+    """TF2_AMD_IM2COL0=0: a 3x3 first layer on the 3-channel image in its plain form (nine taps of [x | xneg] gathered by the ring
+    kernel) instead of the default pointwise layer over the im2col image -- both bit-exact, -128 pixels included, and the input
+    tensor read back as the quantised image either way."""
+    for env in ("0", "1"):
+        monkeypatch.setenv("TF2_AMD_IM2COL0", env)
+        t = cfg.tiny_tables()
+        q = synth.synth_q_values(t, 5, spread=2)
+        x = synth.synth_images(t, 3, 5, kind="int8")
+        x[0, :, :2, :] = -128
+        rig = Rig(t, q, synth.synth_model(t, q, 5), 0)
+        first = rig.net.describe_launches(3, 0)[0]["kernel"]
+        assert ("im2col" in first) == (env == "1"), first
+        rig.check_all_layers(x)
+        t = cfg.squeezenet11_tables(image_hw=67)               # stride 2, no padding
+        q = synth.synth_q_values(t, 6, spread=2)
+        Rig(t, q, synth.synth_model(t, q, 6), 0).check_all_layers(synth.synth_images(t, 2, 6), layers={0, 1, 2})
+
+
 def test_vgg_small_bias_and_2x2_pools():
     t = cfg.vgg16_tables(32, 10)
     q = synth.synth_q_values(t, 7)

@@ -37,7 +37,10 @@ def check_net(t, q, model, images, mode, layers=None):
         kinds.append(int(pl["kind"]))
         if L.ipool:
             continue
-        if L.src == -1:
+        Lx = L
+        if L.src == -1 and L.C == 3 and L.k == 3 and int(pl["Cp_in"]) == 64:
+            Lx, x_t = emu.first_layer_executed(L, outs[-1])       # executed as a pointwise layer over the im2col image
+        elif L.src == -1:
             half = _round_up(L.C, 16)
             x_t = emu.nhwc(outs[-1], 2 * half, signed_half=half)
         elif L.src >= 0:
@@ -53,7 +56,7 @@ def check_net(t, q, model, images, mode, layers=None):
                 full[:, M.n_start:M.n_start + M.N] = outs[M.index]
             x_t = emu.nhwc(full, _round_up(concat_c[cid], 16))
         res = outs[L.add_src] if L.add_src >= 0 else None
-        y = emu.conv_from_packed(blob, pl, L, x_t, res)
+        y = emu.conv_from_packed(blob, pl, Lx, x_t, res)
         # finish the layer with the oracle's post-ops and compare with the oracle's layer output
         if L.pool_en:
             y = np.stack([O.maxpool(yi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for yi in y])

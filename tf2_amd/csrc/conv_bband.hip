@@ -309,7 +309,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // hand-over: requantise (pe.cl:185-203, relu.cl:54) into the halo tile; pixels of rows outside the image keep the pad value
   {
     const int lo_b = a.relu1 ? 0 : -128;
-    const i32x4 nores = {0, 0, 0, 0};
     auto to_mid1 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
@@ -407,7 +406,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
   // hand-over: requantise the 3x3 into the expand's B tile [slab][pixel][64]
   {
     const int lo_b = a.relu2 ? 0 : -128;
-    const i32x4 nores = {0, 0, 0, 0};
     auto to_mid2 = [&](auto fast_c) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll

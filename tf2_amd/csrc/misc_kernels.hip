@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
     for (int i = 0; i < 16; i++) {
       const int c = cg * 16 + i;
       int ci, sr, sc;
-      if (a.rewrite) {
+      if (a.rewrite == 1) {
         // feature_trans (input_loader.cpp:27-73): sub-channel k of image channel ci holds
         // pad3[2*oh + roff][2*ow + coff] with (roff,coff) = k0(0,0) k1(1,0) k2(0,1) k3(1,1)
         // k4(0,2) k5(1,2) k6(2,0) k7(2,1) k8(2,2).
@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
         const int coff = k < 6 ? (k >> 1) : (k - 6);
         sr = 2 * oh + roff - 3;
         sc = 2 * ow + coff - 3;
+      } else if (a.rewrite == 2) {
+        // im2col of a 3x3 first layer: channel c * 9 + fh * 3 + fw of output pixel (oh, ow)
+        ci = c / 9;
+        const int k = c - ci * 9;
+        sr = oh * a.im_stride - a.im_pad_h + k / 3;
+        sc = ow * a.im_stride - a.im_pad_w + k % 3;
       } else {
         ci = c; sr = oh; sc = ow;
       }
@@ -112,7 +118,9 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
 // stride 2 per channel, 27 loads that neighbouring lanes share in L1, 32-bit index arithmetic.  The 64 bytes of
 // [x | xneg] per pixel go through LDS so that every wave store is 1 KiB of contiguous NHWC bytes.
 // XONLY: 32 bytes of x per pixel and no xneg half -- the input of conv_stem.hip, which handles x = -128 itself.
-template <bool SRC_Q, bool XONLY>
+// IM2COL: the same gather for the im2col form of a 3x3 first layer (PrepArgs::rewrite == 2): window origin oh * stride - pad, taps in
+// row-major order.
+template <bool SRC_Q, bool XONLY, bool IM2COL = false>
 __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
   prep_zero_ctrl(a);
   __shared__ __attribute__((aligned(16))) int tile[256][17];        // 64 B per pixel (+1 word: bank spread)
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
     const int t = pix / a.OW;
     const int oh = t % a.OH;
     const int b = t / a.OH;
-    const int r0 = 2 * oh - 3, c0 = 2 * ow - 3;
+    const int r0 = IM2COL ? oh * a.im_stride - a.im_pad_h : 2 * oh - 3, c0 = IM2COL ? ow * a.im_stride - a.im_pad_w : 2 * ow - 3;
     int v[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) v[i] = 0;
@@ -137,8 +145,8 @@ __global__ __launch_bounds__(256) void prep_rewrite3_kernel(PrepArgs a) {
       const int base = ((b * 3 + ci) * a.H + r0) * a.W + c0;          // < 2^31 for any batch the workspace can hold
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        const int roff = k < 6 ? (k & 1) : 2;
-        const int coff = k < 6 ? (k >> 1) : (k - 6);
+        const int roff = IM2COL ? k / 3 : (k < 6 ? (k & 1) : 2);
+        const int coff = IM2COL ? k % 3 : (k < 6 ? (k >> 1) : (k - 6));
         int q = 0;
         if (rok[roff] && cok[coff]) {
           const int si = base + roff * a.W + coff;
@@ -364,7 +372,14 @@ static inline int grid_for(long long total, int block = 256) {
 
 int launch_prep_input(const PrepArgs& a, void* stream) {
   const long long pixels = (long long)a.B * a.OH * a.OW;
-  if (a.rewrite && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
+  if (a.rewrite == 2 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
+    const unsigned grid = (unsigned)((pixels + 255) / 256);
+    TF2_LAUNCH_NAME("prep_rewrite3_kernel<im2col>");
+    if (a.src_is_q) TF2_LAUNCH((prep_rewrite3_kernel<true, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else TF2_LAUNCH((prep_rewrite3_kernel<false, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_ok() ? 0 : -1;
+  }
+  if (a.rewrite == 1 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
     static const bool rows_off = getenv("TF2_AMD_PREP_ROWS") != nullptr && atoi(getenv("TF2_AMD_PREP_ROWS")) == 0;
     if (a.xonly && !rows_off && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2) {

@@ -37,6 +37,24 @@ tf2_status Net::init(const tf2_net_desc* d, const tf2_layer_desc* ls) {
   }
   layers.assign(ls, ls + nd.n_layers);
   const int nl = nd.n_layers;
+  // A 3x3 first layer on a 3-channel image (VGG16, SSD300, SqueezeNet 1.1) is executed as a POINTWISE layer over the im2col image:
+  // the input kernel writes, per OUTPUT pixel, the 27 values x[c][oh * stride - pad + fh][ow * stride - pad + fw] in the order
+  // c * 9 + fh * 3 + fw (zero outside the image: sequencer.cl:287) as [x | xneg], 64 bytes -- exactly the bytes the plain form writes
+  // per INPUT pixel for 3 channels padded to 16 -- and the layer becomes C = 27, k = 1, stride 1 on an OH x OW map: one 64-byte K slab
+  // per output instead of five (nine taps of 32 bytes, 6 of them real).  Same sums term for term; the filter codes [N][3][3][3] of
+  // LoadModel ARE [N][27][1][1] in that channel order, so nothing else changes (the reference does the same kind of thing for its
+  // 7x7 first layers: model_loader.cpp:244-257, input_loader.cpp:98-116).  TF2_AMD_IM2COL0=0 keeps the plain form.
+  im2col0 = false;
+  {
+    const bool off = getenv("TF2_AMD_IM2COL0") != nullptr && atoi(getenv("TF2_AMD_IM2COL0")) == 0;       // (read per handle: tests build both forms)
+    tf2_layer_desc& L0 = layers[0];
+    if (!off && !nd.conv1_rewrite && L0.src == -1 && !L0.ipool && L0.k == 3 && L0.model_k == 3 && L0.C == 3 && L0.model_C == 3 &&
+        L0.dil <= 1 && nd.image_c == 3 && L0.H == nd.image_h && L0.W == nd.image_w && L0.stride >= 1 &&
+        L0.OH == (L0.H + 2 * L0.pad_h - 3) / L0.stride + 1 && L0.OW == (L0.W + 2 * L0.pad_w - 3) / L0.stride + 1) {
+      im2col0 = true; im_stride = L0.stride; im_pad_h = L0.pad_h; im_pad_w = L0.pad_w;
+      L0.C = 27; L0.k = 1; L0.stride = 1; L0.pad_h = L0.pad_w = 0; L0.H = L0.OH; L0.W = L0.OW;
+    }
+  }
   // concat tensor widths
   concat_C.assign(std::max(0, nd.n_concat), 0);
   for (int l = 0; l < nl; l++) {
@@ -55,7 +73,7 @@ tf2_status Net::init(const tf2_net_desc* d, const tf2_layer_desc* ls) {
     if (L.N <= 0 || L.N > nd.max_out_channel) { set_error("layer " + std::to_string(l) + ": bad N"); return TF2_ERR_ARG; }
     // the q table rows Quantization / LoadModel index with this row (quantization.cpp:42-49, model_loader.cpp:159-162)
     if (L.q_in_row < 0 || L.q_in_row >= nd.n_q_rows) { set_error("layer " + std::to_string(l) + ": q_in_row outside the q table"); return TF2_ERR_ARG; }
-    if (L.C <= 0 || (!L.ipool && L.C > nd.max_out_channel)) { set_error("layer " + std::to_string(l) + ": input channels exceed MAX_OUT_CHANNEL"); return TF2_ERR_ARG; }
+    if (L.C <= 0 || (!L.ipool && (l == 0 && im2col0 ? 3 : L.C) > nd.max_out_channel)) { set_error("layer " + std::to_string(l) + ": input channels exceed MAX_OUT_CHANNEL"); return TF2_ERR_ARG; }
     if (L.n_start < 0 || L.n_start + L.N > nd.max_out_channel) { set_error("layer " + std::to_string(l) + ": n_start + N exceeds MAX_OUT_CHANNEL"); return TF2_ERR_ARG; }
     if (L.concat >= 0 && nd.n_conv + 1 + L.concat >= nd.n_q_rows) { set_error("layer " + std::to_string(l) + ": concat Q row outside the q table"); return TF2_ERR_ARG; }
     if (L.pool_en && L.add_src >= 0) { set_error("layer " + std::to_string(l) + ": pool + residual in one layer is not supported"); return TF2_ERR_UNSUPPORTED; }
@@ -479,8 +497,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     pa.img = nullptr; pa.y = base + T(wp->input_tensor).offset;
     pa.B = batch; pa.C = nd.image_c; pa.H = nd.image_h; pa.W = nd.image_w;
     pa.OH = L0.H; pa.OW = L0.W; pa.y_cp = in_layout[0].Cp_in; pa.half = in_layout[0].half;
-    pa.rewrite = nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = 0; pa.xonly = stem ? 1 : 0;
-    if (!nd.conv1_rewrite && (L0.H != nd.image_h || L0.W != nd.image_w || L0.C != nd.image_c)) return fail("layer 0 input does not match the image");
+    pa.rewrite = im2col0 ? 2 : nd.conv1_rewrite; pa.q0 = q[0]; pa.src_is_q = 0; pa.xonly = stem ? 1 : 0;
+    pa.im_stride = im_stride; pa.im_pad_h = im_pad_h; pa.im_pad_w = im_pad_w;
+    if (!nd.conv1_rewrite && !im2col0 && (L0.H != nd.image_h || L0.W != nd.image_w || L0.C != nd.image_c)) return fail("layer 0 input does not match the image");
     lp.steps.push_back(st);
   }
   auto pool_step = [&](int l, const TensorPlan& ti, const int8_t* x, int H, int W) {
@@ -1076,6 +1095,27 @@ tf2_status Net::read_layer(int layer, int batch, const void* ws, int8_t* dst, si
   else { tid = wp.exec[layer].out_tensor; off = wp.exec[layer].out_off; C = layers[layer].N; }
   const TensorPlan& t = wp.tensors[tid];
   const size_t npix = (size_t)batch * t.H * t.W;
+  if (layer == -1 && im2col0) {
+    // the input tensor holds the im2col image (Net::init): hand back the quantised image [batch][3][H][W] it was gathered from --
+    // pixel (r, c) of channel ch is tap (fh, fw) of output pixel (oh, ow) with r + pad_h = oh * stride + fh (a pixel no window covers,
+    // possible with stride > 1, is not in the tensor: 0)
+    const int IH = nd.image_h, IW = nd.image_w;
+    if (cap < (size_t)batch * 3 * IH * IW) { set_error("tf2_net_read_layer: destination too small"); return TF2_ERR_SIZE; }
+    std::vector<int8_t> tmp(npix * t.Cp);
+    HIP_OK(hipMemcpyAsync(tmp.data(), (const int8_t*)ws + t.offset, tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    for (int b = 0; b < batch; b++)
+      for (int ch = 0; ch < 3; ch++)
+        for (int r = 0; r < IH; r++)
+          for (int c = 0; c < IW; c++) {
+            const int oh = std::min((r + im_pad_h) / im_stride, t.H - 1), fh = r + im_pad_h - oh * im_stride;
+            const int ow = std::min((c + im_pad_w) / im_stride, t.W - 1), fw = c + im_pad_w - ow * im_stride;
+            int8_t v = 0;
+            if (fh <= 2 && fw <= 2) v = tmp[(((size_t)b * t.H + oh) * t.W + ow) * t.Cp + ch * 9 + fh * 3 + fw];
+            dst[(((size_t)b * 3 + ch) * IH + r) * IW + c] = v;
+          }
+    return TF2_OK;
+  }
   if (cap < npix * C) { set_error("tf2_net_read_layer: destination too small"); return TF2_ERR_SIZE; }
   const size_t Cp = (layer == -1 && packed_valid && stem_selected(batch)) ? 32 : (size_t)t.Cp;     // x-only image tensor (conv_stem.hip)
   std::vector<int8_t> tmp(npix * Cp);

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 30;
+constexpr uint32_t kPackVersion = 31;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -279,7 +279,9 @@ struct PrepArgs {
   const void* img; int8_t* y;
   int32_t B, C, H, W;         // source image dims
   int32_t OH, OW, y_cp, half; // destination dims, bytes per pixel, offset of the xneg half
-  int32_t rewrite;            // 1: 7x7/s2 space-to-depth form (27 channels on 114x114)
+  int32_t rewrite;            // 1: 7x7/s2 space-to-depth form (27 channels on 114x114); 2: im2col of a 3x3 first layer on 3 channels
+                              //    (27 channels c * 9 + fh * 3 + fw per OUTPUT pixel: the layer then runs as a pointwise one, net.hip)
+  int32_t im_stride, im_pad_h, im_pad_w;   // rewrite == 2: the 3x3 layer's own stride and padding
   int32_t q0;                 // runtime (negated) Q of image channel 0
   int32_t src_is_q;           // 1: source already int8
   int32_t xonly;              // 1 (rewrite form only): 32 bytes of x per pixel, no xneg half (conv_stem.hip)

@@ -122,6 +122,8 @@ struct Net {
 
   // physical input layout of every layer (decided once from the graph)
   struct InLayout { int Cp_in = 0; int half = 0; int signed_in = 0; };
+  // layer 0 executed as a pointwise layer over the im2col image (init(); PrepArgs::rewrite == 2)
+  bool im2col0 = false; int im_stride = 1, im_pad_h = 0, im_pad_w = 0;
   std::vector<InLayout> in_layout;
   std::vector<int> out_Cp;               // channel padding of each layer's own output tensor
   std::vector<int> concat_C;             // channels of each concat tensor
