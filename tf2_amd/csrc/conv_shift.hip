@@ -190,40 +190,42 @@ __global__ __launch_bounds__(256) void conv_shift_kernel(ConvArgs a) {
 
 // ---- few pixels, many channels (a fully connected layer behind a global average: SqueezeNet 1.1's 1000 -> 128 on 32 pixels) ----
 // conv_shift_kernel walks the channel chunks one after the other behind two barriers each: with one block of pixels that is a chain
-// of n_cchunk memory latencies on four blocks (157 us for 63 chunks, measured).  Here one block owns 8 output channels and its
-// sixteen waves take every sixteenth chunk each -- lane = pixel reads its 16 input bytes straight from HBM (one tap: nothing to
-// gather) -- and the sixteen partial sums are added through LDS.  The sum is in Z/2^32, so the order does not matter: same bits.
+// of n_cchunk memory latencies on four blocks (157 us for 63 chunks, measured).  Here one block owns 8 output channels x 32 pixels
+// and its sixteen waves take every sixteenth 16-channel chunk each; a lane is (pixel = lane & 31, channel half = lane >> 5) and
+// reads its 8 input bytes straight from HBM (one tap: nothing to gather), so all 64 lanes work on 32 pixels; the two halves and the
+// sixteen waves' partial sums are added at the end (lane exchange, then LDS).  The sum is in Z/2^32: any order, same bits.
 template <bool SIGNED_IN, bool MUL24, bool PACKED4>
 __global__ __launch_bounds__(1024) void conv_shift_fc_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int8_t lds_raw[];      // [16 waves][8][64] int32 partial sums | PACKED4: [wave][2 signs][128] int32
+  extern __shared__ __attribute__((aligned(16))) int8_t lds_raw[];      // [16 waves][8][32] int32 partial sums | PACKED4: [wave][2 signs][128] int32
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5;                                                // which 8 channels of a 16-channel chunk
   const int n0 = blockIdx.y * 8;
-  const int p = blockIdx.x * 64 + lane;
+  const int p = blockIdx.x * 32 + (lane & 31);
   int* const red = reinterpret_cast<int*>(lds_raw);
-  int* const wl = red + 16 * 8 * 64 + wave * 256;
+  int* const wl = red + 16 * 8 * 32 + wave * 256;
   const int8_t* xsrc = nullptr;
   if (p < g.n_pix) {
     const int b = fast_div(p, g.ohw_m, g.ohw_s);
     const int rem = p - b * g.OHW;
     const int oh = fast_div(rem, g.ow_m, g.ow_s), ow = rem - oh * g.OW;
-    xsrc = a.x + (size_t)(b * g.H * g.W + oh * g.stride * g.W + ow * g.stride) * g.Cp_in;     // k = 1, no padding (checked by the launcher)
+    xsrc = a.x + (size_t)(b * g.H * g.W + oh * g.stride * g.W + ow * g.stride) * g.Cp_in + h * 8;     // k = 1, no padding (checked by the launcher)
   }
   int acc[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) acc[r] = 0;
   for (int cc = wave; cc < a.n_cchunk; cc += 16) {
-    i32x4 xv = {0, 0, 0, 0};
-    if (xsrc) xv = *reinterpret_cast<const i32x4*>(xsrc + cc * 16);
+    int2 xv = {0, 0};
+    if (xsrc) xv = *reinterpret_cast<const int2*>(xsrc + cc * 16);
     if (PACKED4) {
       // 128 codes of this (n8 tile, chunk) = 16 dwords; lanes 0..15 expand one dword (8 channels of one (half, r)) each
       const unsigned* nb = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint8_t*>(a.w) + (((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128) / 2);
       const int8_t* ab = a.w2;
       if (lane < 16) {
-        const int r = lane & 7, h = (lane >> 3) & 1;
+        const int r = lane & 7, hh = (lane >> 3) & 1;
         const int An = (int)ab[n0 + r];
-        const int2 bw = *reinterpret_cast<const int2*>(ab + a.Np + cc * 16 + h * 8);
+        const int2 bw = *reinterpret_cast<const int2*>(ab + a.Np + cc * 16 + hh * 8);
         const unsigned word = nb[lane];
         int wv[8], wn[8];
 #pragma unroll
@@ -246,46 +248,51 @@ __global__ __launch_bounds__(1024) void conv_shift_fc_kernel(ConvArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    const int* wbase = reinterpret_cast<const int*>(a.w) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128;
-    const int* w2base = SIGNED_IN ? reinterpret_cast<const int*>(a.w2) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128 : nullptr;
+    // weights of this lane's channel half: [n8 tile][cchunk][half][8 n][8 c] int32 (two addresses per wave: L1 / LDS broadcast)
+    const int* wp = (PACKED4 ? wl : reinterpret_cast<const int*>(a.w) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128) + h * 64;
+    const int* wq = nullptr;
+    if (SIGNED_IN) wq = (PACKED4 ? wl + 128 : reinterpret_cast<const int*>(a.w2) + ((size_t)(n0 >> 3) * a.n_cchunk + cc) * 128) + h * 64;
+    int xs[8], xn[8];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int xs[8], xn[8];
+    for (int c = 0; c < 8; c++) {
+      const int word = c < 4 ? xv.x : xv.y;
+      xs[c] = (int)(signed char)((word >> (8 * (c & 3))) & 0xff);
+      xn[c] = SIGNED_IN ? (int)(signed char)(-xs[c]) : 0;         // int8 negate: -(-128) == -128 (pe.cl:32-37)
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const i32x4 w0 = *reinterpret_cast<const i32x4*>(wp + r * 8), w1 = *reinterpret_cast<const i32x4*>(wp + r * 8 + 4);
+      i32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+      if (SIGNED_IN) { v0 = *reinterpret_cast<const i32x4*>(wq + r * 8); v1 = *reinterpret_cast<const i32x4*>(wq + r * 8 + 4); }
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        const int word = xv[h * 2 + (c >> 2)];
-        xs[c] = (int)(signed char)((word >> (8 * (c & 3))) & 0xff);
-        xn[c] = SIGNED_IN ? (int)(signed char)(-xs[c]) : 0;       // int8 negate: -(-128) == -128 (pe.cl:32-37)
-      }
-      const int* wp = PACKED4 ? wl + h * 64 : wbase + h * 64;
-      const int* wq = SIGNED_IN ? (PACKED4 ? wl + 128 + h * 64 : w2base + h * 64) : nullptr;
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const int w = wp[r * 8 + c];
-          if (MUL24) acc[r] += __mul24(xs[c], w);
-          else acc[r] = (int)((unsigned)acc[r] + (unsigned)xs[c] * (unsigned)w);
-          if (SIGNED_IN) {
-            const int w2 = wq[r * 8 + c];
-            if (MUL24) acc[r] += __mul24(xn[c], w2);
-            else acc[r] = (int)((unsigned)acc[r] + (unsigned)xn[c] * (unsigned)w2);
-          }
+        const int w = c < 4 ? w0[c] : w1[c - 4];
+        if (MUL24) acc[r] += __mul24(xs[c], w);
+        else acc[r] = (int)((unsigned)acc[r] + (unsigned)xs[c] * (unsigned)w);
+        if (SIGNED_IN) {
+          const int w2 = c < 4 ? v0[c] : v1[c - 4];
+          if (MUL24) acc[r] += __mul24(xn[c], w2);
+          else acc[r] = (int)((unsigned)acc[r] + (unsigned)xn[c] * (unsigned)w2);
         }
       }
     }
     if (PACKED4) __builtin_amdgcn_wave_barrier();                  // the next chunk's expansion overwrites wl
   }
+  // the two channel halves of a pixel sit in lanes l and l + 32
 #pragma unroll
-  for (int r = 0; r < 8; r++) red[(wave * 8 + r) * 64 + lane] = acc[r];
+  for (int r = 0; r < 8; r++) acc[r] = (int)((unsigned)acc[r] + (unsigned)__shfl_xor(acc[r], 32));
+  if (h == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) red[(wave * 8 + r) * 32 + lane] = acc[r];
+  }
   __syncthreads();
-  if (wave != 0 || p >= g.n_pix || n0 + 8 > g.y_nvalid) return;
+  if (wave != 0 || h != 0 || p >= g.n_pix || n0 + 8 > g.y_nvalid) return;
   int q[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     unsigned v = (unsigned)a.bias[n0 + r];
 #pragma unroll
-    for (int w = 0; w < 16; w++) v += (unsigned)red[(w * 8 + r) * 64 + lane];
+    for (int w = 0; w < 16; w++) v += (unsigned)red[(w * 8 + r) * 32 + lane];
     q[r] = requant_i8s((int)v, a.alpha[n0 + r], a.beta[n0 + r], g.relu);
   }
   if (g.has_res) {
@@ -319,8 +326,8 @@ int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, 
   const int taps = a.k * a.k;
   if (taps > kMaxTaps) return -2;
   if (shift_fc_form(a)) {
-    dim3 fgrid((a.g.n_pix + 63) / 64, a.Np / 8);
-    const size_t flds = (size_t)16 * 8 * 64 * 4 + (packed4 ? (size_t)16 * 256 * 4 : 0);
+    dim3 fgrid((a.g.n_pix + 31) / 32, a.Np / 8);
+    const size_t flds = (size_t)16 * 8 * 32 * 4 + (packed4 ? (size_t)16 * 256 * 4 : 0);
 #define TF2_SHF(S, M, P) do { TF2_LAUNCH_NAME("conv_shift_fc_kernel"); TF2_LAUNCH((conv_shift_fc_kernel<S, M, P>), fgrid, dim3(1024), flds, s, a); } while (0)
     if (packed4) {
       if (signed_in) { if (mul24) TF2_SHF(true, true, true); else TF2_SHF(true, false, true); }
