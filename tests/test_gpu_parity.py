@@ -113,6 +113,26 @@ def test_first_3x3_layer_plain_form(monkeypatch):
         Rig(t, q, synth.synth_model(t, q, 6), 0).check_all_layers(synth.synth_images(t, 2, 6), layers={0, 1, 2})
 
 
+@pytest.mark.parametrize("c3", ["1", "0"])
+def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
+    """conv_c3.hip (a 3x3 / 1 / pad 1 layer with the input's halo tile streamed through LDS once: VGG16 / SSD300's body) against the
+    oracle on every layer of a 64 x 64 VGG16 (maps 64 / 32 / 16: 1-8 channel slabs, 64- and 128-channel blocks, one- and two-window
+    rows, partial tiles at the map's edge; the 8 x 8 and 4 x 4 maps stay on the ring / split-K kernels), and the same network with the
+    kernel switched off."""
+    monkeypatch.setenv("TF2_AMD_C3", c3)
+    monkeypatch.setenv("TF2_AMD_C3_MIN", "1")
+    t = cfg.vgg16_tables(64, 10)
+    q = synth.synth_q_values(t, 7, spread=2)
+    rig = Rig(t, q, synth.synth_model(t, q, 7), 0)
+    names = [r["kernel"] for r in rig.net.describe_launches(3, 0)]
+    assert any("conv_c3" in n for n in names) == (c3 == "1"), names
+    x = synth.synth_images(t, 3, 7)
+    rig.check_all_layers(x)
+    t = cfg.tiny_tables(hw=40, widths=(64, 128), classes=10)      # a map of 20 x 20 (one tile with a ragged last column tile), residual net
+    q = synth.synth_q_values(t, 3, spread=2)
+    Rig(t, q, synth.synth_model(t, q, 3), 0).check_all_layers(synth.synth_images(t, 2, 3))
+
+
 def test_vgg_small_bias_and_2x2_pools():
     t = cfg.vgg16_tables(32, 10)
     q = synth.synth_q_values(t, 7)

@@ -1,0 +1,321 @@
+// conv_c3.hip -- 3x3 / stride 1 / pad 1 convolution of a big map (VGG16 / SSD300's body: C, M in 64..512, 14 x 14 .. 300 x 300) with
+// the input's halo tile resident in LDS (gfx950).
+//
+// Why: the ring kernel (conv_mfma2.hip) gathers every tap's activation slab again -- nine LDS-DMA fetches of the same input bytes
+// per output tile, 24 KB of L2 -> LDS traffic per 64-byte K slab of a block -- and on these layers (12 of VGG16's 16 launches,
+// 1.0 of its 1.17 ms) it runs at 0.19 of the dense int8 peak.  conv_bband's 3x3 phase does the same arithmetic from a halo tile in
+// LDS at 95 % of the matrix pipe's rate; this kernel is that phase as a layer of its own:
+//
+//   * a block owns a TH x TW pixel tile (<= 256 pixels = 8 column tiles of 32) of ONE image and TMK = 64 / 128 output channels
+//     (grid.y = channel groups); its 8 waves are (TMK / 32 row tiles) x (pixel columns), one row tile and 8 / WN column tiles each;
+//   * the input streams through LDS in chunks of SC 64-channel slabs of the (TH + 2) x (TW + 2) HALO tile (zero border = the stored
+//     form of x = 0, sequencer.cl:287), two chunk buffers, LDS-DMA; a slab is four PLANES of 16 bytes per pixel (conv_bband.hip):
+//     a lane's MFMA fragment of halo pixel h is 16 bytes at plane[half + 2 ks] + 16 h -- conflict-free without a swizzle, and tap,
+//     slab and K half are immediate offsets of the ds_read;
+//   * every chunk is swept by all nine taps before the next one is touched: the input is fetched ONCE (plus the halo: 1.3-1.5 x);
+//   * weights go global -> registers, a lane's fragment is 16 contiguous bytes of its row in the packed tile, two steps ahead
+//     (three rotating buffers: nine steps per slab keep the rotation aligned with the run-time chunk loop);
+//   * two-window layers keep two accumulator sets over the one input stream and combine them once, (hi << dshift[1]) + lo;
+//   * epilogue: requant_tiles16_rows (parameter rows read once per row tile), 16-byte NHWC stores.
+//
+// Arithmetic, packed image and epilogue are conv_mfma2.hip's (reference: pe.cl:27-43 shift-accumulate, pe.cl:185-203 requant,
+// relu.cl:54); bit-identical to it (tests/test_gpu_parity.py runs both forms of every eligible layer).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include "tf2_internal.h"
+#include "tf2_device.h"
+#include "requant_epilogue.h"
+
+namespace tf2 {
+
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x16 = int __attribute__((ext_vector_type(16)));
+
+#define TF2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int T, int N, class F>
+__device__ __forceinline__ void c3_static_for(F& fn) {
+  if constexpr (T < N) { fn(std::integral_constant<int, T>{}); c3_static_for<T + 1, N>(fn); }
+}
+
+// LDS-DMA hidden from the compiler's wait-count pass (conv_bband.hip bb_dma16): every wait for these is written out below
+__device__ __forceinline__ void c3_dma16(const int8_t* src, int8_t* lds_dst) {
+  const unsigned l = (unsigned)(unsigned long long)TF2_LDS_PTR(lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(l) : "memory", "m0");
+}
+
+constexpr int kC3HaloPx = 384;               // halo pixels of a tile, padded to whole 64-pixel DMA groups (host: c3_pick_tile)
+constexpr int kC3PlaneB = kC3HaloPx * 16;    // bytes of one 16-byte plane of a slab
+constexpr int kC3SlabB = 4 * kC3PlaneB;      // bytes of one 64-channel slab of the halo tile
+
+// PF: steps the weight fragments are loaded ahead of their MFMAs (PF + 1 rotating buffers; PF + 1 divides the nine steps of a slab's
+// chunk walk).  The VM counter retires in order, so a wave's first wait for a fragment loaded AFTER its share of a chunk's DMAs also
+// waits for those DMAs: a chunk gets PF + 1 steps to land before its issuing wave stalls -- 0.75 us at PF = 2 against ~2 us of
+// latency under load, every chunk.  PF = 5 where the registers allow it (one-window 128-channel blocks).
+template <int TMK, int SC, bool DUAL, int PF>
+__global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args a) {
+  constexpr int NBUF = PF + 1;
+  static_assert((SC * 9) % NBUF == 0, "the buffer rotation must close over a chunk");
+  constexpr int WM = TMK / 32, WN = 8 / WM, NT = 8, J = NT / WN;
+  constexpr int NG = kC3HaloPx / 64;                       // DMA groups per plane
+  constexpr int CHUNK = SC * kC3SlabB;
+  constexpr int NSTEP = SC * 9;                            // steps (slab, tap) per chunk
+  constexpr int F = DUAL ? 4 : 2;                          // fragment loads per step and wave
+  __shared__ __attribute__((aligned(1024))) int8_t ring[2 * CHUNK];
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn[];          // header image of the block's channel group
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int half = lane >> 5;
+  const int H = a.H, W = a.W, TH = a.TH, TW = a.TW, HC = TW + 2;
+  const int KS = a.C >> 6;                                 // 64-channel slabs of the input
+  const int NC = KS / SC;                                  // chunks
+  const int tms = a.tm == 128 ? 7 : 6;
+  const int hst = (DUAL ? 28 : 20) << tms;                 // bytes of one storage m-tile's header image
+  // the bands of one image on one XCD (they share halo rows, and all of them the weights)
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int img = fast_div(bid, a.tpi_m, a.tpi_s);
+  const int tile = bid - img * a.tiles_per_img;
+  const int ty = fast_div(tile, a.tx_m, a.tx_s), tx = tile - ty * a.tiles_x;
+  const int r0 = ty * TH, c0 = tx * TW;
+  const int rows = (H - r0) < TH ? (H - r0) : TH, cols = (W - c0) < TW ? (W - c0) : TW;
+  const int cb = blockIdx.y * TMK + wm * 32;               // this wave's first output channel
+  const long long img_px = (long long)img * H * W;
+
+  // ---- this lane's input pixels of the DMA groups: byte offset into x, or -1 for the zero border / outside the image ----------
+  long long poff[NG];
+  const int n_halo = (TH + 2) * HC;
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const int hp = g * 64 + lane;
+    const int hr = fast_div(hp, a.hc_m, a.hc_s), hc = hp - hr * HC;
+    const int r = r0 - 1 + hr, c = c0 - 1 + hc;
+    poff[g] = (hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? (img_px + (long long)r * W + c) * a.x_cp : -1;
+  }
+  // chunk c -> ring buffer: wave w issues (slab w / 4 of the chunk, plane w % 4) for every group (SC = 1: waves 0..3)
+  auto issue_chunk = [&](int c, int8_t* buf) __attribute__((always_inline)) {
+    if (wave < SC * 4) {
+      const int sl = wave >> 2, k = wave & 3;
+      const int coff = (c * SC + sl) * 64 + k * 16;
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int8_t* src = poff[g] >= 0 ? a.x + poff[g] + coff : a.zero2 + coff;
+        c3_dma16(src, buf + sl * kC3SlabB + k * kC3PlaneB + g * 1024);
+      }
+    }
+  };
+  issue_chunk(0, ring);
+  if (NC > 1) issue_chunk(1, ring + CHUNK);
+  // header images of the block's channels (rows {bias | dbl, alpha, addend64} | lo | dshift[P]) by ordinary loads
+  {
+    const int per = (DUAL ? 7 : 5) << (tms - 2);            // 16-byte pieces per storage m-tile
+    const int mt0 = (blockIdx.y * TMK) >> tms, n_mt = TMK > (1 << tms) ? TMK >> tms : 1;
+    for (int i = tid; i < n_mt * per; i += 512) {
+      const int mt = i / per, k = i - mt * per;
+      const i32x4 v = *reinterpret_cast<const i32x4*>(reinterpret_cast<const int8_t*>(a.hdr) + (size_t)(mt0 + mt) * a.hdr_bytes + k * 16);
+      *reinterpret_cast<i32x4*>(dyn + (size_t)mt * (per * 16) + k * 16) = v;
+    }
+  }
+
+  // ---- weight fragments ------------------------------------------------------------------------------------------------------
+  struct Afr { i32x4 k[2]; };
+  const unsigned a_lane_off = (unsigned)((lane & 31) * 64 + half * 16);
+  const int wins = DUAL ? 2 : 1;
+  const int nslab = 9 * KS;
+  const int mt_w = cb >> tms, ro_w = cb & ((1 << tms) - 1);
+  // step (chunk c, e = slab sl * 9 + tap t) -> packed slab t * KS + c * SC + sl
+  auto load_a = [&](Afr& f, int c, int e, int win) __attribute__((always_inline)) {
+    const int sl = e / 9, t = e - sl * 9;
+    const int slab = t * KS + c * SC + sl;
+    const int8_t* pu = a.w + (((((size_t)mt_w * nslab + slab) * wins + win) << tms) + ro_w) * 64;
+    f.k[0] = *reinterpret_cast<const i32x4*>(pu + a_lane_off);
+    f.k[1] = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
+  };
+  Afr fb[NBUF], gb[DUAL ? NBUF : 1];                        // rotating buffers, static indices (hi window; DUAL: gb = lo window)
+#define C3_BUF(v) fb[(v) % NBUF]
+#define C3_BUFL(v) gb[DUAL ? (v) % NBUF : 0]
+#pragma unroll
+  for (int v = 0; v < PF; v++) {
+    load_a(fb[v], v / (SC * 9) < NC ? v / (SC * 9) : 0, v % (SC * 9), 0);
+    if constexpr (DUAL) load_a(gb[v], v / (SC * 9) < NC ? v / (SC * 9) : 0, v % (SC * 9), 1);
+  }
+
+  // ---- this lane's pixels: column tile (wn + j * WN), pixel p = tr * TW + tc of the tile ------------------------------------------
+  int h0[J];
+  int n_j = 0;                                             // column tiles of this wave that hold pixels of the tile
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    const int pt = (wn + j * WN) * 32;
+    if (pt < TH * TW) n_j = j + 1;
+    int p = pt + (lane & 31);
+    if (p >= TH * TW) p = 0;                               // lanes beyond the tile compute on pixel 0 and are never stored
+    const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
+    h0[j] = (tr * HC + tc) * 16 + half * kC3PlaneB;        // tap (0, 0), K half 0
+  }
+  n_j = __builtin_amdgcn_readfirstlane(n_j);
+
+  i32x16 acc[J], acc2[DUAL ? J : 1];
+#pragma unroll
+  for (int j = 0; j < J; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[j][r] = 0; if (DUAL) acc2[j][r] = 0; }
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // chunks 0 and 1, header: complete in every wave
+  asm volatile("" ::: "memory");
+
+  // ---- the K loop: chunks at run time, the NSTEP = SC * 9 steps of a chunk unrolled --------------------------------------------
+#pragma unroll 1
+  for (int c = 0; c < NC; c++) {
+    const int rb = (c & 1) * CHUNK;
+    auto step = [&](auto e_c) __attribute__((always_inline)) {
+      constexpr int e = decltype(e_c)::value;
+      constexpr int sl = e / 9, t = e % 9;
+      if constexpr (e == 0) {
+        if (c > 0) {
+          // chunk c landed in every wave and nobody reads the other buffer any more.  This wave's DMAs of chunk c were issued at the
+          // first step of chunk c - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
+          // other NSTEP - 1 steps, of which at most the last two steps' still fly (conv_bband.hip step0).
+          // (PF steps' loads when the fragments run further ahead)
+          static_assert(PF * F <= 16, "prepared immediates");
+          if constexpr (PF * F == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if constexpr (PF * F == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if constexpr (PF * F == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+          else { static_assert(PF * F == 4 || PF * F == 8 || PF * F == 10 || PF * F == 16, "prepared immediates"); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      Afr& cur = C3_BUF(e);
+      // fragments of step e + PF (the next chunk's first steps at the end; past the last chunk: a valid address, never used)
+      {
+        constexpr int e2 = (e + PF) % NSTEP;
+        const int c2 = (e + PF >= NSTEP) ? (c + 1 < NC ? c + 1 : c) : c;
+        load_a(C3_BUF(e + PF), c2, e2, 0);
+        if constexpr (DUAL) load_a(C3_BUFL(e + PF), c2, e2, 1);
+      }
+      if constexpr (e == 0) {
+        if (c > 0 && c + 1 < NC) {
+          asm volatile("" ::: "memory");
+          issue_chunk(c + 1, ring + ((c + 1) & 1) * CHUNK);   // (behind this step's fragment loads)
+        }
+      }
+      // (slab, tap) -> a wave-uniform byte offset; one address add per column tile, the K half is an immediate
+      const int soff = rb + sl * kC3SlabB + ((t / 3) * HC + (t % 3)) * 16;
+      int addr[J];
+#pragma unroll
+      for (int j = 0; j < J; j++) addr[j] = h0[j] + soff;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int j = 0; j < J; j++)
+          if (j < n_j) {
+            const i32x4 bf = *reinterpret_cast<const i32x4*>(ring + addr[j] + 2 * ks * kC3PlaneB);
+            acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf, acc[j], 0, 0, 0);
+            if constexpr (DUAL) acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(C3_BUFL(e).k[ks], bf, acc2[j], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    c3_static_for<0, NSTEP>(step);
+  }
+#undef C3_BUF
+#undef C3_BUFL
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------------
+  const int8_t* const hd = dyn + (size_t)(TMK > (1 << tms) ? (wm * 32) >> tms : 0) * hst;     // this wave's storage m-tile inside the block's images
+  const int* prm = reinterpret_cast<const int*>(hd);
+  const int row0 = ro_w + 4 * half;
+  if constexpr (DUAL) {
+    // (hi << dshift[1][row]) + lo: the two-window Horner result in Z/2^32; dshift sits behind rows | lo
+    const int* dsh = prm + (6 << tms) + row0;
+#pragma unroll
+    for (int G = 0; G < 4; G++) {
+      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int j = 0; j < J; j++)
+          acc[j][G * 4 + r] = (int)(((unsigned)acc[j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[j][G * 4 + r]);
+    }
+  }
+  const int lo_b = a.relu ? 0 : -128;
+  const int chl = cb + 16 * half;
+  auto finish = [&](auto fast_c) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    i32x4 outs[J];
+    int a16s[J][16];
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
+    requant_tiles16_rows<J, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      const int p = (wn + j * WN) * 32 + (lane & 31);
+      const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
+      if (tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
+        *reinterpret_cast<i32x4*>(a.y + (size_t)(img_px + (long long)(r0 + tr) * W + c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+    }
+  };
+  if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+// the pixel tile of a map: TW columns (the whole width up to 62, else the width in equal parts of <= 62), TH rows such that the
+// tile has <= 256 pixels and its halo <= 384, rows spread evenly over the tiles of a column
+bool conv_c3_pick_tile(int H, int W, int* TH, int* TW) {
+  if (H < 1 || W < 1) return false;
+  const int nx = (W + 61) / 62;
+  const int tw = (W + nx - 1) / nx;
+  int th = std::min(H, 256 / tw);
+  while (th > 1 && (th + 2) * (tw + 2) > kC3HaloPx) th--;
+  if (th < 1 || (th + 2) * (tw + 2) > kC3HaloPx) return false;
+  const int ny = (H + th - 1) / th;
+  th = (H + ny - 1) / ny;
+  *TH = th; *TW = tw;
+  return true;
+}
+
+bool conv_c3_shape_ok(int H, int W, int C, int Np) {
+  int th, tw;
+  if (C % 64 != 0 || C < 64 || C > 1024 || Np % 64 != 0) return false;
+  if (H < 14 || W < 14) return false;                      // (small maps: too few tiles to fill the chip, the ring / split-K kernels stay)
+  return conv_c3_pick_tile(H, W, &th, &tw);
+}
+
+template <int TMK, int SC, bool DUAL>
+static int launch_c3(const C3Args& a, hipStream_t s) {
+  constexpr int PF = (TMK == 128 && !DUAL && SC == 2) ? 5 : 2;
+  const size_t stat = (size_t)2 * SC * kC3SlabB;
+  const int tms = a.tm == 128 ? 7 : 6;
+  const size_t dyn = (size_t)(TMK > a.tm ? TMK / a.tm : 1) * ((DUAL ? 28 : 20) << tms);
+  if (stat + dyn > 160 * 1024) return 1;
+  auto fn = conv_c3_kernel<TMK, SC, DUAL, PF>;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
+  TF2_LAUNCH_NAME("conv_c3_kernel<%d channels x %dx%d pixels per block,C%d,%d slabs per chunk%s>", TMK, a.TH, a.TW, a.C, SC, DUAL ? ",dual" : "");
+  TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img, a.M / TMK), dim3(512), dyn, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
+int launch_conv_c3(const C3Args& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M) || (a.tm != 64 && a.tm != 128)) return 1;
+  const int ks = a.C / 64;
+  if ((a.tmk != 64 && a.tmk != 128) || a.M % a.tmk != 0) return 1;
+  const bool m128 = a.tmk == 128;
+#define TF2_C3(TMK_, SC_) do { return a.dual ? launch_c3<TMK_, SC_, true>(a, s) : launch_c3<TMK_, SC_, false>(a, s); } while (0)
+  if (!m128) TF2_C3(64, 1);                                // (64-channel blocks: one slab per chunk, 48 KiB of ring -- two blocks share a CU)
+  if (ks % 2 == 0) TF2_C3(128, 2);
+  TF2_C3(128, 1);
+#undef TF2_C3
+}
+
+}  // namespace tf2

@@ -386,6 +386,21 @@ bool Net::bband_at(int l, int rows) const {
   return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual);
 }
 
+// a 3x3 / stride 1 / pad 1 layer on an unsigned tensor that holds exactly C (a multiple of 64) bytes per pixel, dense one- or two-window
+// tiles of its own: conv_c3.hip takes it (the halo tile of the input streamed through LDS once instead of nine gathers)
+bool Net::c3_at(int l) const {
+  const tf2_layer_desc& L = layers[l];
+  if (L.ipool || L.k != 3 || L.stride != 1 || L.dil != 1 || L.pad_h != 1 || L.pad_w != 1 || L.src < 0 || L.add_src >= 0 || L.endpool) return false;
+  if (layers[L.src].concat >= 0 || out_Cp[L.src] != L.C || L.OH != L.H || L.OW != L.W) return false;
+  const PackLayer* pl = pack_layer(l);
+  if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128) || pl->w_share || pl->signed_in) return false;
+  if (pl->Cp_in != L.C || pl->Cp_in % 64 != 0 || pl->nslab != 9 * (pl->Cp_in / 64) || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
+  if (pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+  const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+  if (!one_window && !dual) return false;
+  return conv_c3_shape_ok(L.H, L.W, L.C, pl->Np);
+}
+
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
 // space-to-depth prep applies; the input tensor then carries 32 bytes per pixel in the same allocation.
 bool Net::stem_selected(int batch) const {
@@ -404,6 +419,8 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
+  if (const char* e = getenv("TF2_AMD_C3")) o.c3_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_C3_MIN")) o.c3_min_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -764,6 +781,33 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks &&
                           !(concurrent && pl->TM == 128 && opts.bneck_min_blocks > 1);
     if (!make_conv(l, st, !fuse_now)) return nullptr;     // the fused launch needs the pair's own (one m-tile) entries
+    if (!fuse_now && opts.c3_mode && c3_at(l)) {
+      int th = 0, tw = 0;
+      conv_c3_pick_tile(L.H, L.W, &th, &tw);
+      const int tiles_x = (L.W + tw - 1) / tw, tiles = tiles_x * ((L.H + th - 1) / th);
+      // 128 output channels per block (two waves per SIMD, the accumulators of four column tiles per wave) unless the layer has
+      // 64-row tiles only, or is a one-window layer whose 128-channel grid would leave half the chip idle (VGG16's 14 x 14 maps at
+      // batch 32: 29 / 33 us against 33 / 37; two-window rows spill at the 128 registers of the 64-channel form)
+      const PackLayer* pm = pack_layer(l);
+      int tmk = pm->Np % 128 == 0 ? 128 : 64;
+      if (tmk == 128 && !pm->dual && (long)batch * tiles * (pm->Np / 128) < 256) tmk = 64;
+      if (opts.c3_mode == 2) tmk = 64; else if (opts.c3_mode == 3 && pm->Np % 128 == 0) tmk = 128;       // (experiments)
+      Launch sc;
+      if ((long)batch * tiles * (pl->Np / tmk) >= opts.c3_min_blocks && make_conv(l, sc, false) && pack_layer(l)->TM == sc.TM) {
+        const ConvArgs& c = sc.conv;
+        C3Args& f = sc.c3;
+        f.x = c.x; f.y = c.y; f.w = c.w; f.hdr = c.hdr; f.hdr_bytes = c.hdr_bytes; f.zero2 = c.zero; f.tm = sc.TM; f.tmk = tmk;
+        f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
+        f.B = batch; f.H = L.H; f.W = L.W; f.C = L.C; f.M = pl->Np; f.x_cp = c.g.Cp_in;
+        f.TH = th; f.TW = tw; f.tiles_x = tiles_x; f.tiles_per_img = tiles;
+        set_fast_div((uint32_t)tw, &f.tw_m, &f.tw_s); set_fast_div((uint32_t)(tw + 2), &f.hc_m, &f.hc_s);
+        set_fast_div((uint32_t)tiles_x, &f.tx_m, &f.tx_s); set_fast_div((uint32_t)tiles, &f.tpi_m, &f.tpi_s);
+        f.relu = c.g.relu; f.fast = c.g.fast; f.dbl = c.g.dbl_out; f.dual = c.dual;
+        f.y_cp = c.g.y_cp; f.y_off = c.g.y_off; f.y_nvalid = c.g.y_nvalid;
+        sc.sel = Launch::SEL_C3;
+        st = sc;
+      }
+    }
     if (fuse_now) {
       fused_done[pl->fuse_next] = 1;
       // this 3x3 + its only consumer (the 1x1 expand) in one launch; the expand's argument block supplies the second half
@@ -889,6 +933,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
+        case Launch::SEL_C3: return launch_conv_c3(st.c3, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:
           if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);

@@ -144,6 +144,26 @@ struct ConvArgs {
   ConvGeom g;
 };
 
+// conv_c3.hip: a 3x3 / stride 1 / pad 1 layer of a big map, the input's halo tile streamed through LDS once (instead of nine gathers)
+struct C3Args {
+  const int8_t* x; int8_t* y;
+  const int8_t* w;             // dense weight tiles [mtile * 9 * KS + tap * KS + slab][(hi | lo)][tm rows][64]
+  const int32_t* hdr;          // per storage m-tile header images (stride hdr_bytes): rows | lo | dshift
+  const int8_t* zero2;         // C bytes: the stored form of x = 0 per input channel (the pad row of a padded layer)
+  long long* dbg;
+  int32_t hdr_bytes, tm;       // rows of a storage tile (64 / 128)
+  int32_t tmk;                 // output channels per block (64: four waves per SIMD, two blocks per CU; 128: two waves per SIMD)
+  int32_t B, H, W, C, M;       // map, input channels (= bytes per input pixel), output channels rounded up to the tile
+  int32_t x_cp;
+  int32_t TH, TW, tiles_x, tiles_per_img;
+  uint32_t tw_m, hc_m, tx_m, tpi_m; int32_t tw_s, hc_s, tx_s, tpi_s;     // set_fast_div(TW), (TW + 2), (tiles_x), (tiles_per_img)
+  int32_t relu, fast, dbl, dual;
+  int32_t y_cp, y_off, y_nvalid;
+};
+bool conv_c3_pick_tile(int H, int W, int* TH, int* TW);
+bool conv_c3_shape_ok(int H, int W, int C, int Np);
+int launch_conv_c3(const C3Args& a, void* stream);
+
 // conv_bneck.hip: layer C (3x3 / stride 1 / pad 1, C -> C channels, C = 64 / 128 / 256) followed by its only consumer E
 // (1x1, C -> 4C, + residual): one launch per R x W pixel band of an image.
 struct BneckArgs {
