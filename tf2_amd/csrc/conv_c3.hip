@@ -111,6 +111,9 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
       }
     }
   };
+  long long* const dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;     // tools/c3_timeline.py: 100 MHz wall clock
+#define C3_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  C3_STAMP(0);
   issue_chunk(0, ring);
   if (NC > 1) issue_chunk(1, ring + CHUNK);
   // header images of the block's channels (rows {bias | dbl, alpha, addend64} | lo | dshift[P]) by ordinary loads
@@ -161,15 +164,24 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   }
   n_j = __builtin_amdgcn_readfirstlane(n_j);
 
-  i32x16 acc[J], acc2[DUAL ? J : 1];
-#pragma unroll
-  for (int j = 0; j < J; j++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc[j][r] = 0; if (DUAL) acc2[j][r] = 0; }
-
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                            // chunks 0 and 1, header: complete in every wave
   asm volatile("" ::: "memory");
+  C3_STAMP(1);
+
+  // Everything from here on exists twice: for waves all of whose J column tiles hold pixels of the tile, and for waves whose LAST
+  // one lies beyond it (4 x 56 and 7 x 28 pixel tiles fill 7 of 8 column tiles) -- chosen once per wave, so that the K loop is
+  // straight-line code over exactly the tiles that count (a branch per column tile inside the loop put every ds_read right in front
+  // of its MFMA behind a full wait: 58 % of the matrix rate; computing the empty tile costs an eighth of the MFMAs).  Both versions
+  // pass the same barriers.
+  auto run = [&](auto nj_c) __attribute__((always_inline)) {
+  constexpr int NJ = decltype(nj_c)::value;
+  i32x16 acc[NJ], acc2[DUAL ? NJ : 1];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[j][r] = 0; if (DUAL) acc2[j][r] = 0; }
+
 
   // ---- the K loop: chunks at run time, the NSTEP = SC * 9 steps of a chunk unrolled --------------------------------------------
 #pragma unroll 1
@@ -209,23 +221,28 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
       }
       // (slab, tap) -> a wave-uniform byte offset; one address add per column tile, the K half is an immediate
       const int soff = rb + sl * kC3SlabB + ((t / 3) * HC + (t % 3)) * 16;
-      int addr[J];
+      int addr[NJ];
 #pragma unroll
-      for (int j = 0; j < J; j++) addr[j] = h0[j] + soff;
+      for (int j = 0; j < NJ; j++) addr[j] = h0[j] + soff;
+      // (straight-line: a branch per column tile put every ds_read right in front of its MFMA behind a full wait -- 58 % of the
+      //  matrix rate; a column tile beyond the pixel tile, 1 of 8 for a 4 x 56 / 7 x 28 tile, is computed on pixel 0 and dropped)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
+        i32x4 bf[NJ];
 #pragma unroll
-        for (int j = 0; j < J; j++)
-          if (j < n_j) {
-            const i32x4 bf = *reinterpret_cast<const i32x4*>(ring + addr[j] + 2 * ks * kC3PlaneB);
-            acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf, acc[j], 0, 0, 0);
-            if constexpr (DUAL) acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(C3_BUFL(e).k[ks], bf, acc2[j], 0, 0, 0);
-          }
+        for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(ring + addr[j] + 2 * ks * kC3PlaneB);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
+          if constexpr (DUAL) acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(C3_BUFL(e).k[ks], bf[j], acc2[j], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     c3_static_for<0, NSTEP>(step);
+    if (c < 8) C3_STAMP(2 + c);
   }
+  C3_STAMP(10);
 #undef C3_BUF
 #undef C3_BUFL
 
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int j = 0; j < J; j++)
+        for (int j = 0; j < NJ; j++)
           acc[j][G * 4 + r] = (int)(((unsigned)acc[j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[j][G * 4 + r]);
     }
   }
@@ -250,15 +267,15 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   const int chl = cb + 16 * half;
   auto finish = [&](auto fast_c) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_c)::value;
-    i32x4 outs[J];
-    int a16s[J][16];
+    i32x4 outs[NJ];
+    int a16s[NJ][16];
 #pragma unroll
-    for (int j = 0; j < J; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
-    requant_tiles16_rows<J, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+    requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
 #pragma unroll
-    for (int j = 0; j < J; j++) {
+    for (int j = 0; j < NJ; j++) {
       const int p = (wn + j * WN) * 32 + (lane & 31);
       const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
       if (tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
@@ -266,6 +283,10 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
     }
   };
   if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
+  };
+  if (n_j >= J) run(std::integral_constant<int, J>{}); else run(std::integral_constant<int, (J > 1 ? J - 1 : 1)>{});
+  C3_STAMP(11);
+#undef C3_STAMP
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
