@@ -121,6 +121,7 @@ def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
     kernel switched off."""
     monkeypatch.setenv("TF2_AMD_C3", c3)
     monkeypatch.setenv("TF2_AMD_C3_MIN", "1")
+    monkeypatch.setenv("TF2_AMD_C3_MIN256", "1")           # 256-channel blocks (two row tiles per wave) wherever a layer allows them
     t = cfg.vgg16_tables(64, 10)
     q = synth.synth_q_values(t, 7, spread=2)
     rig = Rig(t, q, synth.synth_model(t, q, 7), 0)

@@ -54,11 +54,15 @@ constexpr int kC3SlabB = 4 * kC3PlaneB;      // bytes of one 64-channel slab of 
 // chunk walk).  The VM counter retires in order, so a wave's first wait for a fragment loaded AFTER its share of a chunk's DMAs also
 // waits for those DMAs: a chunk gets PF + 1 steps to land before its issuing wave stalls -- 0.75 us at PF = 2 against ~2 us of
 // latency under load, every chunk.  PF = 5 where the registers allow it (one-window 128-channel blocks).
+// MT: row tiles per wave (TMK = 256: two -- a B fragment then feeds two MFMAs, half the LDS reads per MFMA; one-window layers only,
+// the accumulators of 2 x 4 tiles are 128 registers)
 template <int TMK, int SC, bool DUAL, int PF>
 __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args a) {
+  constexpr int MT = TMK == 256 ? 2 : 1;
+  static_assert(MT == 1 || !DUAL, "two row tiles per wave: one accumulator set only");
   constexpr int NBUF = PF + 1;
   static_assert((SC * 9) % NBUF == 0, "the buffer rotation must close over a chunk");
-  constexpr int WM = TMK / 32, WN = 8 / WM, NT = 8, J = NT / WN;
+  constexpr int WM = TMK / (32 * MT), WN = 8 / WM, NT = 8, J = NT / WN;
   constexpr int NG = kC3HaloPx / 64;                       // DMA groups per plane
   constexpr int CHUNK = SC * kC3SlabB;
   constexpr int NSTEP = SC * 9;                            // steps (slab, tap) per chunk
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   const int ty = fast_div(tile, a.tx_m, a.tx_s), tx = tile - ty * a.tiles_x;
   const int r0 = ty * TH, c0 = tx * TW;
   const int rows = (H - r0) < TH ? (H - r0) : TH, cols = (W - c0) < TW ? (W - c0) : TW;
-  const int cb = blockIdx.y * TMK + wm * 32;               // this wave's first output channel
+  const int cb = blockIdx.y * TMK + wm * (32 * MT);        // this wave's first output channel
   const long long img_px = (long long)img * H * W;
 
   // ---- this lane's input pixels of the DMA groups: byte offset into x, or -1 for the zero border / outside the image ----------
@@ -128,18 +132,22 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   }
 
   // ---- weight fragments ------------------------------------------------------------------------------------------------------
-  struct Afr { i32x4 k[2]; };
+  struct Afr { i32x4 k[MT][2]; };
   const unsigned a_lane_off = (unsigned)((lane & 31) * 64 + half * 16);
   const int wins = DUAL ? 2 : 1;
   const int nslab = 9 * KS;
-  const int mt_w = cb >> tms, ro_w = cb & ((1 << tms) - 1);
   // step (chunk c, e = slab sl * 9 + tap t) -> packed slab t * KS + c * SC + sl
   auto load_a = [&](Afr& f, int c, int e, int win) __attribute__((always_inline)) {
     const int sl = e / 9, t = e - sl * 9;
     const int slab = t * KS + c * SC + sl;
-    const int8_t* pu = a.w + (((((size_t)mt_w * nslab + slab) * wins + win) << tms) + ro_w) * 64;
-    f.k[0] = *reinterpret_cast<const i32x4*>(pu + a_lane_off);
-    f.k[1] = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int ch = cb + i * 32;
+      const int mt_w = ch >> tms, ro_w = ch & ((1 << tms) - 1);
+      const int8_t* pu = a.w + (((((size_t)mt_w * nslab + slab) * wins + win) << tms) + ro_w) * 64;
+      f.k[i][0] = *reinterpret_cast<const i32x4*>(pu + a_lane_off);
+      f.k[i][1] = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
+    }
   };
   Afr fb[NBUF], gb[DUAL ? NBUF : 1];                        // rotating buffers, static indices (hi window; DUAL: gb = lo window)
 #define C3_BUF(v) fb[(v) % NBUF]
@@ -176,11 +184,15 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   // pass the same barriers.
   auto run = [&](auto nj_c) __attribute__((always_inline)) {
   constexpr int NJ = decltype(nj_c)::value;
-  i32x16 acc[NJ], acc2[DUAL ? NJ : 1];
+  i32x16 acc[MT][NJ], acc2[DUAL ? NJ : 1];
 #pragma unroll
   for (int j = 0; j < NJ; j++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) { acc[j][r] = 0; if (DUAL) acc2[j][r] = 0; }
+    for (int r = 0; r < 16; r++) {
+#pragma unroll
+      for (int i = 0; i < MT; i++) acc[i][j][r] = 0;
+      if (DUAL) acc2[j][r] = 0;
+    }
 
 
   // ---- the K loop: chunks at run time, the NSTEP = SC * 9 steps of a chunk unrolled --------------------------------------------
@@ -233,8 +245,9 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
         for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(ring + addr[j] + 2 * ks * kC3PlaneB);
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-          acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
-          if constexpr (DUAL) acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(C3_BUFL(e).k[ks], bf[j], acc2[j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < MT; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[i][ks], bf[j], acc[i][j], 0, 0, 0);
+          if constexpr (DUAL) acc2[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(C3_BUFL(e).k[0][ks], bf[j], acc2[j], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -247,39 +260,43 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
 #undef C3_BUFL
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------------------
-  const int8_t* const hd = dyn + (size_t)(TMK > (1 << tms) ? (wm * 32) >> tms : 0) * hst;     // this wave's storage m-tile inside the block's images
-  const int* prm = reinterpret_cast<const int*>(hd);
-  const int row0 = ro_w + 4 * half;
-  if constexpr (DUAL) {
-    // (hi << dshift[1][row]) + lo: the two-window Horner result in Z/2^32; dshift sits behind rows | lo
-    const int* dsh = prm + (6 << tms) + row0;
-#pragma unroll
-    for (int G = 0; G < 4; G++) {
-      const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-          acc[j][G * 4 + r] = (int)(((unsigned)acc[j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[j][G * 4 + r]);
-    }
-  }
   const int lo_b = a.relu ? 0 : -128;
-  const int chl = cb + 16 * half;
   auto finish = [&](auto fast_c) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_c)::value;
-    i32x4 outs[NJ];
-    int a16s[NJ][16];
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
+    for (int i = 0; i < MT; i++) {
+      const int ch = cb + i * 32;
+      const int8_t* const hd = dyn + (size_t)((ch - blockIdx.y * TMK) >> tms) * hst;     // this row tile's storage m-tile inside the block's images
+      const int* prm = reinterpret_cast<const int*>(hd);
+      const int row0 = (ch & ((1 << tms) - 1)) + 4 * half;
+      if constexpr (DUAL) {
+        // (hi << dshift[1][row]) + lo: the two-window Horner result in Z/2^32; dshift sits behind rows | lo
+        const int* dsh = prm + (6 << tms) + row0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
-    requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+        for (int G = 0; G < 4; G++) {
+          const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int p = (wn + j * WN) * 32 + (lane & 31);
-      const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
-      if (tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
-        *reinterpret_cast<i32x4*>(a.y + (size_t)(img_px + (long long)(r0 + tr) * W + c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+              acc[i][j][G * 4 + r] = (int)(((unsigned)acc[i][j][G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[j][G * 4 + r]);
+        }
+      }
+      const int chl = ch + 16 * half;
+      i32x4 outs[NJ];
+      int a16s[NJ][16];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a16s[j][r] = acc[i][j][r];
+      requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int p = (wn + j * WN) * 32 + (lane & 31);
+        const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
+        if (tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
+          *reinterpret_cast<i32x4*>(a.y + (size_t)(img_px + (long long)(r0 + tr) * W + c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+      }
     }
   };
   if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
@@ -315,6 +332,7 @@ bool conv_c3_shape_ok(int H, int W, int C, int Np) {
 template <int TMK, int SC, bool DUAL>
 static int launch_c3(const C3Args& a, hipStream_t s) {
   constexpr int PF = (TMK == 128 && !DUAL && SC == 2) ? 5 : 2;
+  if constexpr (TMK == 256 && DUAL) return 1; else {
   const size_t stat = (size_t)2 * SC * kC3SlabB;
   const int tms = a.tm == 128 ? 7 : 6;
   const size_t dyn = (size_t)(TMK > a.tm ? TMK / a.tm : 1) * ((DUAL ? 28 : 20) << tms);
@@ -324,15 +342,17 @@ static int launch_c3(const C3Args& a, hipStream_t s) {
   TF2_LAUNCH_NAME("conv_c3_kernel<%d channels x %dx%d pixels per block,C%d,%d slabs per chunk%s>", TMK, a.TH, a.TW, a.C, SC, DUAL ? ",dual" : "");
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img, a.M / TMK), dim3(512), dyn, s, a);
   return launch_ok() ? 0 : -1;
+  }
 }
 
 int launch_conv_c3(const C3Args& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M) || (a.tm != 64 && a.tm != 128)) return 1;
   const int ks = a.C / 64;
-  if ((a.tmk != 64 && a.tmk != 128) || a.M % a.tmk != 0) return 1;
+  if ((a.tmk != 64 && a.tmk != 128 && a.tmk != 256) || a.M % a.tmk != 0 || (a.tmk == 256 && a.dual)) return 1;
   const bool m128 = a.tmk == 128;
 #define TF2_C3(TMK_, SC_) do { return a.dual ? launch_c3<TMK_, SC_, true>(a, s) : launch_c3<TMK_, SC_, false>(a, s); } while (0)
+  if (a.tmk == 256) { if (ks % 2 == 0) return launch_c3<256, 2, false>(a, s); return launch_c3<256, 1, false>(a, s); }
   if (!m128) TF2_C3(64, 1);                                // (64-channel blocks: one slab per chunk, 48 KiB of ring -- two blocks share a CU)
   if (ks % 2 == 0) TF2_C3(128, 2);
   TF2_C3(128, 1);

@@ -421,6 +421,7 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_C3")) o.c3_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_C3_MIN")) o.c3_min_blocks = atol(e);
+  if (const char* e = getenv("TF2_AMD_C3_MIN256")) o.c3_min256 = atol(e);
   if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
   if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -791,6 +792,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const PackLayer* pm = pack_layer(l);
       int tmk = pm->Np % 128 == 0 ? 128 : 64;
       if (tmk == 128 && !pm->dual && (long)batch * tiles * (pm->Np / 128) < 256) tmk = 64;
+      // one-window layers of 256+ channels whose 256-channel grid still covers the chip: two row tiles per wave (a B fragment feeds
+      // two MFMAs: half the LDS reads per MFMA, half the blocks' prologues)
+      if (tmk == 128 && !pm->dual && pm->Np % 256 == 0 && (long)batch * tiles * (pm->Np / 256) >= opts.c3_min256) tmk = 256;
       if (opts.c3_mode == 2) tmk = 64; else if (opts.c3_mode == 3 && pm->Np % 128 == 0) tmk = 128;       // (experiments)
       Launch sc;
       if ((long)batch * tiles * (pl->Np / tmk) >= opts.c3_min_blocks && make_conv(l, sc, false) && pack_layer(l)->TM == sc.TM) {

@@ -88,6 +88,7 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   long bneck_min_blocks = 200;
   int c3_mode = 1;           // TF2_AMD_C3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
   long c3_min_blocks = 96;   // TF2_AMD_C3_MIN: smallest grid that takes it
+  long c3_min256 = 200;      // TF2_AMD_C3_MIN256: smallest grid of 256-channel blocks (one-window layers; else 128-channel blocks)
   long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
   long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
   long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
