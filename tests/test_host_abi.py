@@ -191,6 +191,35 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
         net.describe_launches(0, 0)
 
 
+def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
+    """The other BASELINE configurations' plans, without a device: a 3x3 first layer on the 3-channel image runs as a pointwise layer
+    over the im2col image the input kernel writes (Net::init); the 3x3 / 1 / pad 1 body layers of maps >= 14 x 14 take conv_c3.hip
+    (64 / 128 / 256 output channels per block by channel count, windows and grid); both can be switched off per handle."""
+    def launches(t, batch, seed=0):
+        q = synth.synth_q_values(t, seed, spread=1)
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, seed)); net.Pack(0)
+        return net.describe_launches(batch, 0)
+    v = launches(cfg.vgg16_tables(), 32)
+    assert "im2col" in v[0]["kernel"] and v[1]["layer"] == 0 and "conv_pw" in v[1]["kernel"]
+    c3 = [r for r in v if "conv_c3" in r["kernel"]]
+    assert [r["layer"] for r in c3] == list(range(1, 13))                      # conv1_2 .. conv5_3
+    assert c3[0]["kernel"].startswith("conv_c3_kernel<64 channels x 4x56 pixels") and c3[0]["grid"] == 32 * 4 * 56
+    assert all(r["block"] == 512 and r["lds_bytes"] <= 8192 for r in c3)
+    sizes = {r["layer"]: int(r["kernel"].split("<")[1].split(" ")[0]) for r in c3}
+    duals = {r["layer"] for r in c3 if "dual" in r["kernel"]}
+    assert all(sizes[l] in (64, 128) for l in duals)                            # two accumulator sets: one row tile per wave
+    assert all(sizes[l] in (64, 256) for l in sizes if l >= 5 and l not in duals)      # one-window layers of 256+ channels: 256 per block where the grid allows
+    assert sizes[11] == 64 or 11 in duals                                        # 14 x 14: 32 tiles -- the small grid takes 64-channel blocks
+    s = launches(cfg.squeezenet11_tables(), 32)
+    assert "im2col" in s[0]["kernel"] and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"
+    assert {r["layer"] for r in s if "conv_c3" in r["kernel"]} == {21, 24}       # its 3x3 layers have 16-64 input channels: the two 64-channel ones on 14 x 14
+    assert any("conv_c3" in r["kernel"] for r in launches(cfg.ssd300_tables(), 32))
+    monkeypatch.setenv("TF2_AMD_C3", "0"); monkeypatch.setenv("TF2_AMD_IM2COL0", "0")
+    v0 = launches(cfg.vgg16_tables(), 32)
+    assert not any("conv_c3" in r["kernel"] or "im2col" in r["kernel"] for r in v0) and "conv_mfma2" in v0[1]["kernel"]
+
+
 def test_run_ex_rejects_bad_options_without_touching_the_device():
     t = cfg.tiny_tables()
     q = synth.synth_q_values(t, 0)
