@@ -56,8 +56,9 @@ constexpr int kC3SlabB = 4 * kC3PlaneB;      // bytes of one 64-channel slab of 
 // latency under load, every chunk.  PF = 5 where the registers allow it (one-window 128-channel blocks).
 // MT: row tiles per wave (TMK = 256: two -- a B fragment then feeds two MFMAs, half the LDS reads per MFMA; one-window layers only,
 // the accumulators of 2 x 4 tiles are 128 registers)
-template <int TMK, int SC, bool DUAL, int PF>
-__global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args a) {
+// PERSIST: a block walks several pixel tiles (the host caps the grid); else one tile per block
+template <int TMK, int SC, bool DUAL, int PF, bool PERSIST>
+__global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_kernel(C3Args a) {
   constexpr int MT = TMK == 256 ? 2 : 1;
   static_assert(MT == 1 || !DUAL, "two row tiles per wave: one accumulator set only");
   constexpr int NBUF = PF + 1;
@@ -85,41 +86,59 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
-  const int img = fast_div(bid, a.tpi_m, a.tpi_s);
-  const int tile = bid - img * a.tiles_per_img;
-  const int ty = fast_div(tile, a.tx_m, a.tx_s), tx = tile - ty * a.tiles_x;
-  const int r0 = ty * TH, c0 = tx * TW;
-  const int rows = (H - r0) < TH ? (H - r0) : TH, cols = (W - c0) < TW ? (W - c0) : TW;
   const int cb = blockIdx.y * TMK + wm * (32 * MT);        // this wave's first output channel
-  const long long img_px = (long long)img * H * W;
+  // A block walks pixel tiles bid, bid + gridDim.x, ... of its channel group (the host caps the grid at what the chip holds at once):
+  // the chunk stream runs on across tiles -- while the last chunk of a tile is multiplied, the first chunk of the NEXT tile lands in
+  // the other buffer -- so only a block's first tile pays the DMA latency in the open (3.7 us per tile before: more than the 1.5 us
+  // of MFMA work a 64-channel layer's tile has), and the header image is fetched once per block.
+  const int n_units = PERSIST ? a.B * a.tiles_per_img : bid + 1;      // (one tile per block: the loops below run once)
+  const int ustride = PERSIST ? (int)gridDim.x : 1;
+  struct Tile { int r0, c0, rows, cols; long long img_px; };
+  auto tile_of = [&](int unit) __attribute__((always_inline)) {
+    Tile t;
+    const int img = fast_div(unit, a.tpi_m, a.tpi_s);
+    const int tile = unit - img * a.tiles_per_img;
+    const int ty = fast_div(tile, a.tx_m, a.tx_s), tx = tile - ty * a.tiles_x;
+    t.r0 = ty * TH; t.c0 = tx * TW;
+    t.rows = (H - t.r0) < TH ? (H - t.r0) : TH; t.cols = (W - t.c0) < TW ? (W - t.c0) : TW;
+    t.img_px = (long long)img * H * W;
+    return t;
+  };
 
-  // ---- this lane's input pixels of the DMA groups: byte offset into x, or -1 for the zero border / outside the image ----------
-  long long poff[NG];
+  // ---- the producer side: the tile whose chunks are being fetched, this lane's input pixels of its DMA groups (byte offset into x,
+  // or -1 for the zero border / outside the image)
+  // (the lane's halo pixels are decoded again at every chunk issue -- a dozen VALU instructions per DMA group -- rather than held in
+  //  registers across the K loop)
   const int n_halo = (TH + 2) * HC;
-#pragma unroll
-  for (int g = 0; g < NG; g++) {
-    const int hp = g * 64 + lane;
-    const int hr = fast_div(hp, a.hc_m, a.hc_s), hc = hp - hr * HC;
-    const int r = r0 - 1 + hr, c = c0 - 1 + hc;
-    poff[g] = (hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) ? (img_px + (long long)r * W + c) * a.x_cp : -1;
-  }
-  // chunk c -> ring buffer: wave w issues (slab w / 4 of the chunk, plane w % 4) for every group (SC = 1: waves 0..3)
-  auto issue_chunk = [&](int c, int8_t* buf) __attribute__((always_inline)) {
+  int unit_p = bid, c_p = 0;                               // producer position: (tile, chunk) of the NEXT chunk to fetch
+  // chunk c of tile `unit` -> ring buffer: wave w issues (slab w / 4 of the chunk, plane w % 4) for every group (SC = 1: waves 0..3)
+  auto issue_chunk = [&](int unit, int c, int8_t* buf) __attribute__((always_inline)) {
     if (wave < SC * 4) {
+      const Tile t = tile_of(unit);
       const int sl = wave >> 2, k = wave & 3;
       const int coff = (c * SC + sl) * 64 + k * 16;
 #pragma unroll
       for (int g = 0; g < NG; g++) {
-        const int8_t* src = poff[g] >= 0 ? a.x + poff[g] + coff : a.zero2 + coff;
+        const int hp = g * 64 + lane;
+        const int hr = fast_div(hp, a.hc_m, a.hc_s), hc = hp - hr * HC;
+        const int r = t.r0 - 1 + hr, cc = t.c0 - 1 + hc;
+        const bool in = hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)cc < (unsigned)W;
+        const int8_t* src = in ? a.x + (t.img_px + (long long)r * W + cc) * a.x_cp + coff : a.zero2 + coff;
         c3_dma16(src, buf + sl * kC3SlabB + k * kC3PlaneB + g * 1024);
       }
     }
   };
   long long* const dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;     // tools/c3_timeline.py: 100 MHz wall clock
 #define C3_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  // fetch the producer's next chunk into `buf` (nothing once the block's last tile is complete) and advance
+  auto produce = [&](int8_t* buf) __attribute__((always_inline)) {
+    if (unit_p >= n_units) return;
+    issue_chunk(unit_p, c_p, buf);
+    if (++c_p == NC) { c_p = 0; unit_p += ustride; }
+  };
   C3_STAMP(0);
-  issue_chunk(0, ring);
-  if (NC > 1) issue_chunk(1, ring + CHUNK);
+  produce(ring);
+  produce(ring + CHUNK);
   // header images of the block's channels (rows {bias | dbl, alpha, addend64} | lo | dshift[P]) by ordinary loads
   {
     const int per = (DUAL ? 7 : 5) << (tms - 2);            // 16-byte pieces per storage m-tile
@@ -184,6 +203,12 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
   // pass the same barriers.
   auto run = [&](auto nj_c) __attribute__((always_inline)) {
   constexpr int NJ = decltype(nj_c)::value;
+  int gc = 0;                                              // chunks consumed so far (ring buffer = gc & 1)
+#pragma unroll 1
+  for (int unit = bid; unit < n_units; unit += ustride) {
+  const Tile T = tile_of(unit);
+  const int r0 = T.r0, c0 = T.c0, rows = T.rows, cols = T.cols;
+  const long long img_px = T.img_px;
   i32x16 acc[MT][NJ], acc2[DUAL ? NJ : 1];
 #pragma unroll
   for (int j = 0; j < NJ; j++)
@@ -197,13 +222,13 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
 
   // ---- the K loop: chunks at run time, the NSTEP = SC * 9 steps of a chunk unrolled --------------------------------------------
 #pragma unroll 1
-  for (int c = 0; c < NC; c++) {
-    const int rb = (c & 1) * CHUNK;
+  for (int c = 0; c < NC; c++, gc++) {
+    const int rb = (gc & 1) * CHUNK;
     auto step = [&](auto e_c) __attribute__((always_inline)) {
       constexpr int e = decltype(e_c)::value;
       constexpr int sl = e / 9, t = e % 9;
       if constexpr (e == 0) {
-        if (c > 0) {
+        if (gc > 0) {
           // chunk c landed in every wave and nobody reads the other buffer any more.  This wave's DMAs of chunk c were issued at the
           // first step of chunk c - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
           // other NSTEP - 1 steps, of which at most the last two steps' still fly (conv_bband.hip step0).
@@ -221,14 +246,14 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
       // fragments of step e + PF (the next chunk's first steps at the end; past the last chunk: a valid address, never used)
       {
         constexpr int e2 = (e + PF) % NSTEP;
-        const int c2 = (e + PF >= NSTEP) ? (c + 1 < NC ? c + 1 : c) : c;
+        const int c2 = (e + PF >= NSTEP) ? (c + 1 < NC ? c + 1 : 0) : c;      // (past a tile's last chunk: the next tile's chunk 0 -- the same weights)
         load_a(C3_BUF(e + PF), c2, e2, 0);
         if constexpr (DUAL) load_a(C3_BUFL(e + PF), c2, e2, 1);
       }
       if constexpr (e == 0) {
-        if (c > 0 && c + 1 < NC) {
+        if (gc > 0) {
           asm volatile("" ::: "memory");
-          issue_chunk(c + 1, ring + ((c + 1) & 1) * CHUNK);   // (behind this step's fragment loads)
+          produce(ring + ((gc + 1) & 1) * CHUNK);           // (behind this step's fragment loads; the buffer chunk gc - 1 was read from)
         }
       }
       // (slab, tap) -> a wave-uniform byte offset; one address add per column tile, the K half is an immediate
@@ -253,9 +278,9 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
       __builtin_amdgcn_sched_barrier(0);
     };
     c3_static_for<0, NSTEP>(step);
-    if (c < 8) C3_STAMP(2 + c);
+    if (gc < 8) C3_STAMP(2 + gc);
   }
-  C3_STAMP(10);
+  if (unit == bid) C3_STAMP(10);
 #undef C3_BUF
 #undef C3_BUFL
 
@@ -300,6 +325,7 @@ __global__ __launch_bounds__(512, TMK == 64 ? 4 : 2) void conv_c3_kernel(C3Args 
     }
   };
   if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
+  }
   };
   if (n_j >= J) run(std::integral_constant<int, J>{}); else run(std::integral_constant<int, (J > 1 ? J - 1 : 1)>{});
   C3_STAMP(11);
@@ -329,20 +355,53 @@ bool conv_c3_shape_ok(int H, int W, int C, int Np) {
   return conv_c3_pick_tile(H, W, &th, &tw);
 }
 
-template <int TMK, int SC, bool DUAL>
-static int launch_c3(const C3Args& a, hipStream_t s) {
+// CUs of the current device (256 when only describing a launch, without a device)
+static int tf2_cu_count() {
+  if (launch_recorder()) return 256;
+  static thread_local int cached_dev = -1, n = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev != cached_dev) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cached_dev = dev;
+  }
+  return n;
+}
+
+template <int TMK, int SC, bool DUAL, bool PERSIST>
+static int launch_c3p(const C3Args& a, hipStream_t s) {
   constexpr int PF = (TMK == 128 && !DUAL && SC == 2) ? 5 : 2;
   if constexpr (TMK == 256 && DUAL) return 1; else {
   const size_t stat = (size_t)2 * SC * kC3SlabB;
   const int tms = a.tm == 128 ? 7 : 6;
   const size_t dyn = (size_t)(TMK > a.tm ? TMK / a.tm : 1) * ((DUAL ? 28 : 20) << tms);
   if (stat + dyn > 160 * 1024) return 1;
-  auto fn = conv_c3_kernel<TMK, SC, DUAL, PF>;
+  auto fn = conv_c3_kernel<TMK, SC, DUAL, PF, PERSIST>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
   TF2_LAUNCH_NAME("conv_c3_kernel<%d channels x %dx%d pixels per block,C%d,%d slabs per chunk%s>", TMK, a.TH, a.TW, a.C, SC, DUAL ? ",dual" : "");
-  TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img, a.M / TMK), dim3(512), dyn, s, a);
+  // as many blocks per channel group as the chip holds at once (TMK = 64: two per CU), each walking every grid-th tile
+  const int n_units = a.B * a.tiles_per_img, groups = a.M / TMK;
+  const int resident = ((TMK == 64 && !PERSIST) ? 2 : 1) * tf2_cu_count();
+  int gx = std::max(1, resident / groups);
+  if (gx > n_units || !PERSIST) gx = n_units;
+  if (a.dbg) gx = n_units;                                  // (timeline tool: one tile per block)
+  TF2_LAUNCH(fn, dim3(gx, groups), dim3(512), dyn, s, a);
   return launch_ok() ? 0 : -1;
   }
+}
+
+// the several-tiles form: 128-channel blocks always (no spill); 64-channel blocks where a block would otherwise see a long row of
+// short tiles (one K slab: 1.5 us of MFMA work behind a 3.7 us prologue each) -- then at two waves per SIMD, one block per CU;
+// 256-channel blocks never (they spill in that form: experiment 20)
+template <int TMK, int SC, bool DUAL>
+static int launch_c3(const C3Args& a, hipStream_t s) {
+  if constexpr (TMK == 128) return launch_c3p<TMK, SC, DUAL, true>(a, s);
+  else if constexpr (TMK == 64) {
+    const long tiles_per_block = (long)a.B * a.tiles_per_img * (a.M / 64) / std::max(1, tf2_cu_count());
+    if (a.C == 64 && tiles_per_block >= 8 && !a.dbg) return launch_c3p<TMK, SC, DUAL, true>(a, s);
+    return launch_c3p<TMK, SC, DUAL, false>(a, s);
+  } else return launch_c3p<TMK, SC, DUAL, false>(a, s);
 }
 
 int launch_conv_c3(const C3Args& a, void* stream) {
