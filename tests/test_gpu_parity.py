@@ -122,6 +122,7 @@ def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
     monkeypatch.setenv("TF2_AMD_C3", c3)
     monkeypatch.setenv("TF2_AMD_C3_MIN", "1")
     monkeypatch.setenv("TF2_AMD_C3_MIN256", "1")           # 256-channel blocks (two row tiles per wave) wherever a layer allows them
+    monkeypatch.setenv("TF2_AMD_C3_W9", "2")               # the weights-resident kernel for the 64 -> 64 layer although a block walks few tiles
     t = cfg.vgg16_tables(64, 10)
     q = synth.synth_q_values(t, 7, spread=2)
     rig = Rig(t, q, synth.synth_model(t, q, 7), 0)
@@ -129,6 +130,13 @@ def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
     assert any("conv_c3" in n for n in names) == (c3 == "1"), names
     x = synth.synth_images(t, 3, 7)
     rig.check_all_layers(x)
+    # one Q value per tensor: every layer one-window -- the 64 -> 64 layer then takes the weights-resident kernel (conv_c3_w9: nine
+    # fragments in registers, the input three tiles ahead), the 256- and 512-channel ones 256-channel blocks
+    q1 = synth.synth_q_values(t, 0, spread=1)
+    rig1 = Rig(t, q1, synth.synth_model(t, q1, 0), 0)
+    names1 = [r["kernel"] for r in rig1.net.describe_launches(5, 0)]
+    assert any("conv_c3_w9" in n for n in names1) == (c3 == "1") and any("<256 channels" in n for n in names1) == (c3 == "1"), names1
+    rig1.check_all_layers(synth.synth_images(t, 5, 2))
     t = cfg.tiny_tables(hw=40, widths=(64, 128), classes=10)      # a map of 20 x 20 (one tile with a ragged last column tile), residual net
     q = synth.synth_q_values(t, 3, spread=2)
     Rig(t, q, synth.synth_model(t, q, 3), 0).check_all_layers(synth.synth_images(t, 2, 3))

@@ -204,7 +204,7 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert "im2col" in v[0]["kernel"] and v[1]["layer"] == 0 and "conv_pw" in v[1]["kernel"]
     c3 = [r for r in v if "conv_c3" in r["kernel"]]
     assert [r["layer"] for r in c3] == list(range(1, 13))                      # conv1_2 .. conv5_3
-    assert c3[0]["kernel"].startswith("conv_c3_kernel<64 channels x 4x56 pixels") and c3[0]["grid"] == 256     # 7168 tiles walked by one block per CU
+    assert c3[0]["kernel"].startswith("conv_c3_w9_kernel<64 channels x 4x56 pixels") and c3[0]["grid"] == 256  # 7168 tiles walked by one block per CU, weights resident
     assert all(r["grid"] <= 256 for r in c3 if "<128 channels" in r["kernel"])  # 128-channel blocks: at most what the chip holds at once
     assert all(r["block"] == 512 and r["lds_bytes"] <= 8192 for r in c3)
     sizes = {r["layer"]: int(r["kernel"].split("<")[1].split(" ")[0]) for r in c3}

@@ -332,6 +332,156 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
 #undef C3_STAMP
 }
 
+// ---- one-slab layers (C = 64, one window, 64 output channels: VGG16's conv1_2, SSD300's) -------------------------------------------------
+// A tile of such a layer is 1.1 us of MFMA work behind the latency of its own input: in conv_c3_kernel the next tile's DMAs have one
+// tile's time to land, and issuing them earlier is pointless while weight fragments are loaded inside the loop (the VM counter
+// retires in order).  Here the nine weight fragments (72 registers) are loaded ONCE per block, the K loop holds no load at all, and
+// the input runs THREE tiles ahead through four 24 KiB slab buffers: the only counted wait is on the DMAs themselves (a tile's output
+// stores, younger, only make it stricter).  One block per CU walks every 256th tile.
+__global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
+  constexpr int WM = 2, WN = 4, J = 2, NB = 4, NG = kC3HaloPx / 64;
+  __shared__ __attribute__((aligned(1024))) int8_t ring[NB * kC3SlabB];
+  extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int half = lane >> 5;
+  const int H = a.H, W = a.W, TH = a.TH, TW = a.TW, HC = TW + 2;
+  const int tms = a.tm == 128 ? 7 : 6;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int cb = blockIdx.y * 64 + wm * 32;
+  const int n_units = a.B * a.tiles_per_img, ustride = gridDim.x;
+  struct Tile { int r0, c0, rows, cols; long long img_px; };
+  auto tile_of = [&](int unit) __attribute__((always_inline)) {
+    Tile t;
+    const int img = fast_div(unit, a.tpi_m, a.tpi_s);
+    const int tile = unit - img * a.tiles_per_img;
+    const int ty = fast_div(tile, a.tx_m, a.tx_s), tx = tile - ty * a.tiles_x;
+    t.r0 = ty * TH; t.c0 = tx * TW;
+    t.rows = (H - t.r0) < TH ? (H - t.r0) : TH; t.cols = (W - t.c0) < TW ? (W - t.c0) : TW;
+    t.img_px = (long long)img * H * W;
+    return t;
+  };
+  const int n_halo = (TH + 2) * HC;
+  int unit_p = bid, gp = 0;                                // producer: next tile to fetch, tiles fetched so far
+  auto produce = [&]() __attribute__((always_inline)) {    // waves 0..3: plane `wave` of the tile's slab, six DMA groups each
+    if (unit_p < n_units) {
+      if (wave < 4) {
+        const Tile t = tile_of(unit_p);
+        int8_t* const buf = ring + (gp % NB) * kC3SlabB + wave * kC3PlaneB;
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+          const int hp = g * 64 + lane;
+          const int hr = fast_div(hp, a.hc_m, a.hc_s), hc = hp - hr * HC;
+          const int r = t.r0 - 1 + hr, cc = t.c0 - 1 + hc;
+          const bool in = hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)cc < (unsigned)W;
+          const int8_t* src = in ? a.x + (t.img_px + (long long)r * W + cc) * a.x_cp + wave * 16 : a.zero2 + wave * 16;
+          c3_dma16(src, buf + g * 1024);
+        }
+      }
+      unit_p += ustride;
+    }
+    gp++;
+  };
+  produce(); produce(); produce();
+  // header image of the block's 64 channels
+  {
+    const int per = 5 << (tms - 2);
+    const int mt0 = (blockIdx.y * 64) >> tms;
+    for (int i = tid; i < per; i += 512)
+      *reinterpret_cast<i32x4*>(dyn + i * 16) = *reinterpret_cast<const i32x4*>(reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mt0 * a.hdr_bytes + i * 16);
+  }
+  // the nine taps' weight fragments of this wave's row tile
+  i32x4 fw[9][2];
+  {
+    const unsigned a_lane_off = (unsigned)((lane & 31) * 64 + half * 16);
+    const int mt_w = cb >> tms, ro_w = cb & ((1 << tms) - 1);
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int8_t* pu = a.w + ((((size_t)mt_w * 9 + t) << tms) + ro_w) * 64;
+      fw[t][0] = *reinterpret_cast<const i32x4*>(pu + a_lane_off);
+      fw[t][1] = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
+    }
+  }
+  int h0[J];
+  int n_j = 0;
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    const int pt = (wn + j * WN) * 32;
+    if (pt < TH * TW) n_j = j + 1;
+    int p = pt + (lane & 31);
+    if (p >= TH * TW) p = 0;
+    const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
+    h0[j] = (tr * HC + tc) * 16 + half * kC3PlaneB;
+  }
+  n_j = __builtin_amdgcn_readfirstlane(n_j);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // tiles 0..2, header, fragments
+  asm volatile("" ::: "memory");
+
+  const int* prm = reinterpret_cast<const int*>(dyn);      // (64-channel blocks: at most one storage m-tile's image, rows by position)
+  const int row0 = (cb & ((1 << tms) - 1)) + 4 * half;
+  const int lo_b = a.relu ? 0 : -128;
+  const int chl = cb + 16 * half;
+  auto run = [&](auto nj_c) __attribute__((always_inline)) {
+    constexpr int NJ = decltype(nj_c)::value;
+    int g = 0;
+#pragma unroll 1
+    for (int unit = bid; unit < n_units; unit += ustride, g++) {
+      if (g > 0) {
+        // tile g's DMAs were issued three tiles ago; younger: the DMAs of tiles g + 1, g + 2 (six per issuing wave and tile) and the
+        // output stores in between -- "at most 12 outstanding" therefore covers every DMA of tile g, whatever the stores did
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... in every issuing wave; and nobody reads tile g - 1's buffer any more
+        asm volatile("" ::: "memory");
+      }
+      produce();                                           // tile g + 3 into tile g - 1's buffer
+      const Tile T = tile_of(unit);
+      i32x16 acc[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0;
+      const int rb = (g % NB) * kC3SlabB;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int soff = rb + ((t / 3) * HC + (t % 3)) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          i32x4 bf[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(ring + h0[j] + soff + 2 * ks * kC3PlaneB);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[t][ks], bf[j], acc[j], 0, 0, 0);
+        }
+      }
+      auto finish = [&](auto fast_c) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        i32x4 outs[NJ];
+        int a16s[NJ][16];
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
+        requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int p = (wn + j * WN) * 32 + (lane & 31);
+          const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
+          if (tr < T.rows && tc < T.cols && chl + 16 <= a.y_nvalid)
+            *reinterpret_cast<i32x4*>(a.y + (size_t)(T.img_px + (long long)(T.r0 + tr) * W + T.c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+        }
+      };
+      if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
+    }
+  };
+  if (n_j >= J) run(std::integral_constant<int, J>{}); else run(std::integral_constant<int, 1>{});
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 // the pixel tile of a map: TW columns (the whole width up to 62, else the width in equal parts of <= 62), TH rows such that the
 // tile has <= 256 pixels and its halo <= 384, rows spread evenly over the tiles of a column
@@ -404,8 +554,28 @@ static int launch_c3(const C3Args& a, hipStream_t s) {
   } else return launch_c3p<TMK, SC, DUAL, false>(a, s);
 }
 
+static int launch_c3_w9(const C3Args& a, hipStream_t s) {
+  const size_t stat = (size_t)4 * kC3SlabB;
+  const int tms = a.tm == 128 ? 7 : 6;
+  const size_t dyn = (size_t)(20 << tms);
+  if (stat + dyn > 160 * 1024) return 1;
+  auto fn = conv_c3_w9_kernel;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
+  const int n_units = a.B * a.tiles_per_img, groups = a.M / 64;
+  int gx = std::max(1, tf2_cu_count() / groups);
+  if (gx > n_units) gx = n_units;
+  TF2_LAUNCH_NAME("conv_c3_w9_kernel<64 channels x %dx%d pixels per tile,C64,weights resident>", a.TH, a.TW);
+  TF2_LAUNCH(fn, dim3(gx, groups), dim3(512), dyn, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
 int launch_conv_c3(const C3Args& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  // TF2_AMD_C3_W9: 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
+  const int w9 = getenv("TF2_AMD_C3_W9") ? atoi(getenv("TF2_AMD_C3_W9")) : 1;
+  if (w9 && a.tmk == 64 && a.C == 64 && !a.dual && !a.dbg && conv_c3_shape_ok(a.H, a.W, a.C, a.M) &&
+      (w9 == 2 || (long)a.B * a.tiles_per_img * (a.M / 64) / std::max(1, tf2_cu_count()) >= 8))
+    return launch_c3_w9(a, s);
   if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M) || (a.tm != 64 && a.tm != 128)) return 1;
   const int ks = a.C / 64;
   if ((a.tmk != 64 && a.tmk != 128 && a.tmk != 256) || a.M % a.tmk != 0 || (a.tmk == 256 && a.dual)) return 1;

@@ -791,10 +791,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       // batch 32: 29 / 33 us against 33 / 37; two-window rows spill at the 128 registers of the 64-channel form)
       const PackLayer* pm = pack_layer(l);
       int tmk = pm->Np % 128 == 0 ? 128 : 64;
-      if (tmk == 128 && !pm->dual && (long)batch * tiles * (pm->Np / 128) < 256) tmk = 64;
       // one-window layers of 256+ channels whose 256-channel grid still covers the chip: two row tiles per wave (a B fragment feeds
       // two MFMAs: half the LDS reads per MFMA, half the blocks' prologues)
       if (tmk == 128 && !pm->dual && pm->Np % 256 == 0 && (long)batch * tiles * (pm->Np / 256) >= opts.c3_min256) tmk = 256;
+      else if (tmk == 128 && !pm->dual && (long)batch * tiles * (pm->Np / 128) < 256) tmk = 64;
       if (opts.c3_mode == 2) tmk = 64; else if (opts.c3_mode == 3 && pm->Np % 128 == 0) tmk = 128;       // (experiments)
       Launch sc;
       if ((long)batch * tiles * (pl->Np / tmk) >= opts.c3_min_blocks && make_conv(l, sc, false) && pack_layer(l)->TM == sc.TM) {
