@@ -1,0 +1,155 @@
+// conv_fc.hip -- a layer whose whole input is ONE filter window per image (a k x k / pad 0 convolution of a k x k map, or a 1 x 1 layer
+// of a 1 x 1 map: VGG16's fc6 7x7x512 -> 4096 and fc7) at batch <= 32: a weight stream (gfx950).
+//
+// Such a layer is [Np x K] x [K x 32]: 32 pixels = ONE column tile, K = 25088 for fc6 -- 205 MB of two-window weight tiles for 6.6 GMAC.
+// conv_mfma_sk gives it Np / 64 = 64 blocks (each splits K over its eight waves through LDS rings of two stages): 64 CUs pull
+// 1.95 TB/s, 105 us, the largest launch of VGG16.  Here the stream is split over the whole chip, K included:
+//
+//   fc_partial_kernel  grid (Np / 128, KSPLIT), four waves per block, a wave = 32 output channels x one K slice: weight fragments
+//                      (16 contiguous bytes of a row of the packed tile per lane) and activation fragments (16 bytes of image
+//                      lane & 31) straight from memory into v_mfma_i32_32x32x32_i8, no LDS, no barrier; its 32 x 32 int32 partial sums
+//                      (per window) go to a scratch area of the workspace;
+//   fc_finish_kernel   one thread per (channel, image): adds the KSPLIT partials (Z/2^32: any order), combines the two windows
+//                      ((hi << dshift[1]) + lo), requantises with the header rows (the arithmetic of requant_epilogue.h, one output at
+//                      a time) and stores the int8 activation.
+//
+// Reference semantics: pe.cl:27-43 (shift-accumulate), pe.cl:185-203 (requant), relu.cl:54.  Bit-identical to conv_mfma_sk.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include "tf2_internal.h"
+#include "tf2_device.h"
+
+namespace tf2 {
+
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x16 = int __attribute__((ext_vector_type(16)));
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int n0 = (blockIdx.x * 4 + wave) * 32;             // this wave's 32 output channels
+  if (n0 >= a.Np) return;
+  const int tms = a.tm == 128 ? 7 : 6;
+  const int mt = n0 >> tms, ro = n0 & ((1 << tms) - 1);
+  const int wins = DUAL ? 2 : 1;
+  const int s0 = blockIdx.y * a.slabs_per_split;
+  const int s1 = s0 + a.slabs_per_split < a.nslab ? s0 + a.slabs_per_split : a.nslab;
+  // (images beyond the batch read image 0: their columns are never looked at)
+  const int8_t* xb = a.x + (size_t)(col < a.B ? col : 0) * a.K + half * 16;
+  const int8_t* wb = a.w + ((((size_t)mt * a.nslab) * wins) << tms) * 64 + (size_t)(ro + col) * 64 + half * 16;
+  const size_t ent = (size_t)wins << (tms + 6);            // bytes of one (m-tile, slab) entry
+  const size_t winb = (size_t)1 << (tms + 6);              // bytes of one window of it
+  i32x16 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { hi[r] = 0; lo[r] = 0; }
+  // four slabs' fragments in flight per wave (the loads of a group are issued before its first MFMA)
+  int s = s0;
+  for (; s + 4 <= s1; s += 4) {
+    i32x4 b0[4], b1[4], h0[4], h1[4], l0[DUAL ? 4 : 1], l1[DUAL ? 4 : 1];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int8_t* wp = wb + (size_t)(s + u) * ent;
+      const int8_t* xp = xb + (size_t)(s + u) * 64;
+      b0[u] = *reinterpret_cast<const i32x4*>(xp); b1[u] = *reinterpret_cast<const i32x4*>(xp + 32);
+      h0[u] = *reinterpret_cast<const i32x4*>(wp); h1[u] = *reinterpret_cast<const i32x4*>(wp + 32);
+      if (DUAL) { l0[u] = *reinterpret_cast<const i32x4*>(wp + winb); l1[u] = *reinterpret_cast<const i32x4*>(wp + winb + 32); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h0[u], b0[u], hi, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h1[u], b1[u], hi, 0, 0, 0);
+      if (DUAL) {
+        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l0[u], b0[u], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l1[u], b1[u], lo, 0, 0, 0);
+      }
+    }
+  }
+  for (; s < s1; s++) {
+    const int8_t* wp = wb + (size_t)s * ent;
+    const int8_t* xp = xb + (size_t)s * 64;
+    const i32x4 b0 = *reinterpret_cast<const i32x4*>(xp), b1 = *reinterpret_cast<const i32x4*>(xp + 32);
+    const i32x4 h0 = *reinterpret_cast<const i32x4*>(wp), h1 = *reinterpret_cast<const i32x4*>(wp + 32);
+    hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h0, b0, hi, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h1, b1, hi, 0, 0, 0);
+    if (DUAL) {
+      const i32x4 l0 = *reinterpret_cast<const i32x4*>(wp + winb), l1 = *reinterpret_cast<const i32x4*>(wp + winb + 32);
+      lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l0, b0, lo, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l1, b1, lo, 0, 0, 0);
+    }
+  }
+  // C/D layout: register k of this lane = row 8 * (k / 4) + 4 * half + k % 4 of column col
+  int* const p0 = a.part + ((size_t)(blockIdx.y * wins) * a.Np + n0) * 32 + col;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int row = 8 * (k >> 2) + 4 * half + (k & 3);
+    p0[(size_t)row * 32] = hi[k];
+    if (DUAL) p0[((size_t)a.Np + row) * 32] = lo[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void fc_finish_kernel(FcArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n = idx >> 5, b = idx & 31;
+  if (n >= a.Np || b >= a.B || n >= a.y_nvalid) return;
+  const int wins = a.dual ? 2 : 1;
+  unsigned hi = 0, lo = 0;
+  for (int ks = 0; ks < a.ksplit; ks++) {
+    const int* p = a.part + ((size_t)(ks * wins) * a.Np + n) * 32 + b;
+    hi += (unsigned)p[0];
+    if (a.dual) lo += (unsigned)p[(size_t)a.Np * 32];
+  }
+  const int tms = a.tm == 128 ? 7 : 6, TM = 1 << tms;
+  const int mt = n >> tms, ro = n & (TM - 1);
+  const int* prm = reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mt * a.hdr_bytes);
+  int acc = (int)hi;
+  if (a.dual) acc = (int)((hi << (prm[6 * TM + ro] & 31)) + lo);        // (hi << dshift[1][row]) + lo, Z/2^32
+  // requant_epilogue.h, one output: rows {bias | dbl, alpha, addend64} | lo[TM]
+  const int pr0 = prm[4 * ro], alpha = prm[4 * ro + 1];
+  const long long b64 = (long long)(((unsigned long long)(unsigned)prm[4 * ro + 3] << 32) | (unsigned)prm[4 * ro + 2]);
+  const int low = prm[4 * TM + ro];
+  int y, kd;
+  if (a.fast == 1) {
+    const long long p = (long long)acc * (long long)alpha + b64;
+    y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+    kd = pr0;
+  } else {
+    const int v = (int)((unsigned)pr0 + ((unsigned)acc << (low & 31)));
+    const long long p = (long long)v * (long long)alpha + b64;
+    if (a.fast == 2) y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
+    else { const int x = (int)(p >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
+    kd = low >> 8;
+  }
+  const int lo_b = a.relu ? 0 : -128;
+  int c = y < lo_b ? lo_b : (y > 127 ? 127 : y);
+  if (a.dbl) c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
+  a.y[(size_t)b * a.y_cp + a.y_off + n] = (int8_t)c;
+}
+
+// K split: enough (32-channel wave, K slice) pairs for ~8 waves per CU, at least 8 slabs per slice
+int conv_fc_pick_ksplit(int Np, int nslab) {
+  const int waves_m = Np / 32;
+  int ks = (256 * 8 + waves_m - 1) / waves_m;
+  if (ks > nslab / 8) ks = nslab / 8;
+  if (ks < 1) ks = 1;
+  if (ks > 32) ks = 32;
+  return ks;
+}
+
+size_t conv_fc_scratch_bytes(int Np, int nslab, int dual) { return (size_t)conv_fc_pick_ksplit(Np, nslab) * (dual ? 2 : 1) * Np * 32 * 4; }
+
+int launch_conv_fc(const FcArgs& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (a.B < 1 || a.B > 32 || a.Np % 128 != 0 || (a.tm != 64 && a.tm != 128) || a.ksplit < 1 || a.K != a.nslab * 64) return 1;
+  TF2_LAUNCH_NAME("fc_partial_kernel<%d slabs in %d slices%s>", a.nslab, a.ksplit, a.dual ? ",dual" : "");
+  if (a.dual) TF2_LAUNCH((fc_partial_kernel<true>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
+  else TF2_LAUNCH((fc_partial_kernel<false>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
+  if (!launch_ok()) return -1;
+  TF2_LAUNCH_NAME("fc_finish_kernel");
+  TF2_LAUNCH(fc_finish_kernel, dim3((a.Np * 32 + 255) / 256), dim3(256), 0, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
+}  // namespace tf2

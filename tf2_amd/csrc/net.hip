@@ -282,7 +282,14 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   }
   wp.ctrl_off = (top + 255) / 256 * 256 + 256;
   wp.ctrl_bytes = (wp.ctrl_bytes + 255) / 256 * 256;
-  wp.total_bytes = wp.ctrl_off + wp.ctrl_bytes;
+  // partial sums of the conv_fc launches (one at a time: the largest)
+  wp.scratch_off = wp.ctrl_off + wp.ctrl_bytes;
+  wp.scratch_bytes = 0;
+  if (packed_valid && opts.fc_mode)
+    for (int l = 0; l < nl; l++)
+      if (fc_at(l, batch)) { const PackLayer* pl = pack_layer(l); wp.scratch_bytes = std::max(wp.scratch_bytes, conv_fc_scratch_bytes(pl->Np, pl->nslab, pl->dual)); }
+  wp.scratch_bytes = (wp.scratch_bytes + 255) / 256 * 256;
+  wp.total_bytes = wp.scratch_off + wp.scratch_bytes;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
 }
@@ -401,6 +408,21 @@ bool Net::c3_at(int l) const {
   return conv_c3_shape_ok(L.H, L.W, L.C, pl->Np);
 }
 
+// a layer whose input is ONE filter window per image (k x k / pad 0 on a k x k map), K long, at batch <= 32, not the network's last
+// (that one stores the dense logits itself): conv_fc.hip streams its weights over the whole chip
+bool Net::fc_at(int l, int batch) const {
+  const tf2_layer_desc& L = layers[l];
+  if (batch > 32 || l == nd.n_layers - 1) return false;
+  if (L.ipool || L.k != L.H || L.k != L.W || L.stride != 1 || L.dil != 1 || L.pad_h || L.pad_w || L.OH != 1 || L.OW != 1) return false;
+  if (L.src < 0 || L.add_src >= 0 || L.endpool || L.pool_en || L.concat >= 0 || layers[L.src].concat >= 0 || out_Cp[L.src] != L.C) return false;
+  const PackLayer* pl = pack_layer(l);
+  if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128) || pl->w_share || pl->signed_in || pl->Np % 128 != 0) return false;
+  if (pl->Cp_in != L.C || pl->Cp_in % 64 != 0 || pl->nslab != L.k * L.k * (pl->Cp_in / 64) || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
+  if (pl->nslab < opts.fc_min_slabs || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+  const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
+  return one_window || dual;
+}
+
 // conv_stem.hip takes layer 0 when the packed image holds its x-only weight tiles (weight_pack.cpp) and the fast
 // space-to-depth prep applies; the input tensor then carries 32 bytes per pixel in the same allocation.
 bool Net::stem_selected(int batch) const {
@@ -419,6 +441,8 @@ void Net::load_options() {
   if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
   if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
+  if (const char* e = getenv("TF2_AMD_FC")) o.fc_mode = atoi(e);
+  if (const char* e = getenv("TF2_AMD_FC_MIN")) o.fc_min_slabs = atoi(e);
   if (const char* e = getenv("TF2_AMD_C3")) o.c3_mode = atoi(e);
   if (const char* e = getenv("TF2_AMD_C3_MIN")) o.c3_min_blocks = atol(e);
   if (const char* e = getenv("TF2_AMD_C3_MIN256")) o.c3_min256 = atol(e);
@@ -782,7 +806,23 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks &&
                           !(concurrent && pl->TM == 128 && opts.bneck_min_blocks > 1);
     if (!make_conv(l, st, !fuse_now)) return nullptr;     // the fused launch needs the pair's own (one m-tile) entries
-    if (!fuse_now && opts.c3_mode && c3_at(l)) {
+    if (!fuse_now && opts.fc_mode && fc_at(l, batch) && wp->scratch_bytes) {
+      Launch sc;
+      const PackLayer* pm = pack_layer(l);
+      if (make_conv(l, sc, false) && pm->TM == sc.TM && conv_fc_scratch_bytes(pm->Np, pm->nslab, pm->dual) <= wp->scratch_bytes) {
+        const ConvArgs& c = sc.conv;
+        FcArgs& f = sc.fc;
+        f.x = c.x; f.y = c.y; f.w = c.w; f.hdr = c.hdr; f.hdr_bytes = c.hdr_bytes; f.tm = sc.TM;
+        f.part = reinterpret_cast<int32_t*>(base + wp->scratch_off);
+        f.B = batch; f.nslab = pm->nslab; f.K = pm->nslab * 64; f.Np = pm->Np;
+        f.ksplit = conv_fc_pick_ksplit(pm->Np, pm->nslab); f.slabs_per_split = (pm->nslab + f.ksplit - 1) / f.ksplit;
+        f.dual = c.dual; f.relu = c.g.relu; f.fast = c.g.fast; f.dbl = c.g.dbl_out;
+        f.y_cp = c.g.y_cp; f.y_off = c.g.y_off; f.y_nvalid = c.g.y_nvalid;
+        sc.sel = Launch::SEL_FC; sc.avg_fused = 0;
+        st = sc;
+      }
+    }
+    if (!fuse_now && st.sel != Launch::SEL_FC && opts.c3_mode && c3_at(l)) {
       int th = 0, tw = 0;
       conv_c3_pick_tile(L.H, L.W, &th, &tw);
       const int tiles_x = (L.W + tw - 1) / tw, tiles = tiles_x * ((L.H + th - 1) / th);
@@ -938,6 +978,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_C3: return launch_conv_c3(st.c3, stream);
+        case Launch::SEL_FC: return launch_conv_fc(st.fc, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:
           if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);

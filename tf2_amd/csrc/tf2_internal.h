@@ -144,6 +144,23 @@ struct ConvArgs {
   ConvGeom g;
 };
 
+// conv_fc.hip: a layer whose input is one filter window per image (k x k / pad 0 on a k x k map, 1 x 1 on 1 x 1) at batch <= 32: the
+// weight stream split over the whole chip (output channels x K slices), partial sums through a scratch area of the workspace
+struct FcArgs {
+  const int8_t* x; int8_t* y;
+  const int8_t* w;             // dense weight tiles [mtile * nslab + slab][(hi | lo)][tm rows][64]
+  const int32_t* hdr;          // per storage m-tile header images (stride hdr_bytes)
+  int32_t* part;               // [ksplit][windows][Np][32] int32
+  int32_t hdr_bytes, tm;
+  int32_t B, K, nslab, Np;     // images (<= 32), bytes per image (= nslab * 64), output channels rounded up to the tile
+  int32_t ksplit, slabs_per_split;
+  int32_t dual, relu, fast, dbl;
+  int32_t y_cp, y_off, y_nvalid;
+};
+int conv_fc_pick_ksplit(int Np, int nslab);
+size_t conv_fc_scratch_bytes(int Np, int nslab, int dual);
+int launch_conv_fc(const FcArgs& a, void* stream);
+
 // conv_c3.hip: a 3x3 / stride 1 / pad 1 layer of a big map, the input's halo tile streamed through LDS once (instead of nine gathers)
 struct C3Args {
   const int8_t* x; int8_t* y;

@@ -37,6 +37,7 @@ struct WorkPlan {
   std::vector<LayerExec> exec;
   int input_tensor = -1;
   int final_tensor = -1;
+  size_t scratch_off = 0, scratch_bytes = 0;   // partial sums of conv_fc launches (behind the control area; never zeroed)
   size_t ctrl_off = 0, ctrl_bytes = 0;   // group counters of conv_bgroup launches (two words per image and launch)
   size_t total_bytes = 0;
 };
@@ -44,7 +45,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3 } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -52,6 +53,7 @@ struct Launch {
   ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
   ConvArgs conv_direct{};    // the last layer writing the dense logits itself (y patched per call)
   BneckArgs bneck{};
+  FcArgs fc{};               // SEL_FC: a whole-window layer at batch <= 32 as a weight stream over the whole chip (conv_fc.hip)
   C3Args c3{};               // SEL_C3: a 3x3 / 1 / pad 1 layer from an LDS-resident halo tile (conv_c3.hip)
   BBandArgs bband{};         // SEL_BBAND: rows layer .. layer + 2 (an identity bottleneck) in one launch, no exchange between blocks
   BGroupArgs bgroup{};       // SEL_BGROUP: rows layer .. layer + 2 (an identity bottleneck) in one launch
@@ -88,6 +90,8 @@ struct RunOpts {           // run-time switches, read from the environment by Ne
   long bneck_min_blocks = 200;
   int c3_mode = 1;           // TF2_AMD_C3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
   long c3_min_blocks = 96;   // TF2_AMD_C3_MIN: smallest grid that takes it
+  int fc_mode = 1;           // TF2_AMD_FC: whole-window layers at batch <= 32 on conv_fc.hip
+  int fc_min_slabs = 64;     // TF2_AMD_FC_MIN: shortest K (64-byte slabs) that takes it
   long c3_min256 = 200;      // TF2_AMD_C3_MIN256: smallest grid of 256-channel blocks (one-window layers; else 128-channel blocks)
   long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
   long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
@@ -167,6 +171,7 @@ struct Net {
   bool bband_at(int l, int rows) const;
     // rows l, l + 1, l + 2 are an identity bottleneck conv_bband.hip can take with `rows` output rows per block
   bool c3_at(int l) const;      // layer l can run on conv_c3.hip
+  bool fc_at(int l, int batch) const;   // ... on conv_fc.hip
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)
   long long stat_steps = 0, stat_group_steps = 0, stat_inflight_steps = 0, stat_small_mask_steps = 0;   // tf2_net_run_stats
   void* recent_streams[8] = {};  // streams of the last calls to run(): several distinct ones = batches in flight
