@@ -45,20 +45,22 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
   i32x16 hi, lo;
 #pragma unroll
   for (int r = 0; r < 16; r++) { hi[r] = 0; lo[r] = 0; }
-  // four slabs' fragments in flight per wave (the loads of a group are issued before its first MFMA)
+  // GS slabs' fragments in flight per wave (the loads of a group are issued before its first MFMA)
+  constexpr int GS = 8;
   int s = s0;
-  for (; s + 4 <= s1; s += 4) {
-    i32x4 b0[4], b1[4], h0[4], h1[4], l0[DUAL ? 4 : 1], l1[DUAL ? 4 : 1];
+  for (; s + GS <= s1; s += GS) {
+    i32x4 b0[GS], b1[GS], h0[GS], h1[GS], l0[DUAL ? GS : 1], l1[DUAL ? GS : 1];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < GS; u++) {
       const int8_t* wp = wb + (size_t)(s + u) * ent;
       const int8_t* xp = xb + (size_t)(s + u) * 64;
       b0[u] = *reinterpret_cast<const i32x4*>(xp); b1[u] = *reinterpret_cast<const i32x4*>(xp + 32);
       h0[u] = *reinterpret_cast<const i32x4*>(wp); h1[u] = *reinterpret_cast<const i32x4*>(wp + 32);
       if (DUAL) { l0[u] = *reinterpret_cast<const i32x4*>(wp + winb); l1[u] = *reinterpret_cast<const i32x4*>(wp + winb + 32); }
     }
+    __builtin_amdgcn_sched_barrier(0);                     // (else the scheduler sinks the loads next to their MFMAs: ~8 in flight)
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < GS; u++) {
       hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h0[u], b0[u], hi, 0, 0, 0);
       hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h1[u], b1[u], hi, 0, 0, 0);
       if (DUAL) {
