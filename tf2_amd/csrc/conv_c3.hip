@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
     return t;
   };
   const int n_halo = (TH + 2) * HC;
-  int unit_p = bid, gp = 0;                                // producer: next tile to fetch, tiles fetched so far
+  int unit_p = bid, gp = 0, n_issued = 0;                  // producer: next tile to fetch, produce() calls so far, tiles really fetched
   auto produce = [&]() __attribute__((always_inline)) {    // waves 0..3: plane `wave` of the tile's slab, six DMA groups each
     if (unit_p < n_units) {
       if (wave < 4) {
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
         }
       }
       unit_p += ustride;
+      n_issued++;
     }
     gp++;
   };
@@ -433,9 +434,13 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
 #pragma unroll 1
     for (int unit = bid; unit < n_units; unit += ustride, g++) {
       if (g > 0) {
-        // tile g's DMAs were issued three tiles ago; younger: the DMAs of tiles g + 1, g + 2 (six per issuing wave and tile) and the
-        // output stores in between -- "at most 12 outstanding" therefore covers every DMA of tile g, whatever the stores did
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // tile g's DMAs were issued three tiles ago; younger: the DMAs of the tiles fetched since (six per issuing wave and tile: two
+        // tiles, fewer at the end of the block's walk) and the output stores in between -- "at most 6 x (tiles fetched since)
+        // outstanding" therefore covers every DMA of tile g, whatever the stores did (they only make the wait stricter)
+        const int since = n_issued - (g + 1);
+        if (since >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (since == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... in every issuing wave; and nobody reads tile g - 1's buffer any more
         asm volatile("" ::: "memory");
       }
