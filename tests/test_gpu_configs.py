@@ -217,6 +217,36 @@ def test_four_batches_in_flight_as_bench_times_them(r50, graph):
         np.testing.assert_array_equal(got, serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl} (graph={graph})")
 
 
+def test_vgg16_four_batches_in_flight():
+    """The VGG-style kernels under load: conv_c3 / conv_c3_w9 (counted waits on LDS-DMAs that land later when other batches' kernels
+    share the chip), conv_fc (scratch area per workspace) and the im2col input kernel -- full-size VGG16, four Runners on four streams,
+    batch 24, six inputs round-robin for 24 steps with no synchronisation; every logits row of the last four steps against a serial
+    run of the same input, and one image per input against the oracle."""
+    torch = _torch()
+    t = cfg.vgg16_tables()
+    q = synth.synth_q_values(t, 0, spread=1)
+    rig = Rig(t, q, synth.synth_model(t, q, 0), 0)
+    names = [r["kernel"] for r in rig.net.describe_launches(24, 1)]
+    assert any("conv_c3_w9" in n for n in names) and any("conv_c3_kernel" in n for n in names) and any("fc_partial" in n for n in names), names
+    n_fl, n_in, n_steps, B = 4, 6, 24, 24
+    xs = [synth.synth_images(t, B, 500 + i) for i in range(n_in)]
+    xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
+    serial = [rig.run(x, keep_all=False).copy() for x in xs]
+    np.testing.assert_array_equal(serial[0][:1], rig.ref.logits(rig.ref.run(xs[0][:1])), err_msg="serial run against the oracle")
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_fl)]
+    runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
+    for st, rn, x in zip(streams, runners, xd):
+        with torch.cuda.stream(st):
+            rn.run_batch(x, concurrency=1)
+    torch.cuda.synchronize()
+    for k in range(n_steps):
+        with torch.cuda.stream(streams[k % n_fl]):
+            runners[k % n_fl].run_batch(xd[k % n_in], concurrency=1)
+    torch.cuda.synchronize()
+    for k in range(n_steps - n_fl, n_steps):
+        np.testing.assert_array_equal(runners[k % n_fl]._logits.cpu().numpy(), serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl}")
+
+
 def test_feeder_threads_enqueue_side_by_side(r50):
     """tf2_amd/feeder.py: four host threads, one per stream and workspace, call tf2_net_run_ex on ONE handle at the same time
     (include/tf2_amd.h threading note: the enqueue runs outside the handle's mutex).  40 steps over eight inputs with no
