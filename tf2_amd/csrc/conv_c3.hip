@@ -6,15 +6,18 @@
 // 1.0 of its 1.17 ms) it runs at 0.19 of the dense int8 peak.  conv_bband's 3x3 phase does the same arithmetic from a halo tile in
 // LDS at 95 % of the matrix pipe's rate; this kernel is that phase as a layer of its own:
 //
-//   * a block owns a TH x TW pixel tile (<= 256 pixels = 8 column tiles of 32) of ONE image and TMK = 64 / 128 output channels
-//     (grid.y = channel groups); its 8 waves are (TMK / 32 row tiles) x (pixel columns), one row tile and 8 / WN column tiles each;
+//   * a block owns a TH x TW pixel tile (<= 256 pixels = 8 column tiles of 32) of ONE image and TMK = 64 / 128 / 256 output channels
+//     (grid.y = channel groups); its 8 waves are (row tiles) x (pixel columns), one row tile (two with TMK = 256: one-window layers)
+//     and 8 / WN column tiles each; 128-channel blocks (and the one-slab kernel below) walk several tiles, the chunk stream running
+//     on across tiles;
 //   * the input streams through LDS in chunks of SC 64-channel slabs of the (TH + 2) x (TW + 2) HALO tile (zero border = the stored
 //     form of x = 0, sequencer.cl:287), two chunk buffers, LDS-DMA; a slab is four PLANES of 16 bytes per pixel (conv_bband.hip):
 //     a lane's MFMA fragment of halo pixel h is 16 bytes at plane[half + 2 ks] + 16 h -- conflict-free without a swizzle, and tap,
 //     slab and K half are immediate offsets of the ds_read;
 //   * every chunk is swept by all nine taps before the next one is touched: the input is fetched ONCE (plus the halo: 1.3-1.5 x);
 //   * weights go global -> registers, a lane's fragment is 16 contiguous bytes of its row in the packed tile, two steps ahead
-//     (three rotating buffers: nine steps per slab keep the rotation aligned with the run-time chunk loop);
+//     (three rotating buffers: nine steps per slab keep the rotation aligned with the run-time chunk loop); one-slab 64-channel layers
+//     hold all nine fragments in registers instead (conv_c3_w9_kernel: no load in the K loop, the input three tiles ahead);
 //   * two-window layers keep two accumulator sets over the one input stream and combine them once, (hi << dshift[1]) + lo;
 //   * epilogue: requant_tiles16_rows (parameter rows read once per row tile), 16-byte NHWC stores.
 //
