@@ -155,11 +155,9 @@ def main():
                          "captured with that leg's launch plan during the untimed steps), the one-batch-at-a-time leg launches; 1: both legs "
                          "replay graphs; 0: both launch.  Round 4, three alternating runs at 20 steps: 90.5-91.0 k (in-flight leg replayed) against "
                          "89.1-90.3 k img/s (launched); one batch at a time 60.7 k replayed against 61.2 k launched (profiles/r04_experiments.txt)")
-    ap.add_argument("--partition", type=int, default=0,
-                    help="1: the in-flight streams are created with hipExtStreamCreateWithCUMask (tf2_amd/streams.py) when the number of batches "
-                         "in flight divides 8; 0 (default): plain streams.  Round 4 measured that the interleaved masks of streams.py are IGNORED by "
-                         "the hardware (every block still runs on all 256 CUs: tools/ubench/cumask_probe.hip, profiles/r04_ubench_cumask_probe.txt), "
-                         "so rounds 2-3's 'XCD partitions' were plain streams under another name")
+    ap.add_argument("--buffers", type=int, default=0,
+                    help="distinct input batches rotated through every timed leg (each its own device buffer; with HIP-graph replay one graph per "
+                         "(stream, buffer)); 0 (default): two per stream in flight, at least 8 -- the timed region never re-reads one hot tensor")
     ap.add_argument("--stagger-layer", type=int, default=-1,
                     help=">= 0: stage-interlocked pipelining of the batches in flight -- step k+1's stream waits (hipStreamWaitEvent) for an "
                          "event that step k's run records once its layers 0..L are enqueued (tf2_net_run_ex mark_event), so a batch "
@@ -201,20 +199,14 @@ def main():
     import torch.distributed as dist
     assert world == args.gpus and (world == 1 or dist.get_world_size() == args.gpus), "process group size != --gpus"
 
-    if args.net == "resnet50":
-        tables = cfg.resnet50_tables()
-        qv = np.loadtxt(os.path.join(ROOT, "tests", "golden", "resnet50_Q"), dtype=np.int32)
-        net_name, net_note, seed_m = "ResNet50", "54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights", 0
-    else:
-        tables, net_name, seed_m = {"squeezenet": (cfg.squeezenet11_tables(), "SqueezeNet 1.1", 6), "vgg16": (cfg.vgg16_tables(), "VGG16", 1),
-                                    "ssd300": (cfg.ssd300_tables(), "SSD300-VGG", 3)}[args.net]
-        qv = synth.synth_q_values(tables, seed_m, spread=1)
-        net_note = "TF2 table program built by tf2_amd.config, synthetic per-channel Q values and seeded INQ weights"
+    tables, qv, seed_m, net_name, net_note = synth.bench_network(args.net)
     plan = cfg.build_plan(tables)
     qtext = synth.q_text(qv)
     model = synth.synth_model(tables, qv, seed=seed_m) if rank == 0 else None
     net = network.NetWork(tables)
     tdist.broadcast_network(net, model, qtext, device, pack_mode=args.mode)
+    broadcast = dict(ms=getattr(net, "broadcast_ms", None), bytes=getattr(net, "broadcast_bytes", None),
+                     note="the data path's ONE collective: the packed weight image from rank 0 (RCCL over xGMI), before any timed region")
     img_c, img_h, img_w = int(tables["INPUT_IMAGE_C"]), int(tables["INPUT_IMAGE_H"]), int(tables["INPUT_IMAGE_W"])
     runner = network.Runner(None, net)
 
@@ -229,17 +221,12 @@ def main():
         torch.cuda.synchronize(device)
 
     n_inflight = max(1, args.inflight)
-    fl_streams, partitioned = [], False
-    if n_inflight > 1:
-        if args.partition and 8 % n_inflight == 0:
-            try:
-                from tf2_amd import streams as tstreams
-                fl_streams = tstreams.partitioned_streams(n_inflight, device)
-                partitioned = True
-            except (OSError, RuntimeError, AttributeError) as e:
-                print(f"bench.py: XCD-partitioned streams unavailable ({e}); plain streams", file=sys.stderr)
-        if not fl_streams:
-            fl_streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)]
+    # plain streams: the batches in flight SHARE every CU (rounds 2-3's "XCD-partitioned" streams never partitioned anything: DESIGN.md 3)
+    fl_streams = [torch.cuda.Stream(device=device) for _ in range(n_inflight)] if n_inflight > 1 else []
+    # input rotation: n_buf distinct batches; step k takes buffer k % n_buf on stream k % n_inflight (n_buf a multiple of n_inflight, so a
+    # stream alternates between its own n_buf / n_inflight buffers and a captured graph is keyed by (stream, buffer))
+    n_buf = args.buffers if args.buffers > 0 else max(8, 2 * n_inflight)
+    n_buf = (n_buf + n_inflight - 1) // n_inflight * n_inflight
     fl_runners = [network.Runner(None, net) for _ in range(n_inflight)] if n_inflight > 1 else []
     step_no = [0]
     graphs = {}
@@ -257,7 +244,8 @@ def main():
     mark_ring = [torch.cuda.Event() for _ in range(2 * n_inflight)] if stagger else []
     prev_mark = [None]
 
-    def step(x):
+    def step(xs):
+        x = xs[step_no[0] % len(xs)]
         if n_inflight > 1 and not serial[0]:
             i = step_no[0] % n_inflight
             step_no[0] += 1
@@ -279,6 +267,7 @@ def main():
                 else:
                     one(fl_runners[i], x, concurrency=1)      # the caller's own statement: other batches are in flight
             return
+        step_no[0] += 1
         if graph_serial:
             key = (x.data_ptr(), x.shape[0])
             if key not in graphs:
@@ -288,32 +277,55 @@ def main():
         else:
             one(runner, x)
 
+    input_sets = {}
+    rank_dts = []
+
+    def inputs(batch):
+        """n_buf distinct synthetic batches of this size, resident in HBM (19 MB each at batch 32: together with the workspaces beyond
+        what the Infinity Cache holds for one tensor; the reference reloads ONE image for every frame, runner.cpp:152-154)"""
+        if batch not in input_sets:
+            input_sets[batch] = [torch.from_numpy(synth.synth_images(tables, batch, seed=100 + 17 * k + rank)).to(device) for k in range(n_buf)]
+        return input_sets[batch]
+
     def timed(batch, steps, warmup, spin=True):
-        x = torch.from_numpy(synth.synth_images(tables, batch, seed=100 + rank)).to(device)
-        if n_inflight > 1 and not serial[0]:   # set-up, not a step: every in-flight runner allocates its workspace
+        xs = inputs(batch)
+        x = xs[0]
+        if n_inflight > 1 and not serial[0]:   # set-up, not a step: every in-flight runner allocates its workspace ...
             for st, rn in zip(fl_streams, fl_runners):
                 with torch.cuda.stream(st):
                     one(rn, x, concurrency=1)
+            torch.cuda.synchronize(device)
+            if graph_inflight:                 # ... and every (stream, buffer) graph the leg will replay is captured
+                for k in range(n_buf):
+                    i = k % n_inflight
+                    key = (i, xs[k].data_ptr(), batch)
+                    if key not in graphs:
+                        with torch.cuda.stream(fl_streams[i]):
+                            graphs[key] = fl_runners[i].capture(xs[k], split=args.split, concurrency=1)
         torch.cuda.synchronize(device)
+        step_no[0] = 0
         if args.spinup_ms > 0 and spin:        # bring the device out of its idle power state (set-up, not a step)
             t_end = time.perf_counter() + args.spinup_ms * 1e-3
             while time.perf_counter() < t_end:          # time-bounded: ranks run different counts, so no collective in here
                 for _ in range(4):
-                    step(x)
+                    step(xs)
                 if feeder[0] is not None:
                     feeder[0].drain()
                 torch.cuda.synchronize(device)
         for _ in range(warmup):
-            step(x)
+            step(xs)
         barrier()
         prev_mark[0] = None                 # the timed region starts with an empty pipeline: the first step waits for nobody
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(x)
+            step(xs)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)                          # each rank's own time: the spread across GPUs is printed beside the value
+            rank_dts[:] = [float(e.item()) for e in every]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, x
@@ -329,6 +341,11 @@ def main():
     dt, x = timed(args.batch, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    per_rank = None
+    if world > 1 and rank_dts:
+        rates = [args.batch * args.steps / d for d in rank_dts]
+        per_rank = dict(images_per_s_min=round(min(rates), 1), images_per_s_max=round(max(rates), 1),
+                        note="each rank's own K steps / its own time; `value` = all ranks' images / the SLOWEST rank's time")
 
     serial_value = None
     if n_inflight > 1:
@@ -466,69 +483,95 @@ def main():
         return dict(per_layer_ms=per_layer_ms, nl=nl, kinds=kinds, cv=cv, n_launch=n_launch, dom_ms=dom_ms, event_scale=event_scale,
                     per_class=per_class, top_kernel=top_kernel, kernels=sorted({k for v in kern_of.values() for k in v if k.startswith("conv")}))
 
+    ROUND = "r05"
+
     def committed(name):
         """a profile of THIS round committed under profiles/ for this network / batch / kernel mode (tools/round_evidence.sh)"""
         pj = os.path.join(ROOT, "profiles", name)
-        return pj if (os.path.exists(pj) and args.mode == 0 and args.net == "resnet50") else None
+        return pj if (os.path.exists(pj) and args.mode == 0) else None
+
+    tag = "" if args.net == "resnet50" else f"{args.net}_"
+
+    def rocprof_of(name):
+        """the committed rocprofv3 --kernel-trace summary of the same workload (ONLY batch-N steps in the profiled process, one per
+        launch plan): the conv kernels' time per step as the profiler sees it, next to the live figure"""
+        pj = committed(name)
+        if not pj:
+            return None, None
+        rs = json.load(open(pj))
+        return round(rs["conv_us_per_step"], 1), os.path.basename(pj)
+
+    def traffic_of(name, P):
+        """mean HBM bytes per conv launch from the committed PMC passes of that plan (FETCH_SIZE doubled per the guide's gfx950 note,
+        WRITE_SIZE; separate --pmc runs)"""
+        pj = committed(name)
+        if not pj:
+            return None, "no PMC pass committed for this network / batch size / kernel mode"
+        pm = json.load(open(pj))
+        if len(pm.get("layers", [])) != len(plan):
+            return None, f"{os.path.basename(pj)} does not describe this table program"
+        tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in P["cv"])
+        return round(tb / P["n_launch"]), (f"mean HBM bytes per launch over the step's {P['n_launch']} conv launches, rocprofv3 FETCH_SIZE(x2, gfx950)+WRITE_SIZE "
+                                           f"in separate --pmc passes, {os.path.basename(pj)}")
 
     P0 = profile_plan(0)
     P1 = profile_plan(1) if n_inflight > 1 else None
     cv = P0["cv"]
     dom_ops = sum(lo[i]["ops"] for i in cv) * args.batch
     alg_bytes = sum(lo[i]["bytes"] for i in cv) * args.batch
-    traffic, traffic_note = None, "no PMC pass committed for this network / batch size / kernel mode"
-    pj = committed(f"r04_pmc_conv_b{args.batch}.json")
-    if pj:
-        pm = json.load(open(pj))
-        if len(pm.get("layers", [])) == len(plan):
-            tb = sum(pm["layers"][i]["fetch_bytes"] + pm["layers"][i]["write_bytes"] for i in cv)
-            traffic = round(tb / P0["n_launch"])
-            traffic_note = (f"mean HBM bytes per launch over the step's {P0['n_launch']} conv launches (one batch at a time), rocprofv3 "
-                            f"FETCH_SIZE(x2, gfx950)+WRITE_SIZE in separate --pmc passes, {os.path.basename(pj)}")
-    # the committed rocprofv3 --kernel-trace summaries of the same workload (tools/round_evidence.sh: ONLY batch-N steps in the
-    # profiled process, one per launch plan): the conv kernels' time per step as the profiler sees it, next to the live figure
-    def rocprof_of(name):
-        pj = committed(name)
-        if not pj:
-            return None, None
-        rs = json.load(open(pj))
-        return round(rs["conv_us_per_step"], 1), os.path.basename(pj)
-    rocprof_us, rocprof_src = rocprof_of(f"r04_rocprof_b{args.batch}_summary.json")
-    gbps = alg_bytes / (P0["dom_ms"] * 1e-3) / 1e9 if P0["dom_ms"] > 0 else 0.0
-    tops = dom_ops / (P0["dom_ms"] * 1e-3) / 1e12 if P0["dom_ms"] > 0 else 0.0
-    n_launch = P0["n_launch"]
-    roofline = dict(bound="hbm", kernel=P0["top_kernel"], kernels=P0["kernels"], achieved=round(gbps, 1), peak=PEAK_HBM, unit="GB/s", frac=round(gbps / PEAK_HBM, 4),
-                    traffic=traffic, traffic_note=traffic_note,
-                    algorithmic_bytes_per_launch=round(alg_bytes / n_launch), launches_per_step=n_launch,
-                    avg_launch_us=round(P0["dom_ms"] / n_launch * 1e3, 2), event_pair_scale=round(P0["event_scale"], 4),
-                    kernel_us_per_step=round(P0["dom_ms"] * 1e3, 1), kernel_us_per_step_rocprof=rocprof_us, rocprof_summary=rocprof_src,
-                    mfma_side=dict(achieved_tops=round(tops, 1), peak_tops=PEAK_I8, frac=round(tops / PEAK_I8, 4),
-                                   algorithmic_ops_per_launch=round(dom_ops / n_launch)),
-                    note="achieved = algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d)) of the step's conv launches "
-                         "/ sum of their HIP-event durations on the launch stream, ONE BATCH AT A TIME with that plan's launches (`kernel` = the "
-                         "launch that takes the most time, named by tf2_net_describe_launches); per-layer event times rescaled by event_pair_scale "
-                         "= (one event pair around the whole layer loop) / (their sum).  The plan the TIMED region runs is `in_flight`.")
+
+    def plan_block(P, conc, note):
+        """one launch plan, its launches timed ONE BATCH AT A TIME on one stream: algorithmic bytes (ops) / sum of HIP-event durations"""
+        us, src = rocprof_of(f"{ROUND}_rocprof_{tag}b{args.batch}{'_conc1' if conc else ''}_summary.json")
+        tr, tr_note = traffic_of(f"{ROUND}_pmc_conv_{tag}b{args.batch}{'_conc1' if conc else ''}.json", P)
+        g = alg_bytes / (P["dom_ms"] * 1e-3) / 1e9 if P["dom_ms"] > 0 else 0.0
+        tp = dom_ops / (P["dom_ms"] * 1e-3) / 1e12 if P["dom_ms"] > 0 else 0.0
+        k = P["top_kernel"]
+        dom = None
+        if k is not None:
+            # the dominant launch against ITS OWN roofs: the algorithmic bytes / ops of the table rows it computes over its own duration
+            rows = next(g_ for _, g_ in launch_groups([r["cls"] for r in lo], P["nl"], P["kinds"]) if g_[0] == k["first_row"])
+            kb = sum(lo[i]["bytes"] for i in rows) * args.batch
+            ko = sum(lo[i]["ops"] for i in rows) * args.batch
+            dom = dict(k, rows=[int(r) for r in rows], algorithmic_bytes=kb, achieved_gbps=round(kb / (k["us"] * 1e-6) / 1e9, 1),
+                       frac_hbm_peak=round(kb / (k["us"] * 1e-6) / 1e9 / PEAK_HBM, 4), achieved_tops=round(ko / (k["us"] * 1e-6) / 1e12, 1),
+                       frac_int8_peak=round(ko / (k["us"] * 1e-6) / 1e12 / PEAK_I8, 4))
+        return dict(kernel=dom, kernels=P["kernels"], launches_per_step=P["n_launch"], algorithmic_bytes_per_launch=round(alg_bytes / P["n_launch"]),
+                    avg_launch_us=round(P["dom_ms"] / P["n_launch"] * 1e3, 2), kernel_us_per_step=round(P["dom_ms"] * 1e3, 1),
+                    kernel_us_per_step_rocprof=us, rocprof_summary=src, event_pair_scale=round(P["event_scale"], 4),
+                    one_at_a_time=dict(achieved=round(g, 1), frac=round(g / PEAK_HBM, 4), mfma_tops=round(tp, 1), mfma_frac=round(tp / PEAK_I8, 4)),
+                    traffic=tr, traffic_note=tr_note, note=note)
+
+    note0 = ("the one-batch-at-a-time plan (group launches): algorithmic bytes (activations read + written + residual read; SURVEY.md 8(d)) of the "
+             "step's conv launches / sum of their HIP-event durations on the launch stream; `kernel` = the launch that takes the most time, named "
+             "by tf2_net_describe_launches, against its own rows' bytes and ops; per-layer event times rescaled by event_pair_scale = (one event "
+             "pair around the whole layer loop) / (their sum)")
+    one_batch = plan_block(P0, 0, note0)
     total_bytes = sum(r["bytes"] for r in lo) * args.batch
     hbm_gbps = total_bytes / (ms_per_step * 1e-3) / 1e9
-    # the plan the timed region runs (batches in flight): its launches timed one batch at a time on one stream (live events + the
-    # committed rocprofv3 summary of the same), and the same algorithmic bytes against the TIMED region = the rate the pipeline sustains
-    fl = dict(achieved=round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1), frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM, 4),
-              mfma_frac=round(dom_ops / (ms_per_step * 1e-3) / 1e12 / PEAK_I8, 4),
-              note="conv launches' algorithmic bytes (ops) per step / ms_per_step of the timed region; kernel_us_per_step*: the SAME launches run "
-                   "one batch at a time on one stream (the profiler serialises streams, so their overlap cannot be traced: pipeline_evidence)")
+    # TOP LEVEL = the plan the timed region runs (round 5; rounds 1-4 had the one-batch plan here and this one nested under `in_flight`):
+    # achieved = the conv launches' algorithmic bytes per step / ms_per_step of the TIMED region = the rate the pipeline sustains with
+    # batches in flight; the same launches one at a time are `one_at_a_time` (the profiler serialises streams, so their overlap cannot be
+    # traced: pipeline_evidence), the other plan is `one_batch`
     if P1 is not None:
-        r1_us, r1_src = rocprof_of(f"r04_rocprof_b{args.batch}_conc1_summary.json")
-        fl.update(launches_per_step=P1["n_launch"], kernel_us_per_step=round(P1["dom_ms"] * 1e3, 1), kernel_us_per_step_rocprof=r1_us,
-                  rocprof_summary=r1_src, kernel=P1["top_kernel"], kernels=P1["kernels"], event_pair_scale=round(P1["event_scale"], 4),
-                  overlap_factor=round(P1["dom_ms"] / ms_per_step, 2) if ms_per_step > 0 else None)
-    roofline["in_flight"] = fl
-    per_class = P0["per_class"]
-    # the per-class fractions of the REPORTED number: the in-flight plan's classes, each with its share of that plan's kernel time;
-    # a class's sustained rate in the timed region = its one-at-a-time rate x overlap_factor (kernel time / step time)
-    per_class_in_flight = None
-    if P1 is not None:
-        tot1 = sum(v["ms"] for v in P1["per_class"].values()) or 1.0
-        per_class_in_flight = {k: dict(v, share_of_kernel_time=round(v["ms"] / tot1, 4)) for k, v in P1["per_class"].items()}
+        roofline = plan_block(P1, 1, "the plan of the TIMED region (batches in flight: band launches, no group launches): achieved / frac = the conv launches' "
+                                     "algorithmic bytes per step / ms_per_step; kernel_us_per_step* and one_at_a_time: the SAME launches run one batch at a "
+                                     "time on one stream; overlap_factor = kernel time / step time")
+        ach = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        roofline = dict(dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM, unit="GB/s", frac=round(ach / PEAK_HBM, 4)), **roofline)
+        roofline["mfma_side"] = dict(achieved_tops=round(dom_ops / (ms_per_step * 1e-3) / 1e12, 1), peak_tops=PEAK_I8,
+                                     frac=round(dom_ops / (ms_per_step * 1e-3) / 1e12 / PEAK_I8, 4))
+        roofline["overlap_factor"] = round(P1["dom_ms"] / ms_per_step, 2) if ms_per_step > 0 else None
+        roofline["one_batch"] = one_batch
+    else:
+        roofline = dict(dict(bound="hbm", achieved=one_batch["one_at_a_time"]["achieved"], peak=PEAK_HBM, unit="GB/s", frac=one_batch["one_at_a_time"]["frac"]), **one_batch)
+        roofline["mfma_side"] = dict(achieved_tops=one_batch["one_at_a_time"]["mfma_tops"], peak_tops=PEAK_I8, frac=one_batch["one_at_a_time"]["mfma_frac"])
+    # per layer class (north_star: "%-of-int8-roofline reported per layer class"), keyed by LAUNCH; top level = the timed plan's classes,
+    # each with its share of that plan's kernel time (a class's sustained rate in the timed region = its one-at-a-time rate x overlap_factor)
+    Pt = P1 if P1 is not None else P0
+    tot1 = sum(v["ms"] for v in Pt["per_class"].values()) or 1.0
+    per_class = {k: dict(v, share_of_kernel_time=round(v["ms"] / tot1, 4)) for k, v in Pt["per_class"].items()}
+    per_class_one_batch = P0["per_class"] if P1 is not None else None
 
     # ---- CPU baseline: the oracle (restated reference CPU path) on the host cores, rank 0, N=1 ----
     cpu = None
@@ -564,16 +607,16 @@ def main():
                                 global_batch=args.batch * world, parallelism=f"dp{world}", kernel_mode=args.mode,
                                 sub_batches_per_step=args.split, batches_in_flight=n_inflight, hip_graph=dict(in_flight_leg=bool(graph_inflight), one_batch_at_a_time_leg=bool(graph_serial)),
                                 stage_interlock_layer=(args.stagger_layer if stagger else None),
-                                cu_masked_streams=(n_inflight if partitioned else None),
+                                input_buffers_rotated=n_buf,
                                 host_feeder_threads=(n_inflight if feeder[0] is not None else 1),
                                 spinup_ms=args.spinup_ms,
                                 spinup_note="untimed steps for spinup_ms before the W warm-up steps of every timed leg: an idle MI355X sits "
                                             "at ~150 MHz and needs ~0.4 s of load to reach 2.4 GHz (tools/clock_sample.py); the timed region is "
                                             "still exactly K steps between barrier + synchronize"),
-                    cold_start=cold, roofline=roofline, cpu_baseline=cpu,
+                    cold_start=cold, weight_broadcast=broadcast, per_rank=per_rank, roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
-                    per_layer_class=per_class, per_layer_class_in_flight=per_class_in_flight, images_per_s_by_batch=sweep,
+                    per_layer_class=per_class, per_layer_class_one_batch=per_class_one_batch, images_per_s_by_batch=sweep,
                     images_per_s_one_batch_at_a_time=serial_value, latency_batch1=lat, pipeline_evidence=pipe)
         print(json.dumps(line))
     if world > 1:

@@ -74,6 +74,10 @@ const char* tf2_last_error(void);
 int tf2_abi_version(void);
 /* 1 if the library was built with the gfx950 HIP kernels (always, for the shipped .so). */
 int tf2_has_device_code(void);
+/* 0 for the shipped library.  The same sources also build two TOOL libraries that must never serve a product: 1 = the timing-probe
+ * build (-DTF2_PROBES: can leave work out of a step), 2 = the DMA-check build (-DTF2_CHECK_DMA: stamps and checks sentinels around every
+ * LDS-DMA).  tf2_amd/_lib.py refuses to load a library whose kind is not 0 unless a tool asks for it (TF2_AMD_TOOL_LIB=1). */
+int tf2_build_kind(void);
 
 /* ---- load-time numerics (host CPU; replace model_loader.cpp / quantization.cpp) ----- */
 /* Get_real(float, char): model_loader.cpp:98-126 */
@@ -125,8 +129,11 @@ size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all);
 /* Bytes of the dense int8 output of a run: [batch][H_last * W_last][N_last] (NHWC; H_last = W_last = 1 for the
  * classification networks, i.e. [batch][N_last] -- the buffer Runner::Run reads back, runner.cpp:176-186).      */
 size_t tf2_net_logits_size(const tf2_net* net, int batch);
-/* Re-read the TF2_AMD_* run-time switches (kernel A/B selection for tests and tools) from the environment; they
- * are otherwise sampled once, at tf2_net_create.  Drops the prepared launch plans.                              */
+/* Options: ONE environment string, TF2_AMD_OPTS="name=value,name=value,flag" (INTEGRATION.md section 4 lists the product options:
+ * alt_conc, bgroup, bband, c3, fc, fc4, share), parsed into an immutable snapshot at tf2_net_create and here -- nothing else in the
+ * library reads the environment.  Unknown names, and test-only options (forced kernels, disabled proofs, thresholds: the test-suite's
+ * and the A/B tools') without TF2_AMD_TEST=1, make both calls return TF2_ERR_ARG.  The snapshot is process-wide: packing (pack-time
+ * options) and planning read the one taken last.  Drops the prepared launch plans.                              */
 tf2_status tf2_net_reload_options(tf2_net* net);
 /* images_dev: float32 [batch][image_c][image_h][image_w] on the device (the preprocessed
  * CHW floats LoadInputImage reads, input_loader.cpp:76-96).  Quantises with 2^Q0
@@ -166,7 +173,9 @@ tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void*
                           int8_t* logits_dev, void* hip_stream, const tf2_run_opts* opts);
 /* Group launches (conv_bgroup.hip: the one-batch-at-a-time plan keeps the eight blocks of an image resident together, one block per
  * CU, and lets them meet inside the kernel) have PRECONDITIONS the library checks where it can and the caller owns where it cannot:
- *  - at least 64 CUs for the stream: checked per call (hipExtStreamGetCUMask); a stream masked to fewer runs the step without them.
+ *  - at least 64 CUs for the stream: checked per call of the one-batch-at-a-time path (hipExtStreamGetCUMask: the check counts MASK
+ *    BITS, not granted CUs -- gfx950 ignores interleaved masks, so a stream masked to 32 interleaved bits is treated as small although
+ *    it runs on the whole chip: safe, it merely loses the group launches); a stream masked to fewer runs the step without them.
  *  - one batch at a time: selected only for concurrency == 0, stated or inferred.  A caller that STATES concurrency = 0 on more than
  *    four streams of one device at once (or drives more than four handles that way) breaks the contract: each XCD has 32
  *    one-block slots, four concurrent group kernels always leave room for one complete group, a fifth need not -- a meeting

@@ -33,3 +33,17 @@ def have_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def set_opts(monkeypatch, **kw):
+    """Set / change / remove (value None) options of the library's ONE option string TF2_AMD_OPTS (csrc/opts.h), cumulatively within a
+    test; TF2_AMD_TEST=1 admits the test-only ones (forced kernels, disabled proofs, thresholds).  Takes effect at the next
+    tf2_net_create / tf2_net_reload_options."""
+    cur = dict(item.split("=", 1) for item in os.environ.get("TF2_AMD_OPTS", "").split(",") if item)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    monkeypatch.setenv("TF2_AMD_TEST", "1")
+    monkeypatch.setenv("TF2_AMD_OPTS", ",".join(f"{k}={v}" for k, v in cur.items()))

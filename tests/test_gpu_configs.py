@@ -13,6 +13,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_parity import Rig, _torch  # noqa: E402
 
+from tests.conftest import set_opts  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -162,7 +164,7 @@ def test_resnet50_batch_sizes_and_tile_choices(r50, monkeypatch, conc):
     fused or separate bottleneck pairs, conv_pw or the ring kernel): batch sizes on both sides of every threshold, with the
     one-stream and the several-streams choice forced, against the oracle (three images each) and against themselves (an image
     run alone gives its row of the batch)."""
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    set_opts(monkeypatch, alt_conc=conc)
     rig = Rig(*r50, 0)
     x = synth.synth_images(rig.t, 64, 91)
     want = rig.ref.logits(rig.ref.run(x[:3]))
@@ -217,50 +219,122 @@ def test_four_batches_in_flight_as_bench_times_them(r50, graph):
         np.testing.assert_array_equal(got, serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl} (graph={graph})")
 
 
+def _in_flight(rig, B, n_in, n_steps, graph, seed, oracle_images=1, keep_rows=None, n_fl=4):
+    """`n_fl` Runners of ONE Net on `n_fl` HIP streams, `n_in` different batch-`B` inputs issued round-robin for `n_steps` steps with
+    no synchronisation in between (launched, or replayed from one captured HIP graph per stream): every logits row of the last `n_fl`
+    steps against a serial run of the same input (feature_writer.cl:88-151 is the output contract of each step), the serial run of
+    input 0 against the oracle.  keep_rows: table rows read back as well (a keep_all workspace: SSD300's heads are its outputs)."""
+    torch = _torch()
+    t = rig.t
+    xs = [synth.synth_images(t, B, seed + i) for i in range(n_in)]
+    xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
+    keep = keep_rows is not None
+    serial, serial_rows = [], []
+    for x in xs:
+        serial.append(rig.run(x, keep_all=keep).copy())
+        serial_rows.append({l: rig.runner.read_layer(l, B) for l in (keep_rows or [])})
+    outs = rig.ref.run(xs[0][:oracle_images])
+    np.testing.assert_array_equal(serial[0][:oracle_images], rig.ref.logits(outs), err_msg="serial run against the oracle")
+    for l in (keep_rows or []):
+        np.testing.assert_array_equal(serial_rows[0][l][:oracle_images], outs[l], err_msg=f"serial run, row {l} against the oracle")
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_fl)]
+    runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
+    bufs = [xd[i % n_in].clone() for i in range(n_fl)]
+    for st, rn, b in zip(streams, runners, bufs):                      # set-up call per stream (workspace allocation)
+        with torch.cuda.stream(st):
+            rn.run_batch(b, keep_all=keep, concurrency=1)
+    torch.cuda.synchronize()
+    replays = [None] * n_fl
+    for k in range(n_steps):                                           # no synchronisation inside this loop
+        i = k % n_fl
+        with torch.cuda.stream(streams[i]):
+            if graph:
+                if replays[i] is None:
+                    replays[i] = runners[i].capture(bufs[i], concurrency=1)
+                bufs[i].copy_(xd[k % n_in], non_blocking=True)
+                replays[i]()
+            else:
+                runners[i].run_batch(xd[k % n_in], keep_all=keep, concurrency=1)
+    torch.cuda.synchronize()
+    for k in range(n_steps - n_fl, n_steps):
+        i = k % n_fl
+        np.testing.assert_array_equal(runners[i]._logits.cpu().numpy(), serial[k % n_in], err_msg=f"step {k} on stream {i} (graph={graph})")
+        for l in (keep_rows or []):
+            np.testing.assert_array_equal(runners[i].read_layer(l, B), serial_rows[k % n_in][l], err_msg=f"step {k} on stream {i}, row {l}")
+
+
 def test_vgg16_four_batches_in_flight():
     """The VGG-style kernels under load: conv_c3 / conv_c3_w9 (counted waits on LDS-DMAs that land later when other batches' kernels
     share the chip), conv_fc (scratch area per workspace) and the im2col input kernel -- full-size VGG16, four Runners on four streams,
     batch 24, six inputs round-robin for 24 steps with no synchronisation; every logits row of the last four steps against a serial
     run of the same input, and one image per input against the oracle."""
-    torch = _torch()
     t = cfg.vgg16_tables()
     q = synth.synth_q_values(t, 0, spread=1)
     rig = Rig(t, q, synth.synth_model(t, q, 0), 0)
     names = [r["kernel"] for r in rig.net.describe_launches(24, 1)]
     assert any("conv_c3_w9" in n for n in names) and any("conv_c3_kernel" in n for n in names) and any("fc_partial" in n for n in names), names
-    n_fl, n_in, n_steps, B = 4, 6, 24, 24
-    xs = [synth.synth_images(t, B, 500 + i) for i in range(n_in)]
-    xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
-    serial = [rig.run(x, keep_all=False).copy() for x in xs]
-    np.testing.assert_array_equal(serial[0][:1], rig.ref.logits(rig.ref.run(xs[0][:1])), err_msg="serial run against the oracle")
-    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_fl)]
-    runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
-    for st, rn, x in zip(streams, runners, xd):
-        with torch.cuda.stream(st):
-            rn.run_batch(x, concurrency=1)
-    torch.cuda.synchronize()
-    for k in range(n_steps):
-        with torch.cuda.stream(streams[k % n_fl]):
-            runners[k % n_fl].run_batch(xd[k % n_in], concurrency=1)
-    torch.cuda.synchronize()
-    for k in range(n_steps - n_fl, n_steps):
-        np.testing.assert_array_equal(runners[k % n_fl]._logits.cpu().numpy(), serial[k % n_in], err_msg=f"step {k} on stream {k % n_fl}")
+    _in_flight(rig, B=24, n_in=6, n_steps=24, graph=0, seed=500)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_ssd300_four_batches_in_flight(graph):
+    """BASELINE configs[4] under the load the product is built for: SSD300-VGG at full width (300 x 300 tiles of conv_c3 / conv_c3_w9,
+    the stride-2 and dilated rows on the ring kernel, the L2Norm row, twelve heads), batch 8 on four streams.  Launched: a keep_all
+    workspace per stream, every head row (the network's outputs) of the last four steps against serial runs; replayed from HIP
+    graphs: the last head."""
+    t = cfg.ssd300_tables()
+    q = synth.synth_q_values(t, 3, spread=1)
+    rig = Rig(t, q, synth.synth_model(t, q, 3), 0)
+    names = [r["kernel"] for r in rig.net.describe_launches(8, 1)]
+    assert any("conv_c3_w9" in n for n in names) and any("conv_c3_kernel" in n for n in names), names
+    heads = [l for l, L in enumerate(rig.ref.plan) if l >= 24]
+    _in_flight(rig, B=8, n_in=4, n_steps=16, graph=graph, seed=520, keep_rows=None if graph else heads)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_squeezenet_four_batches_in_flight(graph):
+    """BASELINE configs[1]: SqueezeNet 1.1 at 227 x 227 (im2col first layer on conv_pw, fire modules as concat slices, ceil-mode pools,
+    the global average, the signed 1000 -> 128 classifier on conv_shift_fc), batch 32 on four streams, 32 steps."""
+    t = cfg.squeezenet11_tables()
+    q = synth.synth_q_values(t, 21, spread=2)
+    rig = Rig(t, q, synth.synth_model(t, q, 21), 0)
+    assert any("conv_shift_fc" in r["kernel"] for r in rig.net.describe_launches(32, 1))
+    _in_flight(rig, B=32, n_in=8, n_steps=32, graph=graph, seed=540, oracle_images=2)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_googlenet_four_batches_in_flight(graph, golden_dir):
+    """The reference's second shipped network (googlenet.h tables, shipped googlenet_Q: ipool rows, four-way concat slices, 5x5 convs,
+    pools distributed onto branch tails), batch 16 on four streams, 32 steps."""
+    t = cfg.NetTables(json.load(open(os.path.join(golden_dir, "tables_googlenet.json"))))
+    t.setdefault("xConv1Rewrite", 1)
+    qv = np.loadtxt(os.path.join(golden_dir, "googlenet_Q"), dtype=np.int32)
+    rig = Rig(t, qv, synth.synth_model(t, qv, 7), 0)
+    _in_flight(rig, B=16, n_in=8, n_steps=32, graph=graph, seed=560, oracle_images=2)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_resnet50_pruned_four_batches_in_flight(graph, golden_dir):
+    """The reference's third shipped network (resnet50_pruned.h: widths 32..448, tile tails on every map), batch 32 on four streams."""
+    t = cfg.NetTables(json.load(open(os.path.join(golden_dir, "tables_resnet50_pruned.json"))))
+    t.setdefault("xConv1Rewrite", 1)
+    qv = np.loadtxt(os.path.join(golden_dir, "resnet50_pruned_Q"), dtype=np.int32)
+    rig = Rig(t, qv, synth.synth_model(t, qv, 13), 0)
+    _in_flight(rig, B=32, n_in=8, n_steps=32, graph=graph, seed=580, oracle_images=2)
 
 
 def test_feeder_threads_enqueue_side_by_side(r50):
     """tf2_amd/feeder.py: four host threads, one per stream and workspace, call tf2_net_run_ex on ONE handle at the same time
     (include/tf2_amd.h threading note: the enqueue runs outside the handle's mutex).  40 steps over eight inputs with no
-    synchronisation; the last four steps' logits against serial runs of the same inputs; the XCD-partitioned streams of
-    bench.py."""
+    synchronisation; the last four steps' logits against serial runs of the same inputs; plain streams, as bench.py's."""
     torch = _torch()
-    from tf2_amd import streams as tstreams
     from tf2_amd.feeder import StreamFeeder
     rig = Rig(*r50, 0)
     n_fl, n_in, n_steps = 4, 8, 40
     xs = [synth.synth_images(rig.t, 32, 400 + i) for i in range(n_in)]
     xd = [torch.from_numpy(x).to("cuda:0") for x in xs]
     serial = [rig.run(x, keep_all=False).copy() for x in xs]
-    streams = tstreams.partitioned_streams(n_fl, "cuda:0")
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_fl)]
     runners = [network.Runner(None, rig.net) for _ in range(n_fl)]
     feeder = StreamFeeder(streams, runners, torch.device("cuda:0"))
     try:

@@ -9,6 +9,8 @@ import pytest
 from oracle import netref
 from tf2_amd import config as cfg, network, synth
 
+from tests.conftest import set_opts  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -74,12 +76,12 @@ def test_squeezenet_concat(mode):
     Rig(t, q, model, mode).check_all_layers(x)
 
 
-@pytest.mark.parametrize("nofast", ["0", "1"])
+@pytest.mark.parametrize("nofast", ["0", "1"])     # (the shift kernels' "fast" form is the 4-bit packed one: no4bit = 0 / 1)
 def test_shift_kernel_wave_split_fc(nofast, monkeypatch):
     """conv_shift_fc_kernel (a 1x1 layer on a handful of pixels with a long channel walk: sixteen waves take every sixteenth
     16-channel chunk, partial sums added through LDS) against the oracle -- unsigned input with 4-bit-packed and int32 filters
     (mode 2: every layer on the shift kernels), and the signed input of SqueezeNet's classifier (default mode)."""
-    monkeypatch.setenv("TF2_AMD_NOFAST", nofast)
+    set_opts(monkeypatch, no4bit=nofast)
     t = cfg.tiny_tables(hw=12, widths=(32, 512), classes=100)
     q = synth.synth_q_values(t, 9, spread=2)
     model = synth.synth_model(t, q, 9)
@@ -95,11 +97,11 @@ def test_shift_kernel_wave_split_fc(nofast, monkeypatch):
 
 
 def test_first_3x3_layer_plain_form(monkeypatch):
-    """TF2_AMD_IM2COL0=0: a 3x3 first layer on the 3-channel image in its plain form (nine taps of [x | xneg] gathered by the ring
+    """im2col0=0: a 3x3 first layer on the 3-channel image in its plain form (nine taps of [x | xneg] gathered by the ring
     kernel) instead of the default pointwise layer over the im2col image -- both bit-exact, -128 pixels included, and the input
     tensor read back as the quantised image either way."""
     for env in ("0", "1"):
-        monkeypatch.setenv("TF2_AMD_IM2COL0", env)
+        set_opts(monkeypatch, im2col0=env)
         t = cfg.tiny_tables()
         q = synth.synth_q_values(t, 5, spread=2)
         x = synth.synth_images(t, 3, 5, kind="int8")
@@ -119,10 +121,10 @@ def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
     oracle on every layer of a 64 x 64 VGG16 (maps 64 / 32 / 16: 1-8 channel slabs, 64- and 128-channel blocks, one- and two-window
     rows, partial tiles at the map's edge; the 8 x 8 and 4 x 4 maps stay on the ring / split-K kernels), and the same network with the
     kernel switched off."""
-    monkeypatch.setenv("TF2_AMD_C3", c3)
-    monkeypatch.setenv("TF2_AMD_C3_MIN", "1")
-    monkeypatch.setenv("TF2_AMD_C3_MIN256", "1")           # 256-channel blocks (two row tiles per wave) wherever a layer allows them
-    monkeypatch.setenv("TF2_AMD_C3_W9", "2")               # the weights-resident kernel for the 64 -> 64 layer although a block walks few tiles
+    set_opts(monkeypatch, c3=c3)
+    set_opts(monkeypatch, c3_min="1")
+    set_opts(monkeypatch, c3_min256="1")           # 256-channel blocks (two row tiles per wave) wherever a layer allows them
+    set_opts(monkeypatch, c3_w9="2")               # the weights-resident kernel for the 64 -> 64 layer although a block walks few tiles
     t = cfg.vgg16_tables(64, 10)
     q = synth.synth_q_values(t, 7, spread=2)
     rig = Rig(t, q, synth.synth_model(t, q, 7), 0)
@@ -148,8 +150,8 @@ def test_whole_window_layers_as_a_weight_stream(fc, monkeypatch):
     output channels x K slices, int32 partial sums through the workspace's scratch area, a finishing pass) against the oracle: a 64 x 64
     VGG16 (fc6 = 2 x 2 x 512 -> 4096 on a 2 x 2 map, fc7 1 x 1: 32 and 64 slabs, one and several K slices, one- and two-window rows),
     batches 1, 5 and 32, and the same with the kernel switched off."""
-    monkeypatch.setenv("TF2_AMD_FC", fc)
-    monkeypatch.setenv("TF2_AMD_FC_MIN", "8")
+    set_opts(monkeypatch, fc=fc)
+    set_opts(monkeypatch, fc_min="8")
     t = cfg.vgg16_tables(64, 10)
     for seed, spread in ((7, 2), (0, 1)):
         q = synth.synth_q_values(t, seed, spread=spread)
@@ -250,7 +252,7 @@ def test_resnet50_north_star_split_mode1(r50):
 def test_split_k_kernel_forced_and_disabled(sk, monkeypatch):
     """conv_mfma_sk.hip (four waves split the slab list) forced for every 64-row layer, and disabled:
     both bit-exact, including layers with fewer slabs than waves and several Horner phases."""
-    monkeypatch.setenv("TF2_AMD_SK", sk)
+    set_opts(monkeypatch, sk=sk)
     t = cfg.squeezenet11_tables(image_hw=67)
     q = synth.synth_q_values(t, 12, spread=2)
     model = synth.synth_model(t, q, 12)
@@ -262,9 +264,9 @@ def test_split_k_kernel_forced_and_disabled(sk, monkeypatch):
 
 
 def test_generic_requant_forced(r50, monkeypatch):
-    """TF2_AMD_NOFAST=1 at pack time: every layer takes the 6-instruction wrap-exact requantisation instead of the
+    """nofast=1 at pack time: every layer takes the 6-instruction wrap-exact requantisation instead of the
     range-proven 3-instruction one (most synthetic ResNet-50 layers qualify for the latter); same bits."""
-    monkeypatch.setenv("TF2_AMD_NOFAST", "1")
+    set_opts(monkeypatch, nofast="1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 2, 23), layers={1, 2, 3, 4, 11, 13, 26, 28, 45, 52, 53})
     t = cfg.tiny_tables()
@@ -274,28 +276,28 @@ def test_generic_requant_forced(r50, monkeypatch):
 
 
 def test_single_window_packing_forced(r50, monkeypatch):
-    """TF2_AMD_NODUAL=1 at pack time: two-phase layers keep the Horner form (one exponent window per entry, accumulators
+    """nodual=1 at pack time: two-phase layers keep the Horner form (one exponent window per entry, accumulators
     shifted at the phase boundary) instead of the default dual-window entries; conv_mfma2 and the split-K kernel."""
-    monkeypatch.setenv("TF2_AMD_NODUAL", "1")
+    set_opts(monkeypatch, nodual="1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 2, 29), layers={0, 1, 2, 3, 4, 11, 13, 24, 26, 27, 29, 47, 53})
 
 
 def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
     """conv_pw.hip (weights in registers, activations global -> register -> MFMA, pixel tiles streamed per wave) is the
-    default for dense 1x1 stride-1 layers with K <= 128; TF2_AMD_PW=0 sends them back to conv_mfma2.  Ragged pixel
+    default for dense 1x1 stride-1 layers with K <= 128; pw=0 sends them back to conv_mfma2.  Ragged pixel
     counts (batch 3 and 5), with / without residual, one and two K slabs, single- and dual-window packing."""
-    monkeypatch.setenv("TF2_AMD_PW_SLABS", "2")      # also the two-slab instantiations (default: one slab only)
-    monkeypatch.setenv("TF2_AMD_PW_MINPIX", "0")     # ... and at these small pixel counts (default: from 8192 pixels on)
+    set_opts(monkeypatch, pw_slabs="2")      # also the two-slab instantiations (default: one slab only)
+    set_opts(monkeypatch, pw_minpix="0")     # ... and at these small pixel counts (default: from 8192 pixels on)
     rig = Rig(*r50, 0)
     pw_layers = {1, 2, 4, 7, 10, 14, 17, 20, 23}
     for b, seed in ((3, 51), (5, 52)):
         rig.check_all_layers(synth.synth_images(rig.t, b, seed), layers=pw_layers | {3, 12, 53})
-    monkeypatch.setenv("TF2_AMD_PW", "0")
+    set_opts(monkeypatch, pw="0")
     rig.net.reload_options()
     rig.check_all_layers(synth.synth_images(rig.t, 3, 53), layers=pw_layers)
-    monkeypatch.delenv("TF2_AMD_PW")
-    monkeypatch.setenv("TF2_AMD_NODUAL", "1")       # single-window packing: two-phase layers are not eligible, one-phase are
+    set_opts(monkeypatch, pw=None)
+    set_opts(monkeypatch, nodual="1")       # single-window packing: two-phase layers are not eligible, one-phase are
     t = cfg.tiny_tables(hw=20, widths=(64, 128), classes=100)
     q = synth.synth_q_values(t, 8, spread=0)
     model = synth.synth_model(t, q, 8)
@@ -303,17 +305,17 @@ def test_pointwise_register_kernel_on_and_off(r50, monkeypatch):
 
 
 def test_first_layer_generic_path_and_wide_tile_alternatives(r50, monkeypatch):
-    """Two run-time choices against the oracle, every layer: (1) TF2_AMD_STEM=0 -- the first layer on the generic ring kernel
-    over [x | xneg] instead of conv_stem.hip on x alone; (2) TF2_AMD_ALT_MIN=0 -- the 128-row alternatives of the layers with
+    """Two run-time choices against the oracle, every layer: (1) stem=0 -- the first layer on the generic ring kernel
+    over [x | xneg] instead of conv_stem.hip on x alone; (2) alt_min=0 -- the 128-row alternatives of the layers with
     >= 1024 output channels (normally taken only when their grid fills the chip, i.e. from batch 32 on) at a ragged batch of 3."""
-    monkeypatch.setenv("TF2_AMD_STEM", "0")
-    monkeypatch.setenv("TF2_AMD_ALT_MIN", "0")
+    set_opts(monkeypatch, stem="0")
+    set_opts(monkeypatch, alt_min="0")
     rig = Rig(*r50, 0)
     x = synth.synth_images(rig.t, 3, 71)
     x[1, :, 10:14, :] = -1000.0                      # clamps to -128: the negate quirk through the xneg half
     rig.check_all_layers(x)
-    monkeypatch.delenv("TF2_AMD_STEM")
-    monkeypatch.setenv("TF2_AMD_ALT_MIN", "1000000")  # never: the 64-row tiles / split-K kernel for every small-map layer
+    set_opts(monkeypatch, stem=None)
+    set_opts(monkeypatch, alt_min="1000000")  # never: the 64-row tiles / split-K kernel for every small-map layer
     rig.net.reload_options()
     rig.check_all_layers(x, layers={0, 24, 27, 43, 46, 52, 53})
 
@@ -321,13 +323,13 @@ def test_first_layer_generic_path_and_wide_tile_alternatives(r50, monkeypatch):
 def test_doubled_channels_on_and_off(r50, monkeypatch):
     """Internal two-Q tensors store their higher-Q channels as 2x - 128 (one exponent window for the consumers,
     weight_pack.cpp): the default run reads them back through read_layer's inverse in every other test; here the plain form
-    (TF2_AMD_NODBL=1 at pack time) on the same images, every layer, and both against the oracle.  The images saturate some
+    (nodbl=1 at pack time) on the same images, every layer, and both against the oracle.  The images saturate some
     3x3 borders' neighbourhoods so that padded taps (pad value -128 on doubled channels) matter."""
     x = synth.synth_images(r50[0], 3, 81)
     x[1, :, :8, :] = 150.0
     x[2, :, :, -6:] = -120.0
     Rig(*r50, 0).check_all_layers(x)
-    monkeypatch.setenv("TF2_AMD_NODBL", "1")
+    set_opts(monkeypatch, nodbl="1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(x, layers={2, 3, 4, 6, 7, 12, 13, 14, 16, 17, 26, 27, 53})
 
@@ -336,15 +338,15 @@ def test_fused_bottleneck_pairs(r50, monkeypatch):
     """conv_bneck.hip: branch2b (3x3 / stride 1) + branch2c (1x1 expand, residual, ReLU) of the stride-1 bottlenecks in one
     launch (C = 64 / 128 / 256; halo tile and intermediate tile in LDS, weights from registers): every layer with keep_all
     (the intermediate map is then also stored) at ragged batches, the logits of plain runs, and the unfused path
-    (TF2_AMD_NOFUSE=1 at pack time) on the same inputs.  TF2_AMD_BNECK_MIN=1: the fused launch also for the small grids of
+    (nofuse=1 at pack time) on the same inputs.  bneck_min=1: the fused launch also for the small grids of
     these batches (by default a pair runs fused only when it has at least 256 row bands, i.e. blocks)."""
-    monkeypatch.setenv("TF2_AMD_BNECK_MIN", "1")
+    set_opts(monkeypatch, bneck_min="1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 3, 61))
     x = synth.synth_images(rig.t, 5, 62)
     want = rig.ref.logits(rig.ref.run(x))
     np.testing.assert_array_equal(rig.run(x, keep_all=False), want)
-    monkeypatch.setenv("TF2_AMD_NOFUSE", "1")
+    set_opts(monkeypatch, nofuse="1")
     rig2 = Rig(*r50, 0)
     np.testing.assert_array_equal(rig2.run(x, keep_all=False), want)
     rig2.check_all_layers(synth.synth_images(rig.t, 2, 63), layers={3, 4, 16, 17, 32, 33, 52, 53})
@@ -415,9 +417,9 @@ def test_input_quantisation_ties_and_extremes(r50_rig):
 
 @pytest.mark.parametrize("sk8", ["0", "100000"])
 def test_resnet50_split_k_forced(r50, monkeypatch, sk8):
-    """4-way and 8-way in-block split-K (TF2_AMD_SK8 = largest grid that takes the 8-wave form)."""
-    monkeypatch.setenv("TF2_AMD_SK8", sk8)
-    monkeypatch.setenv("TF2_AMD_SK", "1")
+    """4-way and 8-way in-block split-K (sk8 = largest grid that takes the 8-wave form)."""
+    set_opts(monkeypatch, sk8=sk8)
+    set_opts(monkeypatch, sk="1")
     rig = Rig(*r50, 0)
     rig.check_all_layers(synth.synth_images(rig.t, 2, 21), layers={26, 28, 32, 45, 47, 52, 53})
 
@@ -463,7 +465,7 @@ def test_doubled_channels_written_by_conv_stem_and_by_a_fused_expand(which, monk
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import emu_packed as emu
-    monkeypatch.setenv("TF2_AMD_BNECK_MIN", "1")
+    set_opts(monkeypatch, bneck_min="1")
     t = _stem_nopool_tables() if which == "stem_without_pool" else _expand_nores_tables()
     q = synth.synth_q_values(t, 1, spread=1)
     rig = Rig(t, q, synth.synth_model(t, q, 1), 0)
@@ -478,18 +480,18 @@ def test_doubled_channels_written_by_conv_stem_and_by_a_fused_expand(which, monk
 
 @pytest.mark.parametrize("chain", ["5", "2", "1"])
 def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
-    """TF2_AMD_BGROUP=1 (the default): the five identity bottlenecks of stage 4 (rows 28-42) and the two of stage 5 (rows 47-52, the
+    """bgroup=1 (the default): the five identity bottlenecks of stage 4 (rows 28-42) and the two of stage 5 (rows 47-52, the
     second one ending in the global average) as ONE launch each, eight blocks per image meeting at epoch-tagged flags between
-    the layers (conv_bgroup.hip); stage 4's five in ONE launch together (TF2_AMD_BGROUP_CHAIN=5, the default), as 2 + 2 + 1, or
+    the layers (conv_bgroup.hip); stage 4's five in ONE launch together (bgroup_chain=5, the default), as 2 + 2 + 1, or
     one by one.  Every layer against the oracle at batch 2 and 5, then batch-32 logits of repeated runs on the
     liveness-planned workspace."""
-    monkeypatch.setenv("TF2_AMD_BGROUP", "1")
-    monkeypatch.setenv("TF2_AMD_BGROUP_CHAIN", chain)
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN7", "1")          # (by default batches below 12 keep the separate launches: measured equal or faster there)
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN14", "1")
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN28", "1")
-    monkeypatch.setenv("TF2_AMD_BGROUP_MIN56F", "1")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
+    set_opts(monkeypatch, bgroup="1")
+    set_opts(monkeypatch, bgroup_chain=chain)
+    set_opts(monkeypatch, bgroup_min7="1")          # (by default batches below 12 keep the separate launches: measured equal or faster there)
+    set_opts(monkeypatch, bgroup_min14="1")
+    set_opts(monkeypatch, bgroup_min28="1")
+    set_opts(monkeypatch, bgroup_min56f="1")
+    set_opts(monkeypatch, alt_conc="0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
     stage45 = {"5": [28, 47], "2": [28, 34, 40, 47], "1": [28, 31, 34, 37, 40, 47, 50]}[chain]
@@ -503,20 +505,19 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     np.testing.assert_array_equal(first[:3], rig.ref.logits(rig.ref.run(x[:3])))
     for _ in range(10):
         np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
-    monkeypatch.setenv("TF2_AMD_BGROUP", "0")
+    set_opts(monkeypatch, bgroup="0")
     plain = Rig(*r50, 0)
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
 
 
-@pytest.mark.parametrize("pack_switch", ["TF2_AMD_NOFAST", "TF2_AMD_NODBL", "TF2_AMD_NOSEMI"])
+@pytest.mark.parametrize("pack_switch", ["nofast", "nodbl", "nosemi"])
 def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     """The group kernels share requant_epilogue.h with everything else: the wrap-exact generic requantisation on every row
-    (TF2_AMD_NOFAST), plain instead of doubled channels (TF2_AMD_NODBL: more two-window rows -- some bottlenecks then fall back to
+    (nofast), plain instead of doubled channels (nodbl: more two-window rows -- some bottlenecks then fall back to
     separate launches, by the library's own eligibility rules), no SEMI rows.  Every layer against the oracle, group launches on."""
-    monkeypatch.setenv(pack_switch, "1")
-    for k in ("TF2_AMD_BGROUP_MIN7", "TF2_AMD_BGROUP_MIN14", "TF2_AMD_BGROUP_MIN28", "TF2_AMD_BGROUP_MIN56F"):
-        monkeypatch.setenv(k, "1")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", "0")
+    set_opts(monkeypatch, **{pack_switch: "1"})
+    set_opts(monkeypatch, bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1)
+    set_opts(monkeypatch, alt_conc="0")
     rig = Rig(*r50, 0)
     groups = [r["kernel"] for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]]
     assert len(groups) >= 2 and sum("bottlenecks" in k for k in groups) >= 2      # (consecutive identity bottlenecks share a launch)
@@ -534,14 +535,14 @@ def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc)
     """conv_bband.hip: the identity bottlenecks of stage 3 (rows 15-23: two-window reduce, the last one's 3x3 two-window too) and stage 4
     (rows 28-42) as ONE launch each of independent row bands -- a block owns
     `rows` output rows of one image and all channels, recomputes the reduce for its halo rows, keeps both intermediates in LDS; no
-    exchange between blocks.  The default with batches in flight (7 rows), TF2_AMD_BBAND=2 one batch at a time as well.  Every
+    exchange between blocks.  The default with batches in flight (7 rows), bband=2 one batch at a time as well.  Every
     layer against the oracle at batch 2 and 5 (keep_all: the intermediates are written out too), then batch-32 logits of repeated
     runs on the liveness-planned workspace, and against the plain launches."""
-    monkeypatch.setenv("TF2_AMD_BBAND", "2" if conc == "0" else "1")
-    monkeypatch.setenv("TF2_AMD_BBAND_ROWS", rows)
-    monkeypatch.setenv("TF2_AMD_BBAND_ROWS_ALONE", rows)
-    monkeypatch.setenv("TF2_AMD_BBAND_MIN", "1")
-    monkeypatch.setenv("TF2_AMD_ALT_CONC", conc)
+    set_opts(monkeypatch, bband="2" if conc == "0" else "1")
+    set_opts(monkeypatch, bband_rows=rows)
+    set_opts(monkeypatch, bband_rows_alone=rows)
+    set_opts(monkeypatch, bband_min="1")
+    set_opts(monkeypatch, alt_conc=conc)
     rig = Rig(*r50, 0)
     launches = rig.net.describe_launches(32, int(conc))
     stage3 = [15, 18, 21] if rows != "2" else []          # (28 x 28: bands of 7 or 4 rows)
@@ -557,7 +558,7 @@ def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc)
     np.testing.assert_array_equal(first[:3], rig.ref.logits(rig.ref.run(x[:3])))
     for _ in range(5):
         np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
-    monkeypatch.setenv("TF2_AMD_BBAND", "0")
+    set_opts(monkeypatch, bband="0")
     plain = Rig(*r50, 0)
     assert not any("conv_bband" in r["kernel"] for r in plain.net.describe_launches(32, int(conc)))
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)

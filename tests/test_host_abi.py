@@ -12,6 +12,7 @@ from oracle import netref
 from tf2_amd import _lib, config as cfg, network, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from tests.conftest import set_opts  # noqa: E402
 
 
 def test_library_exports_every_declared_symbol():
@@ -216,7 +217,7 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert "im2col" in s[0]["kernel"] and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"
     assert {r["layer"] for r in s if "conv_c3" in r["kernel"]} == {21, 24}       # its 3x3 layers have 16-64 input channels: the two 64-channel ones on 14 x 14
     assert any("conv_c3" in r["kernel"] for r in launches(cfg.ssd300_tables(), 32))
-    monkeypatch.setenv("TF2_AMD_C3", "0"); monkeypatch.setenv("TF2_AMD_IM2COL0", "0")
+    set_opts(monkeypatch, c3="0"); set_opts(monkeypatch, im2col0="0")
     v0 = launches(cfg.vgg16_tables(), 32)
     assert not any("conv_c3" in r["kernel"] or "im2col" in r["kernel"] for r in v0) and "conv_mfma2" in v0[1]["kernel"]
 
@@ -314,3 +315,63 @@ def test_feeder_reports_every_error_and_never_hangs(monkeypatch):
     with pytest.raises(RuntimeError, match="no device"):
         g.drain()
     g.close()
+
+
+def test_option_string_is_parsed_once_and_checked(monkeypatch):
+    """csrc/opts.h: ONE option string (TF2_AMD_OPTS), unknown names and test-only options without TF2_AMD_TEST=1 are errors of
+    tf2_net_create / tf2_net_reload_options (status codes, never exit), and no source file but opts.cpp reads the environment."""
+    t = cfg.tiny_tables()
+    monkeypatch.delenv("TF2_AMD_TEST", raising=False)
+    monkeypatch.setenv("TF2_AMD_OPTS", "bband=0,c3=0")                    # product options: no TF2_AMD_TEST needed
+    net = network.NetWork(t)
+    monkeypatch.setenv("TF2_AMD_OPTS", "no_such_option=1")
+    with pytest.raises(_lib.Tf2Error, match="unknown option"):
+        net.reload_options()
+    with pytest.raises(_lib.Tf2Error, match="unknown option"):
+        network.NetWork(t)
+    monkeypatch.setenv("TF2_AMD_OPTS", "nofast=1")
+    with pytest.raises(_lib.Tf2Error, match="test-only"):
+        net.reload_options()
+    monkeypatch.setenv("TF2_AMD_TEST", "1")
+    net.reload_options()
+    monkeypatch.setenv("TF2_AMD_OPTS", "bband")                           # a bare name = 1
+    net.reload_options()
+    csrc = os.path.join(ROOT, "tf2_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")) and f != "opts.cpp":
+            assert not re.search(r"\bgetenv\s*\(\s*\"", open(os.path.join(csrc, f)).read()), f
+
+
+def test_a_second_reader_of_the_image_keeps_the_plain_first_layer():
+    """Net::init turns a 3x3 first layer on the 3-channel image into a pointwise layer over the im2col image -- the input TENSOR then
+    holds im2col bytes.  A program in which another row reads the image as well must keep the plain form (round-4 advisor finding)."""
+    t = cfg.vgg16_tables(32, 10)
+    one = network.NetWork(t)
+    q = synth.synth_q_values(t, 3)
+    one.Init(synth.synth_model(t, q, 3), synth.q_text(q))
+    assert "im2col" in one.describe_launches(2, 0)[0]["kernel"]
+    t2 = cfg.vgg16_tables(32, 10)
+    plan = cfg.build_plan(t2)
+    if any(L.src == -1 for L in plan[1:]):
+        pytest.skip("the builder already has a second image reader")
+    # a second consumer of the image: row 1 rewired to read it (same shape as row 0's input: 3 channels, same map)
+    descs = network._layer_descs(t2)
+    plan2, nd, arr = descs
+    import ctypes as C2
+    arr[1].src, arr[1].C, arr[1].model_C, arr[1].q_in_row = -1, 3, 3, arr[0].q_in_row
+    h = C2.c_void_p()
+    _lib.check(_lib.lib().tf2_net_create(C2.byref(nd), arr, C2.byref(h)))
+    try:
+        q2 = np.zeros((nd.n_q_rows, nd.max_out_channel), np.int8)
+        _lib.check(_lib.lib().tf2_net_set_q(h, q2.ctypes.data, q2.size))
+        # an all-zero model stream of the right length: row 1 now has 3 input channels
+        n_f = sum((L.N * (3 if i == 1 else L.model_C) * L.model_k * L.model_k) + (L.N if L.bias_en else 0) + (L.N * 4 + 1 if L.bn_en else 0) for i, L in enumerate(plan2) if not L.ipool)
+        model = np.zeros(n_f, np.float32)
+        _lib.check(_lib.lib().tf2_net_load_model(h, model.ctypes.data, model.size))
+        _lib.check(_lib.lib().tf2_net_pack(h, 0))
+        rows = (_lib.LaunchInfo * 512)()
+        n = C2.c_int(0)
+        _lib.check(_lib.lib().tf2_net_describe_launches(h, 2, 0, rows, 512, C2.byref(n)))
+        assert "im2col" not in rows[0].kernel.decode(), rows[0].kernel
+    finally:
+        _lib.lib().tf2_net_destroy(h)

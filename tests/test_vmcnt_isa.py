@@ -1,0 +1,65 @@
+"""The hand-written `s_waitcnt vmcnt(N)` waits of the LDS-DMA kernels, checked on the COMPILED code (csrc/vm_track.h,
+tools/vmcnt_check.py): on every path of every instantiation's control-flow graph at least N vector-memory loads lie between the last
+`global_load_lds_dwordx4` and the wait that covers it -- the property whose violation is bit-exact on an idle chip and wrong under load
+(round 4: b53d5bf, 7173314).  Needs hipcc (device assembly of conv_bband.hip / conv_c3.hip with the library's own flags), no GPU."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import vmcnt_check  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def isa_files():
+    return vmcnt_check.build_isa()
+
+
+def test_every_counted_wait_is_covered_on_every_path(isa_files):
+    n_waits = 0
+    for f in isa_files:
+        bad, report = vmcnt_check.check_file(f, verbose=False)
+        assert bad == 0, "\n".join(r for r in report if r.startswith("BAD"))
+        n_waits += len(report)
+    # every instantiation the launchers can select is in the assembly: 8 band kernels, 12 halo-tile kernels + the one-slab kernel
+    kernels = {}
+    for f in isa_files:
+        kernels.update(vmcnt_check.parse_kernels(f))
+    assert sum("conv_bband_kernel" in k for k in kernels) == 8
+    assert sum("conv_c3_kernel" in k for k in kernels) >= 10 and sum("conv_c3_w9_kernel" in k for k in kernels) == 1
+    assert n_waits >= 40
+
+
+def test_the_checker_sees_a_wait_that_is_one_load_too_generous(isa_files):
+    """the same analysis on a doctored copy: one vector-memory load removed from behind a chunk's DMAs must be reported"""
+    kernels = vmcnt_check.parse_kernels(isa_files[0])
+    name, items = next((k, v) for k, v in kernels.items() if "conv_bband_kernel" in k)
+    waits, n_dma = vmcnt_check.analyse(items)
+    tight = [w for w in waits if w[0] > 0 and w[1] == min(x[1] for x in waits if x[0] > 0)][0]
+    N, st, at = tight
+    # drop (st - N + 1) loads in front of that wait: the wait then allows one more than was issued
+    doctored, dropped, need = list(items), 0, st - N + 1
+    for i in range(at - 1, -1, -1):
+        if dropped == need:
+            break
+        t, a = doctored[i]
+        if a and t.startswith("global_load_lds"):
+            break
+        if vmcnt_check.VM_LOAD.match(t):
+            doctored[i] = ("s_nop 0", False)
+            dropped += 1
+    assert dropped == need
+    waits2, _ = vmcnt_check.analyse(doctored)
+    assert any(w[2] == at and w[1] < w[0] for w in waits2)
+
+
+def test_no_vmcnt_literal_left_in_the_dma_kernels():
+    """every hand-written vmcnt wait of the DMA kernels goes through vm_track.h (vmcnt(0) drains excepted)"""
+    for f in ("conv_bband.hip", "conv_c3.hip"):
+        src = open(os.path.join(ROOT, "tf2_amd", "csrc", f)).read()
+        lits = [m.group(1) for m in re.finditer(r"s_waitcnt[^\"]*vmcnt\((\d+)\)", src)]
+        assert all(v == "0" for v in lits), (f, lits)
+        assert "vm_wait<" in src

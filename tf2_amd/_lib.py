@@ -23,7 +23,8 @@ if "GPU_MAX_HW_QUEUES" not in os.environ:
         import warnings
         warnings.warn("tf2_amd: HIP was initialised before tf2_amd was imported, GPU_MAX_HW_QUEUES=8 cannot take effect any more: a fourth "
                       "batch in flight will share a hardware queue (export GPU_MAX_HW_QUEUES=8 before starting the process)", RuntimeWarning)
-# TF2_AMD_LIB: another build of the same sources (tools/probe_run.py loads the -DTF2_PROBES library); never a fallback
+# TF2_AMD_LIB: another build of the same sources (the tools' -DTF2_PROBES / -DTF2_CHECK_DMA libraries); never a fallback, and refused
+# unless the process also sets TF2_AMD_TOOL_LIB=1 (lib() below: a tool build can leave work out of a step)
 LIB_PATH = os.environ.get("TF2_AMD_LIB") or os.path.join(_HERE, "libtf2amd.so")
 
 
@@ -91,6 +92,11 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension was not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C tf2_amd/csrc`). tf2_amd has no CPU fallback by design.")
     L = C.CDLL(LIB_PATH)
+    L.tf2_build_kind.restype = C.c_int
+    kind = L.tf2_build_kind()
+    if kind != 0 and os.environ.get("TF2_AMD_TOOL_LIB") != "1":
+        raise ImportError(f"{LIB_PATH} is a TOOL build of the library (tf2_build_kind() = {kind}: 1 timing probes, 2 DMA check), not the "
+                          "product; tools that want it set TF2_AMD_TOOL_LIB=1 next to TF2_AMD_LIB")
     vp, sz, i32p, i8p, u8p, fp = C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
     L.tf2_last_error.restype = C.c_char_p
     L.tf2_abi_version.restype = C.c_int
@@ -134,11 +140,24 @@ def lib() -> C.CDLL:
 
 
 EXPORTED = [
-    "tf2_last_error", "tf2_abi_version", "tf2_has_device_code", "tf2_get_real", "tf2_quantization",
+    "tf2_last_error", "tf2_abi_version", "tf2_has_device_code", "tf2_build_kind", "tf2_get_real", "tf2_quantization",
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
     "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_run_stats", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
+
+
+def set_opts(**kw) -> None:
+    """Tools: set / change / remove (value None) options of TF2_AMD_OPTS (csrc/opts.h) in this process's environment, cumulatively, and
+    admit the test-only ones (TF2_AMD_TEST=1).  Takes effect at the next tf2_net_create / NetWork.reload_options()."""
+    cur = dict(item.split("=", 1) for item in os.environ.get("TF2_AMD_OPTS", "").split(",") if item)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    os.environ["TF2_AMD_TEST"] = "1"
+    os.environ["TF2_AMD_OPTS"] = ",".join(f"{k}={v}" for k, v in cur.items())
 
 
 def check(status: int) -> None:

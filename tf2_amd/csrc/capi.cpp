@@ -3,6 +3,7 @@
 #include <new>
 #include "tf2_net.h"
 #include "tf2_device.h"
+#include "opts.h"
 
 using namespace tf2;
 
@@ -16,11 +17,32 @@ extern "C" {
 const char* tf2_last_error(void) { return last_error().c_str(); }
 int tf2_abi_version(void) { return 1; }
 int tf2_has_device_code(void) { return 1; }
+// 0: the product; 1: the -DTF2_PROBES timing build (leaves work out: tools/probe_run.py); 2: the -DTF2_CHECK_DMA build (vm_track.h)
+int tf2_build_kind(void) {
+#if defined(TF2_PROBES)
+  return 1;
+#elif defined(TF2_CHECK_DMA)
+  return 2;
+#else
+  return 0;
+#endif
+}
+#ifdef TF2_CHECK_DMA
+// tools/dma_stress.py only (not part of include/tf2_amd.h): {fragment reads that saw the sentinel of a DMA not landed, reads checked}
+int tf2_check_dma_errors(unsigned long long out[2]) {
+  unsigned long long a[2] = {0, 0}, b[2] = {0, 0};
+  tf2::conv_bband_check_counts(a); tf2::conv_c3_check_counts(b);
+  out[0] = a[0] + b[0]; out[1] = a[1] + b[1];
+  return 0;
+}
+#endif
 
 uint8_t tf2_get_real(float w, int8_t expand) { return get_real(w, expand); }
 
 tf2_status tf2_net_create(const tf2_net_desc* nd, const tf2_layer_desc* layers, tf2_net** out) {
   if (!nd || !layers || !out) { set_error("tf2_net_create: null argument"); return TF2_ERR_ARG; }
+  // the option snapshot (TF2_AMD_OPTS, opts.h) is taken here and by tf2_net_reload_options, nowhere else
+  { const std::string e = opts_reload(); if (!e.empty()) { set_error(e); return TF2_ERR_ARG; } }
   tf2_net* n = new (std::nothrow) tf2_net();
   if (!n) { set_error("out of memory"); return TF2_ERR_SIZE; }
   tf2_status st = n->impl.init(nd, layers);
@@ -154,7 +176,12 @@ size_t tf2_net_logits_size(const tf2_net* net, int batch) {
   return net->impl.logits_bytes(batch);
 }
 
-tf2_status tf2_net_reload_options(tf2_net* net) { CHECK_NET(net); net->impl.load_options(); return TF2_OK; }
+tf2_status tf2_net_reload_options(tf2_net* net) {
+  CHECK_NET(net);
+  { const std::string e = opts_reload(); if (!e.empty()) { set_error(e); return TF2_ERR_ARG; } }
+  net->impl.load_options();
+  return TF2_OK;
+}
 
 tf2_status tf2_net_run(tf2_net* net, const float* images_dev, int batch, void* ws, size_t ws_bytes,
                        int8_t* logits_dev, void* hip_stream) {

@@ -27,6 +27,7 @@
 #include "tf2_internal.h"
 #include "tf2_device.h"
 #include "requant_epilogue.h"
+#include "vm_track.h"
 
 namespace tf2 {
 
@@ -36,13 +37,30 @@ using i32x16 = int __attribute__((ext_vector_type(16)));
 #define TF2_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define TF2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int N>
-__device__ __forceinline__ void bb_wait_vmcnt() {
-  static_assert(N == 2 || N == 4 || N == 8, "prepared immediates");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-}
+#ifdef TF2_CHECK_DMA
+TF2_DMA_CHECK_COUNTERS(g_bband_dma_check);
+void conv_bband_check_counts(unsigned long long out[2]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bband_dma_check), 16); }
+#endif
+
+// The reduce phase's per-wave VM schedule, stated ONCE: the issue code and the counted wait of step0 both read it (vm_track.h).
+//   step v = chunk ch * SC + slab sl, in issue order:
+//     [sl == 0 and ch > 0]             WAIT for the DMAs of chunk ch, barrier
+//     always                           the fragment loads of step v + 2: frag_loads(v) 16-byte loads
+//     [sl == 0 and 0 < ch < NCH - 1]   the DMAs of chunk ch + 1
+// (chunks 0 and 1 are issued in the prologue and drained there with vmcnt(0))
+template <int KS1, int SC, int MT, bool DUAL1>
+struct BbSched {
+  static constexpr bool low_at(int v) { return DUAL1 && v + 2 < KS1; }      // step v also loads the LOW window's fragments of step v + 2
+  static constexpr int frag_loads(int v) { return 2 * MT + (low_at(v) ? 2 * MT : 0); }
+  // VM operations issued BEHIND the DMAs of chunk c (step (c - 1) * SC, behind that step's own fragment loads) when step c * SC waits
+  static constexpr int since_dma(int c) {
+    int n = 0;
+    for (int v = (c - 1) * SC + 1; v < c * SC; v++) n += frag_loads(v);
+    return n;
+  }
+  // ... of which the compiler's own waits for the fragments leave at most the last two steps' in flight: no point in allowing more
+  static constexpr int wait_n(int c) { return vm_min(since_dma(c), (SC - 1 < 2 ? SC - 1 : 2) * frag_loads(c * SC - 1)); }
+};
 
 template <int T, int N, class F>
 __device__ __forceinline__ void bb_static_for(F& fn) {
@@ -153,6 +171,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       const int row = r0 - 1 + p / W;
       const bool ok = p < n_p0 && (unsigned)row < (unsigned)H;
       const int8_t* src = ok ? a.x + (size_t)(pix0 + p) * C + (c * SC + sl) * 64 + chunk * 16 : a.zero + chunk * 16;
+#ifdef TF2_CHECK_DMA
+      dma_stamp(buf + sl * (NP0 * 64) + grp * 1024);
+#endif
       bb_dma16(src, buf + sl * (NP0 * 64) + grp * 1024);
     }
   };
@@ -242,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     const int row = (wn + j * WN) * 32 + (lane & 31);
     bm0[j] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
   }
+  using Sched = BbSched<KS1, SC, MT, DUAL1>;
   auto step0 = [&](auto v_c) {
     constexpr int v = decltype(v_c)::value;                // slab index
     constexpr int ch = v / SC, sl = v % SC;
@@ -250,15 +272,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
     if constexpr (sl == 0 && ch > 0) {
       // chunk ch landed in every wave and nobody reads buffer (ch + 1) & 1 any more.  This wave's DMAs of chunk ch were issued at
       // the first step of chunk ch - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
-      // other SC - 1 steps, (DUAL1 ? 4 : 2) MT each, of which at most the last two steps' still fly -- so "no more than
-      // min(2, SC - 1) steps' loads outstanding" means every DMA of the chunk has landed.  (SC = 2 with the bound for two steps
-      // let DMAs fly on: wrong logits with batches in flight, round 4.)
-      bb_wait_vmcnt<(SC - 1 < 2 ? SC - 1 : 2) * (DUAL1 ? 4 : 2) * MT>();
+      // other SC - 1 steps -- Sched::since_dma(ch) operations; "at most that many outstanding" means every DMA of the chunk has landed
+      // (vm_track.h; tests/test_vmcnt_isa.py counts the same in the compiled code).  (Round 4 wrote the bound of two steps as a
+      // literal: with SC = 2 it let DMAs fly on -- wrong logits with batches in flight.)
+      static_assert(Sched::wait_n(ch) <= Sched::since_dma(ch), "a wait may never allow more than was issued behind the DMAs");
+      vm_wait<Sched::wait_n(ch)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
     load_step(nxt, std::integral_constant<int, v + 2>{});
-    if constexpr (DUAL1 && v + 2 < KS1) load_a(BB_BUFL(v + 2), a.w1, tms1, KS1, cb_w, v + 2, 2, 1);
+    if constexpr (Sched::low_at(v)) load_a(BB_BUFL(v + 2), a.w1, tms1, KS1, cb_w, v + 2, 2, 1);
     if constexpr (sl == 0 && ch > 0 && ch + 1 < NCH) {
       // (behind this step's fragment loads: the compiler's counted wait for the NEXT step's fragments then still lets these fly)
       asm volatile("" ::: "memory");
@@ -270,6 +293,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
       i32x4 bf[J0];
 #pragma unroll
       for (int j = 0; j < J0; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm0[j] ^ (ks << 5)));
+#ifdef TF2_CHECK_DMA
+#pragma unroll
+      for (int j = 0; j < J0; j++) dma_check(bf[j], g_bband_dma_check);
+#endif
 #pragma unroll
       for (int i = 0; i < MT; i++)
 #pragma unroll

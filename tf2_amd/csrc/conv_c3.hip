@@ -30,6 +30,7 @@
 #include "tf2_internal.h"
 #include "tf2_device.h"
 #include "requant_epilogue.h"
+#include "vm_track.h"
 
 namespace tf2 {
 
@@ -48,6 +49,11 @@ __device__ __forceinline__ void c3_dma16(const int8_t* src, int8_t* lds_dst) {
   const unsigned l = (unsigned)(unsigned long long)TF2_LDS_PTR(lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(l) : "memory", "m0");
 }
+
+#ifdef TF2_CHECK_DMA
+TF2_DMA_CHECK_COUNTERS(g_c3_dma_check);
+void conv_c3_check_counts(unsigned long long out[2]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c3_dma_check), 16); }
+#endif
 
 constexpr int kC3HaloPx = 384;               // halo pixels of a tile, padded to whole 64-pixel DMA groups (host: c3_pick_tile)
 constexpr int kC3PlaneB = kC3HaloPx * 16;    // bytes of one 16-byte plane of a slab
@@ -127,6 +133,9 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
         const int r = t.r0 - 1 + hr, cc = t.c0 - 1 + hc;
         const bool in = hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)cc < (unsigned)W;
         const int8_t* src = in ? a.x + (t.img_px + (long long)r * W + cc) * a.x_cp + coff : a.zero2 + coff;
+#ifdef TF2_CHECK_DMA
+        dma_stamp(buf + sl * kC3SlabB + k * kC3PlaneB + g * 1024);
+#endif
         c3_dma16(src, buf + sl * kC3SlabB + k * kC3PlaneB + g * 1024);
       }
     }
@@ -234,13 +243,13 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
         if (gc > 0) {
           // chunk c landed in every wave and nobody reads the other buffer any more.  This wave's DMAs of chunk c were issued at the
           // first step of chunk c - 1, BEHIND that step's fragment loads: younger than them are the fragment loads of that chunk's
-          // other NSTEP - 1 steps, of which at most the last two steps' still fly (conv_bband.hip step0).
-          // (PF steps' loads when the fragments run further ahead)
-          static_assert(PF * F <= 16, "prepared immediates");
-          if constexpr (PF * F == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if constexpr (PF * F == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if constexpr (PF * F == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-          else { static_assert(PF * F == 4 || PF * F == 8 || PF * F == 10 || PF * F == 16, "prepared immediates"); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+          // other NSTEP - 1 steps, F each -- every step loads, whatever the chunk (past the last one: a valid address, never used) --
+          // plus, across a tile boundary, the previous tile's output stores (VM operations as well: they only make the wait stricter).
+          // Of those the compiler's own waits leave at most the last PF steps' in flight: no point in allowing more (vm_track.h;
+          // tests/test_vmcnt_isa.py counts the same in the compiled code).
+          constexpr int kSinceDma = (NSTEP - 1) * F;
+          static_assert(PF * F <= kSinceDma, "a wait may never allow more than was issued behind the DMAs");
+          vm_wait<vm_min(kSinceDma, PF * F)>();
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
         }
@@ -271,6 +280,10 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
         i32x4 bf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(ring + addr[j] + 2 * ks * kC3PlaneB);
+#ifdef TF2_CHECK_DMA
+#pragma unroll
+        for (int j = 0; j < NJ; j++) dma_check(bf[j], g_c3_dma_check);
+#endif
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
 #pragma unroll
@@ -383,6 +396,9 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
           const int r = t.r0 - 1 + hr, cc = t.c0 - 1 + hc;
           const bool in = hp < n_halo && (unsigned)r < (unsigned)H && (unsigned)cc < (unsigned)W;
           const int8_t* src = in ? a.x + (t.img_px + (long long)r * W + cc) * a.x_cp + wave * 16 : a.zero2 + wave * 16;
+#ifdef TF2_CHECK_DMA
+          dma_stamp(buf + g * 1024);
+#endif
           c3_dma16(src, buf + g * 1024);
         }
       }
@@ -437,13 +453,11 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
 #pragma unroll 1
     for (int unit = bid; unit < n_units; unit += ustride, g++) {
       if (g > 0) {
-        // tile g's DMAs were issued three tiles ago; younger: the DMAs of the tiles fetched since (six per issuing wave and tile: two
-        // tiles, fewer at the end of the block's walk) and the output stores in between -- "at most 6 x (tiles fetched since)
-        // outstanding" therefore covers every DMA of tile g, whatever the stores did (they only make the wait stricter)
-        const int since = n_issued - (g + 1);
-        if (since >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (since == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile g's DMAs were issued three tiles ago; younger: the DMAs of the tiles REALLY fetched since (NG per issuing wave and tile:
+        // two tiles, fewer at the end of the block's walk -- counted by produce(), not assumed) and the output stores in between --
+        // "at most NG x (tiles fetched since) outstanding" therefore covers every DMA of tile g, whatever the stores did (they only make
+        // the wait stricter; vm_track.h)
+        vm_wait_groups<NG, 2>(n_issued - (g + 1));
         __builtin_amdgcn_s_barrier();                      // ... in every issuing wave; and nobody reads tile g - 1's buffer any more
         asm volatile("" ::: "memory");
       }
@@ -463,6 +477,10 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
           i32x4 bf[NJ];
 #pragma unroll
           for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(ring + h0[j] + soff + 2 * ks * kC3PlaneB);
+#ifdef TF2_CHECK_DMA
+#pragma unroll
+          for (int j = 0; j < NJ; j++) dma_check(bf[j], g_c3_dma_check);
+#endif
 #pragma unroll
           for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[t][ks], bf[j], acc[j], 0, 0, 0);
         }
@@ -577,13 +595,16 @@ static int launch_c3_w9(const C3Args& a, hipStream_t s) {
   return launch_ok() ? 0 : -1;
 }
 
+// the one-slab kernel: mode 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests).
+// Decided when the launch plan is built (C3Args::w9): tf2_net_describe_launches and every later step name the same kernel.
+bool conv_c3_takes_w9(const C3Args& a, int mode) {
+  return mode && a.tmk == 64 && a.C == 64 && !a.dual && !a.dbg && conv_c3_shape_ok(a.H, a.W, a.C, a.M) &&
+         (mode == 2 || (long)a.B * a.tiles_per_img * (a.M / 64) / std::max(1, tf2_cu_count()) >= 8);
+}
+
 int launch_conv_c3(const C3Args& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  // TF2_AMD_C3_W9: 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
-  const int w9 = getenv("TF2_AMD_C3_W9") ? atoi(getenv("TF2_AMD_C3_W9")) : 1;
-  if (w9 && a.tmk == 64 && a.C == 64 && !a.dual && !a.dbg && conv_c3_shape_ok(a.H, a.W, a.C, a.M) &&
-      (w9 == 2 || (long)a.B * a.tiles_per_img * (a.M / 64) / std::max(1, tf2_cu_count()) >= 8))
-    return launch_c3_w9(a, s);
+  if (a.w9) return launch_c3_w9(a, s);
   if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M) || (a.tm != 64 && a.tm != 128)) return 1;
   const int ks = a.C / 64;
   if ((a.tmk != 64 && a.tmk != 128 && a.tmk != 256) || a.M % a.tmk != 0 || (a.tmk == 256 && a.dual)) return 1;

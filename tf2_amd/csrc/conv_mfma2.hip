@@ -525,7 +525,7 @@ static int launch_dual(const ConvArgs& a, hipStream_t s) {
 // equal, 16 waves of 32x32 6-9 % slower -- profiles/r03_experiments.txt item 18; both shapes left the tree in round 4).
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  static const long t256 = getenv("TF2_AMD_T256") ? atol(getenv("TF2_AMD_T256")) : 384;
+  constexpr long t256 = 384;
   const long blocks256 = (long)((a.g.n_pix + 255) / 256) * a.n_mtiles;
   if (a.dual) {
     if (TM == 128) return launch_dual<4, 2, 32, 64, 3, 2>(a, s);

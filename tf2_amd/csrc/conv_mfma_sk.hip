@@ -413,9 +413,8 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
   const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);
   const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
-  // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU); TF2_AMD_SK_S3 overrides
-  static const long s3_blocks_env = getenv("TF2_AMD_SK_S3") ? atol(getenv("TF2_AMD_SK_S3")) : -1;
-  const long s3_blocks = s3_blocks_env >= 0 ? s3_blocks_env : 256;
+  // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU)
+  constexpr long s3_blocks = 256;
   if (w8) {
     if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
     return pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);

@@ -190,18 +190,16 @@ static int launch_pw2(const ConvArgs& a, hipStream_t s) {
 
 // Does the layer qualify?  `dense` = every m-tile's entry list is exactly slabs 0..nslab-1 (checked by the caller on
 // the host copy of the packed image).
-bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense) {
+bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix) {
   const ConvGeom& g = a.g;
   if (k != 1 || g.stride != 1 || (g.pad_h | g.pad_w) != 0 || g.H * g.W != g.OHW) return false;
   // two-slab layers (K = 128) measured slower here than in conv_mfma2 (twice the weight registers, half the
   // occupancy headroom): one slab only unless asked
-  const int max_slab = getenv("TF2_AMD_PW_SLABS") ? atoi(getenv("TF2_AMD_PW_SLABS")) : 1;
   if (nslab > max_slab) return false;
   if (!dense || nslab < 1 || nslab > 2 || g.Cp_in != nslab * 64) return false;
   if (a.n_phases > 2 || (a.n_phases == 2 && !a.dual)) return false;
   // a wave streams 32-pixel tiles one after the other: with few pixels (batch 1-2) the ring kernel's many short blocks finish
   // sooner (batch-1 latency 436 -> 428 us without this kernel, batch 32 49.1 -> 48.8 k img/s)
-  const long min_pix = getenv("TF2_AMD_PW_MINPIX") ? atol(getenv("TF2_AMD_PW_MINPIX")) : 8192;
   if (g.n_pix < min_pix) return false;
   return TM == 128 || TM == 64;
 }

@@ -792,8 +792,7 @@ int launch_conv_stem(const StemArgs& a, int nwin, void* stream) {
 #undef TF2_STEMQ
     return launch_ok() ? 0 : -1;
   }
-  static const bool no_pipe = getenv("TF2_AMD_STEM_NOPIPE") != nullptr;
-  if (unit && !no_pipe) {
+  if (unit) {
 #define TF2_STEMP(D_, M_) do { auto fn = conv_stem_pipe_kernel<D_, M_>; if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
                                TF2_LAUNCH_NAME("conv_stem_pipe_kernel<%s,%s>", D_ ? "doubled" : "plain", M_ == 1 ? "fast" : M_ == 2 ? "semi" : "generic"); \
                                TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, s, a); } while (0)

@@ -381,8 +381,7 @@ int launch_prep_input(const PrepArgs& a, void* stream) {
   }
   if (a.rewrite == 1 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
-    static const bool rows_off = getenv("TF2_AMD_PREP_ROWS") != nullptr && atoi(getenv("TF2_AMD_PREP_ROWS")) == 0;
-    if (a.xonly && !rows_off && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2) {
+    if (a.xonly && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2) {
       const unsigned gridr = (unsigned)(a.B * ((a.OH + 1) / 2));
       TF2_LAUNCH_NAME("prep_rewrite3_rows_kernel");
       if (a.src_is_q) TF2_LAUNCH((prep_rewrite3_rows_kernel<true>), dim3(gridr), dim3(256), 0, (hipStream_t)stream, a);

@@ -14,6 +14,7 @@
 #include <mutex>
 #include "tf2_net.h"
 #include "tf2_device.h"
+#include "opts.h"
 
 namespace tf2 {
 
@@ -46,9 +47,12 @@ tf2_status Net::init(const tf2_net_desc* d, const tf2_layer_desc* ls) {
   // 7x7 first layers: model_loader.cpp:244-257, input_loader.cpp:98-116).  TF2_AMD_IM2COL0=0 keeps the plain form.
   im2col0 = false;
   {
-    const bool off = getenv("TF2_AMD_IM2COL0") != nullptr && atoi(getenv("TF2_AMD_IM2COL0")) == 0;       // (read per handle: tests build both forms)
+    const bool off = opt("im2col0", 1) == 0;       // (read per handle: tests build both forms)
+    // (another row that reads the IMAGE would find the im2col bytes in the input tensor: such programs keep the plain form)
+    bool only_consumer = true;
+    for (int l = 1; l < nl; l++) if (layers[l].src == -1) only_consumer = false;
     tf2_layer_desc& L0 = layers[0];
-    if (!off && !nd.conv1_rewrite && L0.src == -1 && !L0.ipool && L0.k == 3 && L0.model_k == 3 && L0.C == 3 && L0.model_C == 3 &&
+    if (!off && only_consumer && !nd.conv1_rewrite && L0.src == -1 && !L0.ipool && L0.k == 3 && L0.model_k == 3 && L0.C == 3 && L0.model_C == 3 &&
         L0.dil <= 1 && nd.image_c == 3 && L0.H == nd.image_h && L0.W == nd.image_w && L0.stride >= 1 &&
         L0.OH == (L0.H + 2 * L0.pad_h - 3) / L0.stride + 1 && L0.OW == (L0.W + 2 * L0.pad_w - 3) / L0.stride + 1) {
       im2col0 = true; im_stride = L0.stride; im_pad_h = L0.pad_h; im_pad_w = L0.pad_w;
@@ -207,7 +211,10 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
         continue;
       }
       const bool grp = opts.bgroup_mode && bgroup_at(l);
-      if (!grp && !(opts.bband_mode && (bband_at(l, opts.bband_rows) || bband_at(l, opts.bband_rows_alone)))) continue;
+      // (band launches: the batch gate of launch_plan applies here too; whether batches are in flight is not known to the workspace
+      //  plan -- one workspace serves both launch plans -- so a batch that COULD take band launches pays their longer lifetimes in
+      //  both: INTEGRATION.md "Workspace")
+      if (!grp && !(opts.bband_mode && batch >= opts.bband_min && (bband_at(l, opts.bband_rows) || bband_at(l, opts.bband_rows_alone)))) continue;
       TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
       tin.last_use = std::max(tin.last_use, l + 2);
       TensorPlan& tm1 = wp.tensors[wp.exec[l].out_tensor];
@@ -437,41 +444,45 @@ bool Net::stem_selected(int batch) const {
 // ---- run-time switches (A/B experiments and forced kernels for the tests), read when a launch plan is built ----
 void Net::load_options() {
   RunOpts o;
-  if (const char* e = getenv("TF2_AMD_EXP")) o.flags |= atoi(e) & 0xff8;    // timing-probe bits of the -DTF2_PROBES build (tf2_device.h kProbe*, tools/probe_run.py); nothing in the product reads them
-  if (const char* e = getenv("TF2_AMD_PW")) o.pw_mode = atoi(e);        // register-resident pointwise kernel: 1 auto (default), 0 never
-  if (const char* e = getenv("TF2_AMD_SK")) o.sk_mode = atoi(e);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
-  if (const char* e = getenv("TF2_AMD_SK8")) o.sk8_blocks = atol(e);
-  if (const char* e = getenv("TF2_AMD_FC")) o.fc_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_FC_MIN")) o.fc_min_slabs = atoi(e);
-  if (const char* e = getenv("TF2_AMD_C3")) o.c3_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_C3_MIN")) o.c3_min_blocks = atol(e);
-  if (const char* e = getenv("TF2_AMD_C3_MIN256")) o.c3_min256 = atol(e);
-  if (const char* e = getenv("TF2_AMD_BNECK_MIN")) o.bneck_min_blocks = atol(e);   // smallest grid that takes conv_bneck (default 200)
-  if (const char* e = getenv("TF2_AMD_STEM")) o.stem_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN7")) o.bgroup_min7 = atoi(e);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN14")) o.bgroup_min14 = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN28")) o.bgroup_min28 = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_MIN56F")) o.bgroup_min56f = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP_CHAIN")) o.bgroup_chain = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BGROUP")) o.bgroup_mode = atoi(e);     // 1: identity bottlenecks of the 14 x 14 maps as one launch each (conv_bgroup.hip), one batch at a time
-  if (const char* e = getenv("TF2_AMD_BBAND")) o.bband_mode = atoi(e);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
-  if (const char* e = getenv("TF2_AMD_BBAND_ROWS")) o.bband_rows = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BBAND_ROWS_ALONE")) o.bband_rows_alone = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BBAND_MIN")) o.bband_min = atoi(e);
-  if (const char* e = getenv("TF2_AMD_BBAND_ALONE_MAPS")) o.bband_alone_maps = atoi(e);
+  // (the snapshot of TF2_AMD_OPTS was taken by the caller: tf2_net_create / tf2_net_reload_options, opts.h)
+  o.flags |= (int)opt("exp", 0) & 0xff8;    // timing-probe bits of the -DTF2_PROBES build (tf2_device.h kProbe*, tools/probe_run.py); nothing in the product reads them
+  o.pw_mode = (int)opt("pw", o.pw_mode);        // register-resident pointwise kernel: 1 auto (default), 0 never
+  o.sk_mode = (int)opt("sk", o.sk_mode);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
+  o.sk8_blocks = (long)opt("sk8", o.sk8_blocks);
+  o.fc_mode = (int)opt("fc", o.fc_mode);
+  o.fc_min_slabs = (int)opt("fc_min", o.fc_min_slabs);
+  o.c3_mode = (int)opt("c3", o.c3_mode);
+  o.c3_min_blocks = (long)opt("c3_min", o.c3_min_blocks);
+  o.c3_min256 = (long)opt("c3_min256", o.c3_min256);
+  o.c3_w9 = (int)opt("c3_w9", o.c3_w9);
+  o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
+  o.stem_mode = (int)opt("stem", o.stem_mode);
+  o.bgroup_min7 = (int)opt("bgroup_min7", o.bgroup_min7);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
+  o.bgroup_min14 = (int)opt("bgroup_min14", o.bgroup_min14);
+  o.bgroup_min28 = (int)opt("bgroup_min28", o.bgroup_min28);
+  o.bgroup_min56f = (int)opt("bgroup_min56f", o.bgroup_min56f);
+  o.bgroup_chain = (int)opt("bgroup_chain", o.bgroup_chain);
+  o.bgroup_mode = (int)opt("bgroup", o.bgroup_mode);     // 1: identity bottlenecks of the small maps as group launches (conv_bgroup.hip), one batch at a time
+  o.bband_mode = (int)opt("bband", o.bband_mode);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
+  o.bband_rows = (int)opt("bband_rows", o.bband_rows);
+  o.bband_rows_alone = (int)opt("bband_rows_alone", o.bband_rows_alone);
+  o.bband_min = (int)opt("bband_min", o.bband_min);
+  o.bband_alone_maps = (int)opt("bband_alone_maps", o.bband_alone_maps);
   if (o.bband_mode == 2) o.bband_alone_maps = 6;
-  if (const char* e = getenv("TF2_AMD_PAIR")) o.pair_mode = atoi(e);          // 1 (default): independent neighbouring rows in one launch; 0: never
-  if (const char* e = getenv("TF2_AMD_STEM_POOL")) o.stem_pool = atoi(e);
-  if (const char* e = getenv("TF2_AMD_AVG_FUSE")) o.avg_fuse = atoi(e);     // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel   // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
-  if (const char* e = getenv("TF2_AMD_DENSE_MAX")) o.dense_max_slabs = atoi(e);
-  if (const char* e = getenv("TF2_AMD_DENSE")) o.dense_mode = atoi(e);  // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
-  if (const char* e = getenv("TF2_AMD_ALT_MIN")) o.alt_min_blocks = o.alt_min_blocks_conc = atol(e);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
-  if (const char* e = getenv("TF2_AMD_ALT_MIN_CONC")) o.alt_min_blocks_conc = atol(e);
-  if (const char* e = getenv("TF2_AMD_ALT_NARROW")) o.alt_narrow_blocks = atol(e);   // a 128-row layer takes its 64-row alternative below this many 128 x 128 blocks
-  if (const char* e = getenv("TF2_AMD_ALT_CONC")) o.alt_conc_mode = atoi(e);
-  if (const char* e = getenv("TF2_AMD_DBGPTR")) o.dbg = (long long*)strtoull(e, nullptr, 0);
-  if (const char* e = getenv("TF2_AMD_DBGPTR2")) o.dbg2 = (long long*)strtoull(e, nullptr, 0);
-  if (const char* e = getenv("TF2_AMD_DBGLAYER")) o.dbg_layer = atoi(e);
+  o.pair_mode = (int)opt("pair", o.pair_mode);          // 1 (default): independent neighbouring rows in one launch; 0: never
+  o.stem_pool = (int)opt("stem_pool", o.stem_pool);     // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
+  o.avg_fuse = (int)opt("avg_fuse", o.avg_fuse);        // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel
+  o.dense_max_slabs = (int)opt("dense_max", o.dense_max_slabs);
+  o.dense_mode = (int)opt("dense", o.dense_mode);       // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
+  if (opt("alt_min", -1) >= 0) o.alt_min_blocks = o.alt_min_blocks_conc = (long)opt("alt_min", 0);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
+  o.alt_min_blocks_conc = (long)opt("alt_min_conc", o.alt_min_blocks_conc);
+  o.alt_narrow_blocks = (long)opt("alt_narrow", o.alt_narrow_blocks);   // a 128-row layer takes its 64-row alternative below this many 128 x 128 blocks
+  o.alt_conc_mode = (int)opt("alt_conc", o.alt_conc_mode);
+  o.pw_slabs = (int)opt("pw_slabs", o.pw_slabs);
+  o.pw_minpix = (long)opt("pw_minpix", o.pw_minpix);
+  o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
+  o.dbg2 = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr2", 0);
+  o.dbg_layer = (int)opt("dbglayer", -1);
   opts = o;
   launch_plans.clear();
   // tensor lifetimes depend on which rows may share a launch (TF2_AMD_PAIR): re-plan what was planned (a caller's keep_all
@@ -651,7 +662,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         st.sel = Launch::SEL_SK; st.avg_fused = 1;
       } else
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
-      if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0)) st.sel = Launch::SEL_PW;
+      if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, opts.pw_slabs, opts.pw_minpix)) st.sel = Launch::SEL_PW;
     } else if (pl->kind == KIND_SHIFT) {
       st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {
@@ -848,6 +859,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         set_fast_div((uint32_t)tiles_x, &f.tx_m, &f.tx_s); set_fast_div((uint32_t)tiles, &f.tpi_m, &f.tpi_s);
         f.relu = c.g.relu; f.fast = c.g.fast; f.dbl = c.g.dbl_out; f.dual = c.dual;
         f.y_cp = c.g.y_cp; f.y_off = c.g.y_off; f.y_nvalid = c.g.y_nvalid;
+        f.w9 = conv_c3_takes_w9(f, opts.c3_w9) ? 1 : 0;
         sc.sel = Launch::SEL_C3;
         st = sc;
       }
@@ -1074,7 +1086,9 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   hipStream_t s = (hipStream_t)stream;
   // group launches spin until the eight members of an image are resident together, one block per CU: never on a stream whose CU
   // mask leaves fewer than 64 CUs (asked per call: the handle does not know what the caller's next stream looks like)
-  const bool wide_stream = stream_cu_count(s) >= 64;
+  // (asked only where group launches could be selected: a runtime call per step under the handle's mutex otherwise;
+  //  tf2_net_run_stats' small_mask_steps therefore counts such steps of the one-batch-at-a-time path only)
+  const bool wide_stream = (concurrent || !opts.bgroup_mode) ? true : stream_cu_count(s) >= 64;
   const bool allow_groups = !concurrent && opts.bgroup_mode && wide_stream;
   const LaunchPlan* lp = launch_plan(batch, wp, ws, concurrent, allow_groups);
   if (!lp) return TF2_ERR_ARG;
@@ -1111,9 +1125,8 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
   bool mark_pending = mark_event != nullptr;
 #ifdef TF2_PROBES
   // tools/probe_run.py: leave out the launches of a layer range (results are then wrong; only durations are read)
-  static const char* skip_env = getenv("TF2_AMD_SKIP_LAYERS");
   int skip_lo = 1 << 30, skip_hi = -1 << 30;
-  if (const char* e = getenv("TF2_AMD_SKIP_LAYERS")) { (void)skip_env; if (sscanf(e, "%d-%d", &skip_lo, &skip_hi) != 2) { skip_lo = 1 << 30; skip_hi = -1 << 30; } }
+  if (const long long sk = opt("skip_layers", -1); sk >= 0) { skip_lo = (int)(sk >> 32); skip_hi = (int)(unsigned)sk; }
 #endif
   for (const Launch& st : lp->steps) {
 #ifdef TF2_PROBES

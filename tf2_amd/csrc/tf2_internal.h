@@ -176,10 +176,16 @@ struct C3Args {
   uint32_t tw_m, hc_m, tx_m, tpi_m; int32_t tw_s, hc_s, tx_s, tpi_s;     // set_fast_div(TW), (TW + 2), (tiles_x), (tiles_per_img)
   int32_t relu, fast, dbl, dual;
   int32_t y_cp, y_off, y_nvalid;
+  int32_t w9;                  // the one-slab kernel (conv_c3_w9_kernel) takes the launch: decided in the launch PLAN (conv_c3_takes_w9)
 };
+bool conv_c3_takes_w9(const C3Args& a, int mode);      // mode = RunOpts::c3_w9: 0 never, 1 where a block walks at least eight tiles, 2 wherever allowed
 bool conv_c3_pick_tile(int H, int W, int* TH, int* TW);
 bool conv_c3_shape_ok(int H, int W, int C, int Np);
 int launch_conv_c3(const C3Args& a, void* stream);
+#ifdef TF2_CHECK_DMA
+void conv_bband_check_counts(unsigned long long out[2]);      // -DTF2_CHECK_DMA builds only (vm_track.h)
+void conv_c3_check_counts(unsigned long long out[2]);
+#endif
 
 // conv_bneck.hip: layer C (3x3 / stride 1 / pad 1, C -> C channels, C = 64 / 128 / 256) followed by its only consumer E
 // (1x1, C -> 4C, + residual): one launch per R x W pixel band of an image.
@@ -332,7 +338,7 @@ int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
-bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense);   // register-resident pointwise kernel takes the layer?
+bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix);   // register-resident pointwise kernel takes the layer? (max_slab / min_pix: RunOpts::pw_slabs / pw_minpix)
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);

@@ -84,33 +84,35 @@ struct LaunchPlan {
   int walkers = 0;
 };
 
-struct RunOpts {           // run-time switches, read from the environment by Net::load_options (tf2_net_reload_options)
+struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snapshot (opts.h) by Net::load_options (tf2_net_reload_options)
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 200;
-  int c3_mode = 1;           // TF2_AMD_C3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
-  long c3_min_blocks = 96;   // TF2_AMD_C3_MIN: smallest grid that takes it
-  int fc_mode = 1;           // TF2_AMD_FC: whole-window layers at batch <= 32 on conv_fc.hip
-  int fc_min_slabs = 64;     // TF2_AMD_FC_MIN: shortest K (64-byte slabs) that takes it
-  long c3_min256 = 200;      // TF2_AMD_C3_MIN256: smallest grid of 256-channel blocks (one-window layers; else 128-channel blocks)
-  long alt_min_blocks = 200;   // TF2_AMD_ALT_MIN: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
-  long alt_narrow_blocks = 64;     // TF2_AMD_ALT_NARROW
-  long alt_min_blocks_conc = 90;   // TF2_AMD_ALT_MIN_CONC: the same when the caller keeps several batches in flight
-  int alt_conc_mode = 2;       // TF2_AMD_ALT_CONC: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
-  int dense_max_slabs = 17;   // TF2_AMD_DENSE_MAX: layers with more K slabs than this on grids of more than one round keep the header tables
-  int dense_mode = 1;      // TF2_AMD_DENSE: gather words of dense layers computed from the step index (1) or read from the header tables (0)
-  int bgroup_mode = 1;     // TF2_AMD_BGROUP (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
+  int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
+  int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
+  int c3_mode = 1;           // c3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
+  long c3_min_blocks = 96;   // c3_min: smallest grid that takes it
+  int fc_mode = 1;           // fc: whole-window layers at batch <= 32 on conv_fc.hip
+  int fc_min_slabs = 64;     // fc_min: shortest K (64-byte slabs) that takes it
+  long c3_min256 = 200;      // c3_min256: smallest grid of 256-channel blocks (one-window layers; else 128-channel blocks)
+  long alt_min_blocks = 200;   // alt_min: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
+  long alt_narrow_blocks = 64;     // alt_narrow
+  long alt_min_blocks_conc = 90;   // alt_min_conc: the same when the caller keeps several batches in flight
+  int alt_conc_mode = 2;       // alt_conc: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
+  int dense_max_slabs = 17;   // dense_max: layers with more K slabs than this on grids of more than one round keep the header tables
+  int dense_mode = 1;      // dense: gather words of dense layers computed from the step index (1) or read from the header tables (0)
+  int bgroup_mode = 1;     // bgroup (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
   int bgroup_chain = 5;             // consecutive identity bottlenecks of the 28 x 28 / 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
-  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // TF2_AMD_BGROUP_MIN7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
-  int bband_mode = 1;      // TF2_AMD_BBAND: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
-  int bband_rows = 7, bband_rows_alone = 2;   // TF2_AMD_BBAND_ROWS / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
-  int bband_alone_maps = 0;   // TF2_AMD_BBAND_ALONE_MAPS: maps that take band launches one batch at a time too, instead of the group launches (bit 1: 28 x 28, bit 2: 14 x 14; TF2_AMD_BBAND=2 = both)
-  int bband_min = 8;       // TF2_AMD_BBAND_MIN: smallest batch that takes them
-  int pair_mode = 1;       // TF2_AMD_PAIR: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
-  int avg_fuse = 1;        // TF2_AMD_AVG_FUSE: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
-  int stem_pool = 1;       // TF2_AMD_STEM_POOL: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
-  int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (TF2_AMD_STEM)
-  long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (TF2_AMD_SK8)
+  int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // bgroup_min7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
+  int bband_mode = 1;      // bband: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
+  int bband_rows = 7, bband_rows_alone = 2;   // bband_rows / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
+  int bband_alone_maps = 0;   // bband_alone_maps: maps that take band launches one batch at a time too, instead of the group launches (bit 1: 28 x 28, bit 2: 14 x 14; bband=2 = both)
+  int bband_min = 8;       // bband_min: smallest batch that takes them
+  int pair_mode = 1;       // pair: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
+  int avg_fuse = 1;        // avg_fuse: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
+  int stem_pool = 1;       // stem_pool: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
+  int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (stem)
+  long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (sk8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };
 

@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "tf2_net.h"
+#include "opts.h"
 
 namespace tf2 {
 
@@ -114,7 +115,7 @@ tf2_status Net::pack(int mode) {
   // also pass the kernel's limits (dense weights, at most two exponent windows, LDS), else the image is repacked without it.
   std::vector<int> fuse_next(nl, 0), fused_into(nl, -1);
   std::vector<char> nofuse(nl, 0);
-  const bool fusion_on = mode == 0 && getenv("TF2_AMD_NOFUSE") == nullptr;
+  const bool fusion_on = mode == 0 && !opt_set("nofuse");
   auto decide_fusion = [&]() {
     std::fill(fuse_next.begin(), fuse_next.end(), 0); std::fill(fused_into.begin(), fused_into.end(), -1);
     if (!fusion_on) return;
@@ -149,7 +150,7 @@ tf2_status Net::pack(int mode) {
   // concat, L2Norm, final output), written by a layer with ReLU, qualify: in ResNet-50 the 64/128/256-channel tensors inside
   // the bottlenecks.  The producer's header rows carry the -128 (requant_epilogue.h).
   std::vector<std::vector<uint8_t>> dbl(nl);
-  if (mode == 0 && getenv("TF2_AMD_NODBL") == nullptr) {
+  if (mode == 0 && !opt_set("nodbl")) {
     const int M = nd.max_out_channel;
     for (int p = 0; p + 1 < nl; p++) {
       const tf2_layer_desc& P_ = layers[p];
@@ -243,7 +244,7 @@ tf2_status Net::pack(int mode) {
       // half keeps its one-m-tile entry for the fused launch and gets the narrow one for its own)
       const bool wide = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 256 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0;
       const bool narrow = p0.kind == KIND_MFMA && p0.TM == 128 && p0.fused_into < 0 && L.OH * L.OW <= 784;
-      if (!(wide || narrow) || getenv("TF2_AMD_NOALT") != nullptr) break;
+      if (!(wide || narrow)) break;
       alt_TM = wide ? 128 : 64;
       pl = PackLayer{}; pl.fused_into = -1;
     }
@@ -289,7 +290,7 @@ tf2_status Net::pack(int mode) {
       const int Np = round_up(N, 64);
       // 128-row tiles for the big-map layers; 64-row tiles where one image has <= 14x14 output
       // pixels, so that the grid still covers the 256 CUs at small batch (conv_mfma2.hip)
-      static const int tm128_minpix = getenv("TF2_AMD_TM128_MINPIX") ? atoi(getenv("TF2_AMD_TM128_MINPIX")) : 196;
+      constexpr int tm128_minpix = 196;
       int TM = (Np % 128 == 0 && L.OH * L.OW > tm128_minpix) ? 128 : 64;
       if (fuse_next[l] > 0) TM = Np;                                   // fused pair: the 3x3 in one m-tile ...
       if (fused_into[l] >= 0) TM = layers[fused_into[l]].N;            // ... and the expand in four of the same height
@@ -349,7 +350,7 @@ tf2_status Net::pack(int mode) {
       // slab that is non-zero in either window, holding [hi window TM x 64][lo window TM x 64].  The kernels then
       // fetch each activation slab once, keep two accumulators and combine them once at the end,
       // (hi << dshift[1]) + lo -- exact in Z/2^32 like the Horner form -- which halves the K steps.
-      const bool dual = P == 2 && getenv("TF2_AMD_NODUAL") == nullptr;
+      const bool dual = P == 2 && !opt_set("nodual");
       pl.dual = dual ? 1 : 0;
       std::vector<int32_t> dir((size_t)n_mtiles * (P + 1), 0);
       std::vector<int32_t> entries;
@@ -409,12 +410,12 @@ tf2_status Net::pack(int mode) {
       // [window][tap][K half][64 rows][16 bytes] of SIGNED window values (x half minus the magnitudes of the xneg half).
       // The x = -128 correction is derived from these in the kernel.
       if (is_image && in_signed && il.Cp_in == 64 && il.half == 32 && k == 3 && L.stride == 1 && L.dil == 1 && (L.pad_h | L.pad_w) == 0 &&
-          Np == 64 && TM == 64 && P <= 2 && C <= 32 && !L.endpool && getenv("TF2_AMD_NOSTEM") == nullptr) {
+          Np == 64 && TM == 64 && P <= 2 && C <= 32 && !L.endpool) {
         // Is the low window nothing but the rewrite's unit taps?  (+x << 0 on the x half, identical positions in every row, window
         // base 0.)  Then it contributes the SAME per-pixel sum to every output channel: conv_stem adds that sum instead of sweeping
-        // a second window (half the MFMAs and half the weight tile).  TF2_AMD_NOUNIT keeps the two-window form.
+        // a second window (half the MFMAs and half the weight tile).  nounit keeps the two-window form.
         std::vector<int8_t> unit(9 * 32, 0);
-        bool unit_ok = P == 2 && getenv("TF2_AMD_NOUNIT") == nullptr;
+        bool unit_ok = P == 2 && !opt_set("nounit");
         for (int t = 0; t < 9 && unit_ok; t++)
           for (int c = 0; c < 32 && unit_ok; c++) {
             const int8_t v0 = W[((size_t)1 * Np + 0) * Kp + (size_t)t * 64 + c];
@@ -447,8 +448,8 @@ tf2_status Net::pack(int mode) {
       bool share = false;
       // (Only the WIDE alternatives -- 128-row tiles as pairs of the main 64-row tiles, 22 of the 24 duplicate MB of ResNet-50 -- share
       //  by default: the narrow ones serve the tiny grids of batch 1-2, where reading halves of 8-KiB-strided tiles measured +2 % on the
-      //  batch-1 latency; TF2_AMD_SHARE=2 shares those too, TF2_AMD_NOSHARE=1 none.)
-      const int share_mode = getenv("TF2_AMD_NOSHARE") ? 0 : (getenv("TF2_AMD_SHARE") ? atoi(getenv("TF2_AMD_SHARE")) : 1);
+      //  batch-1 latency; share=2 shares those too, share=01 none.)
+      const int share_mode = (int)opt("share", 1);
       if (variant == 1 && main_TM && share_mode && main_P == P && main_dual == (dual ? 1 : 0) &&
           (2 * main_TM == TM || (share_mode >= 2 && main_TM == 2 * TM))) {
         share = true;
@@ -507,7 +508,7 @@ tf2_status Net::pack(int mode) {
       // 2^51  (x = p >> 20 fits int32 and x + 2^14 does not saturate), then
       //   y = (acc * (alpha << lo) + B') >> 35,   B' = bias * alpha + (beta << 20) + 2^34
       // is the reference result exactly, and the kernels use it (3 VALU instructions per output instead of 6).
-      bool fast = getenv("TF2_AMD_NOFAST") == nullptr;
+      bool fast = !opt_set("nofast");
       for (int n = 0; n < N && fast; n++) {
         unsigned __int128 amax = 0;
         const uint8_t* rc = m.codes.data() + (size_t)n * C * taps;
@@ -521,7 +522,7 @@ tf2_status Net::pack(int mode) {
         else if ((amax + ab) * aa + (abeta << kAlphaInflat) + (one << 34) >= (one << 51)) fast = false;
       }
       // SEMI (requant_epilogue.h): the rows that may wrap v still get the short form when x cannot leave 32 bits
-      bool semi = !fast && getenv("TF2_AMD_NOFAST") == nullptr && getenv("TF2_AMD_NOSEMI") == nullptr;
+      bool semi = !fast && !opt_set("nofast") && !opt_set("nosemi");
       for (int n = 0; n < N && semi; n++) {
         const unsigned __int128 aa = (unsigned __int128)std::llabs((long long)m.alpha[n]);
         const unsigned __int128 abeta = (unsigned __int128)std::llabs((long long)m.beta[n]);
@@ -613,7 +614,7 @@ tf2_status Net::pack(int mode) {
       {
         const int M = nd.max_out_channel;
         std::vector<int> Bc(n_cchunk * 16, 0), An(Np, -1000);
-        bool ok4 = getenv("TF2_AMD_NO4BIT") == nullptr && taps <= (in_signed ? 25 : 49);
+        bool ok4 = !opt_set("no4bit") && taps <= (in_signed ? 25 : 49);
         for (int pass = 0; pass < 2 && ok4; pass++) {          // pass 0: B from the input's Q row; pass 1: B = 0
           std::fill(Bc.begin(), Bc.end(), 0); std::fill(An.begin(), An.end(), -1000);
           if (pass == 0) {

@@ -53,7 +53,9 @@ def broadcast_network(net: network.NetWork, model, q_file, device, pack_mode: in
     else:
         blob, size = None, torch.tensor([0], dtype=torch.int64)
     on_gpu = device is not None and str(device) != "cpu"
+    net.broadcast_ms, net.broadcast_bytes = None, int(size.item()) if rank == src else None
     if distributed:
+        import time
         size_d = size.to(device) if on_gpu else size
         dist.broadcast(size_d, src=src)
         n = int(size_d.item())
@@ -61,7 +63,13 @@ def broadcast_network(net: network.NetWork, model, q_file, device, pack_mode: in
             blob_d = blob.to(device) if on_gpu else blob
         else:
             blob_d = torch.empty(n, dtype=torch.uint8, device=device if on_gpu else "cpu")
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
         dist.broadcast(blob_d, src=src)          # the one collective of the data path
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        net.broadcast_ms, net.broadcast_bytes = round((time.perf_counter() - t0) * 1e3, 3), n
         if rank != src:
             net.adopt_packed(blob_d.cpu().numpy())
     else:

@@ -168,7 +168,7 @@ class NetWork:
         self.device = packed_dev.device
 
     def reload_options(self):
-        """Re-read the TF2_AMD_* run-time switches from the environment (sampled at creation otherwise)."""
+        """Re-read the option string TF2_AMD_OPTS (csrc/opts.h) from the environment (sampled at creation otherwise)."""
         _lib.check(_lib.lib().tf2_net_reload_options(self._h))
 
     def describe_launches(self, batch: int, concurrency: int = 0):

@@ -1,17 +1,14 @@
-"""HIP streams created with hipExtStreamCreateWithCUMask.
+"""A HIP stream created with hipExtStreamCreateWithCUMask, for the tests and tools that need a CU-restricted stream (the library asks a
+stream for its CU count before it selects group launches one batch at a time: Net::run, conv_bgroup.hip).
 
-Rounds 2-3 built "XCD partitions" with this: every in-flight batch on its own pair of XCDs, mask bits chosen as (i % 8) in a set of
-XCD residues.  Round 4 measured what such a stream really uses (tools/ubench/cumask_probe.hip, profiles/r04_ubench_cumask_probe.txt:
-every block records its XCC id and hardware id): the INTERLEAVED masks are ignored -- a stream masked to the bits i % 8 in {0, 1}
-(or i % 8 == 0, or i % 4 == 0) runs on all 256 CUs of all 8 XCDs at a plain stream's speed -- and only CONTIGUOUS bit ranges restrict:
-[0, 64) gives 64 CUs, eight on EVERY XCD.  So partitioned_streams() below never partitioned anything (its +2...7 % in round 3 was run-to-run
-noise), real CU partitions lose badly (round 3, experiment 30), and bench.py uses plain streams now.  The functions stay for the
-tests and tools that create masked streams (the library asks a stream for its CU count before it selects group launches:
-Net::run, conv_bgroup.hip)."""
+Only CONTIGUOUS mask bit ranges restrict a stream on gfx950 ([0, 64) = 64 CUs, eight on every XCD); interleaved masks are ignored by the
+hardware (tools/ubench/cumask_probe.hip, profiles/r04_ubench_cumask_probe.txt) -- which is why rounds 2-3's "XCD-partitioned streams"
+were plain streams under another name; they left the tree in round 5, and bench.py runs its batches in flight on plain streams.  The
+library's 64-CU test for group launches counts MASK BITS (hipExtStreamGetCUMask), not granted CUs: an interleaved 32-bit mask is
+treated as a small stream although it runs on the whole chip -- safe (no group launches), and noted in include/tf2_amd.h."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import List
 
 _hip = None
 
@@ -32,14 +29,6 @@ def _hiplib():
     return _hip
 
 
-def xcd_mask_bits(part: int, n_parts: int, n_cu: int, n_xcd: int = 8) -> List[int]:
-    """CU-mask bit indices of partition `part` of `n_parts` (n_parts must divide n_xcd): whole XCDs."""
-    if n_xcd % n_parts:
-        raise ValueError(f"{n_parts} partitions do not divide {n_xcd} XCDs")
-    per = n_xcd // n_parts
-    return [i for i in range(n_cu) if (i % n_xcd) // per == part]
-
-
 def masked_stream(bits, device="cuda:0"):
     """One torch stream whose CU mask has exactly `bits` set (contiguous ranges are what the hardware honours: [0, 32) = 32 CUs,
     four on every XCD)."""
@@ -56,24 +45,3 @@ def masked_stream(bits, device="cuda:0"):
     if rc != 0 or not h.value:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
     return torch.cuda.ExternalStream(h.value, device=dev)
-
-
-def partitioned_streams(n_parts: int, device="cuda:0"):
-    """n_parts torch streams, stream k restricted to XCDs [k * 8 / n_parts, (k + 1) * 8 / n_parts).  Raises OSError / RuntimeError
-    when the runtime refuses; callers fall back to plain streams."""
-    import torch
-    dev = torch.device(device)
-    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    words = (n_cu + 31) // 32
-    out = []
-    with torch.cuda.device(dev):
-        for k in range(n_parts):
-            arr = (C.c_uint32 * words)()
-            for b in xcd_mask_bits(k, n_parts, n_cu):
-                arr[b // 32] |= 1 << (b % 32)
-            h = C.c_void_p()
-            rc = _hiplib().hipExtStreamCreateWithCUMask(C.byref(h), words, arr)
-            if rc != 0 or not h.value:
-                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-            out.append(torch.cuda.ExternalStream(h.value, device=dev))
-    return out

@@ -140,3 +140,19 @@ def squeezenet_calibration_images(seed: int = 17) -> np.ndarray:
     """Three seeded 1x3x227x227 float images (BASELINE configs[0] shape), [3, 1, 3, 227, 227]."""
     rng = np.random.default_rng(seed)
     return (rng.standard_normal((3, 1, 3, 227, 227)) * 50.0).astype(np.float32)
+
+
+def bench_network(name: str):
+    """The BASELINE.json networks as bench.py, tools/steps_only.py, tools/pmc_summary.py and tools/dma_stress.py run them:
+    (tables, Q values, model seed, display name, note).  resnet50: the shipped resnet50_Q + seeded INQ weights; the others: table
+    programs of tf2_amd.config with synthetic per-channel Q values (spread 1) and seeded INQ weights."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if name == "resnet50":
+        t = cfg.resnet50_tables()
+        qv = np.loadtxt(os.path.join(root, "tests", "golden", "resnet50_Q"), dtype=np.int32)
+        return t, qv, 0, "ResNet50", "54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights"
+    mk, disp, seed = {"squeezenet": (cfg.squeezenet11_tables, "SqueezeNet 1.1", 6), "vgg16": (cfg.vgg16_tables, "VGG16", 1),
+                      "ssd300": (cfg.ssd300_tables, "SSD300-VGG", 3)}[name]
+    t = mk()
+    return t, synth_q_values(t, seed, spread=1), seed, disp, "TF2 table program built by tf2_amd.config, synthetic per-channel Q values and seeded INQ weights"

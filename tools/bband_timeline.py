@@ -4,10 +4,11 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=31)
 ap.add_argument("--rows", type=int, default=7); ap.add_argument("--conc", type=int, default=1)
 a = ap.parse_args()
-os.environ["TF2_AMD_BBAND"] = "2"; os.environ["TF2_AMD_BBAND_ROWS"] = str(a.rows); os.environ["TF2_AMD_BBAND_ROWS_ALONE"] = str(a.rows); os.environ["TF2_AMD_BBAND_MIN"] = "1"
+set_opts(bband="2"); set_opts(bband_rows=str(a.rows)); set_opts(bband_rows_alone=str(a.rows)); set_opts(bband_min="1")
 import torch
 from tf2_amd import config as cfg, network, synth
 t = cfg.resnet50_tables()
@@ -19,7 +20,7 @@ for _ in range(3): r.run_batch(x, concurrency=a.conc)
 torch.cuda.synchronize()
 nblk = [l for l in net.describe_launches(a.batch, a.conc) if l["layer"] == a.layer][0]["grid"]
 dbg = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda:0")
-os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
+set_opts(dbgptr2=str(dbg.data_ptr())); set_opts(dbglayer=str(a.layer))
 net.reload_options()
 for _ in range(2): r.run_batch(x, concurrency=a.conc)
 torch.cuda.synchronize()

@@ -5,7 +5,8 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1";      # every batch size takes the group launches here
+from tf2_amd._lib import set_opts  # noqa: E402
+set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1");      # every batch size takes the group launches here
 import torch
 from tf2_amd import config as cfg, network, synth
 t = cfg.resnet50_tables()
@@ -15,9 +16,9 @@ net = network.NetWork(t); net.Init(model, synth.q_text(qv), device="cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for B in ([int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (32, 1, 7, 64, 9, 32)):
     x = torch.from_numpy(synth.synth_images(t, B, B)).to("cuda:0")
-    os.environ["TF2_AMD_BGROUP"] = "0"; net.reload_options()
+    set_opts(bgroup="0"); net.reload_options()
     ref = network.Runner(None, net).run_batch(x, concurrency=0).clone(); torch.cuda.synchronize()
-    os.environ["TF2_AMD_BGROUP"] = "1"; net.reload_options()
+    set_opts(bgroup="1"); net.reload_options()
     r = network.Runner(None, net)
     assert any("bgroup" in l["kernel"] for l in net.describe_launches(B, 0))
     bad = 0; t0 = time.perf_counter()

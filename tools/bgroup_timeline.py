@@ -4,7 +4,8 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TF2_AMD_BGROUP"] = "1"; os.environ["TF2_AMD_BGROUP_MIN7"] = "1"; os.environ["TF2_AMD_BGROUP_MIN14"] = "1"; os.environ["TF2_AMD_BGROUP_MIN28"] = "1"; os.environ["TF2_AMD_BGROUP_MIN56F"] = "1";
+from tf2_amd._lib import set_opts  # noqa: E402
+set_opts(bgroup="1"); set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1");
 import torch
 from tf2_amd import config as cfg, network, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=31)
@@ -18,7 +19,7 @@ x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
 for _ in range(3): r.run_batch(x, concurrency=0)
 torch.cuda.synchronize()
 dbg = torch.zeros(8 * a.batch * 16, dtype=torch.int64, device="cuda:0")
-os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
+set_opts(dbgptr2=str(dbg.data_ptr())); set_opts(dbglayer=str(a.layer))
 net.reload_options()
 for _ in range(2): r.run_batch(x, concurrency=0)
 torch.cuda.synchronize()

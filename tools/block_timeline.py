@@ -4,6 +4,7 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 import torch
 from tf2_amd import config as cfg, network, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=1)
@@ -17,7 +18,7 @@ x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
 for _ in range(3): r.run_batch(x)
 torch.cuda.synchronize()
 dbg = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda:0")
-os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
+set_opts(dbgptr2=str(dbg.data_ptr())); set_opts(dbglayer=str(a.layer))
 net.reload_options()
 r.run_batch(x); torch.cuda.synchronize()
 from tf2_amd import _lib

@@ -5,6 +5,7 @@ import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 ap = argparse.ArgumentParser(); ap.add_argument("--net", default="vgg16"); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=8)
 a = ap.parse_args()
 import torch
@@ -20,7 +21,7 @@ row = [l for l in net.describe_launches(a.batch, 0) if l["layer"] == a.layer and
 print(row["kernel"])
 nblk = row["grid"] * 8
 dbg = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda:0")
-os.environ["TF2_AMD_DBGPTR2"] = str(dbg.data_ptr()); os.environ["TF2_AMD_DBGLAYER"] = str(a.layer)
+set_opts(dbgptr2=str(dbg.data_ptr())); set_opts(dbglayer=str(a.layer))
 net.reload_options()
 for _ in range(2): r.run_batch(x)
 torch.cuda.synchronize()

@@ -5,6 +5,7 @@ kernels for the same CUs.  Prints img/s for ResNet50 at batch 32 per partitionin
 import argparse, ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 import torch
@@ -59,7 +60,7 @@ torch.cuda.synchronize()
 
 
 def rate(streams, steps, conc):
-    os.environ["TF2_AMD_ALT_CONC"] = str(conc)
+    set_opts(alt_conc=str(conc))
     net.reload_options()
     k = len(streams)
     rs = [network.Runner(None, net) for _ in streams]

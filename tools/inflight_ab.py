@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of launch-plan switches in ONE process: ResNet50, batch N, several batches in flight on XCD-partitioned streams (what
-bench.py times) and one batch at a time, per setting of TF2_AMD_* run-time switches (re-read through tf2_net_reload_options).
-Usage: inflight_ab.py --set "BBAND=0" --set "BBAND=1,BBAND_ROWS=7" ...  (names without the TF2_AMD_ prefix).
+bench.py times) and one batch at a time, per setting of the library's option string TF2_AMD_OPTS (re-read through tf2_net_reload_options).
+Usage: inflight_ab.py --set "bband=0" --set "bband=1,bband_rows=7" ...
 Prints img/s and whether the logits equal the first setting's."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,10 +34,8 @@ ref = None
 touched = set()
 for rep in range(a.reps):
     for s in settings:
-        for k in touched: os.environ.pop(k, None)
-        for kv in s.split(","):
-            if not kv: continue
-            k, v = kv.split("="); os.environ["TF2_AMD_" + k] = v; touched.add("TF2_AMD_" + k)
+        # one setting = one TF2_AMD_OPTS string (csrc/opts.h), e.g. "bband=0" or "bband=1,bband_rows=7"
+        os.environ["TF2_AMD_TEST"] = "1"; os.environ["TF2_AMD_OPTS"] = s.lower()
         net.reload_options()
         rs = [network.Runner(None, net) for _ in sts]
         def loop(n, conc):

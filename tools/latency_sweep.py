@@ -13,4 +13,4 @@ for b in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8,16").s
     torch.cuda.synchronize(); n = 60; t0 = time.perf_counter()
     for _ in range(n): r.run_batch(x); torch.cuda.synchronize()
     out.append("b%d %.1f" % (b, (time.perf_counter() - t0) / n * 1e6))
-print(os.environ.get("TF2_AMD_ALT_NARROW", "default"), " ".join(out))
+print(os.environ.get("TF2_AMD_OPTS", "default"), " ".join(out))

@@ -4,6 +4,7 @@ import argparse, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 import torch
 from tf2_amd import config as cfg, network, synth, _lib
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,7 +34,7 @@ r = network.Runner(None, net)
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
 dbg = torch.zeros(64 * 16, dtype=torch.int64, device="cuda:0")
 if a.stamps:
-    os.environ["TF2_AMD_DBGPTR"] = str(dbg.data_ptr())
+    set_opts(dbgptr=str(dbg.data_ptr()))
     net.reload_options()
 for _ in range(3): r.run_batch(x)
 torch.cuda.synchronize()

@@ -7,8 +7,9 @@ only durations are read.  The product library has no probe code (tf2_device.h TF
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tf2_amd._lib import set_opts  # noqa: E402
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ["TF2_AMD_LIB"] = os.path.join(ROOT, "tf2_amd", "libtf2amd_probe.so")
+os.environ["TF2_AMD_LIB"] = os.path.join(ROOT, "tf2_amd", "libtf2amd_probe.so"); os.environ["TF2_AMD_TOOL_LIB"] = "1"     # (built on demand: make -C tf2_amd/csrc probe)
 import numpy as np
 import torch
 from tf2_amd import config as cfg, network, synth, _lib
@@ -33,7 +34,7 @@ streams = [torch.cuda.Stream(device="cuda:0") for _ in range(4)]
 
 
 def layer_table(conc):
-    os.environ["TF2_AMD_ALT_CONC"] = "1" if conc else "0"
+    set_opts(alt_conc="1" if conc else "0")
     net.reload_options()
     r = network.Runner(None, net)
     for _ in range(3): r.run_batch(x)
@@ -48,7 +49,7 @@ def layer_table(conc):
 
 
 def serial_wall():
-    os.environ["TF2_AMD_ALT_CONC"] = "0"
+    set_opts(alt_conc="0")
     net.reload_options()
     r = network.Runner(None, net)
     for _ in range(3): r.run_batch(x)
@@ -60,7 +61,7 @@ def serial_wall():
 
 
 def inflight_rate():
-    os.environ["TF2_AMD_ALT_CONC"] = "1"
+    set_opts(alt_conc="1")
     net.reload_options()
     rs = [network.Runner(None, net) for _ in streams]
     for st, r in zip(streams, rs):
@@ -78,7 +79,7 @@ def inflight_rate():
 
 res = {}
 for name, bits in PROBES:
-    os.environ["TF2_AMD_EXP"] = str(bits)
+    set_opts(exp=str(bits))
     ser = layer_table(False)
     con = layer_table(True)
     rate = inflight_rate()

@@ -4,7 +4,8 @@ stage left out (probe build: TF2_AMD_SKIP_LAYERS; results wrong, durations only)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TF2_AMD_LIB"] = os.path.join(ROOT, "tf2_amd", "libtf2amd_probe.so")
+from tf2_amd._lib import set_opts  # noqa: E402
+os.environ["TF2_AMD_LIB"] = os.path.join(ROOT, "tf2_amd", "libtf2amd_probe.so"); os.environ["TF2_AMD_TOOL_LIB"] = "1"     # (built on demand: make -C tf2_amd/csrc probe)
 import numpy as np, torch
 from tf2_amd import config as cfg, network, synth, _lib
 t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
@@ -30,7 +31,7 @@ ranges = {"all": None, "only prep+stem+pool (skip 1-53)": ["1-53"], "skip stem..
           "skip stage4 (24-42)": ["24-42"], "skip stage5+fc (43-53)": ["43-53"], "skip 11-53 (stem+stage2 only)": ["11-53"],
           "skip 0-23 (stage 4,5 only)": ["0-23"], "skip 0-42 (stage 5 only)": ["0-42"]}
 for name, rg in ranges.items():
-    if rg: os.environ["TF2_AMD_SKIP_LAYERS"] = rg[0]
-    else: os.environ.pop("TF2_AMD_SKIP_LAYERS", None)
+    if rg: set_opts(skip_layers=rg[0])
+    else: set_opts(skip_layers=None)
     s = serial(); f = inflight()
     print(f"{name:>36}: one at a time {s:7.1f} us/step   four in flight {f:7.1f} us/step", flush=True)

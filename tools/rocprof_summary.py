@@ -15,10 +15,23 @@ for r in rows:
     kern.append(dict(kernel=name.split("(")[0], calls=int(r["Calls"]), calls_per_step=int(r["Calls"]) / steps,
                      total_us=float(r["TotalDurationNs"]) / 1e3, average_us=float(r["AverageNs"]) / 1e3,
                      us_per_step=float(r["TotalDurationNs"]) / 1e3 / steps))
-conv = [k for k in kern if "conv_" in k["kernel"]]
-n_conv_plan = sum(1 for l in meta["launches"] if "conv_" in l["kernel"])
-out = dict(note="rocprofv3 --kernel-trace --stats of tools/steps_only.py: ResNet50, batch %d, %d steps one batch at a time on one stream with the %s launch plan, nothing else in the process but a clock spin-up of torch matrix products before them (tools/steps_only.py --spinup-ms)" % (meta["batch"], steps, "batches-in-flight (--conc 1: what bench.py's timed region launches)" if meta.get("conc") else "one-batch-at-a-time"),
-           conc=meta.get("conc", 0),
+# launches of CONVOLUTION rows (the row's conv kernel(s) + its own pool / average launch: what bench.py's per-row HIP events bracket); the
+# input preparation, L2Norm and independent-pool rows are not.  A kernel name that serves both kinds of rows (maxpool_kernel) counts by
+# the share of its launches that belong to convolution rows.
+conv_rows = set(meta.get("conv_rows", [l["layer"] for l in meta["launches"] if l["layer"] >= 0]))
+base = lambda n: n.replace("void ", "").replace("tf2::", "").split("<")[0].split("(")[0].strip()
+n_all, n_cv = {}, {}
+for l in meta["launches"]:
+    b = base(l["kernel"])
+    n_all[b] = n_all.get(b, 0) + 1
+    n_cv[b] = n_cv.get(b, 0) + (1 if l["layer"] in conv_rows else 0)
+for k in kern:
+    b = base(k["kernel"])
+    k["conv_row_share"] = n_cv.get(b, 0) / n_all[b] if n_all.get(b) else 0.0
+conv = [dict(k, us_per_step=k["us_per_step"] * k["conv_row_share"], calls_per_step=k["calls_per_step"] * k["conv_row_share"]) for k in kern if k["conv_row_share"] > 0]
+n_conv_plan = sum(1 for l in meta["launches"] if l["layer"] in conv_rows)
+out = dict(note="rocprofv3 --kernel-trace --stats of tools/steps_only.py: %s, batch %d, %d steps one batch at a time on one stream with the %s launch plan, nothing else in the process but a clock spin-up of torch matrix products before them (tools/steps_only.py --spinup-ms)" % (meta.get("net", "ResNet50"), meta["batch"], steps, "batches-in-flight (--conc 1: what bench.py's timed region launches)" if meta.get("conc") else "one-batch-at-a-time"),
+           conc=meta.get("conc", 0), net=meta.get("net", "ResNet50"),
            batch=meta["batch"], steps=steps,
            conv_launches_per_step=sum(k["calls_per_step"] for k in conv), conv_launches_per_step_launch_plan=n_conv_plan,
            conv_us_per_step=sum(k["us_per_step"] for k in conv), all_kernels_us_per_step=sum(k["us_per_step"] for k in kern),

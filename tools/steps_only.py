@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N steps of ResNet50 at one batch size, one batch at a time on one stream, and nothing else (no latency leg, no sweep, no
+"""N steps of ResNet50 (or --net: another BASELINE.json network) at one batch size, one batch at a time on one stream, and nothing else (no latency leg, no sweep, no
 event records): the workload rocprofv3 --kernel-trace --stats and the --pmc passes are run on (tools/round_evidence.sh), so
 that every row of their per-kernel tables is this configuration only."""
 import argparse, json, os, sys
@@ -17,12 +17,11 @@ ap.add_argument("--conc", type=int, default=0, help="launch plan: 0 one batch at
 ap.add_argument("--spinup-ms", type=float, default=600.0,
                 help="keep the device busy this long with torch matrix products first (other kernel names: they do not enter the tf2 rows "
                      "of the profile): an idle MI355X needs ~0.4 s of load to reach its engine clock (tools/clock_sample.py)")
-ap.add_argument("--partition", type=int, default=0, help="N > 0: run on ONE stream restricted to 8 / N XCDs (tf2_amd.streams): what one of N in-flight batches sees")
+ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300"])
 ap.add_argument("--meta", default=None, help="write {batch, steps, launches} here")
 a = ap.parse_args()
-t = cfg.resnet50_tables()
-qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
-net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device="cuda:0")
+t, qv, seed, net_name, _ = synth.bench_network(a.net)
+net = network.NetWork(t); net.Init(synth.synth_model(t, qv, seed), synth.q_text(qv), device="cuda:0")
 r = network.Runner(None, net)
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
 if a.spinup_ms > 0:
@@ -34,15 +33,9 @@ if a.spinup_ms > 0:
             m2 = m @ m
         torch.cuda.synchronize()
     del m, m2
-if a.partition > 0:
-    from tf2_amd import streams
-    st = streams.partitioned_streams(a.partition, "cuda:0")[0]
-    with torch.cuda.stream(st):
-        for _ in range(a.warmup + a.steps):
-            r.run_batch(x, concurrency=a.conc)
-else:
-    for _ in range(a.warmup + a.steps):
-        r.run_batch(x, concurrency=a.conc)
+for _ in range(a.warmup + a.steps):
+    r.run_batch(x, concurrency=a.conc)
 torch.cuda.synchronize()
 if a.meta:
-    json.dump(dict(batch=a.batch, steps=a.warmup + a.steps, conc=a.conc, launches=net.describe_launches(a.batch, a.conc)), open(a.meta, "w"), indent=0)
+    conv_rows = [l for l, L in enumerate(cfg.build_plan(t)) if not L.ipool]        # table rows that are convolutions (their pool / average launches included)
+    json.dump(dict(net=net_name, batch=a.batch, steps=a.warmup + a.steps, conc=a.conc, conv_rows=conv_rows, launches=net.describe_launches(a.batch, a.conc)), open(a.meta, "w"), indent=0)
