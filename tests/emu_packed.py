@@ -10,7 +10,8 @@ HDR = np.dtype([("magic", "<u4"), ("version", "<u4"), ("n_layers", "<u4"), ("dir
 PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab", "Np", "signed_in", "Cp_in",
                                      "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into", "w_share", "w_main_TM")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
-                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_unit")])
+                                    "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_unit",
+                                    "off_lut", "off_cls")] + [(n, "<i4") for n in ("fc4", "n_cls")])
 
 
 def parse(blob: np.ndarray):
@@ -73,6 +74,34 @@ def first_layer_executed(L, img_q):
     return Le, t
 
 
+def fc4_tiles(blob, pl, nt):
+    """PackLayer::fc4 (weight_pack.cpp): nibble tiles [m-tile * nslab + slab][TM rows][32 bytes] + per-row tables + K classes -> the int8
+    window tiles [entry][window][TM][64] the kernel feeds its MFMAs, following conv_fc.hip's fc4_expand byte for byte: a row's 32 bytes
+    = [K half h][K step ks] 8 bytes each; word w, byte j: low nibble = K position ks * 32 + h * 16 + 8 w + j, high nibble = that + 4;
+    value = table[class of the K position][window][e] with the sign bit (8) negating it."""
+    TM, nslab, nm, Np = int(pl["TM"]), int(pl["nslab"]), int(pl["n_mtiles"]), int(pl["Np"])
+    nib = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + nm * nslab * TM * 32].tobytes(), np.uint8).reshape(nm, nslab, TM, 2, 2, 2, 4)   # [mt][sl][r][h][ks][w][j]
+    lut = np.frombuffer(blob[int(pl["off_lut"]):int(pl["off_lut"]) + Np * 32].tobytes(), np.uint8).reshape(nm, TM, 2, 2, 8).astype(np.int16)      # [mt][r][class][window][e]
+    cls = (np.frombuffer(blob[int(pl["off_cls"]):int(pl["off_cls"]) + nslab * 64].tobytes(), np.uint8) != 0).astype(np.int64).reshape(nslab, 64)
+    assert int(pl["n_cls"]) in (1, 2) and (int(pl["n_cls"]) == 2 or not cls.any())
+    codes = np.zeros((nm, nslab, TM, 64), np.uint8)
+    for h in range(2):
+        for ks in range(2):
+            for w in range(2):
+                for j in range(4):
+                    k = ks * 32 + h * 16 + 8 * w + j
+                    codes[..., k] = nib[..., h, ks, w, j] & 15
+                    codes[..., k + 4] = nib[..., h, ks, w, j] >> 4
+    out = np.zeros((nm * nslab, nt, TM, 64), np.int8)
+    mt_i = np.arange(nm)[:, None, None, None]; r_i = np.arange(TM)[None, None, :, None]
+    cl = np.broadcast_to(cls[None, :, None, :], codes.shape)
+    for wdw in range(nt):
+        v = lut[mt_i, r_i, cl, wdw, (codes & 7).astype(np.int64)]
+        v = np.where(codes & 8, -v, v)
+        out[:, wdw] = v.reshape(nm * nslab, TM, 64).astype(np.int8)
+    return out
+
+
 def conv_from_packed(blob, pl, L, x_t, res=None):
     """L: LayerSpec.  x_t: input tensor [B,H,W,Cp_in] int8.  Returns conv-stage output NCHW
     [B,N,OH,OW] after requant/relu/residual (before pool / global average)."""
@@ -104,8 +133,11 @@ def conv_from_packed(blob, pl, L, x_t, res=None):
         # weight tiles: the layer's own storage, or (alternative entries, PackLayer::w_share) the main entry's tiles of the other
         # height -- halves of 128-row tiles / pairs of the 64-row tiles of two neighbouring m-tiles (ConvArgs w_* in the kernels)
         sTM = int(pl["w_main_TM"]) if int(pl["w_share"]) else TM
-        st = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * nt * sTM * 64].tobytes(), np.int8)
-        st = st.reshape(-1, nt, sTM, 64)
+        if int(pl["fc4"]):
+            st = fc4_tiles(blob, pl, nt)                # 4-bit codes expanded as conv_fc.hip does (fc4_expand)
+        else:
+            st = np.frombuffer(blob[int(pl["off_w"]):int(pl["off_w"]) + int(pl["n_entries"]) * nt * sTM * 64].tobytes(), np.int8)
+            st = st.reshape(-1, nt, sTM, 64)
         nent0 = int(dirs[0, P] - dirs[0, 0])
 
         class _Tiles:

@@ -144,21 +144,26 @@ def test_3x3_layers_from_an_lds_resident_halo_tile(c3, monkeypatch):
     Rig(t, q, synth.synth_model(t, q, 3), 0).check_all_layers(synth.synth_images(t, 2, 3))
 
 
-@pytest.mark.parametrize("fc", ["1", "0"])
-def test_whole_window_layers_as_a_weight_stream(fc, monkeypatch):
+@pytest.mark.parametrize("form", ["codes", "tiles", "off"])
+def test_whole_window_layers_as_a_weight_stream(form, monkeypatch):
     """conv_fc.hip (a layer whose input is one filter window per image -- VGG16's fc6 / fc7 -- as a weight stream over the whole chip:
     output channels x K slices, int32 partial sums through the workspace's scratch area, a finishing pass) against the oracle: a 64 x 64
-    VGG16 (fc6 = 2 x 2 x 512 -> 4096 on a 2 x 2 map, fc7 1 x 1: 32 and 64 slabs, one and several K slices, one- and two-window rows),
-    batches 1, 5 and 32, and the same with the kernel switched off."""
-    set_opts(monkeypatch, fc=fc)
-    set_opts(monkeypatch, fc_min="8")
+    VGG16 (fc6 = 2 x 2 x 512 -> 4096 on a 2 x 2 map, fc7 1 x 1: 32 and 64 slabs, one and several K slices, one- and two-window rows).
+    codes: the default -- the filters stay 4-BIT CODES in HBM and are expanded in registers (PackLayer::fc4, fc4_partial_kernel; two
+    input-channel classes with spread-1 Q values, one behind doubled channels; spread 2 = three classes keeps int8 tiles), any batch in
+    chunks of 32 images; tiles: fc4=0, int8 window tiles (batch <= 32, else the split-K kernel); off: the split-K kernel."""
+    set_opts(monkeypatch, fc="0" if form == "off" else "1", fc4="1" if form == "codes" else "0", fc_min="8")
     t = cfg.vgg16_tables(64, 10)
     for seed, spread in ((7, 2), (0, 1)):
         q = synth.synth_q_values(t, seed, spread=spread)
         rig = Rig(t, q, synth.synth_model(t, q, seed), 0)
         names = [r["kernel"] for r in rig.net.describe_launches(5, 0)]
-        assert any("fc_partial" in n for n in names) == (fc == "1"), names
-        for b in (1, 5, 32):
+        assert any("fc_partial" in n or "fc4_partial" in n for n in names) == (form != "off"), names
+        assert any("fc4_partial" in n for n in names) == (form == "codes" and spread == 1), names
+        batches = (1, 5, 32, 33, 70) if form == "codes" else (1, 5, 32)
+        if form == "codes" and spread == 1:
+            assert sum("fc4_partial" in r["kernel"] for r in rig.net.describe_launches(70, 1)) == 2       # three chunks of 32 images, still conv_fc
+        for b in batches:
             rig.check_all_layers(synth.synth_images(t, b, seed + b), layers={12, 13, 14, 15})
 
 

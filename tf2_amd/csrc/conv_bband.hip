@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_bband_kernel(BBandArgs a
               int a16[16];
 #pragma unroll
               for (int r = 0; r < 16; r++) a16[r] = acc[i][j][r];
-              const i32x4 out = requant_tile16<true, LEAN, FAST>(a16, prm, 1 << tms3, ro + 4 * half, lo_b3, rlo, rv[i][j], false, a.fast3 == 2);
+              const i32x4 out = requant_tile16<true, LEAN, FAST, true>(a16, prm, 1 << tms3, ro + 4 * half, lo_b3, rlo, rv[i][j], false, a.fast3 == 2);      // (RNN: Net::bband_at admits only such expands)
               const int p = (wn + j * WN) * 32 + (lane & 31);
               if (p < n_px) *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
             }

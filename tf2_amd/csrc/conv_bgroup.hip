@@ -411,10 +411,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
           for (int r = 0; r < 16; r++) a16[r] = acc[q][r];
           i32x4 out;
           if (a.fast3 == 1) {
-            if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rv[2 * pair + q], false, false);
+            if (a.has_res) out = requant_tile16<true, 0, true, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rv[2 * pair + q], false, false);
             else out = requant_tile16<false, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
           } else {
-            if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rv[2 * pair + q], false, a.fast3 == 2);
+            if (a.has_res) out = requant_tile16<true, 0, false, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rv[2 * pair + q], false, a.fast3 == 2);
             else out = requant_tile16<false, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
           }
           // (the launch's last output is read by later kernels: ordinary stores; an inner one by the group, like mid1 / mid2)
@@ -1018,10 +1018,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
       for (int r = 0; r < 16; r++) a16[r] = (int)((unsigned)acc[r] + (unsigned)acc1[r]);
       i32x4 out;
       if (a.fast3 == 1) {
-        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, false);
+        if (a.has_res) out = requant_tile16<true, 0, true, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, false);
         else out = requant_tile16<false, 0, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
       } else {
-        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
+        if (a.has_res) out = requant_tile16<true, 0, false, true>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, rcur, false, a.fast3 == 2);
         else out = requant_tile16<false, 0, false>(a16, pm, a.tm3, ro + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
       }
       *reinterpret_cast<i32x4*>(slot) = out;
@@ -1379,10 +1379,10 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
       for (int r = 0; r < 16; r++) a16[r] = acc[pt][r];
       i32x4 out;
       if (a.fast3 == 1) {
-        if (a.has_res) out = requant_tile16<true, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, false);
+        if (a.has_res) out = requant_tile16<true, 0, true, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, false);
         else out = requant_tile16<false, 0, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, false);
       } else {
-        if (a.has_res) out = requant_tile16<true, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, a.fast3 == 2);
+        if (a.has_res) out = requant_tile16<true, 0, false, true>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, rv[pt], false, a.fast3 == 2);
         else out = requant_tile16<false, 0, false>(a16, pm, 64, ro3 + 4 * half, lo_b, rlo, nores, a.dbl3 != 0, a.fast3 == 2);
       }
       const int p = 32 * pt + (lane & 31);

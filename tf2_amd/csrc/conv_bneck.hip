@@ -288,16 +288,17 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
       int* const pm = reinterpret_cast<int*>(reinterpret_cast<int8_t*>(prm2) + (size_t)mt * a.hdr2_used);
       const int chl = mt * TM + wm * 32 + 16 * half;
       i32x4 (&rv)[NTN] = (mt & 1) ? res1 : res0;
-      auto epilogue = [&](auto has_res_c, auto fast_c) {
+      auto epilogue = [&](auto has_res_c, auto fast_c, auto rnn_c) {
         constexpr bool HAS_RES = decltype(has_res_c)::value;
         constexpr bool FAST = decltype(fast_c)::value;
+        constexpr bool RNN = decltype(rnn_c)::value;        // the residual is a post-ReLU tensor and the sum is clamped to [0, 127]: one clamp (requant_epilogue.h)
         int a16s[NTN][16];
         i32x4 outs[NTN];
 #pragma unroll
         for (int j = 0; j < NTN; j++)
 #pragma unroll
           for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
-        requant_tiles16<NTN, HAS_RES, 1, FAST>(a16s, outs, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv, a.dbl_out != 0, a.fast2 == 2);
+        requant_tiles16<NTN, HAS_RES, 1, FAST, RNN>(a16s, outs, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv, a.dbl_out != 0, a.fast2 == 2);
 #pragma unroll
         for (int j = 0; j < NTN; j++) {
           const i32x4 out = outs[j];
@@ -307,8 +308,10 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
             *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
         }
       };
-      if (a.fast2 == 1) { if (a.has_res) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::false_type{}, std::true_type{}); }
-      else { if (a.has_res) epilogue(std::true_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}); }
+      if (a.fast2 == 1) {
+        if (a.has_res) { if (a.rnn) epilogue(std::true_type{}, std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::true_type{}, std::false_type{}); }
+        else epilogue(std::false_type{}, std::true_type{}, std::false_type{});
+      } else { if (a.has_res) epilogue(std::true_type{}, std::false_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}, std::false_type{}); }
 #pragma unroll
       for (int j = 0; j < NTN; j++)
 #pragma unroll

@@ -92,14 +92,132 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
   }
 }
 
+// ---- the same stream with the filters as 4-BIT CODES in HBM (PackLayer::fc4, weight_pack.cpp; 4bit_data_format.txt) -----------------
+// A lane's 16 bytes of a slab are the 32 codes {sign << 3 | e} of its row's K half (both K steps); they are expanded to the int8 window
+// values in registers, in front of the MFMAs: per word of eight codes -- the exponent codes of the low / high nibbles as byte selectors of
+// v_perm_b32 into the row's 8-byte table "window value of e" (one table per window and input-channel class; the class of a K position
+// picks between two permutes with v_bfi_b32), then the sign applied to all four bytes at once, (v ^ m) + s with m = 0xff / s = 1 in the
+// bytes of negative weights (|value| <= 64: no carry between bytes).  ~25 VALU instructions per eight weights and two windows: the kernel
+// stays HBM-bound (fc6: 51 MB of codes instead of 205 MB of window tiles).  Image chunks of 32 (batch > 32) are grid.z: a layer stored
+// this way has no int8 tiles any other kernel could run on.
+struct Fc4Lut { unsigned lo, hi; };      // eight table bytes: e = 0..3 | e = 4..7
+
+template <int NCLS>
+__device__ __forceinline__ unsigned fc4_dec(unsigned e, unsigned cm, unsigned s, unsigned m, const Fc4Lut (&t)[2]) {
+  unsigned v = __builtin_amdgcn_perm(t[0].hi, t[0].lo, e);
+  if constexpr (NCLS == 2) {
+    const unsigned v1 = __builtin_amdgcn_perm(t[1].hi, t[1].lo, e);
+    v = (v1 & cm) | (v & ~cm);
+  }
+  return (v ^ m) + s;
+}
+
+// the 16 codes of one K step (two words) -> the 16 window values (four dwords) of window `w`'s MFMA operand
+template <bool DUAL, int NCLS>
+__device__ __forceinline__ void fc4_expand(unsigned w0, unsigned w1, const i32x4& cm, const Fc4Lut (&th)[2], const Fc4Lut (&tl)[2], i32x4& hi, i32x4& lo) {
+  const unsigned wd[2] = {w0, w1};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const unsigned x = wd[j];
+    const unsigned eL = x & 0x07070707u, eH = (x >> 4) & 0x07070707u;
+    const unsigned sL = (x >> 3) & 0x01010101u, sH = (x >> 7) & 0x01010101u;
+    // 0xff in the bytes of negative weights: v_perm_b32 selectors 0x0c / 0x0d give the constant bytes 0x00 / 0xff (s * 255 would be a
+    // quarter-rate 32-bit multiply, and hipcc turns (s << 8) - s back into one)
+    const unsigned mL = __builtin_amdgcn_perm(0u, 0u, sL | 0x0c0c0c0cu), mH = __builtin_amdgcn_perm(0u, 0u, sH | 0x0c0c0c0cu);
+    hi[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], sL, mL, th);
+    hi[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], sH, mH, th);
+    if constexpr (DUAL) {
+      lo[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], sL, mL, tl);
+      lo[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], sH, mH, tl);
+    }
+  }
+}
+
+template <bool DUAL, int NCLS>
+__global__ __launch_bounds__(256) void fc4_partial_kernel(FcArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int n0 = (blockIdx.x * 4 + wave) * 32;             // this wave's 32 output channels
+  if (n0 >= a.Np) return;
+  const int tms = a.tm == 128 ? 7 : 6;
+  const int mt = n0 >> tms, ro = n0 & ((1 << tms) - 1);
+  const int wins = DUAL ? 2 : 1;
+  const int s0 = blockIdx.y * a.slabs_per_split;
+  const int s1 = s0 + a.slabs_per_split < a.nslab ? s0 + a.slabs_per_split : a.nslab;
+  const int img = blockIdx.z * 32 + col;                   // (images beyond the batch read image 0: their columns are never looked at)
+  // wave-uniform bases + 32-bit lane offsets (the scalar-base form of global_load: no 64-bit address arithmetic per lane and load)
+  const unsigned x_lane = (unsigned)(img < a.B ? img : 0) * (unsigned)a.K + half * 16;
+  const unsigned w_lane = (unsigned)(ro + col) * 32 + half * 16;
+  const unsigned c_lane = half * 16;
+  const int8_t* const xb = a.x;
+  const int8_t* const wb = a.w + (((size_t)mt * a.nslab) << tms) * 32;
+  const size_t ent = (size_t)32 << tms;                    // bytes of one (m-tile, slab) nibble tile
+  const uint8_t* const cb = a.cls;
+  // the row's tables: [class][window][8 bytes]
+  Fc4Lut th[2], tl[2];
+  {
+    const i32x4 q0 = *reinterpret_cast<const i32x4*>(a.lut + (size_t)(n0 + col) * 32);
+    const i32x4 q1 = *reinterpret_cast<const i32x4*>(a.lut + (size_t)(n0 + col) * 32 + 16);
+    th[0] = {(unsigned)q0[0], (unsigned)q0[1]}; tl[0] = {(unsigned)q0[2], (unsigned)q0[3]};
+    th[1] = {(unsigned)q1[0], (unsigned)q1[1]}; tl[1] = {(unsigned)q1[2], (unsigned)q1[3]};
+  }
+  i32x16 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { hi[r] = 0; lo[r] = 0; }
+  constexpr int GS = 4;                                    // slabs' loads in flight per wave
+  auto body = [&](const i32x4& nb, const i32x4& b0, const i32x4& b1, const i32x4& c0, const i32x4& c1) __attribute__((always_inline)) {
+    i32x4 h0, h1, l0, l1;
+    fc4_expand<DUAL, NCLS>((unsigned)nb[0], (unsigned)nb[1], c0, th, tl, h0, l0);
+    fc4_expand<DUAL, NCLS>((unsigned)nb[2], (unsigned)nb[3], c1, th, tl, h1, l1);
+    hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h0, b0, hi, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h1, b1, hi, 0, 0, 0);
+    if constexpr (DUAL) {
+      lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l0, b0, lo, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l1, b1, lo, 0, 0, 0);
+    }
+  };
+  int s = s0;
+  for (; s + GS <= s1; s += GS) {
+    i32x4 nb[GS], b0[GS], b1[GS], c0[NCLS == 2 ? GS : 1], c1[NCLS == 2 ? GS : 1];
+#pragma unroll
+    for (int u = 0; u < GS; u++) {
+      nb[u] = *reinterpret_cast<const i32x4*>(wb + (size_t)(s + u) * ent + w_lane);
+      const int8_t* xp = xb + (size_t)(s + u) * 64;
+      b0[u] = *reinterpret_cast<const i32x4*>(xp + x_lane); b1[u] = *reinterpret_cast<const i32x4*>(xp + 32 + x_lane);
+      if constexpr (NCLS == 2) {
+        c0[u] = *reinterpret_cast<const i32x4*>(cb + (size_t)(s + u) * 64 + c_lane); c1[u] = *reinterpret_cast<const i32x4*>(cb + (size_t)(s + u) * 64 + 32 + c_lane);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // (the loads of a group in front of its first expansion)
+#pragma unroll
+    for (int u = 0; u < GS; u++) body(nb[u], b0[u], b1[u], c0[NCLS == 2 ? u : 0], c1[NCLS == 2 ? u : 0]);
+  }
+  for (; s < s1; s++) {
+    const i32x4 nb = *reinterpret_cast<const i32x4*>(wb + (size_t)s * ent + w_lane);
+    const int8_t* xp = xb + (size_t)s * 64;
+    const i32x4 b0 = *reinterpret_cast<const i32x4*>(xp + x_lane), b1 = *reinterpret_cast<const i32x4*>(xp + 32 + x_lane);
+    i32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+    if constexpr (NCLS == 2) { c0 = *reinterpret_cast<const i32x4*>(cb + (size_t)s * 64 + c_lane); c1 = *reinterpret_cast<const i32x4*>(cb + (size_t)s * 64 + 32 + c_lane); }
+    body(nb, b0, b1, c0, c1);
+  }
+  int* const p0 = a.part + (((size_t)blockIdx.z * a.ksplit + blockIdx.y) * wins * a.Np + n0) * 32 + col;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int row = 8 * (k >> 2) + 4 * half + (k & 3);
+    p0[(size_t)row * 32] = hi[k];
+    if (DUAL) p0[((size_t)a.Np + row) * 32] = lo[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void fc_finish_kernel(FcArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int n = idx >> 5, b = idx & 31;
+  const int n = idx >> 5, b32 = idx & 31, b = blockIdx.y * 32 + b32;        // (blockIdx.y: the image chunk)
   if (n >= a.Np || b >= a.B || n >= a.y_nvalid) return;
   const int wins = a.dual ? 2 : 1;
   unsigned hi = 0, lo = 0;
   for (int ks = 0; ks < a.ksplit; ks++) {
-    const int* p = a.part + ((size_t)(ks * wins) * a.Np + n) * 32 + b;
+    const int* p = a.part + (((size_t)blockIdx.y * a.ksplit + ks) * wins * a.Np + n) * 32 + b32;
     hi += (unsigned)p[0];
     if (a.dual) lo += (unsigned)p[(size_t)a.Np * 32];
   }
@@ -140,17 +258,28 @@ int conv_fc_pick_ksplit(int Np, int nslab) {
   return ks;
 }
 
-size_t conv_fc_scratch_bytes(int Np, int nslab, int dual) { return (size_t)conv_fc_pick_ksplit(Np, nslab) * (dual ? 2 : 1) * Np * 32 * 4; }
+size_t conv_fc_scratch_bytes(int Np, int nslab, int dual, int batch) {
+  return (size_t)((batch + 31) / 32) * conv_fc_pick_ksplit(Np, nslab) * (dual ? 2 : 1) * Np * 32 * 4;
+}
 
 int launch_conv_fc(const FcArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.B < 1 || a.B > 32 || a.Np % 128 != 0 || (a.tm != 64 && a.tm != 128) || a.ksplit < 1 || a.K != a.nslab * 64) return 1;
-  TF2_LAUNCH_NAME("fc_partial_kernel<%d slabs in %d slices%s>", a.nslab, a.ksplit, a.dual ? ",dual" : "");
-  if (a.dual) TF2_LAUNCH((fc_partial_kernel<true>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
-  else TF2_LAUNCH((fc_partial_kernel<false>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
+  if (a.B < 1 || a.chunks != (a.B + 31) / 32 || a.Np % 128 != 0 || (a.tm != 64 && a.tm != 128) || a.ksplit < 1 || a.K != a.nslab * 64) return 1;
+  if (a.fc4) {
+    if (a.n_cls != 1 && a.n_cls != 2) return 1;
+    TF2_LAUNCH_NAME("fc4_partial_kernel<4-bit codes,%d slabs in %d slices%s,%d class%s>", a.nslab, a.ksplit, a.dual ? ",dual" : "", a.n_cls, a.n_cls == 2 ? "es" : "");
+    const dim3 g(a.Np / 128, a.ksplit, a.chunks);
+    if (a.dual) { if (a.n_cls == 2) TF2_LAUNCH((fc4_partial_kernel<true, 2>), g, dim3(256), 0, s, a); else TF2_LAUNCH((fc4_partial_kernel<true, 1>), g, dim3(256), 0, s, a); }
+    else { if (a.n_cls == 2) TF2_LAUNCH((fc4_partial_kernel<false, 2>), g, dim3(256), 0, s, a); else TF2_LAUNCH((fc4_partial_kernel<false, 1>), g, dim3(256), 0, s, a); }
+  } else {
+    if (a.B > 32) return 1;                                // (the int8 form: one chunk; larger batches run on the split-K kernel)
+    TF2_LAUNCH_NAME("fc_partial_kernel<%d slabs in %d slices%s>", a.nslab, a.ksplit, a.dual ? ",dual" : "");
+    if (a.dual) TF2_LAUNCH((fc_partial_kernel<true>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
+    else TF2_LAUNCH((fc_partial_kernel<false>), dim3(a.Np / 128, a.ksplit), dim3(256), 0, s, a);
+  }
   if (!launch_ok()) return -1;
   TF2_LAUNCH_NAME("fc_finish_kernel");
-  TF2_LAUNCH(fc_finish_kernel, dim3((a.Np * 32 + 255) / 256), dim3(256), 0, s, a);
+  TF2_LAUNCH(fc_finish_kernel, dim3((a.Np * 32 + 255) / 256, a.chunks), dim3(256), 0, s, a);
   return launch_ok() ? 0 : -1;
 }
 

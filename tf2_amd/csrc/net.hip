@@ -292,9 +292,11 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   // partial sums of the conv_fc launches (one at a time: the largest)
   wp.scratch_off = wp.ctrl_off + wp.ctrl_bytes;
   wp.scratch_bytes = 0;
-  if (packed_valid && opts.fc_mode)
-    for (int l = 0; l < nl; l++)
-      if (fc_at(l, batch)) { const PackLayer* pl = pack_layer(l); wp.scratch_bytes = std::max(wp.scratch_bytes, conv_fc_scratch_bytes(pl->Np, pl->nslab, pl->dual)); }
+  if (packed_valid)
+    for (int l = 0; l < nl; l++) {
+      const PackLayer* pl = pack_layer(l);
+      if (pl && (opts.fc_mode || pl->fc4) && fc_at(l, batch)) wp.scratch_bytes = std::max(wp.scratch_bytes, conv_fc_scratch_bytes(pl->Np, pl->nslab, pl->dual, batch));
+    }
   wp.scratch_bytes = (wp.scratch_bytes + 255) / 256 * 256;
   wp.total_bytes = wp.scratch_off + wp.scratch_bytes;
   auto res = plans.emplace(key, std::move(wp));
@@ -341,6 +343,22 @@ bool Net::bgroup_first_at(int l) const {
   return n_dual == 0 || n_dual == 3;
 }
 
+// The tensor layer l writes holds no negative value (its last operation is a ReLU)
+bool Net::out_nonneg(int l) const {
+  if (l < 0) return false;                                  // the image
+  const tf2_layer_desc& L = layers[l];
+  if (L.ipool == 2) return false;                           // L2Norm: sign(w) * sign(x)
+  if (L.ipool) return out_nonneg(L.src);                    // a pool row keeps its input's range
+  return L.add_src >= 0 ? L.add_relu != 0 : L.relu != 0;
+}
+
+// Row l adds a residual under the conditions of requant_epilogue.h's RNN form: no ReLU of its own, a post-ReLU residual tensor, the sum
+// clamped to [0, 127] -- clamp(clamp(y, -128, 127) + r, 0, 127) == clamp(y + r, 0, 127), the first clamp is left out
+bool Net::res_nonneg_single_clamp(int l) const {
+  const tf2_layer_desc& L = layers[l];
+  return L.add_src >= 0 && !L.relu && L.add_relu && layers[L.add_src].concat < 0 && out_nonneg(L.add_src);
+}
+
 // Rows l, l + 1, l + 2 = 1x1 reduce, 3x3 / 1 / pad 1, 1x1 expand + residual from the reduce's input, of a shape conv_bgroup.hip
 // is instantiated for, every row single-window in 64- or 128-row dense tiles.
 bool Net::bgroup_at(int l) const {
@@ -354,6 +372,7 @@ bool Net::bgroup_at(int l) const {
   if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
   if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
   if (layers[A.src].concat >= 0 || A.H != A.W || !conv_bgroup_shape_ok(A.H, A.C, A.N)) return false;
+  if (!res_nonneg_single_clamp(l + 2)) return false;        // (the group kernels' expands use the single-clamp form)
   for (int k = l; k <= l + 2; k++) {
     const PackLayer* pl = pack_layer(k);
     if (!pl || pl->kind != KIND_MFMA) return false;
@@ -383,6 +402,7 @@ bool Net::bband_at(int l, int rows) const {
   if (B.src != l || B.k != 3 || B.pad_h != 1 || B.pad_w != 1 || B.add_src >= 0 || B.C != A.N || B.N != A.N) return false;
   if (E.src != l + 1 || E.k != 1 || E.pad_h || E.pad_w || E.add_src != A.src || E.N != A.C) return false;
   if (layers[A.src].concat >= 0) return false;
+  if (!res_nonneg_single_clamp(l + 2)) return false;        // (conv_bband's expand uses the single-clamp form)
   {
     const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1);
     if (!p0 || !p1) return false;
@@ -419,13 +439,14 @@ bool Net::c3_at(int l) const {
 // (that one stores the dense logits itself): conv_fc.hip streams its weights over the whole chip
 bool Net::fc_at(int l, int batch) const {
   const tf2_layer_desc& L = layers[l];
-  if (batch > 32 || l == nd.n_layers - 1) return false;
+  if (l == nd.n_layers - 1) return false;
+  { const PackLayer* p4 = pack_layer(l); if (batch > 32 && !(p4 && p4->fc4)) return false; }      // (4-bit code layers: any batch, in chunks of 32 -- they have no int8 tiles)
   if (L.ipool || L.k != L.H || L.k != L.W || L.stride != 1 || L.dil != 1 || L.pad_h || L.pad_w || L.OH != 1 || L.OW != 1) return false;
   if (L.src < 0 || L.add_src >= 0 || L.endpool || L.pool_en || L.concat >= 0 || layers[L.src].concat >= 0 || out_Cp[L.src] != L.C) return false;
   const PackLayer* pl = pack_layer(l);
   if (!pl || pl->kind != KIND_MFMA || (pl->TM != 64 && pl->TM != 128) || pl->w_share || pl->signed_in || pl->Np % 128 != 0) return false;
   if (pl->Cp_in != L.C || pl->Cp_in % 64 != 0 || pl->nslab != L.k * L.k * (pl->Cp_in / 64) || (long)pl->n_entries != (long)pl->n_mtiles * pl->nslab) return false;
-  if (pl->nslab < opts.fc_min_slabs || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
+  if ((pl->nslab < opts.fc_min_slabs && !pl->fc4) || pl->fuse_next > 0 || pl->fused_into >= 0) return false;
   const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
   return one_window || dual;
 }
@@ -817,10 +838,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const bool fuse_now = pl->fuse_next > 0 && (long)batch * ((L.H + bn_R - 1) / bn_R) >= opts.bneck_min_blocks &&
                           !(concurrent && pl->TM == 128 && opts.bneck_min_blocks > 1);
     if (!make_conv(l, st, !fuse_now)) return nullptr;     // the fused launch needs the pair's own (one m-tile) entries
-    if (!fuse_now && opts.fc_mode && fc_at(l, batch) && wp->scratch_bytes) {
+    if (!fuse_now && (opts.fc_mode || pack_layer(l)->fc4) && fc_at(l, batch) && wp->scratch_bytes) {
       Launch sc;
       const PackLayer* pm = pack_layer(l);
-      if (make_conv(l, sc, false) && pm->TM == sc.TM && conv_fc_scratch_bytes(pm->Np, pm->nslab, pm->dual) <= wp->scratch_bytes) {
+      if (make_conv(l, sc, false) && pm->TM == sc.TM && conv_fc_scratch_bytes(pm->Np, pm->nslab, pm->dual, batch) <= wp->scratch_bytes) {
         const ConvArgs& c = sc.conv;
         FcArgs& f = sc.fc;
         f.x = c.x; f.y = c.y; f.w = c.w; f.hdr = c.hdr; f.hdr_bytes = c.hdr_bytes; f.tm = sc.TM;
@@ -828,11 +849,14 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.B = batch; f.nslab = pm->nslab; f.K = pm->nslab * 64; f.Np = pm->Np;
         f.ksplit = conv_fc_pick_ksplit(pm->Np, pm->nslab); f.slabs_per_split = (pm->nslab + f.ksplit - 1) / f.ksplit;
         f.dual = c.dual; f.relu = c.g.relu; f.fast = c.g.fast; f.dbl = c.g.dbl_out;
+        f.fc4 = pm->fc4; f.n_cls = pm->n_cls; f.chunks = (batch + 31) / 32;
+        f.lut = pk + pm->off_lut; f.cls = pk + pm->off_cls;
         f.y_cp = c.g.y_cp; f.y_off = c.g.y_off; f.y_nvalid = c.g.y_nvalid;
         sc.sel = Launch::SEL_FC; sc.avg_fused = 0;
         st = sc;
       }
     }
+    if (pack_layer(l)->fc4 && st.sel != Launch::SEL_FC) return fail("layer " + std::to_string(l) + " is packed as 4-bit codes (fc4) but conv_fc cannot take it");
     if (!fuse_now && st.sel != Launch::SEL_FC && opts.c3_mode && c3_at(l)) {
       int th = 0, tw = 0;
       conv_c3_pick_tile(L.H, L.W, &th, &tw);
@@ -880,6 +904,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.y = cb.y; f.y_cp = cb.g.y_cp; f.y_off = cb.g.y_off; f.y_nvalid = cb.g.y_nvalid;
       f.res = cb.res; f.res_cp = cb.g.res_cp; f.res_off = cb.g.res_off; f.add_relu = cb.g.add_relu; f.has_res = cb.g.has_res;
       f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0; f.dbl_out = pb->off_dbl != 0;
+      f.rnn = res_nonneg_single_clamp(pl->fuse_next) ? 1 : 0;
       f.B = batch; f.H = L.H; f.W = L.W; f.probe = opts.flags;
       set_fast_div((uint32_t)L.W, &f.w_m, &f.w_s); set_fast_div((uint32_t)(L.W + 2), &f.wp_m, &f.wp_s);
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)

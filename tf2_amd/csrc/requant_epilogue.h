@@ -39,10 +39,16 @@ constexpr int kPrmWordsPerRow = 5;
 // Returns the lane's 16 contiguous NHWC bytes (lanes 0-31: channels 0..15 of the tile, lanes 32-63: 16..31).
 // LEAN (1 or 2): for kernels compiled for 8 waves/SIMD (64 registers); the number of rows read ahead.
 // resv: with HAS_RES the 16 residual bytes of the same NHWC position (as loaded, before the swaps).
+// RNN ("residual non-negative", round 5): the layer has no ReLU of its own (lo_bound = -128), adds a residual r that is a post-ReLU
+// tensor (0 <= r <= 127) and clamps the sum to [0, 127] (add_relu) -- every identity bottleneck's expand.  Then
+//     clamp(clamp(y, -128, 127) + r, 0, 127) == clamp(y + r, 0, 127)
+// (y > 127: both 127; y < -128: the left side is clamp(r - 128) = 0, the right one clamp(y + r < -1) = 0; else identical), and the
+// first v_med3 -- one of the 5.75 VALU instructions per output of these VALU-bound phases -- is left out.  The launch plan sets it
+// (Net::res_nonneg_single_clamp); the kernels that always run such rows (conv_bband, the group kernels) are only selected for them.
 // DBL (layers without a residual whose output tensor has "doubled" channels, weight_pack.cpp): header word 0 of a row (FAST;
 // generic rows: bits 8.. of the row's shift word) is -128 for a doubled channel, 0 otherwise, and the stored value is
 // (c << 1) - 128 resp. c.
-template <bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI = false>
+template <bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI = false, bool RNN = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], const int* prm, int TM, int row0 /* tile row base + 4*half */,
                                                         int lo_bound, int rlo, const rq_i32x4& resv) {
   unsigned rd[4] = {0, 0, 0, 0};
@@ -93,8 +99,9 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
         const int x = (int)(p >> kAlphaInflat);
         y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat;
       }
-      int c;
-      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+      static_assert(!RNN || (HAS_RES && !DBL), "RNN: a residual layer");
+      int c = y;
+      if (!RNN) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
       if (DBL) {
         const int kd = FAST ? pr[0] : (lo4[r] >> 8);          // -128 or 0 (generic rows keep it above the shift amount)
         c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
@@ -120,7 +127,7 @@ __device__ __forceinline__ rq_i32x4 requant_tile16_impl(const int (&a16)[16], co
 // ---- NJ column tiles of one row tile in lockstep: every parameter row is read ONCE and applied to all NJ tiles ------------------
 // (conv_bneck: two tiles per wave at 128 registers -- the row-by-row order of LEAN costs no register beyond the tiles' own
 // packed words, and halves the parameter reads, which were two thirds of that kernel's LDS instructions)
-template <int NJ, bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI>
+template <int NJ, bool HAS_RES, int LEAN, bool FAST, bool DBL, bool SEMI, bool RNN = false>
 __device__ __forceinline__ void requant_tiles16_impl(const int (&a16)[NJ][16], rq_i32x4 (&out)[NJ], const int* prm, int TM, int row0,
                                                      int lo_bound, int rlo, const rq_i32x4 (&resv)[NJ]) {
   static_assert(LEAN >= 1, "row-ordered form");
@@ -162,8 +169,9 @@ __device__ __forceinline__ void requant_tiles16_impl(const int (&a16)[NJ][16], r
           if (SEMI) y = (int)(p >> 32) >> (kAlphaInflat + kInflat - 32);
           else { const int x = (int)(p >> kAlphaInflat); y = __builtin_elementwise_add_sat(x, 1 << (kInflat - 1)) >> kInflat; }
         }
-        int c;
-        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
+        static_assert(!RNN || (HAS_RES && !DBL), "RNN: a residual layer");
+        int c = y;
+        if (!RNN) asm("v_med3_i32 %0, %1, %2, %3" : "=v"(c) : "v"(y), "s"(lo_bound), "v"(127));
         if (DBL) {
           const int kd = FAST ? pr[0] : (lo4[r] >> 8);
           c = (int)(((unsigned)c << ((unsigned)kd >> 31)) + (unsigned)kd);
@@ -192,7 +200,7 @@ __device__ __forceinline__ void requant_tiles16_impl(const int (&a16)[NJ][16], r
 }
 
 // (same dispatch as requant_tile16: dbl only without a residual, semi only read when !FAST)
-template <int NJ, bool HAS_RES, int LEAN, bool FAST>
+template <int NJ, bool HAS_RES, int LEAN, bool FAST, bool RNN = false>
 __device__ __forceinline__ void requant_tiles16(const int (&a16)[NJ][16], rq_i32x4 (&out)[NJ], const int* prm, int TM, int row0, int lo_bound, int rlo,
                                                 const rq_i32x4 (&resv)[NJ], bool dbl = false /* wave-uniform */, bool semi = false) {
   if constexpr (!FAST) {
@@ -200,13 +208,13 @@ __device__ __forceinline__ void requant_tiles16(const int (&a16)[NJ][16], rq_i32
       if constexpr (!HAS_RES) {
         if (dbl) return requant_tiles16_impl<NJ, false, LEAN, false, true, true>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
       }
-      return requant_tiles16_impl<NJ, HAS_RES, LEAN, false, false, true>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+      return requant_tiles16_impl<NJ, HAS_RES, LEAN, false, false, true, RNN>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
     }
   }
   if constexpr (!HAS_RES) {
     if (dbl) return requant_tiles16_impl<NJ, false, LEAN, FAST, true, false>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
   }
-  return requant_tiles16_impl<NJ, HAS_RES, LEAN, FAST, false, false>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
+  return requant_tiles16_impl<NJ, HAS_RES, LEAN, FAST, false, false, RNN>(a16, out, prm, TM, row0, lo_bound, rlo, resv);
 }
 
 // ---- the same arithmetic with the rows' parameters held in registers across column tiles ------------------------------------------
@@ -287,7 +295,7 @@ __device__ __forceinline__ void requant_tiles16_rows(AccOf acc_of, rq_i32x4 (&ou
 }
 
 // FAST = the layer's PackLayer::fast == 1; semi (wave-uniform, only read when !FAST) = PackLayer::fast == 2
-template <bool HAS_RES, int LEAN = 0, bool FAST = false>
+template <bool HAS_RES, int LEAN = 0, bool FAST = false, bool RNN = false>
 __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const int* prm, int TM, int row0, int lo_bound, int rlo, const rq_i32x4& resv,
                                                    bool dbl = false /* wave-uniform */, bool semi = false) {
   if constexpr (!FAST) {
@@ -295,13 +303,13 @@ __device__ __forceinline__ rq_i32x4 requant_tile16(const int (&a16)[16], const i
       if constexpr (!HAS_RES) {
         if (dbl) return requant_tile16_impl<false, LEAN, false, true, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
       }
-      return requant_tile16_impl<HAS_RES, LEAN, false, false, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
+      return requant_tile16_impl<HAS_RES, LEAN, false, false, true, RNN>(a16, prm, TM, row0, lo_bound, rlo, resv);
     }
   }
   if constexpr (!HAS_RES) {
     if (dbl) return requant_tile16_impl<false, LEAN, FAST, true>(a16, prm, TM, row0, lo_bound, rlo, resv);
   }
-  return requant_tile16_impl<HAS_RES, LEAN, FAST, false>(a16, prm, TM, row0, lo_bound, rlo, resv);
+  return requant_tile16_impl<HAS_RES, LEAN, FAST, false, false, RNN>(a16, prm, TM, row0, lo_bound, rlo, resv);
 }
 
 }  // namespace tf2

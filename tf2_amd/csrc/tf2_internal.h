@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 31;
+constexpr uint32_t kPackVersion = 32;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -62,6 +62,15 @@ struct PackLayer {
                          // rewrite's memset rows, model_loader.cpp:244-257), the same (tap, channel) set in every output row:
                          // int8[9][32] 0/1 mask; off_w2 then holds the HIGH window alone and the kernel adds the per-pixel sum
                          // of the masked inputs to every channel's accumulator instead of sweeping a second window
+  // conv_fc layers with their filters as 4-bit codes in HBM (round 5; TransForm_Kit/Compression/compress_net/4bit_data_format.txt: sign +
+  // 3-bit exponent code per weight).  fc4 != 0: off_w holds NIBBLE tiles [m-tile * nslab + slab][TM rows][32 bytes] instead of int8
+  // window tiles -- no int8 copy of the layer's weights exists in the image; conv_fc.hip expands a lane's 16 codes to the int8 window
+  // values in registers, in front of the MFMA, through the row's look-up tables:
+  uint64_t off_lut;      // uint8[Np][2 classes][2 windows][8]: window value of exponent code e (e = 7: zero weight) for this output
+                         // channel, per input-channel class (channels whose Q differs shift every code by that much) and window
+  uint64_t off_cls;      // uint8[nslab * 64]: 0xff where K position k belongs to an input channel of class 1 (n_cls == 2), else 0
+  int32_t fc4;
+  int32_t n_cls;         // 1 or 2 input-channel classes
 };
 
 struct PackHeader {
@@ -148,7 +157,11 @@ struct ConvArgs {
 // weight stream split over the whole chip (output channels x K slices), partial sums through a scratch area of the workspace
 struct FcArgs {
   const int8_t* x; int8_t* y;
-  const int8_t* w;             // dense weight tiles [mtile * nslab + slab][(hi | lo)][tm rows][64]
+  const int8_t* w;             // dense weight tiles [mtile * nslab + slab][(hi | lo)][tm rows][64]; fc4: nibble tiles [mtile * nslab + slab][tm rows][32]
+  const uint8_t* lut;          // fc4: PackLayer::off_lut
+  const uint8_t* cls;          // fc4: PackLayer::off_cls
+  int32_t fc4, n_cls;          // fc4: 4-bit codes expanded in registers (conv_fc.hip fc4_partial_kernel)
+  int32_t chunks;              // image chunks of 32 (grid.z of the partial kernel; the int8 form: always 1)
   const int32_t* hdr;          // per storage m-tile header images (stride hdr_bytes)
   int32_t* part;               // [ksplit][windows][Np][32] int32
   int32_t hdr_bytes, tm;
@@ -158,7 +171,7 @@ struct FcArgs {
   int32_t y_cp, y_off, y_nvalid;
 };
 int conv_fc_pick_ksplit(int Np, int nslab);
-size_t conv_fc_scratch_bytes(int Np, int nslab, int dual);
+size_t conv_fc_scratch_bytes(int Np, int nslab, int dual, int batch);
 int launch_conv_fc(const FcArgs& a, void* stream);
 
 // conv_c3.hip: a 3x3 / stride 1 / pad 1 layer of a big map, the input's halo tile streamed through LDS once (instead of nine gathers)
@@ -204,6 +217,8 @@ struct BneckArgs {
   int32_t dual1, fast1, relu1, dual2, fast2, relu2, add_relu, has_res, keep_mid;
   int32_t dbl_mid;           // the 3x3's output (the intermediate tile) has doubled channels
   int32_t dbl_out;           // the expand's output has doubled channels (only without a residual: weight_pack.cpp)
+  int32_t rnn;               // the expand has no ReLU of its own, its residual is a post-ReLU tensor and the sum is clamped to [0, 127]:
+                             // one clamp instead of two (requant_epilogue.h RNN; Net::res_nonneg_single_clamp)
   int32_t probe;             // timing probes (ConvGeom::flags of the pair; read by -DTF2_PROBES builds only)
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
   uint32_t w_m, wp_m; int32_t w_s, wp_s;     // set_fast_div(W), set_fast_div(W + 2): the pixel decodes without a run-time division

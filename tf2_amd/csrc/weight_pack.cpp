@@ -465,7 +465,111 @@ tf2_status Net::pack(int mode) {
         same_lists(main_entries, main_dir, main_nm);
         same_lists(entries, dir, n_mtiles);
       }
-      if (share) {
+      // ---- conv_fc layers: the filters stay 4-BIT CODES in HBM (PackLayer::fc4; 4bit_data_format.txt) ----
+      // A whole-window layer (k x k / pad 0 on a k x k map, 1 x 1 on 1 x 1: VGG16's fc6 / fc7) is a weight stream: every weight byte is
+      // read once per batch of 32, the kernel is HBM-bound with idle VALUs -- the one place where the reference's storage format pays on
+      // this chip.  INQ weights are sign + one of 7 exponents, and the shift of a code is 15 + Q_in[c] - Q_out[n] - i
+      // (model_loader.cpp:159-162): s = A[n] + B[c] - e, e in 0..6.  Stored: one nibble {sign << 3 | e} (e = 7: zero) per weight, per
+      // output channel a table "window value of e" for each of at most TWO input-channel classes (B[c] takes two values where the
+      // input's channels carry two Q values) and each exponent window, and the class of every K position.  conv_fc.hip expands a
+      // lane's 16 codes with two v_perm_b32 per four weights and window.  Every weight is decoded here once more and compared with
+      // the dense window matrices: the form is used only when it reproduces them byte for byte.
+      std::vector<uint8_t> nibt, lutv, clsm;
+      int n_cls = 1;
+      bool fc4 = variant == 0 && mode == 0 && opt("fc4", 1) != 0 && !L.ipool && L.k == L.H && L.k == L.W && L.stride == 1 && L.dil <= 1 &&
+                 (L.pad_h | L.pad_w) == 0 && L.OH == 1 && L.OW == 1 && L.src >= 0 && L.add_src < 0 && !L.endpool && !L.pool_en && L.concat < 0 &&
+                 layers[L.src].concat < 0 && l != nl - 1 && !in_signed && (P == 1 || dual) && Np % 128 == 0 && il.Cp_in % 64 == 0 &&
+                 il.Cp_in == round_up(C, 16) && Kp == Ktot && (long)entries.size() == (long)n_mtiles * nslab && nslab >= 16 && fuse_next[l] <= 0 && fused_into[l] < 0;
+      if (fc4) {
+        const int Mq = nd.max_out_channel;
+        std::vector<int> Bc(il.Cp_in, 0), An(Np, -1000);
+        bool fits = false;
+        for (int pass = 0; pass < 2 && !fits; pass++) {           // pass 0: B from the input's Q row; pass 1: B = 0
+          std::fill(Bc.begin(), Bc.end(), 0); std::fill(An.begin(), An.end(), -1000);
+          if (pass == 0) {
+            if (L.q_in_row < 0 || C > Mq) continue;
+            const int8_t* q_in = q.data() + (size_t)L.q_in_row * Mq;
+            for (int c = 0; c < C; c++) Bc[c] = (int)q_in[c] - ((in_dbl && (*in_dbl)[c]) ? 1 : 0);      // (doubled channels: codes one exponent down)
+          }
+          fits = true;
+          for (int n = 0; n < N; n++)
+            for (int c = 0; c < C; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (!code_zero(code)) An[n] = std::max(An[n], code_shift(code) - Bc[c]);
+              }
+          for (int n = 0; n < N && fits; n++)
+            for (int c = 0; c < C && fits; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (code_zero(code)) continue;
+                const int e = An[n] + Bc[c] - code_shift(code);
+                if (e < 0 || e > 6) { fits = false; break; }
+              }
+        }
+        int b0 = 0, b1 = 0;
+        if (fits) {
+          b0 = b1 = Bc[0];
+          for (int c = 0; c < C; c++) { b0 = std::min(b0, Bc[c]); b1 = std::max(b1, Bc[c]); }
+          for (int c = 0; c < C && fits; c++) if (Bc[c] != b0 && Bc[c] != b1) fits = false;      // more than two classes: int8 tiles
+          n_cls = b0 == b1 ? 1 : 2;
+        }
+        if (fits) {
+          // look-up tables [Np][class][window][e]
+          lutv.assign((size_t)Np * 32, 0);
+          for (int n = 0; n < N; n++) {
+            if (An[n] == -1000) continue;                          // an all-zero row
+            const auto& r = row_lo[n];
+            for (int k2 = 0; k2 < 2; k2++)
+              for (int e = 0; e < 7; e++) {
+                const int sft = An[n] + (k2 ? b1 : b0) - e;
+                if (sft < 0 || sft > 31 || r.empty()) continue;
+                int pw = 0;
+                while (pw + 1 < (int)r.size() && sft < r[pw]) pw++;
+                const int rel = sft - r[pw];
+                if (pw < 2 && rel >= 0 && rel <= 6) lutv[(size_t)n * 32 + k2 * 16 + pw * 8 + e] = (uint8_t)(1 << rel);
+              }
+          }
+          clsm.assign((size_t)nslab * 64, 0);
+          for (int kk = 0; kk < Ktot; kk++) { const int pc = kk % il.Cp_in; if (n_cls == 2 && pc < C && Bc[pc] == b1) clsm[kk] = 0xff; }
+          // nibble tiles [m-tile * nslab + slab][TM rows][32 bytes]; a row's 32 bytes = [K half h][K step ks] 8 bytes each, inside them
+          // word w (4 bytes), byte j: low nibble = K position h * 16 + ks * 32 + 8 w + j of the slab, high nibble = that + 4 -- a lane's
+          // 16 bytes (its K half) expand to the two 16-byte MFMA operands of the slab word by word (conv_fc.hip fc4_expand)
+          nibt.assign((size_t)n_mtiles * nslab * TM * 32, 0x77);
+          for (int n = 0; n < N; n++)
+            for (int c = 0; c < C; c++)
+              for (int t = 0; t < taps; t++) {
+                const uint8_t code = m.codes[((size_t)n * C + c) * taps + t];
+                if (code_zero(code)) continue;
+                const int kk = t * il.Cp_in + c, sl = kk >> 6, ki = kk & 63;
+                const int h = (ki >> 4) & 1, ks = ki >> 5, within = ki & 15, w = within >> 3, j = within & 3, hi_nib = (within >> 2) & 1;
+                const unsigned v = (unsigned)(An[n] + Bc[c] - code_shift(code)) | (code_neg(code) ? 8u : 0u);
+                uint8_t& bt = nibt[(((size_t)(n / TM) * nslab + sl) * TM + (n % TM)) * 32 + h * 16 + ks * 8 + w * 4 + j];
+                bt = hi_nib ? (uint8_t)((bt & 0x0f) | (v << 4)) : (uint8_t)((bt & 0xf0) | v);
+              }
+          // the proof: every (row, K position) decoded as the kernel does == the dense window matrices
+          for (int n = 0; n < N && fits; n++)
+            for (int kk = 0; kk < Kp && fits; kk++) {
+              const int sl = kk >> 6, ki = kk & 63;
+              const int h = (ki >> 4) & 1, ks = ki >> 5, within = ki & 15, w = within >> 3, j = within & 3, hi_nib = (within >> 2) & 1;
+              const uint8_t bt = nibt[(((size_t)(n / TM) * nslab + sl) * TM + (n % TM)) * 32 + h * 16 + ks * 8 + w * 4 + j];
+              const unsigned nb = hi_nib ? bt >> 4 : bt & 15;
+              const int cl = clsm[kk] ? 1 : 0;
+              for (int pw = 0; pw < P; pw++) {
+                int val = lutv[(size_t)n * 32 + cl * 16 + pw * 8 + (nb & 7)];
+                if (nb & 8) val = -val;
+                if (val != (int)W[((size_t)pw * Np + n) * Kp + kk]) { fits = false; break; }
+              }
+            }
+        }
+        fc4 = fits;
+      }
+      if (fc4) {
+        pl.fc4 = 1; pl.n_cls = n_cls;
+        pl.off_w = blob.alloc(nibt.size()); std::memcpy(blob.at<uint8_t>(pl.off_w), nibt.data(), nibt.size());
+        pl.off_lut = blob.alloc(lutv.size()); std::memcpy(blob.at<uint8_t>(pl.off_lut), lutv.data(), lutv.size());
+        pl.off_cls = blob.alloc(clsm.size()); std::memcpy(blob.at<uint8_t>(pl.off_cls), clsm.data(), clsm.size());
+      } else if (share) {
         pl.off_w = main_off_w; pl.w_share = 1; pl.w_main_TM = main_TM;
         // the alternative's m-tile mt starts at the main m-tile's first entry: mt / 2 (halves of 128-row tiles) or 2 mt (pairs)
         const int nent = main_dir[P] - main_dir[0];
