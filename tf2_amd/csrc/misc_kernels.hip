@@ -251,6 +251,99 @@ __global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
   }
 }
 
+// The im2col input of a 3x3 first layer (PrepArgs::rewrite == 2), every image element fetched and quantised ONCE (round 5).
+// prep_rewrite3_kernel<im2col> gathers an output pixel's 27 source values straight from global memory: each image element is loaded
+// and quantised nine times (VGG16 at batch 32: 57 us, 7 % of the step; SSD300 96 us).  Here a block owns R consecutive output rows of
+// one image: the (R - 1) * stride + 3 image rows they look at (3 channels) come in once -- 16-byte loads where the image width allows
+// -- are quantised (runner.cpp:158-163) into an int8 LDS tile whose border is the zero padding (sequencer.cl:287), and every thread
+// then assembles output pixels' 27 bytes c * 9 + fh * 3 + fw and their int8 negations (pe.cl:32-37) from LDS; the 64-byte pixels
+// leave through an LDS transpose as contiguous 16-byte pieces.  Same bytes as prep_rewrite3_kernel<*, false, true>
+// (tf2_net_read_layer(-1) and every first-layer test compare them).
+constexpr int kImPadL = 4;                                  // tile column of image column 0 (pad_w <= 4: launcher-checked)
+template <bool SRC_Q>
+__global__ __launch_bounds__(256) void prep_im2col_rows_kernel(PrepArgs a, int R, int WS) {
+  prep_zero_ctrl(a);
+  extern __shared__ __attribute__((aligned(16))) int8_t im_lds[];
+  const int s_ = a.im_stride, TR = (R - 1) * s_ + 3;
+  int8_t* const img = im_lds;                               // [3][TR][WS]
+  int (*const tile)[17] = reinterpret_cast<int (*)[17]>(im_lds + ((3 * TR * WS + 15) & ~15));      // [256][17]: 64 B per pixel (+1 word: bank spread)
+  const int rows_per_img = (a.OH + R - 1) / R;
+  const int b = blockIdx.x / rows_per_img;
+  const int oh0 = (blockIdx.x - b * rows_per_img) * R;
+  const int r_first = oh0 * s_ - a.im_pad_h;               // image row of tile row 0
+  const int tid = threadIdx.x;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  for (int i = tid; i < 3 * TR * WS / 4; i += 256) reinterpret_cast<int*>(img)[i] = 0;      // borders, rows outside the image
+  __syncthreads();
+  if ((a.W & 3) == 0) {
+    const int w4 = a.W >> 2;
+    for (int i = tid; i < 3 * TR * w4; i += 256) {
+      const int line = i / w4, x4 = i - line * w4;
+      const int ci = line / TR, rr = line - ci * TR;
+      const int sr = r_first + rr;
+      if ((unsigned)sr >= (unsigned)a.H) continue;
+      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x4 * 4;
+      int q[4];
+      if (SRC_Q) {
+        const int v = *reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = (int)(signed char)((v >> (8 * j)) & 0xff);
+      } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = quant_input(v[j], trans);
+      }
+      *reinterpret_cast<unsigned*>(&img[(ci * TR + rr) * WS + kImPadL + x4 * 4]) =
+          (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+    }
+  } else {
+    for (int i = tid; i < 3 * TR * a.W; i += 256) {
+      const int line = i / a.W, x = i - line * a.W;
+      const int ci = line / TR, rr = line - ci * TR;
+      const int sr = r_first + rr;
+      if ((unsigned)sr >= (unsigned)a.H) continue;
+      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x;
+      const int q = SRC_Q ? (int)reinterpret_cast<const int8_t*>(a.img)[si] : quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
+      img[(ci * TR + rr) * WS + kImPadL + x] = (int8_t)q;
+    }
+  }
+  __syncthreads();
+  const int rows = (a.OH - oh0) < R ? (a.OH - oh0) : R;
+  const int n_px = rows * a.OW;
+  const size_t px_base = ((size_t)b * a.OH + oh0) * a.OW;   // the block's output pixels are contiguous in the NHWC tensor
+  for (int p0 = 0; p0 < n_px; p0 += 256) {
+    const int p = p0 + tid;
+    if (p < n_px) {
+      const int rsel = p / a.OW, ow = p - rsel * a.OW;
+      const int8_t* base = img + (rsel * s_) * WS + kImPadL + ow * s_ - a.im_pad_w;
+      unsigned wx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const int q = (int)base[(ci * TR + k / 3) * WS + k % 3];
+          const int c = ci * 9 + k;
+          wx[c >> 2] |= (unsigned)(q & 0xff) << (8 * (c & 3));
+          wn[c >> 2] |= (unsigned)((-q) & 0xff) << (8 * (c & 3));        // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+        }
+#pragma unroll
+      for (int w = 0; w < 8; w++) { tile[tid][w] = (int)wx[w]; tile[tid][8 + w] = (int)wn[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = r * 256 + tid;                          // 16-byte chunk inside this pass's 256 pixels
+      const int pl = c >> 2, ch = c & 3;
+      if (p0 + pl < n_px) {
+        const i32x4 o = {tile[pl][ch * 4], tile[pl][ch * 4 + 1], tile[pl][ch * 4 + 2], tile[pl][ch * 4 + 3]};
+        *reinterpret_cast<i32x4*>(a.y + (px_base + p0 + pl) * 64 + ch * 16) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
   // one thread per (output pixel, 16-channel group)
   const long long total = (long long)a.B * a.PH * a.PW * a.C16;
@@ -373,6 +466,21 @@ static inline int grid_for(long long total, int block = 256) {
 int launch_prep_input(const PrepArgs& a, void* stream) {
   const long long pixels = (long long)a.B * a.OH * a.OW;
   if (a.rewrite == 2 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
+    // every image element quantised once through an LDS row tile (prep_im2col_rows_kernel) where the geometry allows it
+    if (a.im_stride >= 1 && a.im_stride <= 4 && a.im_pad_w <= kImPadL && a.im_pad_h <= 4 && a.OW >= 8) {
+      const int R = a.OW >= 256 ? 1 : (256 / a.OW < a.OH ? 256 / a.OW : a.OH);        // output rows per block: up to 256 pixels
+      const int TR = (R - 1) * a.im_stride + 3;
+      const int span = (a.OW - 1) * a.im_stride - a.im_pad_w + 3;                        // image columns [-pad_w, span - pad_w) are looked at
+      const int WS = (kImPadL + (a.W > span ? a.W : span) + 4 + 3) & ~3;
+      const size_t lds = (size_t)((3 * TR * WS + 15) & ~15) + 256 * 17 * 4;
+      if (lds <= 64 * 1024) {
+        const unsigned gridr = (unsigned)(a.B * ((a.OH + R - 1) / R));
+        TF2_LAUNCH_NAME("prep_im2col_rows_kernel<%d rows per block>", R);
+        if (a.src_is_q) TF2_LAUNCH((prep_im2col_rows_kernel<true>), dim3(gridr), dim3(256), lds, (hipStream_t)stream, a, R, WS);
+        else TF2_LAUNCH((prep_im2col_rows_kernel<false>), dim3(gridr), dim3(256), lds, (hipStream_t)stream, a, R, WS);
+        return launch_ok() ? 0 : -1;
+      }
+    }
     const unsigned grid = (unsigned)((pixels + 255) / 256);
     TF2_LAUNCH_NAME("prep_rewrite3_kernel<im2col>");
     if (a.src_is_q) TF2_LAUNCH((prep_rewrite3_kernel<true, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
