@@ -97,7 +97,9 @@ def fc4_tiles(blob, pl, nt):
     cl = np.broadcast_to(cls[None, :, None, :], codes.shape)
     for wdw in range(nt):
         v = lut[mt_i, r_i, cl, wdw, (codes & 7).astype(np.int64)]
-        v = np.where(codes & 8, -v, v)
+        # (the kernel feeds the one's complement v ^ 0xff = -v - 1 for negative weights and adds sum(x over their K positions) through
+        #  one more MFMA: together -v, also where the weight is zero in this window)
+        v = np.where(codes & 8, (v ^ 0xff).astype(np.uint8).astype(np.int8).astype(np.int16) + 1, v)
         out[:, wdw] = v.reshape(nm * nslab, TM, 64).astype(np.int8)
     return out
 

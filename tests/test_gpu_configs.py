@@ -272,7 +272,7 @@ def test_vgg16_four_batches_in_flight():
     q = synth.synth_q_values(t, 0, spread=1)
     rig = Rig(t, q, synth.synth_model(t, q, 0), 0)
     names = [r["kernel"] for r in rig.net.describe_launches(24, 1)]
-    assert any("conv_c3_w9" in n for n in names) and any("conv_c3_kernel" in n for n in names) and any("fc_partial" in n for n in names), names
+    assert any("conv_c3_w9" in n for n in names) and any("conv_c3_kernel" in n for n in names) and any("fc4_partial" in n or "fc_partial" in n for n in names), names
     _in_flight(rig, B=24, n_in=6, n_steps=24, graph=0, seed=500)
 
 

@@ -96,25 +96,29 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
 // A lane's 16 bytes of a slab are the 32 codes {sign << 3 | e} of its row's K half (both K steps); they are expanded to the int8 window
 // values in registers, in front of the MFMAs: per word of eight codes -- the exponent codes of the low / high nibbles as byte selectors of
 // v_perm_b32 into the row's 8-byte table "window value of e" (one table per window and input-channel class; the class of a K position
-// picks between two permutes with v_bfi_b32), then the sign applied to all four bytes at once, (v ^ m) + s with m = 0xff / s = 1 in the
-// bytes of negative weights (|value| <= 64: no carry between bytes).  ~25 VALU instructions per eight weights and two windows: the kernel
+// picks between two permutes with v_bfi_b32), then the sign applied to all four bytes at once.  Two's complement would be (v ^ m) + s
+// with m = 0xff / s = 1 in the bytes of negative weights -- but a negative weight is ZERO in the window it does not belong to, and
+// (0 ^ 0xff) + 1 carries into the neighbouring byte (the first version did exactly that: fc6 off by one in 3 % of its outputs).  So
+// the operand is the ONE'S complement v ^ m = -v - 1, and the missing "+1 per negative weight" is one more MFMA per K step with the
+// sign bytes s themselves as its operand: sum((v ^ m) x) + sum(s x) = sum(+-v x), for v = 0 as well, exact in Z/2^32; its accumulator
+// is added to both windows' once, at the end.  ~25 VALU instructions per eight weights and two windows: the kernel
 // stays HBM-bound (fc6: 51 MB of codes instead of 205 MB of window tiles).  Image chunks of 32 (batch > 32) are grid.z: a layer stored
 // this way has no int8 tiles any other kernel could run on.
 struct Fc4Lut { unsigned lo, hi; };      // eight table bytes: e = 0..3 | e = 4..7
 
 template <int NCLS>
-__device__ __forceinline__ unsigned fc4_dec(unsigned e, unsigned cm, unsigned s, unsigned m, const Fc4Lut (&t)[2]) {
+__device__ __forceinline__ unsigned fc4_dec(unsigned e, unsigned cm, unsigned m, const Fc4Lut (&t)[2]) {
   unsigned v = __builtin_amdgcn_perm(t[0].hi, t[0].lo, e);
   if constexpr (NCLS == 2) {
     const unsigned v1 = __builtin_amdgcn_perm(t[1].hi, t[1].lo, e);
     v = (v1 & cm) | (v & ~cm);
   }
-  return (v ^ m) + s;
+  return v ^ m;                                           // one's complement for negative weights; the +1 rides in the sign MFMA
 }
 
 // the 16 codes of one K step (two words) -> the 16 window values (four dwords) of window `w`'s MFMA operand
 template <bool DUAL, int NCLS>
-__device__ __forceinline__ void fc4_expand(unsigned w0, unsigned w1, const i32x4& cm, const Fc4Lut (&th)[2], const Fc4Lut (&tl)[2], i32x4& hi, i32x4& lo) {
+__device__ __forceinline__ void fc4_expand(unsigned w0, unsigned w1, const i32x4& cm, const Fc4Lut (&th)[2], const Fc4Lut (&tl)[2], i32x4& hi, i32x4& lo, i32x4& sg) {
   const unsigned wd[2] = {w0, w1};
 #pragma unroll
   for (int j = 0; j < 2; j++) {
@@ -124,11 +128,12 @@ __device__ __forceinline__ void fc4_expand(unsigned w0, unsigned w1, const i32x4
     // 0xff in the bytes of negative weights: v_perm_b32 selectors 0x0c / 0x0d give the constant bytes 0x00 / 0xff (s * 255 would be a
     // quarter-rate 32-bit multiply, and hipcc turns (s << 8) - s back into one)
     const unsigned mL = __builtin_amdgcn_perm(0u, 0u, sL | 0x0c0c0c0cu), mH = __builtin_amdgcn_perm(0u, 0u, sH | 0x0c0c0c0cu);
-    hi[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], sL, mL, th);
-    hi[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], sH, mH, th);
+    sg[2 * j] = (int)sL; sg[2 * j + 1] = (int)sH;          // 1 in the bytes of negative weights: the sign MFMA's operand
+    hi[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], mL, th);
+    hi[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], mH, th);
     if constexpr (DUAL) {
-      lo[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], sL, mL, tl);
-      lo[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], sH, mH, tl);
+      lo[2 * j] = (int)fc4_dec<NCLS>(eL, (unsigned)cm[2 * j], mL, tl);
+      lo[2 * j + 1] = (int)fc4_dec<NCLS>(eH, (unsigned)cm[2 * j + 1], mH, tl);
     }
   }
 }
@@ -162,16 +167,18 @@ __global__ __launch_bounds__(256) void fc4_partial_kernel(FcArgs a) {
     th[0] = {(unsigned)q0[0], (unsigned)q0[1]}; tl[0] = {(unsigned)q0[2], (unsigned)q0[3]};
     th[1] = {(unsigned)q1[0], (unsigned)q1[1]}; tl[1] = {(unsigned)q1[2], (unsigned)q1[3]};
   }
-  i32x16 hi, lo;
+  i32x16 hi, lo, sgn;                                      // sgn: sum over the negative weights' K positions of x (added to both windows at the end)
 #pragma unroll
-  for (int r = 0; r < 16; r++) { hi[r] = 0; lo[r] = 0; }
+  for (int r = 0; r < 16; r++) { hi[r] = 0; lo[r] = 0; sgn[r] = 0; }
   constexpr int GS = 4;                                    // slabs' loads in flight per wave
   auto body = [&](const i32x4& nb, const i32x4& b0, const i32x4& b1, const i32x4& c0, const i32x4& c1) __attribute__((always_inline)) {
-    i32x4 h0, h1, l0, l1;
-    fc4_expand<DUAL, NCLS>((unsigned)nb[0], (unsigned)nb[1], c0, th, tl, h0, l0);
-    fc4_expand<DUAL, NCLS>((unsigned)nb[2], (unsigned)nb[3], c1, th, tl, h1, l1);
+    i32x4 h0, h1, l0, l1, g0, g1;
+    fc4_expand<DUAL, NCLS>((unsigned)nb[0], (unsigned)nb[1], c0, th, tl, h0, l0, g0);
+    fc4_expand<DUAL, NCLS>((unsigned)nb[2], (unsigned)nb[3], c1, th, tl, h1, l1, g1);
     hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h0, b0, hi, 0, 0, 0);
     hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(h1, b1, hi, 0, 0, 0);
+    sgn = __builtin_amdgcn_mfma_i32_32x32x32_i8(g0, b0, sgn, 0, 0, 0);
+    sgn = __builtin_amdgcn_mfma_i32_32x32x32_i8(g1, b1, sgn, 0, 0, 0);
     if constexpr (DUAL) {
       lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l0, b0, lo, 0, 0, 0);
       lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(l1, b1, lo, 0, 0, 0);
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(256) void fc4_partial_kernel(FcArgs a) {
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int row = 8 * (k >> 2) + 4 * half + (k & 3);
-    p0[(size_t)row * 32] = hi[k];
-    if (DUAL) p0[((size_t)a.Np + row) * 32] = lo[k];
+    p0[(size_t)row * 32] = (int)((unsigned)hi[k] + (unsigned)sgn[k]);
+    if (DUAL) p0[((size_t)a.Np + row) * 32] = (int)((unsigned)lo[k] + (unsigned)sgn[k]);
   }
 }
 
