@@ -11,7 +11,7 @@ PL = np.dtype([(n, "<i4") for n in ("kind", "TM", "n_mtiles", "n_phases", "nslab
                                      "max_shift", "n_entries", "n_cchunk", "max_ent", "fast", "dual", "fuse_next", "fused_into", "w_share", "w_main_TM")] +
               [(n, "<u8") for n in ("off_w", "off_w2", "off_entries", "off_dir", "off_kinfo", "off_bias",
                                     "off_alpha", "off_beta", "off_lo", "off_dshift", "off_hdr", "hdr_bytes", "off_dbl", "off_pad", "off_unit",
-                                    "off_lut", "off_cls")] + [(n, "<i4") for n in ("fc4", "n_cls")])
+                                    "off_lut", "off_cls")] + [(n, "<i4") for n in ("fc4", "n_cls", "merge_next", "merged_into")])
 
 
 def parse(blob: np.ndarray):

@@ -567,3 +567,19 @@ def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc)
     plain = Rig(*r50, 0)
     assert not any("conv_bband" in r["kernel"] for r in plain.net.describe_launches(32, int(conc)))
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
+
+
+@pytest.mark.parametrize("merge", ["1", "0"])
+def test_merged_expand_rows(merge, monkeypatch):
+    """PackLayer::merge_next (weight_pack.cpp, round 5): a fire module's expand1x1 and expand3x3 rows -- same input tensor, adjacent
+    slices of one concat tensor (kNStart / kBranchTail, quantization.cpp:42-49) -- run as ONE 3x3 launch whose first rows carry the 1x1
+    filters as centre taps (and, for fire3 / fire5, ONE pool launch).  Every row of a 67 x 67 and a 131 x 131 SqueezeNet 1.1 against the
+    oracle with the rows merged and separate (doubled squeeze outputs, 64- and 128-row tiles, pooled and unpooled pairs)."""
+    set_opts(monkeypatch, merge=merge)
+    for hw, seed, b in ((67, 6, 5), (131, 8, 3)):
+        t = cfg.squeezenet11_tables(image_hw=hw)
+        q = synth.synth_q_values(t, seed, spread=2)
+        rig = Rig(t, q, synth.synth_model(t, q, seed), 0)
+        rows = {r["layer"] for r in rig.net.describe_launches(b, 1)}
+        assert (3 in rows) == (merge == "0") and (6 in rows) == (merge == "0")
+        rig.check_all_layers(synth.synth_images(t, b, seed))

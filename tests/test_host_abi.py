@@ -215,7 +215,13 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert sizes[11] == 64 or 11 in duals                                        # 14 x 14: 32 tiles -- the small grid takes 64-channel blocks
     s = launches(cfg.squeezenet11_tables(), 32)
     assert "im2col" in s[0]["kernel"] and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"
-    assert {r["layer"] for r in s if "conv_c3" in r["kernel"]} == {21, 24}       # its 3x3 layers have 16-64 input channels: the two 64-channel ones on 14 x 14
+    # merged rows (round 5): every fire module's expand1x1 | expand3x3 pair is ONE launch (PackLayer::merge_next) -- 24 launches, not 34,
+    # none on the second row of a pair; merge=0 brings the separate rows back (its 64-channel 3x3 rows on 14 x 14 then take conv_c3)
+    assert len(s) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s}
+    set_opts(monkeypatch, merge="0")
+    s0 = launches(cfg.squeezenet11_tables(), 32)
+    set_opts(monkeypatch, merge=None)
+    assert len(s0) == 34 and {r["layer"] for r in s0 if "conv_c3" in r["kernel"]} == {21, 24}
     assert any("conv_c3" in r["kernel"] for r in launches(cfg.ssd300_tables(), 32))
     set_opts(monkeypatch, c3="0"); set_opts(monkeypatch, im2col0="0")
     v0 = launches(cfg.vgg16_tables(), 32)

@@ -56,13 +56,24 @@ def check_net(t, q, model, images, mode, layers=None):
                 full[:, M.n_start:M.n_start + M.N] = outs[M.index]
             x_t = emu.nhwc(full, _round_up(concat_c[cid], 16))
         res = outs[L.add_src] if L.add_src >= 0 else None
+        if int(pl["merged_into"]) >= 0:
+            continue                                        # computed (and checked) with the row in front of it
+        want = outs[L.index]
+        if int(pl["merge_next"]) > 0:
+            # merged rows (weight_pack.cpp): this 1x1 row and the 3x3 row behind it are ONE packed 3x3 layer of both rows' channels
+            import dataclasses
+            Ln = plan[int(pl["merge_next"])]
+            Lx = dataclasses.replace(Ln, N=L.N + Ln.N)
+            want = np.concatenate([outs[L.index], outs[Ln.index]], axis=1)
         y = emu.conv_from_packed(blob, pl, Lx, x_t, res)
         # finish the layer with the oracle's post-ops and compare with the oracle's layer output
         if L.pool_en:
             y = np.stack([O.maxpool(yi, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW) for yi in y])
         if L.endpool:
             y = np.stack([O.global_avg(yi, L.endpool_mult) for yi in y]).reshape(y.shape[0], L.N, 1, 1)
-        np.testing.assert_array_equal(y, outs[L.index], err_msg=f"layer {L.index} kind {int(pl['kind'])}")
+        if L.endpool and want.ndim == 4 and want.shape[2:] != (1, 1):
+            want = want.reshape(want.shape[0], -1, 1, 1)
+        np.testing.assert_array_equal(y, want, err_msg=f"layer {L.index} kind {int(pl['kind'])}")
     return kinds, pls
 
 

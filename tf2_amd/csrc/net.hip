@@ -161,10 +161,16 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
     }
     layer_out[l] = E.out_tensor;
     E.conv_tensor = E.out_tensor;
-    if (!L.ipool && (L.pool_en || L.endpool)) {
-      // conv (+residual) result before pooling / global average
+    const PackLayer* plm = packed_valid ? pack_layer(l) : nullptr;
+    if (plm && plm->merged_into >= 0) {
+      // computed by the merged launch of the row in front of it: its conv-stage tensor is that row's (channels behind that row's)
+      E.conv_tensor = wp.exec[plm->merged_into].conv_tensor;
+      wp.tensors[E.conv_tensor].last_use = std::max(wp.tensors[E.conv_tensor].last_use, l);
+    } else if (!L.ipool && (L.pool_en || L.endpool)) {
+      // conv (+residual) result before pooling / global average (merged rows: both rows' channels)
       const int th = L.pool_en ? L.OH : L.PH, tw = L.pool_en ? L.OW : L.PW;
-      E.conv_tensor = add_tensor(th, tw, L.N, out_Cp[l]);
+      const int Nx = (plm && plm->merge_next > 0) ? L.N + layers[plm->merge_next].N : L.N;
+      E.conv_tensor = add_tensor(th, tw, Nx, round_up(Nx, 16));
       born.push_back(l);
       wp.tensors[E.conv_tensor].last_use = l;
     }
@@ -341,6 +347,15 @@ bool Net::bgroup_first_at(int l) const {
     if (k == l && pl->off_dbl) return false;            // (the shortcut's output is only ever a residual)
   }
   return n_dual == 0 || n_dual == 3;
+}
+
+// Row l as it is EXECUTED: the table row, or -- merged rows (PackLayer::merge_next, weight_pack.cpp: a 1x1 row and the 3x3 / pad 1 row
+// behind it, same input, adjacent concat slices) -- the 3x3 layer of both rows' output channels
+tf2_layer_desc Net::exec_desc(int l) const {
+  tf2_layer_desc L = layers[l];
+  const PackLayer* pl = pack_layer(l);
+  if (pl && pl->merge_next > 0) { L.N += layers[pl->merge_next].N; L.k = 3; L.pad_h = L.pad_w = 1; }
+  return L;
 }
 
 // The tensor layer l writes holds no negative value (its last operation is a ReLU)
@@ -577,7 +592,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     lp.steps.push_back(st);
   }
   auto pool_step = [&](int l, const TensorPlan& ti, const int8_t* x, int H, int W) {
-    const tf2_layer_desc& L = layers[l];
+    const tf2_layer_desc L = exec_desc(l);
     const LayerExec& E = wp->exec[l];
     Launch st; st.kind = Launch::POOL; st.layer = l;
     PoolArgs& pa = st.pool;
@@ -590,7 +605,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   };
   // argument block + kernel selection of one conv layer
   auto make_conv = [&](int l, Launch& st, bool allow_alt) -> bool {
-    const tf2_layer_desc& L = layers[l];
+    const tf2_layer_desc L = exec_desc(l);
     const LayerExec& E = wp->exec[l];
     const PackLayer* pl = pack_layer(l);
     // the wide-tile alternative (128-row tiles, weight_pack.cpp) where its grid still fills the chip: fewer operand bytes and
@@ -697,8 +712,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   bool stem_pool_fused = false;
   const bool profiling_pairs_off = false;
   for (int l = 0; l < nl; l++) {
-    const tf2_layer_desc& L = layers[l];
+    const tf2_layer_desc L = exec_desc(l);
     const LayerExec& E = wp->exec[l];
+    if (pack_layer(l)->merged_into >= 0) continue;           // computed by the merged launch of the row in front of it
     if (L.ipool == 2) {                  // L2Norm row
       const PackLayer* pl2 = pack_layer(l);
       const TensorPlan& ti = T(E.in_tensor); const TensorPlan& to = T(E.out_tensor);

@@ -21,6 +21,7 @@ const OptSpec kOptSpecs[] = {
   {"fc4", 0, "pack time: conv_fc layers keep their filters as 4-bit codes in HBM (expanded in registers): 1 (default) / 0 int8 window tiles"},
   {"share", 0, "pack time: alternative tile heights share the main entry's weight tiles: 1 (default: the wide ones), 2 all, 0 none"},
   // ---- test-only: forced kernels, disabled proofs, thresholds (need TF2_AMD_TEST=1) ----
+  {"merge", 1, "pack time: 0 = no merged rows (a 1x1 row and the 3x3 row behind it as one 3x3 layer)"},
   {"nodbl", 1, "pack time: no doubled channels"}, {"nofuse", 1, "pack time: no conv_bneck pairs"}, {"nodual", 1, "pack time: two-window layers in the Horner form"},
   {"nofast", 1, "pack time: generic requantisation everywhere"}, {"nosemi", 1, "pack time: no SEMI requantisation"}, {"nounit", 1, "pack time: conv1's low window as a window"},
   {"no4bit", 1, "pack time: shift-kernel layers keep int32 weights"}, {"im2col0", 1, "0: a 3x3 first layer on 3 channels keeps its plain form"},

@@ -11,7 +11,7 @@ namespace tf2 {
 constexpr int kInflat = 15;        // host/inc/types.h:34
 constexpr int kAlphaInflat = 20;   // host/inc/types.h:33
 constexpr uint32_t kPackMagic = 0x32465441u;  // "ATF2"
-constexpr uint32_t kPackVersion = 32;
+constexpr uint32_t kPackVersion = 33;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -71,6 +71,13 @@ struct PackLayer {
   uint64_t off_cls;      // uint8[nslab * 64]: 0xff where K position k belongs to an input channel of class 1 (n_cls == 2), else 0
   int32_t fc4;
   int32_t n_cls;         // 1 or 2 input-channel classes
+  // Merged rows (round 5, weight_pack.cpp): a 1x1 row and the 3x3 / pad 1 row behind it that read the SAME tensor and write ADJACENT
+  // slices of the same concat tensor (SqueezeNet's expand1x1 | expand3x3; kNStart / kBranchTail, quantization.cpp:42-49) are ONE 3x3
+  // layer of N1 + N3 output channels -- a 1x1 filter is a 3x3 filter whose only non-zero tap is the centre, and all-zero weight tiles
+  // are not stored, so the 1x1 rows' m-tiles walk one K slab per input-channel slab, exactly as before.  One launch (and one pool
+  // launch) instead of two.
+  int32_t merge_next;    // > 0: this row's packed layer also computes row merge_next (its output channels behind this row's)
+  int32_t merged_into;   // >= 0 (or -1): this row is computed by that row's launch and has no weights of its own in the image
 };
 
 struct PackHeader {

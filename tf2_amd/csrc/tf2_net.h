@@ -172,6 +172,7 @@ struct Net {
   bool bgroup_first_at(int l) const;       // rows l .. l + 3 = projection shortcut | reduce, 3x3, expand of the 56 x 56 stage (conv_bgroup56f_kernel)
   bool bband_at(int l, int rows) const;
     // rows l, l + 1, l + 2 are an identity bottleneck conv_bband.hip can take with `rows` output rows per block
+  tf2_layer_desc exec_desc(int l) const;   // row l as executed (merged rows: the 3x3 layer of both rows' channels)
   bool out_nonneg(int l) const;            // the tensor layer l writes holds no negative value
   bool res_nonneg_single_clamp(int l) const;     // row l's residual epilogue may take the one-clamp form (requant_epilogue.h RNN)
   bool c3_at(int l) const;      // layer l can run on conv_c3.hip

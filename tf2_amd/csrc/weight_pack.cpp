@@ -190,6 +190,21 @@ tf2_status Net::pack(int mode) {
       if (ok) dbl[p] = f;
     }
   }
+  // ---- merged rows (PackLayer::merge_next): a 1x1 row A and the 3x3 / pad 1 row B right behind it, same input tensor, same geometry,
+  // ReLU and pool, adjacent slices of one concat tensor, A's channels whole 64-row tiles.  B's launch disappears: A's packed layer is
+  // the 3x3 layer [A's filters as centre taps | B's filters].
+  std::vector<int> merge_next(nl, 0), merged_into(nl, -1);
+  if (mode == 0 && opt("merge", 1) != 0)
+    for (int l = 0; l + 1 < nl; l++) {
+      const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1];
+      if (merged_into[l] >= 0 || A.ipool || B.ipool || A.src != B.src || A.src == -1 || src_signed(A.src)) continue;
+      if (A.k != 1 || A.stride != 1 || (A.pad_h | A.pad_w) != 0 || A.dil > 1 || B.k != 3 || B.stride != 1 || B.pad_h != 1 || B.pad_w != 1 || B.dil > 1) continue;
+      if (A.C != B.C || A.H != B.H || A.W != B.W || A.OH != B.OH || A.OW != B.OW || A.relu != B.relu || A.q_in_row != B.q_in_row) continue;
+      if (A.add_src >= 0 || B.add_src >= 0 || A.endpool || B.endpool) continue;
+      if (A.pool_en != B.pool_en || (A.pool_en && (A.pool_S != B.pool_S || A.pool_st != B.pool_st || A.pool_pad != B.pool_pad || A.PH != B.PH || A.PW != B.PW))) continue;
+      if (A.concat < 0 || A.concat != B.concat || B.n_start != A.n_start + A.N || A.N % 64 != 0) continue;
+      merge_next[l] = l + 1; merged_into[l + 1] = l;
+    }
   for (int attempt = 0; attempt < 8; attempt++) {
   decide_fusion();
   packed.clear();
@@ -199,9 +214,33 @@ tf2_status Net::pack(int mode) {
   for (int l = 0; l < nl; l++) zero_bytes = std::max(zero_bytes, (size_t)round_up(in_layout[l].Cp_in + 16, 256));
   if (blob.alloc(zero_bytes) != zero_off) { set_error("tf2_net_pack: internal layout error"); return TF2_ERR_STATE; }
   for (int l = 0; l < nl; l++) {
-    const tf2_layer_desc& L = layers[l];
     PackLayer pl{};
-    pl.fused_into = -1;
+    pl.fused_into = -1; pl.merged_into = -1;
+    if (merged_into[l] >= 0) {                // computed by the row in front of it (merged rows): no weights of its own
+      pl.kind = KIND_MFMA; pl.merged_into = merged_into[l];
+      *(blob.at<PackLayer>(sizeof(PackHeader)) + l) = pl;
+      continue;
+    }
+    // the layer as it is packed and executed: the table row, or (merged rows) the 3x3 layer of both rows' output channels
+    tf2_layer_desc Lx = layers[l];
+    LayerModel merged_model;
+    if (merge_next[l] > 0) {
+      const tf2_layer_desc& B = layers[merge_next[l]];
+      const LayerModel& ma = models[l]; const LayerModel& mb = models[merge_next[l]];
+      const int Na = Lx.N, Nb = B.N, Cc = Lx.C;
+      merged_model.codes.assign((size_t)(Na + Nb) * Cc * 9, 0x40);            // 0x40: the zero weight (model_loader.cpp:101-102)
+      for (int n = 0; n < Na; n++)
+        for (int c = 0; c < Cc; c++) merged_model.codes[((size_t)n * Cc + c) * 9 + 4] = ma.codes[(size_t)n * Cc + c];     // the centre tap
+      std::copy(mb.codes.begin(), mb.codes.end(), merged_model.codes.begin() + (size_t)Na * Cc * 9);
+      for (auto f : {&LayerModel::bias, &LayerModel::alpha, &LayerModel::beta}) {
+        (merged_model.*f) = ma.*f;
+        (merged_model.*f).insert((merged_model.*f).end(), (mb.*f).begin(), (mb.*f).end());
+      }
+      Lx.N = Na + Nb; Lx.k = 3; Lx.pad_h = Lx.pad_w = 1; Lx.model_k = 3;
+      pl.merge_next = merge_next[l];
+    }
+    const tf2_layer_desc& L = Lx;
+    const LayerModel& base_model = merge_next[l] > 0 ? merged_model : models[l];
     if (L.ipool == 2) {
       // L2Norm row: per channel a = 2^-Qx, b = w * 2^Qy (doubles), e = qs - Qx (left shifts of the exact integer sum of
       // squares), qs = max Qx -- the constants of tf2o_l2norm / l2norm_kernel
@@ -246,13 +285,13 @@ tf2_status Net::pack(int mode) {
       const bool narrow = p0.kind == KIND_MFMA && p0.TM == 128 && p0.fused_into < 0 && L.OH * L.OW <= 784;
       if (!(wide || narrow)) break;
       alt_TM = wide ? 128 : 64;
-      pl = PackLayer{}; pl.fused_into = -1;
+      pl = PackLayer{}; pl.fused_into = -1; pl.merged_into = -1; pl.merge_next = merge_next[l];
     }
     // doubled input channels: weights one exponent lower, 64 * sum(w) into the bias (Z/2^32 like the accumulator)
     const std::vector<uint8_t>* in_dbl = (L.src >= 0 && !dbl[L.src].empty()) ? &dbl[L.src] : nullptr;
     LayerModel mm;
     if (in_dbl) {
-      mm = models[l];
+      mm = base_model;
       const int tp = L.k * L.k;
       for (int n = 0; n < L.N; n++)
         for (int c = 0; c < L.C; c++) {
@@ -267,7 +306,7 @@ tf2_status Net::pack(int mode) {
           }
         }
     }
-    const LayerModel& m = in_dbl ? mm : models[l];
+    const LayerModel& m = in_dbl ? mm : base_model;
     const int N = L.N, C = L.C, k = L.k, taps = k * k;
     const InLayout& il = in_layout[l];
     const bool in_signed = src_signed(L.src) != 0;
@@ -836,6 +875,7 @@ tf2_status Net::pack(int mode) {
   packed_valid = true;
   pack_mode = mode;
   packed_dev = nullptr; packed_dev_bytes = 0;
+  launch_plans.clear(); plans.clear();       // tensor lifetimes and launches depend on the image (fused / merged rows)
   return TF2_OK;
 }
 

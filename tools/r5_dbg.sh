@@ -1,14 +1,13 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dbg; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests -m gpu -q -x -k "whole_window or vgg16 or first_3x3 or vgg_small or squeezenet" > $O/t1.log 2>&1; grep -E "passed|failed|FAILED|layer [0-9]+|network input" $O/t1.log | head -30
-cd /tmp && export TMPDIR=/tmp
-for NET in squeezenet vgg16; do
-  rm -rf /tmp/ps_$NET; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_$NET -o ks -- python $R/tools/steps_only.py --net $NET --batch 32 --conc 1 --steps 30 --meta $O/steps_$NET.json > $O/rp_$NET.log 2>&1
-  find /tmp/ps_$NET -name "*kernel_stats.csv" -exec cp {} $O/ks_$NET.csv \;
+timeout 600 python -m pytest tests -m gpu -q -k "merged_expand or squeezenet or googlenet" > $O/t1.log 2>&1; grep -E "passed|failed|FAILED|layer [0-9]+|network input" $O/t1.log | head -30
+for M in 1 0 1 0; do
+  TF2_AMD_TEST=1 TF2_AMD_OPTS="merge=$M" timeout 200 python bench.py --net squeezenet --no-cpu --steps 40 --warmup 5 --extra-batches "" > $O/sq_$M.log 2>&1
   python - <<EOF
-import csv
-rows=list(csv.DictReader(open("$O/ks_$NET.csv")))
-for r in rows[:12]:
-    if "tf2::" in r["Name"]: print("$NET", r["Name"][:90], r["Calls"], round(float(r["AverageNs"])/1e3,2))
+import json
+try:
+    d=json.loads(open("$O/sq_$M.log").read().strip().splitlines()[-1]); r=d["roofline"]
+    print("merge=$M", d["value"], "cold", d["cold_start"]["value"], "one-batch", d["images_per_s_one_batch_at_a_time"], "launches", r["launches_per_step"], "kus", r["kernel_us_per_step"])
+except Exception as e: print("failed", e)
 EOF
 done
