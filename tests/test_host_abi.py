@@ -205,7 +205,10 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert "im2col" in v[0]["kernel"] and v[1]["layer"] == 0 and "conv_pw" in v[1]["kernel"]
     c3 = [r for r in v if "conv_c3" in r["kernel"]]
     assert [r["layer"] for r in c3] == list(range(1, 13))                      # conv1_2 .. conv5_3
-    assert c3[0]["kernel"].startswith("conv_c3_w9_kernel<64 channels x 4x56 pixels") and c3[0]["grid"] == 256  # 7168 tiles walked by one block per CU, weights resident
+    # conv1_2: its 2x2 pool rides in the launch (round 5: tiles of 8 x 32 pixels, a column tile of the MFMA layout = a tile row); 7168 tiles
+    # walked by one block per CU, weights resident
+    assert c3[0]["kernel"].startswith("conv_c3_w9_kernel<64 channels x 8x32 pixels") and "2x2 pool" in c3[0]["kernel"] and c3[0]["grid"] == 256
+    assert {r["layer"] for r in c3 if "2x2 pool" in r["kernel"]} == {1, 3, 6, 9} and [r["layer"] for r in v if "maxpool" in r["kernel"]] == [12]
     assert all(r["grid"] <= 256 for r in c3 if "<128 channels" in r["kernel"])  # 128-channel blocks: at most what the chip holds at once
     assert all(r["block"] == 512 and r["lds_bytes"] <= 8192 for r in c3)
     sizes = {r["layer"]: int(r["kernel"].split("<")[1].split(" ")[0]) for r in c3}

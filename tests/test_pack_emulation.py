@@ -223,6 +223,7 @@ def test_fc_layers_as_4bit_codes():
     expansion (tests/emu_packed.py fc4_tiles = conv_fc.hip fc4_expand) reproduces the oracle layer by layer.  A 64 x 64 VGG16: fc6 is a
     2 x 2 window over 512 channels (32 K slabs, two-window, two classes with spread-1 Q values), fc7 reads fc6's DOUBLED channels (one
     class).  The image holds no int8 tiles for those rows: its size drops accordingly; fc4=0 keeps the window tiles (same results)."""
+    os.environ["TF2_AMD_TEST"] = "1"; os.environ["TF2_AMD_OPTS"] = "fc_min=8"       # (the 64 x 64 network's fc6 has 32 K slabs; default: from 64 on)
     t = cfg.vgg16_tables(64, 40)
     q = synth.synth_q_values(t, 4, spread=1)
     model = synth.synth_model(t, q, 4)
@@ -233,7 +234,7 @@ def test_fc_layers_as_4bit_codes():
     net = network.NetWork(t)
     net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
     size4 = net.packed_host().size
-    os.environ["TF2_AMD_OPTS"] = "fc4=0"
+    os.environ["TF2_AMD_OPTS"] = "fc4=0,fc_min=8"
     try:
         net8 = network.NetWork(t)
         net8.Quantization(synth.q_text(q)); net8.LoadModel(model); net8.Pack(0)
@@ -241,7 +242,7 @@ def test_fc_layers_as_4bit_codes():
         _, pls8 = emu.parse(net8.packed_host())
         assert int(pls8[13]["fc4"]) == 0
     finally:
-        del os.environ["TF2_AMD_OPTS"]
+        os.environ["TF2_AMD_OPTS"] = "fc_min=8"
     # fc6: 2 windows x 4096 x 2048 int8 -> 4096 x 2048 / 2; fc7: 4096 x 4096 -> / 2
     saved = 2 * 4096 * 2048 - 4096 * 2048 // 2 + 4096 * 4096 - 4096 * 4096 // 2
     assert abs((size8 - size4) - saved) < 0.02 * saved, (size8, size4, saved)
@@ -251,4 +252,5 @@ def test_fc_layers_as_4bit_codes():
     net3.Quantization(synth.q_text(q3)); net3.LoadModel(synth.synth_model(t, q3, 4)); net3.Pack(0)
     _, pls3 = emu.parse(net3.packed_host())
     check_net(t, q3, synth.synth_model(t, q3, 4), x, 0, layers={13, 14})
-    print("fc4 with spread 2:", int(pls3[13]["fc4"]), int(pls3[14]["fc4"]))
+    assert int(pls3[13]["fc4"]) == 0
+    del os.environ["TF2_AMD_OPTS"]; del os.environ["TF2_AMD_TEST"]

@@ -55,6 +55,42 @@ TF2_DMA_CHECK_COUNTERS(g_c3_dma_check);
 void conv_c3_check_counts(unsigned long long out[2]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c3_dma_check), 16); }
 #endif
 
+// ---- the layer's 2x2 / stride 2 / pad 0 max pool inside the launch (round 5; pool.cl:152-260 + pool_tail.cl:91-216 in the reference) --
+// Tiles of pooled layers are TH x 32 pixels (host: conv_c3_pick_tile_pool), so that a 32-pixel column tile of the MFMA layout IS one
+// tile row: a wave owns CONSECUTIVE tile rows (2 j, 2 j + 1 meet in its registers), the window's other column is the neighbouring lane
+// (one DPP quad permute).  After ReLU every byte is 0..127: the byte-wise maximum is two v_pk_max_u16 on the even / odd bytes, and a
+// tap outside the map (ceil-mode pools: SSD300's pool3) counts as 0 = the identity (pool.cl:119-140, the S < 3 window slots).  The
+// conv map is neither written nor read back (VGG16 at batch 32: 196 MB written + 245 MB through maxpool_kernel, five launches).
+struct C3Split { unsigned e[4], o[4]; };                  // a 16-byte vector's even / odd bytes as 16-bit lanes
+__device__ __forceinline__ C3Split c3_split(const i32x4& v, bool keep) {
+  C3Split r;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const unsigned x = keep ? (unsigned)v[q] : 0u;
+    r.e[q] = x & 0x00ff00ffu; r.o[q] = (x >> 8) & 0x00ff00ffu;
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned c3_pkmax(unsigned a, unsigned b) {
+  using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// rows tr / tr + 1 of one pixel column (this lane's tc) -> the 2x2 window maximum of the lane pair (tc, tc ^ 1), valid in both lanes
+__device__ __forceinline__ i32x4 c3_pool2x2(const i32x4& top, const i32x4& bot, bool bot_ok, bool self_ok, bool right_ok) {
+  const C3Split a = c3_split(top, self_ok), b = c3_split(bot, self_ok && bot_ok);
+  i32x4 out;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const unsigned ve = c3_pkmax(a.e[q], b.e[q]), vo = c3_pkmax(a.o[q], b.o[q]);
+    // the neighbouring lane's column maxima (quad_perm [1, 0, 3, 2]); a lane whose own column lies beyond the map contributed zeros
+    unsigned ne = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ve, 0xb1, 0xf, 0xf, false);
+    unsigned no = (unsigned)__builtin_amdgcn_update_dpp(0, (int)vo, 0xb1, 0xf, 0xf, false);
+    if (!right_ok) { ne = 0; no = 0; }
+    out[q] = (int)(c3_pkmax(ve, ne) | (c3_pkmax(vo, no) << 8));
+  }
+  return out;
+}
+
 constexpr int kC3HaloPx = 384;               // halo pixels of a tile, padded to whole 64-pixel DMA groups (host: c3_pick_tile)
 constexpr int kC3PlaneB = kC3HaloPx * 16;    // bytes of one 16-byte plane of a slab
 constexpr int kC3SlabB = 4 * kC3PlaneB;      // bytes of one 64-channel slab of the halo tile
@@ -66,7 +102,7 @@ constexpr int kC3SlabB = 4 * kC3PlaneB;      // bytes of one 64-channel slab of 
 // MT: row tiles per wave (TMK = 256: two -- a B fragment then feeds two MFMAs, half the LDS reads per MFMA; one-window layers only,
 // the accumulators of 2 x 4 tiles are 128 registers)
 // PERSIST: a block walks several pixel tiles (the host caps the grid); else one tile per block
-template <int TMK, int SC, bool DUAL, int PF, bool PERSIST>
+template <int TMK, int SC, bool DUAL, int PF, bool PERSIST, bool POOL = false>
 __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_kernel(C3Args a) {
   constexpr int MT = TMK == 256 ? 2 : 1;
   static_assert(MT == 1 || !DUAL, "two row tiles per wave: one accumulator set only");
@@ -194,7 +230,7 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
   int n_j = 0;                                             // column tiles of this wave that hold pixels of the tile
 #pragma unroll
   for (int j = 0; j < J; j++) {
-    const int pt = (wn + j * WN) * 32;
+    const int pt = (POOL ? wn * J + j : wn + j * WN) * 32;   // (POOL: consecutive column tiles = consecutive tile rows per wave)
     if (pt < TH * TW) n_j = j + 1;
     int p = pt + (lane & 31);
     if (p >= TH * TW) p = 0;                               // lanes beyond the tile compute on pixel 0 and are never stored
@@ -331,12 +367,27 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
 #pragma unroll
         for (int r = 0; r < 16; r++) a16s[j][r] = acc[i][j][r];
       requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+      if constexpr (POOL) {
+        // TW == 32: column tile (wn * J + j) is tile row tr = wn * J + j, lane & 31 the column; tile rows come in pairs (TH, r0 even)
+        const int tc = lane & 31;
+        const long long pimg = (long long)fast_div(unit, a.tpi_m, a.tpi_s) * a.PH * a.PW;      // pooled pixels in front of this image
+#pragma unroll
+        for (int jj = 0; jj < (NJ + 1) / 2; jj++) {
+          const int tr = wn * J + 2 * jj;
+          constexpr int kNJ = NJ;
+          const int jb = 2 * jj + 1 < kNJ ? 2 * jj + 1 : 2 * jj;
+          const i32x4 pv = c3_pool2x2(outs[2 * jj], outs[jb], 2 * jj + 1 < kNJ && tr + 1 < rows, tr < rows && tc < cols, tc + 1 < cols);
+          if ((tc & 1) == 0 && tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
+            *reinterpret_cast<i32x4*>(a.y + (size_t)(pimg + (long long)((r0 + tr) >> 1) * a.PW + ((c0 + tc) >> 1)) * a.y_cp + a.y_off + chl) = pv;
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         const int p = (wn + j * WN) * 32 + (lane & 31);
         const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
         if (tr < rows && tc < cols && chl + 16 <= a.y_nvalid)
           *reinterpret_cast<i32x4*>(a.y + (size_t)(img_px + (long long)(r0 + tr) * W + c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+      }
       }
     }
   };
@@ -354,6 +405,7 @@ __global__ __launch_bounds__(512, (TMK == 64 && !PERSIST) ? 4 : 2) void conv_c3_
 // retires in order).  Here the nine weight fragments (72 registers) are loaded ONCE per block, the K loop holds no load at all, and
 // the input runs THREE tiles ahead through four 24 KiB slab buffers: the only counted wait is on the DMAs themselves (a tile's output
 // stores, younger, only make it stricter).  One block per CU walks every 256th tile.
+template <bool POOL>
 __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
   constexpr int WM = 2, WN = 4, J = 2, NB = 4, NG = kC3HaloPx / 64;
   __shared__ __attribute__((aligned(1024))) int8_t ring[NB * kC3SlabB];
@@ -431,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
   int n_j = 0;
 #pragma unroll
   for (int j = 0; j < J; j++) {
-    const int pt = (wn + j * WN) * 32;
+    const int pt = (POOL ? wn * J + j : wn + j * WN) * 32;  // (POOL: a wave's two column tiles are two consecutive tile rows)
     if (pt < TH * TW) n_j = j + 1;
     int p = pt + (lane & 31);
     if (p >= TH * TW) p = 0;
@@ -494,12 +546,21 @@ __global__ __launch_bounds__(512, 2) void conv_c3_w9_kernel(C3Args a) {
 #pragma unroll
           for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
         requant_tiles16_rows<NJ, FAST>([&](int j) -> const int (&)[16] { return a16s[j]; }, outs, prm, 1 << tms, row0, lo_b, a.dbl != 0, a.fast == 2);
+        if constexpr (POOL) {
+          const int tc = lane & 31, tr = wn * J;
+          const long long pimg = (long long)fast_div(unit, a.tpi_m, a.tpi_s) * a.PH * a.PW;
+          constexpr int kNJ = NJ;
+          const i32x4 pv = c3_pool2x2(outs[0], outs[kNJ > 1 ? 1 : 0], kNJ > 1 && tr + 1 < T.rows, tr < T.rows && tc < T.cols, tc + 1 < T.cols);
+          if ((tc & 1) == 0 && tr < T.rows && tc < T.cols && chl + 16 <= a.y_nvalid)
+            *reinterpret_cast<i32x4*>(a.y + (size_t)(pimg + (long long)((T.r0 + tr) >> 1) * a.PW + ((T.c0 + tc) >> 1)) * a.y_cp + a.y_off + chl) = pv;
+        } else {
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
           const int p = (wn + j * WN) * 32 + (lane & 31);
           const int tr = fast_div(p, a.tw_m, a.tw_s), tc = p - tr * TW;
           if (tr < T.rows && tc < T.cols && chl + 16 <= a.y_nvalid)
             *reinterpret_cast<i32x4*>(a.y + (size_t)(T.img_px + (long long)(T.r0 + tr) * W + T.c0 + tc) * a.y_cp + a.y_off + chl) = outs[j];
+        }
         }
       };
       if (a.fast == 1) finish(std::true_type{}); else finish(std::false_type{});
@@ -522,6 +583,16 @@ bool conv_c3_pick_tile(int H, int W, int* TH, int* TW) {
   th = (H + ny - 1) / ny;
   *TH = th; *TW = tw;
   return true;
+}
+
+// tiles of a layer whose 2x2 / 2 pool rides in the launch: 32 columns (one column tile of the MFMA layout = one tile row), 8 rows;
+// taken where the 32-column tiling wastes at most 15 % of the pixels (28, 56, 112, 150, 224, 300 wide maps; not 38 or 75)
+bool conv_c3_pick_tile_pool(int H, int W, int* TH, int* TW) {
+  if (H < 2 || W < 28) return false;
+  const int nx = (W + 31) / 32;
+  if ((long)nx * 32 * 100 > (long)W * 115) return false;
+  *TW = 32; *TH = H < 8 ? (H + 1) / 2 * 2 : 8;
+  return (*TH + 2) * (*TW + 2) <= kC3HaloPx;
 }
 
 bool conv_c3_shape_ok(int H, int W, int C, int Np) {
@@ -553,9 +624,10 @@ static int launch_c3p(const C3Args& a, hipStream_t s) {
   const int tms = a.tm == 128 ? 7 : 6;
   const size_t dyn = (size_t)(TMK > a.tm ? TMK / a.tm : 1) * ((DUAL ? 28 : 20) << tms);
   if (stat + dyn > 160 * 1024) return 1;
-  auto fn = conv_c3_kernel<TMK, SC, DUAL, PF, PERSIST>;
+  auto fn = a.pool ? conv_c3_kernel<TMK, SC, DUAL, PF, PERSIST, true> : conv_c3_kernel<TMK, SC, DUAL, PF, PERSIST, false>;
+  if (a.pool && (a.TW != 32 || (a.TH & 1))) return 1;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
-  TF2_LAUNCH_NAME("conv_c3_kernel<%d channels x %dx%d pixels per block,C%d,%d slabs per chunk%s>", TMK, a.TH, a.TW, a.C, SC, DUAL ? ",dual" : "");
+  TF2_LAUNCH_NAME("conv_c3_kernel<%d channels x %dx%d pixels per block,C%d,%d slabs per chunk%s%s>", TMK, a.TH, a.TW, a.C, SC, DUAL ? ",dual" : "", a.pool ? ",2x2 pool" : "");
   // as many blocks per channel group as the chip holds at once (TMK = 64: two per CU), each walking every grid-th tile
   const int n_units = a.B * a.tiles_per_img, groups = a.M / TMK;
   const int resident = ((TMK == 64 && !PERSIST) ? 2 : 1) * tf2_cu_count();
@@ -585,12 +657,13 @@ static int launch_c3_w9(const C3Args& a, hipStream_t s) {
   const int tms = a.tm == 128 ? 7 : 6;
   const size_t dyn = (size_t)(20 << tms);
   if (stat + dyn > 160 * 1024) return 1;
-  auto fn = conv_c3_w9_kernel;
+  auto fn = a.pool ? conv_c3_w9_kernel<true> : conv_c3_w9_kernel<false>;
+  if (a.pool && (a.TW != 32 || (a.TH & 1))) return 1;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024 - (int)stat)) return -1;
   const int n_units = a.B * a.tiles_per_img, groups = a.M / 64;
   int gx = std::max(1, tf2_cu_count() / groups);
   if (gx > n_units) gx = n_units;
-  TF2_LAUNCH_NAME("conv_c3_w9_kernel<64 channels x %dx%d pixels per tile,C64,weights resident>", a.TH, a.TW);
+  TF2_LAUNCH_NAME("conv_c3_w9_kernel<64 channels x %dx%d pixels per tile,C64,weights resident%s>", a.TH, a.TW, a.pool ? ",2x2 pool" : "");
   TF2_LAUNCH(fn, dim3(gx, groups), dim3(512), dyn, s, a);
   return launch_ok() ? 0 : -1;
 }

@@ -491,6 +491,7 @@ void Net::load_options() {
   o.c3_min_blocks = (long)opt("c3_min", o.c3_min_blocks);
   o.c3_min256 = (long)opt("c3_min256", o.c3_min256);
   o.c3_w9 = (int)opt("c3_w9", o.c3_w9);
+  o.c3_pool = (int)opt("c3_pool", o.c3_pool);
   o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
   o.stem_mode = (int)opt("stem", o.stem_mode);
   o.bgroup_min7 = (int)opt("bgroup_min7", o.bgroup_min7);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -873,9 +874,14 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       }
     }
     if (pack_layer(l)->fc4 && st.sel != Launch::SEL_FC) return fail("layer " + std::to_string(l) + " is packed as 4-bit codes (fc4) but conv_fc cannot take it");
+    bool c3_pool_fused = false;
     if (!fuse_now && st.sel != Launch::SEL_FC && opts.c3_mode && c3_at(l)) {
       int th = 0, tw = 0;
       conv_c3_pick_tile(L.H, L.W, &th, &tw);
+      // the layer's 2x2 / stride 2 / pad 0 max pool inside the launch (conv_c3.hip POOL: tiles of TH x 32 pixels): ReLU layers whose
+      // map the 32-column tiling fits; the conv map is then neither written nor read back, and the pool launch is gone
+      const bool pool_in = opts.c3_pool && L.pool_en && L.relu && L.pool_S == 2 && L.pool_st == 2 && L.pool_pad == 0 && E.conv_tensor != E.out_tensor &&
+                           L.PH == (L.OH + 1) / 2 && L.PW == (L.OW + 1) / 2 && conv_c3_pick_tile_pool(L.H, L.W, &th, &tw);
       const int tiles_x = (L.W + tw - 1) / tw, tiles = tiles_x * ((L.H + th - 1) / th);
       // 128 output channels per block (two waves per SIMD, the accumulators of four column tiles per wave) unless the layer has
       // 64-row tiles only, or is a one-window layer whose 128-channel grid would leave half the chip idle (VGG16's 14 x 14 maps at
@@ -899,6 +905,11 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         set_fast_div((uint32_t)tiles_x, &f.tx_m, &f.tx_s); set_fast_div((uint32_t)tiles, &f.tpi_m, &f.tpi_s);
         f.relu = c.g.relu; f.fast = c.g.fast; f.dbl = c.g.dbl_out; f.dual = c.dual;
         f.y_cp = c.g.y_cp; f.y_off = c.g.y_off; f.y_nvalid = c.g.y_nvalid;
+        if (pool_in) {
+          const TensorPlan& to = T(E.out_tensor);
+          f.pool = 1; f.PH = L.PH; f.PW = L.PW; f.y = base + to.offset; f.y_cp = to.Cp; f.y_off = E.out_off;
+          c3_pool_fused = true;
+        }
         f.w9 = conv_c3_takes_w9(f, opts.c3_w9) ? 1 : 0;
         sc.sel = Launch::SEL_C3;
         st = sc;
@@ -988,7 +999,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
-    if (L.pool_en && !(l == 0 && stem_pool_fused)) {
+    if (L.pool_en && !(l == 0 && stem_pool_fused) && !(c3_pool_fused && st.sel == Launch::SEL_C3)) {
       pool_step(l, tc, base + tc.offset, L.OH, L.OW);
     } else if (L.endpool && !st.avg_fused) {
       Launch sa; sa.kind = Launch::AVG; sa.layer = l;

@@ -196,10 +196,13 @@ struct C3Args {
   uint32_t tw_m, hc_m, tx_m, tpi_m; int32_t tw_s, hc_s, tx_s, tpi_s;     // set_fast_div(TW), (TW + 2), (tiles_x), (tiles_per_img)
   int32_t relu, fast, dbl, dual;
   int32_t y_cp, y_off, y_nvalid;
+  int32_t pool, PH, PW;        // pool != 0: the layer's 2x2 / stride 2 / pad 0 max pool rides in the launch -- y / y_cp / y_off then describe the
+                               // POOLED tensor [B][PH][PW][y_cp], tiles are TH (even) x 32 pixels (conv_c3_pick_tile_pool)
   int32_t w9;                  // the one-slab kernel (conv_c3_w9_kernel) takes the launch: decided in the launch PLAN (conv_c3_takes_w9)
 };
 bool conv_c3_takes_w9(const C3Args& a, int mode);      // mode = RunOpts::c3_w9: 0 never, 1 where a block walks at least eight tiles, 2 wherever allowed
 bool conv_c3_pick_tile(int H, int W, int* TH, int* TW);
+bool conv_c3_pick_tile_pool(int H, int W, int* TH, int* TW);
 bool conv_c3_shape_ok(int H, int W, int C, int Np);
 int launch_conv_c3(const C3Args& a, void* stream);
 #ifdef TF2_CHECK_DMA

@@ -88,6 +88,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 200;
+  int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
   int c3_mode = 1;           // c3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
