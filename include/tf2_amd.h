@@ -129,7 +129,7 @@ size_t tf2_net_workspace_size(tf2_net* net, int batch, int keep_all);
 /* Bytes of the dense int8 output of a run: [batch][H_last * W_last][N_last] (NHWC; H_last = W_last = 1 for the
  * classification networks, i.e. [batch][N_last] -- the buffer Runner::Run reads back, runner.cpp:176-186).      */
 size_t tf2_net_logits_size(const tf2_net* net, int batch);
-/* Options: ONE environment string, TF2_AMD_OPTS="name=value,name=value,flag" (INTEGRATION.md section 4 lists the product options:
+/* Options: ONE environment string, TF2_AMD_OPTS="name=value,name=value,flag" (INTEGRATION.md section 5 lists the product options:
  * alt_conc, bgroup, bband, c3, fc, fc4, share), parsed into an immutable snapshot at tf2_net_create and here -- nothing else in the
  * library reads the environment.  Unknown names, and test-only options (forced kernels, disabled proofs, thresholds: the test-suite's
  * and the A/B tools') without TF2_AMD_TEST=1, make both calls return TF2_ERR_ARG.  The snapshot is process-wide: packing (pack-time

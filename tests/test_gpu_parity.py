@@ -583,3 +583,22 @@ def test_merged_expand_rows(merge, monkeypatch):
         rows = {r["layer"] for r in rig.net.describe_launches(b, 1)}
         assert (3 in rows) == (merge == "0") and (6 in rows) == (merge == "0")
         rig.check_all_layers(synth.synth_images(t, b, seed))
+
+
+@pytest.mark.parametrize("first", ["1", "0"])
+def test_first_layer_with_its_input_preparation_in_one_launch(first, monkeypatch):
+    """conv_first_kernel (round 5): a 3x3 / stride 1 first layer on the 3-channel image -- quantisation, the im2col tile (kept in LDS) and
+    the pointwise MFMA layer over it in ONE launch -- against the oracle: the quantised image read back (-128 pixels included), row 0 and
+    everything behind it; float and int8 inputs, one- and two-window first layers (spread 1 / 2), ragged widths (40, 72: several rows per
+    block; 176: one row), batch 1 and 5; first=0: the two separate launches."""
+    set_opts(monkeypatch, first=first)
+    for hw, seed, spread, kind, b in ((40, 3, 1, "int8", 5), (72, 4, 2, "float", 2), (176, 5, 2, "float", 1)):
+        t = cfg.vgg16_tables(hw, 10) if hw >= 64 else cfg.vgg16_tables(hw, 10, with_fc=False)
+        q = synth.synth_q_values(t, seed, spread=spread)
+        rig = Rig(t, q, synth.synth_model(t, q, seed), 0)
+        k0 = rig.net.describe_launches(b, 1)[0]
+        assert ("conv_first_kernel" in k0["kernel"] and k0["layer"] == 0) == (first == "1"), k0
+        x = synth.synth_images(t, b, seed, kind=kind)
+        if kind == "int8":
+            x[0, :, :3, :] = -128
+        rig.check_all_layers(x, layers={0, 1, 2})

@@ -202,7 +202,8 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
         net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, seed)); net.Pack(0)
         return net.describe_launches(batch, 0)
     v = launches(cfg.vgg16_tables(), 32)
-    assert "im2col" in v[0]["kernel"] and v[1]["layer"] == 0 and "conv_pw" in v[1]["kernel"]
+    # round 5: input preparation + conv1_1 in ONE launch (conv_first_kernel: the im2col tile stays in LDS), attributed to table row 0
+    assert "conv_first_kernel<im2col" in v[0]["kernel"] and v[0]["layer"] == 0 and v[1]["layer"] == 1
     c3 = [r for r in v if "conv_c3" in r["kernel"]]
     assert [r["layer"] for r in c3] == list(range(1, 13))                      # conv1_2 .. conv5_3
     # conv1_2: its 2x2 pool rides in the launch (round 5: tiles of 8 x 32 pixels, a column tile of the MFMA layout = a tile row); 7168 tiles
@@ -217,7 +218,7 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert all(sizes[l] in (64, 256) for l in sizes if l >= 5 and l not in duals)      # one-window layers of 256+ channels: 256 per block where the grid allows
     assert sizes[11] == 64 or 11 in duals                                        # 14 x 14: 32 tiles -- the small grid takes 64-channel blocks
     s = launches(cfg.squeezenet11_tables(), 32)
-    assert "im2col" in s[0]["kernel"] and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"
+    assert "im2col" in s[0]["kernel"] and s[0]["layer"] == -1 and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"      # (stride 2: its own input kernel)
     # merged rows (round 5): every fire module's expand1x1 | expand3x3 pair is ONE launch (PackLayer::merge_next) -- 24 launches, not 34,
     # none on the second row of a pair; merge=0 brings the separate rows back (its 64-channel 3x3 rows on 14 x 14 then take conv_c3)
     assert len(s) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s}

@@ -9,10 +9,12 @@
 #include <cstdlib>
 #include "tf2_internal.h"
 #include "tf2_device.h"
+#include "requant_epilogue.h"
 
 namespace tf2 {
 
 using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x16 = int __attribute__((ext_vector_type(16)));
 
 // runner.cpp:158-163: tmp = x * trans ; (int)(tmp > 0 ? tmp + 0.5 : tmp - 0.5) ; clamp, with tmp +- 0.5 evaluated in
 // double and truncated toward zero.  Restated without double precision (the DP conversions run at a fraction of the
@@ -342,6 +344,158 @@ __global__ __launch_bounds__(256) void prep_im2col_rows_kernel(PrepArgs a, int R
     }
     __syncthreads();
   }
+}
+
+// ---- conv_first_kernel: a 3x3 / stride 1 first layer on the 3-channel image in ONE launch (round 5) ---------------------------------
+// prep_im2col_rows_kernel writes the im2col image (64 bytes per output pixel: VGG16 103 MB at batch 32) and conv_pw reads it back: 69 of
+// VGG16's 735 us per step, 120 of SSD300's 1645.  Here the im2col tile of a block's output rows never leaves the CU: the image rows are
+// quantised once into LDS (as in prep_im2col_rows_kernel), every thread assembles its pixels' 64 bytes [x(27) | 0 | xneg(27) | 0] into an
+// LDS tile of 80-byte pixels (16-byte aligned, conflict-free for the 16 lanes a ds_read_b128 services together), and the eight waves
+// -- two 32-channel row groups x four pixel streams, the layer's one weight slab in registers like conv_pw -- run
+// v_mfma_i32_32x32x32_i8 over it, requantise (requant_epilogue.h) and store the layer's NHWC output.  Same sums, term for term
+// (pe.cl:27-43, the -128 quirk through the xneg half); with `keep` (per-layer parity runs) the im2col tensor is written as well, so that
+// tf2_net_read_layer(-1) still hands back the quantised image.
+template <bool SRC_Q, bool DUAL>
+__global__ __launch_bounds__(512) void conv_first_kernel(FirstArgs f) {
+  const PrepArgs& a = f.p;
+  prep_zero_ctrl(a);
+  extern __shared__ __attribute__((aligned(16))) int8_t im_lds[];
+  const int R = f.R, WS = f.WS, TR = R + 2;
+  int8_t* const img = im_lds;                               // [3][TR][WS]
+  int8_t* const col = im_lds + ((3 * TR * WS + 15) & ~15);  // [R * OW pixels][80]
+  const int n_px_max = R * a.OW;
+  int* const prm = reinterpret_cast<int*>(col + (((size_t)n_px_max * 80 + 15) & ~(size_t)15));
+  const int rows_per_img = (a.OH + R - 1) / R;
+  const int b = blockIdx.x / rows_per_img;
+  const int oh0 = (blockIdx.x - b * rows_per_img) * R;
+  const int r_first = oh0 - a.im_pad_h;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  for (int i = tid; i < 3 * TR * WS / 4; i += 512) reinterpret_cast<int*>(img)[i] = 0;
+  for (int i = tid; i < (f.hdr_used >> 4); i += 512) reinterpret_cast<i32x4*>(prm)[i] = reinterpret_cast<const i32x4*>(f.hdr)[i];
+  // this wave's weights: the layer's one K slab, [window][64 rows][64 bytes]
+  const int wr = wave & 1, wp = wave >> 1;
+  i32x4 wf[DUAL ? 2 : 1][2];
+  {
+    const int row = wr * 32 + (lane & 31);
+#pragma unroll
+    for (int h = 0; h < (DUAL ? 2 : 1); h++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) wf[h][ks] = *reinterpret_cast<const i32x4*>(f.w + ((size_t)h * 64 + row) * 64 + (ks * 2 + half) * 16);
+  }
+  __syncthreads();
+  {
+    const int w4 = a.W >> 2;                                // W % 4 == 0 (launcher-checked)
+    for (int i = tid; i < 3 * TR * w4; i += 512) {
+      const int line = i / w4, x4 = i - line * w4;
+      const int ci = line / TR, rr = line - ci * TR;
+      const int sr = r_first + rr;
+      if ((unsigned)sr >= (unsigned)a.H) continue;
+      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x4 * 4;
+      int q[4];
+      if (SRC_Q) {
+        const int v = *reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = (int)(signed char)((v >> (8 * j)) & 0xff);
+      } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.img) + si);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = quant_input(v[j], trans);
+      }
+      *reinterpret_cast<unsigned*>(&img[(ci * TR + rr) * WS + kImPadL + x4 * 4]) =
+          (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+    }
+  }
+  __syncthreads();
+  const int rows = (a.OH - oh0) < R ? (a.OH - oh0) : R;
+  const int n_px = rows * a.OW;
+  const size_t px_base = ((size_t)b * a.OH + oh0) * a.OW;
+  for (int p = tid; p < n_px; p += 512) {
+    const int rsel = p / a.OW, ow = p - rsel * a.OW;
+    const int8_t* base = img + rsel * WS + kImPadL + ow - a.im_pad_w;
+    unsigned wx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int q = (int)base[(ci * TR + k / 3) * WS + k % 3];
+        const int c = ci * 9 + k;
+        wx[c >> 2] |= (unsigned)(q & 0xff) << (8 * (c & 3));
+        wn[c >> 2] |= (unsigned)((-q) & 0xff) << (8 * (c & 3));          // (int8)(-x): -128 stays -128 (pe.cl:32-37)
+      }
+    i32x4* d = reinterpret_cast<i32x4*>(col + (size_t)p * 80);
+    d[0] = i32x4{(int)wx[0], (int)wx[1], (int)wx[2], (int)wx[3]}; d[1] = i32x4{(int)wx[4], (int)wx[5], (int)wx[6], (int)wx[7]};
+    d[2] = i32x4{(int)wn[0], (int)wn[1], (int)wn[2], (int)wn[3]}; d[3] = i32x4{(int)wn[4], (int)wn[5], (int)wn[6], (int)wn[7]};
+    if (f.keep) {
+      i32x4* g = reinterpret_cast<i32x4*>(f.im + (px_base + p) * 64);
+      g[0] = d[0]; g[1] = d[1]; g[2] = d[2]; g[3] = d[3];
+    }
+  }
+  __syncthreads();
+  const int lo_bound = f.relu ? 0 : -128;
+  const int chl = wr * 32 + 16 * half;
+  const rq_i32x4 nores = {0, 0, 0, 0};
+  for (int t = wp; t * 32 < n_px; t += 4) {
+    const int p_raw = t * 32 + (lane & 31);
+    const int p = p_raw < n_px ? p_raw : n_px - 1;
+    const i32x4 b0 = *reinterpret_cast<const i32x4*>(col + (size_t)p * 80 + half * 16);
+    const i32x4 b1 = *reinterpret_cast<const i32x4*>(col + (size_t)p * 80 + half * 16 + 32);
+    i32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0; acc2[r] = 0; }
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][0], b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][1], b1, acc, 0, 0, 0);
+    int a16[16];
+    if constexpr (DUAL) {
+      acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][0], b0, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][1], b1, acc2, 0, 0, 0);
+      const int* dsh = prm + kPrmWordsPerRow * 64 + 64 + wr * 32 + 4 * half;       // dshift[1] behind rows | lo | dshift[0]
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++) a16[G * 4 + r] = (int)(((unsigned)acc[G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[G * 4 + r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[r];
+    }
+    i32x4 out;
+    if (f.fast == 1) out = requant_tile16<false, 0, true>(a16, prm, 64, wr * 32 + 4 * half, lo_bound, -128, nores, f.dbl != 0, false);
+    else out = requant_tile16<false, 0, false>(a16, prm, 64, wr * 32 + 4 * half, lo_bound, -128, nores, f.dbl != 0, f.fast == 2);
+    if (p_raw < n_px && chl + 16 <= f.y_nvalid)
+      *reinterpret_cast<i32x4*>(f.y + (px_base + p_raw) * f.y_cp + f.y_off + chl) = out;
+  }
+}
+
+// the fused first layer fits?  (stride 1, 16-byte image rows, one weight slab of <= 64 rows, up to 320 pixels per block)
+bool conv_first_fits(const PrepArgs& a, int* R_out, int* WS_out, size_t* lds_out, int hdr_used) {
+  if (a.rewrite != 2 || a.C != 3 || a.half != 32 || a.y_cp != 64 || a.im_stride != 1 || (a.W & 3) || a.im_pad_w > kImPadL || a.im_pad_h > 4) return false;
+  if (a.OW < 8 || a.OW > 320) return false;
+  const int R = a.OW > 160 ? 1 : (320 / a.OW < a.OH ? 320 / a.OW : a.OH);
+  const int span = a.OW - 1 - a.im_pad_w + 3;
+  const int WS = (kImPadL + (a.W > span ? a.W : span) + 4 + 3) & ~3;
+  const size_t lds = (size_t)((3 * (R + 2) * WS + 15) & ~15) + (((size_t)R * a.OW * 80 + 15) & ~(size_t)15) + (size_t)hdr_used;
+  if (lds > 64 * 1024) return false;
+  *R_out = R; *WS_out = WS; *lds_out = lds;
+  return true;
+}
+
+int launch_conv_first(const FirstArgs& f0, void* stream) {
+  FirstArgs f = f0;
+  int R, WS; size_t lds;
+  if (!conv_first_fits(f.p, &R, &WS, &lds, f.hdr_used)) return 1;
+  f.R = R; f.WS = WS;
+  const PrepArgs& a = f.p;
+  if ((long long)a.B * a.OH * a.OW * 64 >= (1ll << 31) || (long long)a.B * 3 * a.H * a.W >= (1ll << 31)) return 1;
+  const unsigned grid = (unsigned)(a.B * ((a.OH + R - 1) / R));
+  TF2_LAUNCH_NAME("conv_first_kernel<im2col tile in LDS,%d rows per block%s>", R, f.dual ? ",dual" : "");
+  if (a.src_is_q) { if (f.dual) TF2_LAUNCH((conv_first_kernel<true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_kernel<true, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
+  else { if (f.dual) TF2_LAUNCH((conv_first_kernel<false, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_kernel<false, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
+  return launch_ok() ? 0 : -1;
 }
 
 __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {

@@ -492,6 +492,7 @@ void Net::load_options() {
   o.c3_min256 = (long)opt("c3_min256", o.c3_min256);
   o.c3_w9 = (int)opt("c3_w9", o.c3_w9);
   o.c3_pool = (int)opt("c3_pool", o.c3_pool);
+  o.first_fuse = (int)opt("first", o.first_fuse);
   o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
   o.stem_mode = (int)opt("stem", o.stem_mode);
   o.bgroup_min7 = (int)opt("bgroup_min7", o.bgroup_min7);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -997,6 +998,23 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       gd.y_cp = L.N; gd.y_off = 0; gd.y_nvalid = L.N / 16 * 16; gd.y_tail = L.N % 16;
       lp.logits_direct = (int)lp.steps.size();
     }
+    // a 3x3 / stride 1 first layer on the 3-channel image: input preparation and the pointwise layer over the im2col tile in ONE
+    // launch (conv_first_kernel: the tile stays in LDS); the step's first launch then belongs to table row 0
+    if (l == 0 && im2col0 && opts.first_fuse && st.sel == Launch::SEL_PW && pl->TM == 64 && pl->n_mtiles == 1 && pl->nslab == 1 &&
+        (pl->n_phases == 1 || pl->dual) && !L.pool_en && !L.endpool && L.concat < 0 && L.add_src < 0 && E.conv_tensor == E.out_tensor) {
+      Launch& s0 = lp.steps[0];
+      const int hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
+      int R = 0, WS = 0; size_t lds = 0;
+      if (s0.kind == Launch::PREP && conv_first_fits(s0.prep, &R, &WS, &lds, hdr_used)) {
+        const ConvArgs& ca = st.conv;
+        FirstArgs& f = s0.first;
+        f.w = ca.w; f.hdr = ca.hdr; f.y = ca.y; f.im = s0.prep.y;
+        f.hdr_used = hdr_used; f.dual = ca.dual; f.relu = ca.g.relu; f.fast = ca.g.fast; f.dbl = ca.g.dbl_out;
+        f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid; f.keep = wp->keep_all ? 1 : 0;
+        s0.sel = Launch::SEL_FIRST; s0.layer = 0;
+        continue;
+      }
+    }
     lp.steps.push_back(st);
     const TensorPlan& tc = T(E.conv_tensor);
     if (L.pool_en && !(l == 0 && stem_pool_fused) && !(c3_pool_fused && st.sel == Launch::SEL_C3)) {
@@ -1023,6 +1041,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
   switch (st.kind) {
     case Launch::PREP: {
       PrepArgs pa = st.prep; pa.img = images; pa.src_is_q = images_are_q ? 1 : 0;
+      if (st.sel == Launch::SEL_FIRST) { FirstArgs f = st.first; f.p = pa; return launch_conv_first(f, stream); }
       return launch_prep_input(pa, stream);
     }
     case Launch::POOL: return launch_maxpool(st.pool, stream);

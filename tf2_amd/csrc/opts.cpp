@@ -12,7 +12,7 @@ namespace tf2 {
 namespace {
 struct OptSpec { const char* name; int test_only; const char* doc; };
 const OptSpec kOptSpecs[] = {
-  // ---- product options (INTEGRATION.md section 4) ----
+  // ---- product options (INTEGRATION.md section 5) ----
   {"alt_conc", 0, "how Net::run decides that batches are in flight: 0 never, 1 always, 2 (default) the caller's tf2_net_run_ex statement, else calls on >= 2 streams among the last eight"},
   {"bgroup", 0, "group launches (conv_bgroup.hip: eight co-resident blocks per image that meet inside the kernel) one batch at a time: 1 (default) / 0"},
   {"bband", 0, "band launches (conv_bband.hip) of identity bottlenecks: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well"},
@@ -28,6 +28,7 @@ const OptSpec kOptSpecs[] = {
   {"pw", 1, "conv_pw: 1 auto, 0 never"}, {"pw_slabs", 1, "conv_pw: most K slabs"}, {"pw_minpix", 1, "conv_pw: fewest pixels"},
   {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"},
   {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
+  {"first", 1, "a 3x3 / stride 1 first layer on the image in one launch with its input preparation: 1 / 0"},
   {"c3_pool", 1, "a layer's 2x2 / 2 max pool inside its conv_c3 launch: 1 / 0"},
   {"c3_w9", 1, "conv_c3_w9_kernel: 0 never, 1 auto, 2 wherever allowed"},
   {"bneck_min", 1, "conv_bneck: smallest grid"}, {"stem", 1, "conv_stem: 1 auto, 0 never"}, {"stem_pool", 1, "conv1's pool in its launch"},

@@ -7,7 +7,7 @@
 // anywhere else: launchers run on several feeder threads, and getenv racing with a setenv is undefined behaviour).  Unknown names are
 // an error (TF2_ERR_ARG from create / reload), and so is a TEST-ONLY option unless TF2_AMD_TEST=1 is set as well: those force
 // kernels, disable proofs or lower thresholds for the test-suite and the A/B tools and are no part of the product's interface.
-// The table of names is in opts.cpp (kOptSpecs); INTEGRATION.md section 4 documents the product options.
+// The table of names is in opts.cpp (kOptSpecs); INTEGRATION.md section 5 documents the product options.
 #pragma once
 #include <string>
 

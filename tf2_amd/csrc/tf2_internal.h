@@ -358,6 +358,20 @@ struct PrepArgs {
   int32_t n_flag_words;
 };
 
+// conv_first_kernel (misc_kernels.hip): a 3x3 / stride 1 first layer on the 3-channel image in one launch -- input preparation (the im2col
+// tile stays in LDS) + the pointwise MFMA layer over it
+struct FirstArgs {
+  PrepArgs p;                  // the input side: image, quantisation, im2col geometry (rewrite == 2)
+  const int8_t* w;             // the layer's one weight slab [window][64 rows][64 bytes]
+  const int32_t* hdr;          // its header image (rows | lo | dshift)
+  int8_t* y;                   // the layer's output tensor
+  int8_t* im;                  // the im2col tensor (written only with keep: per-layer parity runs read the quantised image back from it)
+  int32_t hdr_used, dual, relu, fast, dbl, y_cp, y_off, y_nvalid, keep;
+  int32_t R, WS;               // set by the launcher: output rows per block, row stride of the LDS image tile
+};
+bool conv_first_fits(const PrepArgs& a, int* R_out, int* WS_out, size_t* lds_out, int hdr_used);
+int launch_conv_first(const FirstArgs& f, void* stream);
+
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch

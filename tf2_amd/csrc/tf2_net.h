@@ -45,7 +45,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -64,6 +64,7 @@ struct Launch {
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
+  FirstArgs first{};         // kind PREP, SEL_FIRST: input preparation + table row 0 in one launch (conv_first_kernel); prep = its input side
   L2NormArgs l2n{};
 };
 
@@ -88,6 +89,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 200;
+  int first_fuse = 1;        // first: a 3x3 / stride 1 first layer on the 3-channel image as ONE launch with its input preparation (conv_first_kernel): 1 (default) / 0
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
