@@ -1000,7 +1000,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     // a 3x3 / stride 1 first layer on the 3-channel image: input preparation and the pointwise layer over the im2col tile in ONE
     // launch (conv_first_kernel: the tile stays in LDS); the step's first launch then belongs to table row 0
-    if (l == 0 && im2col0 && opts.first_fuse && st.sel == Launch::SEL_PW && pl->TM == 64 && pl->n_mtiles == 1 && pl->nslab == 1 &&
+    if (l == 0 && im2col0 && opts.first_fuse && (st.sel == Launch::SEL_PW || st.sel == Launch::SEL_MFMA2 || st.sel == Launch::SEL_SK) && !fuse_now &&
+        st.TM == 64 && pl->TM == 64 && pl->n_mtiles == 1 && pl->nslab == 1 && pl->n_entries == 1 && !pl->w_share &&
         (pl->n_phases == 1 || pl->dual) && !L.pool_en && !L.endpool && L.concat < 0 && L.add_src < 0 && E.conv_tensor == E.out_tensor) {
       Launch& s0 = lp.steps[0];
       const int hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
