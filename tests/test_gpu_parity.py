@@ -569,19 +569,24 @@ def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc)
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
 
 
-@pytest.mark.parametrize("merge", ["1", "0"])
+@pytest.mark.parametrize("merge", ["fire", "1", "0"])
 def test_merged_expand_rows(merge, monkeypatch):
     """PackLayer::merge_next (weight_pack.cpp, round 5): a fire module's expand1x1 and expand3x3 rows -- same input tensor, adjacent
     slices of one concat tensor (kNStart / kBranchTail, quantization.cpp:42-49) -- run as ONE 3x3 launch whose first rows carry the 1x1
     filters as centre taps (and, for fire3 / fire5, ONE pool launch).  Every row of a 67 x 67 and a 131 x 131 SqueezeNet 1.1 against the
     oracle with the rows merged and separate (doubled squeeze outputs, 64- and 128-row tiles, pooled and unpooled pairs)."""
-    set_opts(monkeypatch, merge=merge)
-    for hw, seed, b in ((67, 6, 5), (131, 8, 3)):
+    # "fire" (the default): the merged rows AND, for unpooled fire modules on 56 / 28 / 14-wide maps, the squeeze in the same launch
+    # (conv_fire.hip: squeeze over the halo rows, its requantised output in LDS planes, the merged expand from there) -- 227 x 227 images
+    set_opts(monkeypatch, merge="0" if merge == "0" else "1", fire="1" if merge == "fire" else "0")
+    for hw, seed, b, spread in ((67, 6, 5, 2), (131, 8, 3, 2)) + (((227, 6, 2, 1), (227, 10, 3, 2)) if merge == "fire" else ()):
         t = cfg.squeezenet11_tables(image_hw=hw)
-        q = synth.synth_q_values(t, seed, spread=2)
+        q = synth.synth_q_values(t, seed, spread=spread)
         rig = Rig(t, q, synth.synth_model(t, q, seed), 0)
-        rows = {r["layer"] for r in rig.net.describe_launches(b, 1)}
+        ls = rig.net.describe_launches(b, 1)
+        rows = {r["layer"] for r in ls}
         assert (3 in rows) == (merge == "0") and (6 in rows) == (merge == "0")
+        if hw == 227 and seed == 6:                        # (bench.py's Q values: every squeeze output doubled, the merged expands one-window)
+            assert sum("conv_fire" in r["kernel"] for r in ls) >= 2
         rig.check_all_layers(synth.synth_images(t, b, seed))
 
 

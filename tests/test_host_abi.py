@@ -221,10 +221,18 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert "im2col" in s[0]["kernel"] and s[0]["layer"] == -1 and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"      # (stride 2: its own input kernel)
     # merged rows (round 5): every fire module's expand1x1 | expand3x3 pair is ONE launch (PackLayer::merge_next) -- 24 launches, not 34,
     # none on the second row of a pair; merge=0 brings the separate rows back (its 64-channel 3x3 rows on 14 x 14 then take conv_c3)
-    assert len(s) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s}
+    # ... and an unpooled fire module (squeeze + merged expands) on a map >= 28 wide is ONE launch of row bands (conv_fire.hip): 22 launches
+    # (fire=1: the 14 x 14 modules as well, 18 -- measured slower; fire=0: 24)
+    assert len(s) == 22 and [r["layer"] for r in s if "conv_fire" in r["kernel"]] == [1, 7]
+    set_opts(monkeypatch, fire="1")
+    s2 = launches(cfg.squeezenet11_tables(), 32)
+    assert len(s2) == 18 and [r["layer"] for r in s2 if "conv_fire" in r["kernel"]] == [1, 7, 13, 16, 19, 22]
+    set_opts(monkeypatch, fire="0")
+    s1 = launches(cfg.squeezenet11_tables(), 32)
+    assert len(s1) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s1}
     set_opts(monkeypatch, merge="0")
     s0 = launches(cfg.squeezenet11_tables(), 32)
-    set_opts(monkeypatch, merge=None)
+    set_opts(monkeypatch, merge=None, fire=None)
     assert len(s0) == 34 and {r["layer"] for r in s0 if "conv_c3" in r["kernel"]} == {21, 24}
     assert any("conv_c3" in r["kernel"] for r in launches(cfg.ssd300_tables(), 32))
     set_opts(monkeypatch, c3="0"); set_opts(monkeypatch, im2col0="0")

@@ -233,6 +233,17 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       }
       l += 2;
     }
+  // Fire launches (conv_fire.hip: rows l .. l + 2 in one launch): what the launch reads stays live to its last row, what it writes exists from
+  // its first
+  if (packed_valid && opts.fire_mode)
+    for (int l = 0; l + 2 < nl; l++) {
+      if (!fire_at(l)) continue;
+      TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
+      tin.last_use = std::max(tin.last_use, l + 2);
+      for (size_t t = 0; t < wp.tensors.size(); t++)
+        if (born[t] == l + 1 || born[t] == l + 2) born[t] = l;
+      l += 2;
+    }
   // ... and consecutive identity bottlenecks of the 14 x 14 maps may share a launch (bgroup_chain): nothing such a run touches
   // shares memory (the exchange inside a launch is ordered by flags and cache scopes, not by kernel boundaries)
   if (packed_valid && opts.bgroup_mode && opts.bgroup_chain > 1)
@@ -435,6 +446,23 @@ bool Net::bband_at(int l, int rows) const {
   return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual);
 }
 
+// Rows l (1x1 squeeze, ReLU), l + 1 and l + 2 (the merged expand1x1 | expand3x3 pair, PackLayer::merge_next) of an unpooled fire module
+// whose squeeze output nothing else reads: conv_fire.hip takes them as one launch
+bool Net::fire_at(int l) const {
+  if (l < 0 || l + 2 >= nd.n_layers) return false;
+  const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1];
+  if (A.ipool || A.pool_en || A.endpool || A.concat >= 0 || A.add_src >= 0 || !A.relu || A.k != 1 || A.stride != 1 || (A.pad_h | A.pad_w) || A.src == -1) return false;
+  if (in_layout[l].Cp_in != A.C || A.C % 64 != 0 || in_layout[l].signed_in) return false;
+  const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1); const PackLayer* p2 = pack_layer(l + 2);
+  if (!p0 || !p1 || !p2 || p0->kind != KIND_MFMA || p1->kind != KIND_MFMA || p1->merge_next != l + 2 || p2->merged_into != l + 1) return false;
+  if (B.src != l || B.pool_en || B.endpool || B.add_src >= 0 || !B.relu) return false;
+  for (int j = 0; j < nd.n_layers; j++)
+    if (j != l + 1 && j != l + 2 && (layers[j].src == l || layers[j].add_src == l)) return false;      // the squeeze's tensor is not written
+  if (p0->TM != 64 || p0->n_mtiles != 1 || (long)p0->n_entries != p0->nslab || !(p0->n_phases == 1 || p0->dual) || p0->w_share || p0->fuse_next > 0 || p0->fused_into >= 0) return false;
+  if (p1->n_phases != 1 || p1->dual || p1->w_share || (p1->TM != 64 && p1->TM != 128) || p1->Cp_in != round_up(A.N, 16) || p1->off_dbl) return false;
+  return conv_fire_geometry(A.H, A.W, A.C, round_up(A.N, 16), p1->Np, p0->TM, p1->TM, p0->dual, nullptr, nullptr) && p1->Np == layers[l + 1].N + layers[l + 2].N;
+}
+
 // a 3x3 / stride 1 / pad 1 layer on an unsigned tensor that holds exactly C (a multiple of 64) bytes per pixel, dense one- or two-window
 // tiles of its own: conv_c3.hip takes it (the halo tile of the input streamed through LDS once instead of nine gathers)
 bool Net::c3_at(int l) const {
@@ -493,6 +521,7 @@ void Net::load_options() {
   o.c3_w9 = (int)opt("c3_w9", o.c3_w9);
   o.c3_pool = (int)opt("c3_pool", o.c3_pool);
   o.first_fuse = (int)opt("first", o.first_fuse);
+  o.fire_mode = (int)opt("fire", o.fire_mode);
   o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
   o.stem_mode = (int)opt("stem", o.stem_mode);
   o.bgroup_min7 = (int)opt("bgroup_min7", o.bgroup_min7);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -767,6 +796,28 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
         lp.steps.push_back(st);
         continue;
+      }
+    }
+    // a fire module (squeeze + the merged expands) as ONE launch of independent row bands (conv_fire.hip)
+    if (opts.fire_mode && fire_at(l) && (opts.fire_mode == 1 || L.W >= 28)) {
+      Launch s0, s1;
+      if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false)) return nullptr;
+      const PackLayer* p1 = pack_layer(l + 1);
+      if (s0.conv.dense && s0.TM == 64 && s1.TM == p1->TM) {
+        Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_FIRE; st.layer = l;
+        FireArgs& f = st.fire;
+        const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv;
+        f.x = c0.x; f.mid = c0.y; f.y = c1.y; f.w1 = c0.w; f.w2 = c1.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr2_bytes = c1.hdr_bytes;
+        f.ent2 = reinterpret_cast<const int32_t*>(pk + p1->off_entries); f.dir2 = reinterpret_cast<const int32_t*>(pk + p1->off_dir);
+        f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
+        f.tm1 = s0.TM; f.tm2 = s1.TM; f.B = batch; f.H = L.H; f.W = L.W; f.Cin = L.C; f.Sp = round_up(L.N, 16); f.N2 = p1->Np;
+        f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.dbl1 = c0.g.dbl_out; f.dual1 = c0.dual;
+        f.keep_mid = wp->keep_all ? 1 : 0; f.mid_cp = c0.g.y_cp; f.y_cp = c1.g.y_cp; f.y_off = c1.g.y_off; f.y_nvalid = c1.g.y_nvalid;
+        if (conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, &f, nullptr)) {
+          pair_done[l + 1] = 1;
+          lp.steps.push_back(st);
+          continue;
+        }
       }
     }
     // an identity bottleneck as ONE launch of independent row bands (conv_bband.hip): no exchange between blocks, so it may share
@@ -1062,6 +1113,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_C3: return launch_conv_c3(st.c3, stream);
+        case Launch::SEL_FIRE: return launch_conv_fire(st.fire, stream);
         case Launch::SEL_FC: return launch_conv_fc(st.fc, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
         case Launch::SEL_BGROUP:

@@ -358,6 +358,28 @@ struct PrepArgs {
   int32_t n_flag_words;
 };
 
+// conv_fire.hip: a fire module (squeeze 1x1, then the merged expand1x1 | expand3x3 layer) in one launch of independent row bands
+struct FireArgs {
+  const int8_t* x;           // the module's input [B][H*W][Cin], exactly Cin bytes per pixel
+  int8_t* mid;               // the squeeze's output tensor [B][H*W][mid_cp] (written only with keep_mid)
+  int8_t* y;                 // the concat tensor the expands write
+  const int8_t* w1;          // squeeze: dense weight tiles [slab][(hi | lo)][tm1 rows][64] of its single m-tile
+  const int8_t* w2;          // merged expand: weight tiles [entry][tm2 rows][64] (one window), entries per m-tile from dir2 / ent2
+  const int32_t* hdr1; const int32_t* hdr2;      // header images (hdr2: one per m-tile, stride hdr2_bytes)
+  const int32_t* ent2;       // merged expand: slab id of every entry (PackLayer::off_entries)
+  const int32_t* dir2;       // merged expand: [m-tile][2] first / end entry (PackLayer::off_dir, one window)
+  const int8_t* zero;        // zero page
+  const int8_t* zero2;       // the expand's pad row (the stored form of x = 0 of the squeeze's output tensor)
+  int32_t hdr2_bytes, tm1, tm2;
+  int32_t B, H, W, Cin, Sp, N2;                  // Sp: squeeze channels rounded up to 16 (= bytes per pixel of its tensor); N2: both expands' channels
+  int32_t R, tiles_per_img, NT0, WM;             // set by conv_fire_geometry: rows per band, bands per image, halo-band column tiles, wave grid rows
+  int32_t relu1, relu2, fast1, fast2, dbl1, dual1, keep_mid;
+  int32_t mid_cp, y_cp, y_off, y_nvalid;
+  uint32_t w_m, g_m; int32_t w_s, g_s;           // set_fast_div(W), set_fast_div(Sp / 16)
+};
+bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, FireArgs* f, size_t* lds_out);
+int launch_conv_fire(const FireArgs& a, void* stream);      // 1: shape not instantiated / does not fit
+
 // conv_first_kernel (misc_kernels.hip): a 3x3 / stride 1 first layer on the 3-channel image in one launch -- input preparation (the im2col
 // tile stays in LDS) + the pointwise MFMA layer over it
 struct FirstArgs {

@@ -45,7 +45,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -64,6 +64,7 @@ struct Launch {
   PoolArgs pool{};
   AvgArgs avg{};
   PrepArgs prep{};
+  FireArgs fire{};           // SEL_FIRE: rows layer (squeeze), layer + 1 and layer + 2 (the merged expands) in one launch (conv_fire.hip)
   FirstArgs first{};         // kind PREP, SEL_FIRST: input preparation + table row 0 in one launch (conv_first_kernel); prep = its input side
   L2NormArgs l2n{};
 };
@@ -89,6 +90,8 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int flags = 0;           // ConvGeom::flags
   int pw_mode = 1, sk_mode = 0;
   long bneck_min_blocks = 200;
+  int fire_mode = 2;         // fire: a fire module (squeeze + merged expands) as ONE launch (conv_fire.hip): 0 never, 1 wherever it fits, 2 (default) on maps
+                             // >= 28 wide (14 x 14 modules measured SLOWER fused: 64-128 blocks of long dependent chains, r05_experiments.txt item 10)
   int first_fuse = 1;        // first: a 3x3 / stride 1 first layer on the 3-channel image as ONE launch with its input preparation (conv_first_kernel): 1 (default) / 0
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
@@ -178,6 +181,7 @@ struct Net {
   tf2_layer_desc exec_desc(int l) const;   // row l as executed (merged rows: the 3x3 layer of both rows' channels)
   bool out_nonneg(int l) const;            // the tensor layer l writes holds no negative value
   bool res_nonneg_single_clamp(int l) const;     // row l's residual epilogue may take the one-clamp form (requant_epilogue.h RNN)
+  bool fire_at(int l) const;    // rows l (squeeze), l + 1, l + 2 (merged expands) are a fire module conv_fire.hip can take
   bool c3_at(int l) const;      // layer l can run on conv_c3.hip
   bool fc_at(int l, int batch) const;   // ... on conv_fc.hip
   bool bgroup_at(int l) const;             // rows l, l + 1, l + 2 are an identity bottleneck conv_bgroup.hip can take (tables + packed image)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of launch-plan switches in ONE process: ResNet50, batch N, several batches in flight on XCD-partitioned streams (what
-bench.py times) and one batch at a time, per setting of the library's option string TF2_AMD_OPTS (re-read through tf2_net_reload_options).
+"""A/B of launch-plan switches in ONE process: ResNet50, batch N, several batches in flight on plain streams (as
+bench.py times them) and one batch at a time, per setting of the library's option string TF2_AMD_OPTS (re-read through tf2_net_reload_options).
 Usage: inflight_ab.py --set "bband=0" --set "bband=1,bband_rows=7" ...
 Prints img/s and whether the logits equal the first setting's."""
 import argparse, os, sys, time
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from tf2_amd import config as cfg, network, synth, streams
+from tf2_amd import config as cfg, network, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
@@ -18,12 +18,12 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--serial", type=int, default=1, help="also time one batch at a time")
 a = ap.parse_args()
-settings = a.set or ["BBAND=0", "BBAND=1"]
+settings = a.set or ["bband=0", "bband=1"]
 t = cfg.resnet50_tables()
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device="cuda:0")
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
-sts = streams.partitioned_streams(a.inflight, "cuda:0")
+sts = [torch.cuda.Stream(device="cuda:0") for _ in range(a.inflight)]
 # device spin-up (an idle MI355X needs ~0.4 s of load to reach its clock)
 m = torch.randn(4096, 4096, device="cuda:0", dtype=torch.float16)
 t_end = time.perf_counter() + 0.6

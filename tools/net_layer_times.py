@@ -8,9 +8,8 @@ from tf2_amd import config as cfg, network, synth, _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--net", default="vgg16"); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--conc", type=int, default=0); ap.add_argument("--steps", type=int, default=10)
 a = ap.parse_args()
-t = {"vgg16": cfg.vgg16_tables, "ssd300": cfg.ssd300_tables, "squeezenet": cfg.squeezenet11_tables, "resnet50": cfg.resnet50_tables}[a.net]()
-q = synth.synth_q_values(t, 0, spread=1) if a.net != "resnet50" else np.loadtxt(os.path.join(os.path.dirname(__file__), "..", "tests/golden/resnet50_Q"), dtype=np.int32)
-net = network.NetWork(t); net.Init(synth.synth_model(t, q, 0), synth.q_text(q), device="cuda:0", pack_mode=0)
+t, q, seed, _, _ = synth.bench_network(a.net)          # the networks exactly as bench.py runs them
+net = network.NetWork(t); net.Init(synth.synth_model(t, q, seed), synth.q_text(q), device="cuda:0", pack_mode=0)
 dev = torch.device("cuda:0")
 runner = network.Runner(None, net)
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to(dev)

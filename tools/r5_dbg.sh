@@ -1,5 +1,13 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dbg; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests -m gpu -q -k "first_layer_with or first_3x3 or tiny" > $O/t1.log 2>&1; grep -E "passed|failed|FAILED|layer [0-9]+|network input|Mismatched" $O/t1.log | head -30
-timeout 1500 tools/round_evidence.sh "vgg16 ssd300" 0 > $O/evidence.log 2>&1; tail -8 $O/evidence.log
-for NET in vgg16 ssd300; do timeout 600 python bench.py --net $NET --steps 20 --warmup 5 --extra-batches "" --cpu-seconds 6 > $O/bench_$NET.log 2>&1; tail -1 $O/bench_$NET.log > $R/gpurun_out/evidence/bench_$NET.json; tail -c 300 $R/gpurun_out/evidence/bench_$NET.json; echo; done
+timeout 600 python -m pytest tests -m gpu -q -k "merged_expand or squeezenet" > $O/t1.log 2>&1; grep -E "passed|failed|FAILED|layer [0-9]+|network input|Mismatched|Error" $O/t1.log | head -30
+for M in 1 0 2 1 0 2; do
+  TF2_AMD_TEST=1 TF2_AMD_OPTS="fire=$M" timeout 200 python bench.py --net squeezenet --no-cpu --steps 40 --warmup 5 --extra-batches "" > $O/fi_$M.log 2>&1
+  python - <<EOF
+import json
+try:
+    d=json.loads(open("$O/fi_$M.log").read().strip().splitlines()[-1]); r=d["roofline"]
+    print("fire=$M", d["value"], "cold", d["cold_start"]["value"], "one-batch", d["images_per_s_one_batch_at_a_time"], "launches", r["launches_per_step"], "kus", r["kernel_us_per_step"])
+except Exception as e: print("failed", e)
+EOF
+done
