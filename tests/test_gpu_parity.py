@@ -607,3 +607,24 @@ def test_first_layer_with_its_input_preparation_in_one_launch(first, monkeypatch
         if kind == "int8":
             x[0, :, :3, :] = -128
         rig.check_all_layers(x, layers={0, 1, 2})
+
+
+@pytest.mark.parametrize("first_pool", ["1", "0"])
+def test_first_layer_with_its_pool_in_one_launch(first_pool, monkeypatch):
+    """conv_first_pool_kernel (round 5): SqueezeNet 1.1's front -- input quantisation, the stride-2 3x3 conv1 over the im2col tile and the
+    3x3 / 2 ceil-mode pool1, conv map in LDS -- in ONE launch, against the oracle: the quantised image read back, the conv map, the pooled
+    tensor and the rows behind it; float and int8 inputs (-128 pixels included), image sizes whose last pool window hangs over the map
+    (ceil mode: 47 -> 23 -> 11 wide with one column / row beyond it) and not (227), one- and two-window conv1 (spread 1 / 2), batch 1 and 3;
+    first_pool=0: the three separate launches."""
+    set_opts(monkeypatch, first_pool=first_pool)
+    for hw, seed, spread, kind, b in ((47, 3, 1, "int8", 3), (63, 4, 2, "float", 2), (227, 6, 1, "float", 1)):
+        t = cfg.squeezenet11_tables(hw)
+        q = synth.synth_q_values(t, seed, spread=spread)
+        rig = Rig(t, q, synth.synth_model(t, q, seed), 0)
+        k0 = rig.net.describe_launches(b, 1)[0]
+        assert ("conv_first_pool_kernel" in k0["kernel"] and k0["layer"] == 0) == (first_pool == "1"), k0
+        x = synth.synth_images(t, b, seed, kind=kind)
+        if kind == "int8":
+            x[0, :, :3, :] = -128
+        want = rig.check_all_layers(x, layers={0, 1, 2, 3})
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), want)         # ... and the plan of a plain run (no per-layer tensors kept)

@@ -218,21 +218,24 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert all(sizes[l] in (64, 256) for l in sizes if l >= 5 and l not in duals)      # one-window layers of 256+ channels: 256 per block where the grid allows
     assert sizes[11] == 64 or 11 in duals                                        # 14 x 14: 32 tiles -- the small grid takes 64-channel blocks
     s = launches(cfg.squeezenet11_tables(), 32)
-    assert "im2col" in s[0]["kernel"] and s[0]["layer"] == -1 and "conv_pw" in s[1]["kernel"] and s[-1]["kernel"] == "conv_shift_fc_kernel"      # (stride 2: its own input kernel)
+    # round 5: input preparation + the stride-2 conv1 + pool1 in ONE launch (conv_first_pool_kernel: im2col tile and conv map stay in LDS)
+    assert s[0]["kernel"].startswith("conv_first_pool_kernel<stride 2,2 pooled rows") and s[0]["layer"] == 0 and s[0]["grid"] == 32 * 28 and s[1]["layer"] == 1
+    assert s[0]["lds_bytes"] <= 78 * 1024 and s[-1]["kernel"] == "conv_shift_fc_kernel"
     # merged rows (round 5): every fire module's expand1x1 | expand3x3 pair is ONE launch (PackLayer::merge_next) -- 24 launches, not 34,
     # none on the second row of a pair; merge=0 brings the separate rows back (its 64-channel 3x3 rows on 14 x 14 then take conv_c3)
-    # ... and an unpooled fire module (squeeze + merged expands) on a map >= 28 wide is ONE launch of row bands (conv_fire.hip): 22 launches
-    # (fire=1: the 14 x 14 modules as well, 18 -- measured slower; fire=0: 24)
-    assert len(s) == 22 and [r["layer"] for r in s if "conv_fire" in r["kernel"]] == [1, 7]
+    # ... and an unpooled fire module (squeeze + merged expands) on a map >= 28 wide is ONE launch of row bands (conv_fire.hip): 20 launches
+    # (fire=1: the 14 x 14 modules as well, 16 -- measured slower; fire=0: 22; first_pool=0: the front as three launches, 24)
+    assert len(s) == 20 and [r["layer"] for r in s if "conv_fire" in r["kernel"]] == [1, 7]
     set_opts(monkeypatch, fire="1")
     s2 = launches(cfg.squeezenet11_tables(), 32)
-    assert len(s2) == 18 and [r["layer"] for r in s2 if "conv_fire" in r["kernel"]] == [1, 7, 13, 16, 19, 22]
-    set_opts(monkeypatch, fire="0")
+    assert len(s2) == 16 and [r["layer"] for r in s2 if "conv_fire" in r["kernel"]] == [1, 7, 13, 16, 19, 22]
+    set_opts(monkeypatch, fire="0", first_pool="0")
     s1 = launches(cfg.squeezenet11_tables(), 32)
+    assert "im2col" in s1[0]["kernel"] and s1[0]["layer"] == -1 and "conv_pw" in s1[1]["kernel"] and "maxpool" in s1[2]["kernel"]      # (stride 2: its own input kernel)
     assert len(s1) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s1}
     set_opts(monkeypatch, merge="0")
     s0 = launches(cfg.squeezenet11_tables(), 32)
-    set_opts(monkeypatch, merge=None, fire=None)
+    set_opts(monkeypatch, merge=None, fire=None, first_pool=None)
     assert len(s0) == 34 and {r["layer"] for r in s0 if "conv_c3" in r["kernel"]} == {21, 24}
     assert any("conv_c3" in r["kernel"] for r in launches(cfg.ssd300_tables(), 32))
     set_opts(monkeypatch, c3="0"); set_opts(monkeypatch, im2col0="0")

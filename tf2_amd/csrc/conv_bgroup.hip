@@ -1440,7 +1440,7 @@ int launch_conv_bgroup_first(const BGroupArgs& a, void* stream) {
     b.img0 = i0;
     const int n = std::min(32, a.B - i0);
     const dim3 grid(kBgMembers * ((n + 7) / 8 * 8));
-    TF2_LAUNCH_NAME("conv_bgroup56f_kernel<56x56,shortcut 64->256 | 64->64->64->256%s> (8 blocks per image, images %d..%d)", a.dual1 ? ",dual" : "", i0, i0 + n - 1);
+    TF2_LAUNCH_NAME("conv_bgroup56f_kernel<56x56,shortcut | 64->64->64->256%s> (8 blocks per image, images %d..%d)", a.dual1 ? ",dual" : "", i0, i0 + n - 1);
     if (a.dual1) TF2_LAUNCH((conv_bgroup56f_kernel<true>), grid, dim3(512), lds, s, b);
     else TF2_LAUNCH((conv_bgroup56f_kernel<false>), grid, dim3(512), lds, s, b);
     if (!launch_ok()) return -1;

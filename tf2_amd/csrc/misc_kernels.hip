@@ -262,24 +262,15 @@ __global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
 // leave through an LDS transpose as contiguous 16-byte pieces.  Same bytes as prep_rewrite3_kernel<*, false, true>
 // (tf2_net_read_layer(-1) and every first-layer test compare them).
 constexpr int kImPadL = 4;                                  // tile column of image column 0 (pad_w <= 4: launcher-checked)
-template <bool SRC_Q>
-__global__ __launch_bounds__(256) void prep_im2col_rows_kernel(PrepArgs a, int R, int WS) {
-  prep_zero_ctrl(a);
-  extern __shared__ __attribute__((aligned(16))) int8_t im_lds[];
-  const int s_ = a.im_stride, TR = (R - 1) * s_ + 3;
-  int8_t* const img = im_lds;                               // [3][TR][WS]
-  int (*const tile)[17] = reinterpret_cast<int (*)[17]>(im_lds + ((3 * TR * WS + 15) & ~15));      // [256][17]: 64 B per pixel (+1 word: bank spread)
-  const int rows_per_img = (a.OH + R - 1) / R;
-  const int b = blockIdx.x / rows_per_img;
-  const int oh0 = (blockIdx.x - b * rows_per_img) * R;
-  const int r_first = oh0 * s_ - a.im_pad_h;               // image row of tile row 0
-  const int tid = threadIdx.x;
-  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
-  for (int i = tid; i < 3 * TR * WS / 4; i += 256) reinterpret_cast<int*>(img)[i] = 0;      // borders, rows outside the image
-  __syncthreads();
+
+// The (3 channels x TR rows x WS bytes) int8 image tile of the row-tile kernels below: image rows r_first .. r_first + TR - 1 of image b,
+// column 0 at tile column kImPadL, quantised (runner.cpp:158-163) on the way in; rows outside the image and the border columns keep the
+// zeros the caller wrote (the padding of sequencer.cl:287).  16-byte source loads where the image width allows.
+template <bool SRC_Q, int NT>
+__device__ __forceinline__ void fill_image_tile(const PrepArgs& a, int8_t* img, int TR, int WS, int b, int r_first, int tid, float trans) {
   if ((a.W & 3) == 0) {
     const int w4 = a.W >> 2;
-    for (int i = tid; i < 3 * TR * w4; i += 256) {
+    for (int i = tid; i < 3 * TR * w4; i += NT) {
       const int line = i / w4, x4 = i - line * w4;
       const int ci = line / TR, rr = line - ci * TR;
       const int sr = r_first + rr;
@@ -300,16 +291,58 @@ __global__ __launch_bounds__(256) void prep_im2col_rows_kernel(PrepArgs a, int R
           (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
     }
   } else {
-    for (int i = tid; i < 3 * TR * a.W; i += 256) {
-      const int line = i / a.W, x = i - line * a.W;
-      const int ci = line / TR, rr = line - ci * TR;
-      const int sr = r_first + rr;
-      if ((unsigned)sr >= (unsigned)a.H) continue;
-      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x;
-      const int q = SRC_Q ? (int)reinterpret_cast<const int8_t*>(a.img)[si] : quant_input(reinterpret_cast<const float*>(a.img)[si], trans);
-      img[(ci * TR + rr) * WS + kImPadL + x] = (int8_t)q;
-    }
+    // rows that are not 16-byte aligned (227-wide images): a wave takes a tile line at a time, four lines' loads (dword / byte per lane,
+    // a line = <= 4 coalesced loads per 256 columns) in flight before the first is quantised -- the per-element walk of the first version
+    // (one dependent load per thread and trip, two divisions by run-time widths each) was 20 of that kernel's 34 us
+    static_assert(NT % 64 == 0, "whole waves");
+    constexpr int NW = NT / 64, LPI = 5;          // (SqueezeNet 1.1: 33 tile lines on 8 waves = one trip)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int x0 = 0; x0 < a.W; x0 += 256)
+      for (int l0 = wave; l0 < 3 * TR; l0 += LPI * NW) {
+        float vf[LPI][4]; int vq[LPI][4]; int dst[LPI];
+#pragma unroll
+        for (int jl = 0; jl < LPI; jl++) {
+          const int line = l0 + jl * NW;
+          const int ci = (line >= TR) + (line >= 2 * TR), rr = line - ci * TR;
+          const int sr = r_first + rr;
+          dst[jl] = (line < 3 * TR && (unsigned)sr < (unsigned)a.H) ? (ci * TR + rr) * WS + kImPadL : -1;
+          const size_t si = ((size_t)(b * 3 + ci) * a.H + (dst[jl] >= 0 ? sr : 0)) * a.W;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int x = x0 + k * 64 + lane;
+            vf[jl][k] = 0.f; vq[jl][k] = 0;
+            if (dst[jl] >= 0 && x < a.W) {
+              if (SRC_Q) vq[jl][k] = (int)reinterpret_cast<const int8_t*>(a.img)[si + x];
+              else vf[jl][k] = reinterpret_cast<const float*>(a.img)[si + x];
+            }
+          }
+        }
+#pragma unroll
+        for (int jl = 0; jl < LPI; jl++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int x = x0 + k * 64 + lane;
+            if (dst[jl] >= 0 && x < a.W) img[dst[jl] + x] = (int8_t)(SRC_Q ? vq[jl][k] : quant_input(vf[jl][k], trans));
+          }
+      }
   }
+}
+template <bool SRC_Q>
+__global__ __launch_bounds__(256) void prep_im2col_rows_kernel(PrepArgs a, int R, int WS) {
+  prep_zero_ctrl(a);
+  extern __shared__ __attribute__((aligned(16))) int8_t im_lds[];
+  const int s_ = a.im_stride, TR = (R - 1) * s_ + 3;
+  int8_t* const img = im_lds;                               // [3][TR][WS]
+  int (*const tile)[17] = reinterpret_cast<int (*)[17]>(im_lds + ((3 * TR * WS + 15) & ~15));      // [256][17]: 64 B per pixel (+1 word: bank spread)
+  const int rows_per_img = (a.OH + R - 1) / R;
+  const int b = blockIdx.x / rows_per_img;
+  const int oh0 = (blockIdx.x - b * rows_per_img) * R;
+  const int r_first = oh0 * s_ - a.im_pad_h;               // image row of tile row 0
+  const int tid = threadIdx.x;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  for (int i = tid; i < 3 * TR * WS / 4; i += 256) reinterpret_cast<int*>(img)[i] = 0;      // borders, rows outside the image
+  __syncthreads();
+  fill_image_tile<SRC_Q, 256>(a, img, TR, WS, b, r_first, tid, trans);
   __syncthreads();
   const int rows = (a.OH - oh0) < R ? (a.OH - oh0) : R;
   const int n_px = rows * a.OW;
@@ -386,29 +419,7 @@ __global__ __launch_bounds__(512) void conv_first_kernel(FirstArgs f) {
       for (int ks = 0; ks < 2; ks++) wf[h][ks] = *reinterpret_cast<const i32x4*>(f.w + ((size_t)h * 64 + row) * 64 + (ks * 2 + half) * 16);
   }
   __syncthreads();
-  {
-    const int w4 = a.W >> 2;                                // W % 4 == 0 (launcher-checked)
-    for (int i = tid; i < 3 * TR * w4; i += 512) {
-      const int line = i / w4, x4 = i - line * w4;
-      const int ci = line / TR, rr = line - ci * TR;
-      const int sr = r_first + rr;
-      if ((unsigned)sr >= (unsigned)a.H) continue;
-      const size_t si = ((size_t)(b * 3 + ci) * a.H + sr) * a.W + x4 * 4;
-      int q[4];
-      if (SRC_Q) {
-        const int v = *reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(a.img) + si);
-#pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = (int)(signed char)((v >> (8 * j)) & 0xff);
-      } else {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.img) + si);
-#pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = quant_input(v[j], trans);
-      }
-      *reinterpret_cast<unsigned*>(&img[(ci * TR + rr) * WS + kImPadL + x4 * 4]) =
-          (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
-    }
-  }
+  fill_image_tile<SRC_Q, 512>(a, img, TR, WS, b, r_first, tid, trans);
   __syncthreads();
   const int rows = (a.OH - oh0) < R ? (a.OH - oh0) : R;
   const int n_px = rows * a.OW;
@@ -495,6 +506,191 @@ int launch_conv_first(const FirstArgs& f0, void* stream) {
   TF2_LAUNCH_NAME("conv_first_kernel<im2col tile in LDS,%d rows per block%s>", R, f.dual ? ",dual" : "");
   if (a.src_is_q) { if (f.dual) TF2_LAUNCH((conv_first_kernel<true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_kernel<true, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
   else { if (f.dual) TF2_LAUNCH((conv_first_kernel<false, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_kernel<false, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
+  return launch_ok() ? 0 : -1;
+}
+
+// ---- conv_first_pool_kernel: a 3x3 first layer (stride 1 or 2) on the 3-channel image AND its 3x3 / stride 2 max pool in ONE launch ---
+// SqueezeNet 1.1's front was three launches -- im2col input preparation 16 us, conv1 as a pointwise layer 12 us, pool1 9.5 us: 19 % of the
+// step -- that write and re-read the im2col image (13 MB) and the 113 x 113 x 64 conv map (26 MB per batch of 32).  Here a block owns PR
+// pooled rows x the full width of one image: the (PR - 1) * 2 + 3 conv rows under them are computed as in conv_first_kernel (image rows
+// quantised once into LDS, the im2col tile in LDS, one weight slab in registers, v_mfma_i32_32x32x32_i8, requant_epilogue.h) into an
+// LDS tile of the layer's NHWC bytes, and the pool (pool.cl:152-260 + pool_tail.cl:91-216: zero beyond the valid area) runs from there.
+// Neighbouring blocks recompute one conv row each ((2 PR + 1) / 2 PR of the layer).
+//   * im2col tile: 48 bytes per pixel -- x(27) | 0 in the first 32 -- conflict-free for the sixteen lanes of a ds_read_b128 (12 i mod 64
+//     words are 16 disjoint groups of four); the xneg K half (pe.cl:32-37, (int8)(-x), -128 stays -128) is derived in registers from
+//     the fragment: per byte ~x + 1 without a carry into the next byte;
+//   * conv tile: 64 bytes per pixel, 16-byte chunk g of pixel p at chunk g ^ ((p >> 2) & 3) (the 16 lanes of a ds_write_b128 -- consecutive
+//     pixels, one chunk -- land in 16 different bank groups);
+//   * the layer has a ReLU (launcher-checked): every byte is 0..127 and the pool is v_pk_max_u16 on the even / odd bytes, window slots
+//     outside the map are skipped (they are zeros, pool.cl:119-140, and no byte is below zero).
+// With `keep` (per-layer parity runs) the im2col tensor and the conv map are written as well (valid rows; neighbours write equal bytes).
+__device__ __forceinline__ unsigned first_neg_bytes(unsigned x) {
+  const unsigned t = ~x;
+  return ((t & 0x7f7f7f7fu) + 0x01010101u) ^ (t & 0x80808080u);
+}
+__device__ __forceinline__ unsigned first_pkmax(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool SRC_Q, bool DUAL>
+__global__ __launch_bounds__(512, 4) void conv_first_pool_kernel(FirstArgs f) {
+  const PrepArgs& a = f.p;
+  prep_zero_ctrl(a);
+  extern __shared__ __attribute__((aligned(16))) int8_t im_lds[];
+  const int s_ = a.im_stride, RC = f.R, WS = f.WS, TR = (RC - 1) * s_ + 3;
+  const int OW = a.OW, OH = a.OH;
+  const int n_px = RC * OW;                                  // conv pixels of the block's tile (rows outside the map included: skipped by the pool)
+  int8_t* const img = im_lds;                               // [3][TR][WS]
+  int8_t* const col = im_lds + ((3 * TR * WS + 15) & ~15);  // [n_px][48]
+  int8_t* const cy = col + (size_t)n_px * 48;               // [n_px][64], chunk-swizzled
+  int* const prm = reinterpret_cast<int*>(cy + (size_t)n_px * 64);
+  const int bands = (f.PH + f.PR - 1) / f.PR;
+  const int b = blockIdx.x / bands;
+  const int ph0 = (blockIdx.x - b * bands) * f.PR;
+  const int oh0 = ph0 * 2 - f.ppad;                          // conv row of tile row 0
+  const int r_first = oh0 * s_ - a.im_pad_h;                 // image row of image-tile row 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const float trans = a.q0 > 0 ? (1.0f / (float)(1 << a.q0)) : (float)(1 << (-a.q0));
+  for (int i = tid; i < 3 * TR * WS / 4; i += 512) reinterpret_cast<int*>(img)[i] = 0;
+  for (int i = tid; i < (f.hdr_used >> 4); i += 512) reinterpret_cast<i32x4*>(prm)[i] = reinterpret_cast<const i32x4*>(f.hdr)[i];
+  const int wr = wave & 1, wp = wave >> 1;
+  i32x4 wf[DUAL ? 2 : 1][2];
+  {
+    const int row = wr * 32 + (lane & 31);
+#pragma unroll
+    for (int h = 0; h < (DUAL ? 2 : 1); h++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) wf[h][ks] = *reinterpret_cast<const i32x4*>(f.w + ((size_t)h * 64 + row) * 64 + (ks * 2 + half) * 16);
+  }
+  __syncthreads();
+  fill_image_tile<SRC_Q, 512>(a, img, TR, WS, b, r_first, tid, trans);
+  __syncthreads();
+  for (int p = tid; p < n_px; p += 512) {
+    const int rsel = p / OW, ow = p - rsel * OW;
+    const int8_t* base = img + (rsel * s_) * WS + kImPadL + ow * s_ - a.im_pad_w;
+    unsigned wx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const int q = (int)base[(ci * TR + k / 3) * WS + k % 3];
+        const int c = ci * 9 + k;
+        wx[c >> 2] |= (unsigned)(q & 0xff) << (8 * (c & 3));
+      }
+    i32x4* d = reinterpret_cast<i32x4*>(col + (size_t)p * 48);
+    d[0] = i32x4{(int)wx[0], (int)wx[1], (int)wx[2], (int)wx[3]}; d[1] = i32x4{(int)wx[4], (int)wx[5], (int)wx[6], (int)wx[7]};
+    if (f.keep && (unsigned)(oh0 + rsel) < (unsigned)OH) {
+      i32x4* g = reinterpret_cast<i32x4*>(f.im + (((size_t)b * OH + oh0 + rsel) * OW + ow) * 64);
+      g[0] = d[0]; g[1] = d[1];
+      g[2] = i32x4{(int)first_neg_bytes(wx[0]), (int)first_neg_bytes(wx[1]), (int)first_neg_bytes(wx[2]), (int)first_neg_bytes(wx[3])};
+      g[3] = i32x4{(int)first_neg_bytes(wx[4]), (int)first_neg_bytes(wx[5]), (int)first_neg_bytes(wx[6]), (int)first_neg_bytes(wx[7])};
+    }
+  }
+  __syncthreads();
+  const int chl = wr * 32 + 16 * half;
+  const int g_out = wr * 2 + half;                           // this lane's 16-byte chunk of a conv pixel
+  const rq_i32x4 nores = {0, 0, 0, 0};
+  for (int t = wp; t * 32 < n_px; t += 4) {
+    const int p_raw = t * 32 + (lane & 31);
+    const int p = p_raw < n_px ? p_raw : n_px - 1;
+    const i32x4 b0 = *reinterpret_cast<const i32x4*>(col + (size_t)p * 48 + half * 16);
+    const i32x4 b1 = {(int)first_neg_bytes((unsigned)b0[0]), (int)first_neg_bytes((unsigned)b0[1]), (int)first_neg_bytes((unsigned)b0[2]), (int)first_neg_bytes((unsigned)b0[3])};
+    i32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0; acc2[r] = 0; }
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][0], b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][1], b1, acc, 0, 0, 0);
+    int a16[16];
+    if constexpr (DUAL) {
+      acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][0], b0, acc2, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][1], b1, acc2, 0, 0, 0);
+      const int* dsh = prm + kPrmWordsPerRow * 64 + 64 + wr * 32 + 4 * half;       // dshift[1] behind rows | lo | dshift[0]
+#pragma unroll
+      for (int G = 0; G < 4; G++) {
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+        for (int r = 0; r < 4; r++) a16[G * 4 + r] = (int)(((unsigned)acc[G * 4 + r] << (d[r] & 31)) + (unsigned)acc2[G * 4 + r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) a16[r] = acc[r];
+    }
+    i32x4 out;
+    if (f.fast == 1) out = requant_tile16<false, 0, true>(a16, prm, 64, wr * 32 + 4 * half, 0, -128, nores, false, false);
+    else out = requant_tile16<false, 0, false>(a16, prm, 64, wr * 32 + 4 * half, 0, -128, nores, false, f.fast == 2);
+    if (p_raw < n_px) {
+      *reinterpret_cast<i32x4*>(cy + (size_t)p_raw * 64 + ((g_out ^ ((p_raw >> 2) & 3)) << 4)) = out;
+      if (f.keep && chl + 16 <= f.y_nvalid) {
+        const int rsel = p_raw / OW, ow = p_raw - rsel * OW;
+        if ((unsigned)(oh0 + rsel) < (unsigned)OH)
+          *reinterpret_cast<i32x4*>(f.y + (((size_t)b * OH + oh0 + rsel) * OW + ow) * f.y_cp + f.y_off + chl) = out;
+      }
+    }
+  }
+  __syncthreads();
+  const int pr_n = (f.PH - ph0) < f.PR ? (f.PH - ph0) : f.PR;
+  const int n_out = pr_n * f.PW * 4;
+  for (int idx = tid; idx < n_out; idx += 512) {
+    const int g = idx & 3, pix = idx >> 2;
+    const int pr = pix / f.PW, pw = pix - pr * f.PW;
+    unsigned me[4] = {0, 0, 0, 0}, mo[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int r = pr * 2 + i;
+      if ((unsigned)(oh0 + r) >= (unsigned)OH) continue;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int ow = pw * 2 - f.ppad + j;
+        if ((unsigned)ow >= (unsigned)OW) continue;
+        const int p = r * OW + ow;
+        const i32x4 v = *reinterpret_cast<const i32x4*>(cy + (size_t)p * 64 + ((g ^ ((p >> 2) & 3)) << 4));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          me[q] = first_pkmax(me[q], (unsigned)v[q] & 0x00ff00ffu);
+          mo[q] = first_pkmax(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
+        }
+      }
+    }
+    if (g * 16 + 16 <= f.y_nvalid) {
+      const i32x4 o = {(int)(me[0] | (mo[0] << 8)), (int)(me[1] | (mo[1] << 8)), (int)(me[2] | (mo[2] << 8)), (int)(me[3] | (mo[3] << 8))};
+      *reinterpret_cast<i32x4*>(f.yp + (((size_t)b * f.PH + ph0 + pr) * f.PW + pw) * f.yp_cp + f.yp_off + g * 16) = o;
+    }
+  }
+}
+
+// the pooled form fits?  (3x3 layer of stride 1 / 2 with a ReLU, 3x3 / stride 2 pool, one weight slab of <= 64 rows; two blocks per CU)
+bool conv_first_pool_fits(const PrepArgs& a, int pool_S, int pool_st, int pool_pad, int PH, int PW, int relu, int hdr_used,
+                          int* PR_out, int* WS_out, size_t* lds_out) {
+  if (a.rewrite != 2 || a.C != 3 || a.half != 32 || a.y_cp != 64 || (a.im_stride != 1 && a.im_stride != 2) || a.im_pad_w > kImPadL || a.im_pad_h > 4) return false;
+  if (pool_S != 3 || pool_st != 2 || pool_pad < 0 || pool_pad > 1 || !relu || a.OW < 8 || PH < 1 || PW < 1) return false;
+  if ((PH - 1) * 2 - pool_pad >= a.OH || (PW - 1) * 2 - pool_pad >= a.OW) return false;      // (every window holds a valid element)
+  const int span = (a.OW - 1) * a.im_stride - a.im_pad_w + 3;
+  const int WS = (kImPadL + (a.W > span ? a.W : span) + 4 + 3) & ~3;
+  for (int PR = 4; PR >= 1; PR--) {
+    const int RC = (PR - 1) * 2 + 3, TR = (RC - 1) * a.im_stride + 3;
+    const size_t lds = (size_t)((3 * TR * WS + 15) & ~15) + (size_t)RC * a.OW * (48 + 64) + (size_t)hdr_used;
+    if (lds > 78 * 1024 || PR * PW * 4 > 4096) continue;
+    *PR_out = PR < PH ? PR : PH; *WS_out = WS; *lds_out = lds;
+    return true;
+  }
+  return false;
+}
+
+int launch_conv_first_pool(const FirstArgs& f0, void* stream) {
+  FirstArgs f = f0;
+  int PR, WS; size_t lds;
+  if (!conv_first_pool_fits(f.p, 3, 2, f.ppad, f.PH, f.PW, f.relu, f.hdr_used, &PR, &WS, &lds)) return 1;
+  f.PR = PR; f.R = (PR - 1) * 2 + 3; f.WS = WS;
+  const PrepArgs& a = f.p;
+  if ((long long)a.B * a.OH * a.OW * 64 >= (1ll << 31) || (long long)a.B * 3 * a.H * a.W >= (1ll << 31)) return 1;
+  const unsigned grid = (unsigned)(a.B * ((f.PH + PR - 1) / PR));
+  TF2_LAUNCH_NAME("conv_first_pool_kernel<stride %d,%d pooled rows per block%s>", a.im_stride, PR, f.dual ? ",dual" : "");
+  if (a.src_is_q) { if (f.dual) TF2_LAUNCH((conv_first_pool_kernel<true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_pool_kernel<true, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
+  else { if (f.dual) TF2_LAUNCH((conv_first_pool_kernel<false, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_pool_kernel<false, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
   return launch_ok() ? 0 : -1;
 }
 

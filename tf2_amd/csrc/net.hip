@@ -521,6 +521,7 @@ void Net::load_options() {
   o.c3_w9 = (int)opt("c3_w9", o.c3_w9);
   o.c3_pool = (int)opt("c3_pool", o.c3_pool);
   o.first_fuse = (int)opt("first", o.first_fuse);
+  o.first_pool = (int)opt("first_pool", o.first_pool);
   o.fire_mode = (int)opt("fire", o.fire_mode);
   o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
   o.stem_mode = (int)opt("stem", o.stem_mode);
@@ -1053,16 +1054,26 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     // launch (conv_first_kernel: the tile stays in LDS); the step's first launch then belongs to table row 0
     if (l == 0 && im2col0 && opts.first_fuse && (st.sel == Launch::SEL_PW || st.sel == Launch::SEL_MFMA2 || st.sel == Launch::SEL_SK) && !fuse_now &&
         st.TM == 64 && pl->TM == 64 && pl->n_mtiles == 1 && pl->nslab == 1 && pl->n_entries == 1 && !pl->w_share &&
-        (pl->n_phases == 1 || pl->dual) && !L.pool_en && !L.endpool && L.concat < 0 && L.add_src < 0 && E.conv_tensor == E.out_tensor) {
+        (pl->n_phases == 1 || pl->dual) && !L.endpool && L.concat < 0 && L.add_src < 0 && (L.pool_en != 0) == (E.conv_tensor != E.out_tensor)) {
       Launch& s0 = lp.steps[0];
       const int hdr_used = round_up((5 + pl->n_phases) * 64 * 4, 1024);
       int R = 0, WS = 0; size_t lds = 0;
-      if (s0.kind == Launch::PREP && conv_first_fits(s0.prep, &R, &WS, &lds, hdr_used)) {
-        const ConvArgs& ca = st.conv;
+      const ConvArgs& ca = st.conv;
+      // ... and, with a 3x3 / stride 2 pool behind a ReLU (SqueezeNet 1.1's front: stride-2 conv1 + pool1), the pool as well
+      // (conv_first_pool_kernel: the conv map stays in LDS)
+      const bool plain = !L.pool_en && s0.kind == Launch::PREP && conv_first_fits(s0.prep, &R, &WS, &lds, hdr_used);
+      const bool pooled = L.pool_en && opts.first_pool && s0.kind == Launch::PREP && !ca.g.dbl_out && ca.g.y_nvalid == 64 &&
+                          conv_first_pool_fits(s0.prep, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW, ca.g.relu, hdr_used, &R, &WS, &lds);
+      if (plain || pooled) {
         FirstArgs& f = s0.first;
         f.w = ca.w; f.hdr = ca.hdr; f.y = ca.y; f.im = s0.prep.y;
         f.hdr_used = hdr_used; f.dual = ca.dual; f.relu = ca.g.relu; f.fast = ca.g.fast; f.dbl = ca.g.dbl_out;
         f.y_cp = ca.g.y_cp; f.y_off = ca.g.y_off; f.y_nvalid = ca.g.y_nvalid; f.keep = wp->keep_all ? 1 : 0;
+        f.pool = pooled ? 1 : 0;
+        if (pooled) {
+          const TensorPlan& to = T(E.out_tensor);
+          f.yp = base + to.offset; f.PH = L.PH; f.PW = L.PW; f.ppad = L.pool_pad; f.yp_cp = to.Cp; f.yp_off = E.out_off;
+        }
         s0.sel = Launch::SEL_FIRST; s0.layer = 0;
         continue;
       }
@@ -1093,7 +1104,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
   switch (st.kind) {
     case Launch::PREP: {
       PrepArgs pa = st.prep; pa.img = images; pa.src_is_q = images_are_q ? 1 : 0;
-      if (st.sel == Launch::SEL_FIRST) { FirstArgs f = st.first; f.p = pa; return launch_conv_first(f, stream); }
+      if (st.sel == Launch::SEL_FIRST) { FirstArgs f = st.first; f.p = pa; return f.pool ? launch_conv_first_pool(f, stream) : launch_conv_first(f, stream); }
       return launch_prep_input(pa, stream);
     }
     case Launch::POOL: return launch_maxpool(st.pool, stream);

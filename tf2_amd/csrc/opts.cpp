@@ -30,6 +30,7 @@ const OptSpec kOptSpecs[] = {
   {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
   {"fire", 1, "a fire module (squeeze + merged expands) as one launch: 0 never, 1 wherever it fits, 2 (default) on maps >= 28 wide"},
   {"first", 1, "a 3x3 / stride 1 first layer on the image in one launch with its input preparation: 1 / 0"},
+  {"first_pool", 1, "... a 3x3 first layer (stride 1 / 2) with a 3x3 / 2 max pool behind its ReLU, the pool included: 1 / 0"},
   {"c3_pool", 1, "a layer's 2x2 / 2 max pool inside its conv_c3 launch: 1 / 0"},
   {"c3_w9", 1, "conv_c3_w9_kernel: 0 never, 1 auto, 2 wherever allowed"},
   {"bneck_min", 1, "conv_bneck: smallest grid"}, {"stem", 1, "conv_stem: 1 auto, 0 never"}, {"stem_pool", 1, "conv1's pool in its launch"},

@@ -389,10 +389,17 @@ struct FirstArgs {
   int8_t* y;                   // the layer's output tensor
   int8_t* im;                  // the im2col tensor (written only with keep: per-layer parity runs read the quantised image back from it)
   int32_t hdr_used, dual, relu, fast, dbl, y_cp, y_off, y_nvalid, keep;
-  int32_t R, WS;               // set by the launcher: output rows per block, row stride of the LDS image tile
+  int32_t R, WS;               // set by the launcher: output (conv) rows per block, row stride of the LDS image tile
+  // conv_first_pool_kernel: the layer's 3x3 / stride 2 max pool in the same launch
+  int8_t* yp;                  // the pooled tensor
+  int32_t pool, PH, PW, ppad, yp_cp, yp_off;
+  int32_t PR;                  // set by the launcher: pooled rows per block
 };
 bool conv_first_fits(const PrepArgs& a, int* R_out, int* WS_out, size_t* lds_out, int hdr_used);
 int launch_conv_first(const FirstArgs& f, void* stream);
+bool conv_first_pool_fits(const PrepArgs& a, int pool_S, int pool_st, int pool_pad, int PH, int PW, int relu, int hdr_used,
+                          int* PR_out, int* WS_out, size_t* lds_out);
+int launch_conv_first_pool(const FirstArgs& f, void* stream);
 
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
