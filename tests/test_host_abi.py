@@ -223,13 +223,18 @@ def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     assert s[0]["lds_bytes"] <= 78 * 1024 and s[-1]["kernel"] == "conv_shift_fc_kernel"
     # merged rows (round 5): every fire module's expand1x1 | expand3x3 pair is ONE launch (PackLayer::merge_next) -- 24 launches, not 34,
     # none on the second row of a pair; merge=0 brings the separate rows back (its 64-channel 3x3 rows on 14 x 14 then take conv_c3)
-    # ... and an unpooled fire module (squeeze + merged expands) on a map >= 28 wide is ONE launch of row bands (conv_fire.hip): 20 launches
-    # (fire=1: the 14 x 14 modules as well, 16 -- measured slower; fire=0: 22; first_pool=0: the front as three launches, 24)
-    assert len(s) == 20 and [r["layer"] for r in s if "conv_fire" in r["kernel"]] == [1, 7]
+    # ... and a fire module (squeeze + merged expands) on a map >= 28 wide is ONE launch of row bands (conv_fire.hip; a pool behind the
+    # expands stays a launch of its own): 18 launches
+    # (fire=1: the 14 x 14 modules as well, 14 -- measured slower; fire_pool=0: only the unpooled modules, 20; fire=0: 22;
+    #  first_pool=0: the front as three launches, 24)
+    assert len(s) == 18 and [r["layer"] for r in s if "conv_fire" in r["kernel"]] == [1, 4, 7, 10] and [r["layer"] for r in s if "maxpool" in r["kernel"]] == [5, 11]
     set_opts(monkeypatch, fire="1")
     s2 = launches(cfg.squeezenet11_tables(), 32)
-    assert len(s2) == 16 and [r["layer"] for r in s2 if "conv_fire" in r["kernel"]] == [1, 7, 13, 16, 19, 22]
-    set_opts(monkeypatch, fire="0", first_pool="0")
+    assert len(s2) == 14 and [r["layer"] for r in s2 if "conv_fire" in r["kernel"]] == [1, 4, 7, 10, 13, 16, 19, 22]
+    set_opts(monkeypatch, fire="2", fire_pool="0")
+    s3 = launches(cfg.squeezenet11_tables(), 32)
+    assert len(s3) == 20 and [r["layer"] for r in s3 if "conv_fire" in r["kernel"]] == [1, 7]
+    set_opts(monkeypatch, fire="0", first_pool="0", fire_pool=None)
     s1 = launches(cfg.squeezenet11_tables(), 32)
     assert "im2col" in s1[0]["kernel"] and s1[0]["layer"] == -1 and "conv_pw" in s1[1]["kernel"] and "maxpool" in s1[2]["kernel"]      # (stride 2: its own input kernel)
     assert len(s1) == 24 and not {3, 6, 9, 12, 15, 18, 21, 24} & {r["layer"] for r in s1}

@@ -446,8 +446,8 @@ bool Net::bband_at(int l, int rows) const {
   return conv_bband_windows_ok(A.N, pack_layer(l)->dual, pack_layer(l + 1)->dual);
 }
 
-// Rows l (1x1 squeeze, ReLU), l + 1 and l + 2 (the merged expand1x1 | expand3x3 pair, PackLayer::merge_next) of an unpooled fire module
-// whose squeeze output nothing else reads: conv_fire.hip takes them as one launch
+// Rows l (1x1 squeeze, ReLU), l + 1 and l + 2 (the merged expand1x1 | expand3x3 pair, PackLayer::merge_next) of a fire module whose
+// squeeze output nothing else reads: conv_fire.hip takes them as one launch (a pool behind the expands follows as its own launch)
 bool Net::fire_at(int l) const {
   if (l < 0 || l + 2 >= nd.n_layers) return false;
   const tf2_layer_desc& A = layers[l]; const tf2_layer_desc& B = layers[l + 1];
@@ -455,7 +455,7 @@ bool Net::fire_at(int l) const {
   if (in_layout[l].Cp_in != A.C || A.C % 64 != 0 || in_layout[l].signed_in) return false;
   const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1); const PackLayer* p2 = pack_layer(l + 2);
   if (!p0 || !p1 || !p2 || p0->kind != KIND_MFMA || p1->kind != KIND_MFMA || p1->merge_next != l + 2 || p2->merged_into != l + 1) return false;
-  if (B.src != l || B.pool_en || B.endpool || B.add_src >= 0 || !B.relu) return false;
+  if (B.src != l || B.endpool || B.add_src >= 0 || !B.relu) return false;      // (a pool behind the expands: its own launch after the fire launch)
   for (int j = 0; j < nd.n_layers; j++)
     if (j != l + 1 && j != l + 2 && (layers[j].src == l || layers[j].add_src == l)) return false;      // the squeeze's tensor is not written
   if (p0->TM != 64 || p0->n_mtiles != 1 || (long)p0->n_entries != p0->nslab || !(p0->n_phases == 1 || p0->dual) || p0->w_share || p0->fuse_next > 0 || p0->fused_into >= 0) return false;
@@ -523,6 +523,7 @@ void Net::load_options() {
   o.first_fuse = (int)opt("first", o.first_fuse);
   o.first_pool = (int)opt("first_pool", o.first_pool);
   o.fire_mode = (int)opt("fire", o.fire_mode);
+  o.fire_pool = (int)opt("fire_pool", o.fire_pool);
   o.bneck_min_blocks = (long)opt("bneck_min", o.bneck_min_blocks);   // smallest grid that takes conv_bneck (default 200)
   o.stem_mode = (int)opt("stem", o.stem_mode);
   o.bgroup_min7 = (int)opt("bgroup_min7", o.bgroup_min7);    // smallest batch that takes the group launches of the 7 x 7 / 14 x 14 bottlenecks
@@ -800,7 +801,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       }
     }
     // a fire module (squeeze + the merged expands) as ONE launch of independent row bands (conv_fire.hip)
-    if (opts.fire_mode && fire_at(l) && (opts.fire_mode == 1 || L.W >= 28)) {
+    if (opts.fire_mode && fire_at(l) && (opts.fire_mode == 1 || L.W >= 28) &&
+        (!layers[l + 1].pool_en || opts.fire_pool == 2 || (opts.fire_pool == 1 && L.W >= 56))) {
       Launch s0, s1;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false)) return nullptr;
       const PackLayer* p1 = pack_layer(l + 1);
@@ -817,6 +819,8 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         if (conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, &f, nullptr)) {
           pair_done[l + 1] = 1;
           lp.steps.push_back(st);
+          const tf2_layer_desc L1 = exec_desc(l + 1);
+          if (L1.pool_en) { const TensorPlan& tc1 = T(wp->exec[l + 1].conv_tensor); pool_step(l + 1, tc1, base + tc1.offset, L1.OH, L1.OW); }
           continue;
         }
       }
