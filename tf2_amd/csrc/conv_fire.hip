@@ -66,6 +66,9 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
   const int n_p0 = (R + 2) * W;
   const long long pix_base = ((long long)img * H + r0) * W;
   const long long pix0 = pix_base - W;
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/fire_timeline.py: 100 MHz wall clock per phase
+#define FIRE_STAMP(i) do { if (dbg && (tid & 63) == 0) dbg[(i) + (wave == 7 ? 8 : 0)] = (long long)wall_clock64(); } while (0)
+  if (wave == 0 || wave == 7) FIRE_STAMP(0);
 
   // ---- prologue: pad fill of the halo tile, the input band, the headers ----
   for (int gi = wave; gi < NPL * (planeb >> 10); gi += 8) {
@@ -92,12 +95,16 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (wave == 0 || wave == 7) FIRE_STAMP(1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (wave == 0 || wave == 7) FIRE_STAMP(2);
 
   // ---- phase 0: the squeeze over the halo band; wave = (row tile wave % MT0, pixel tiles wave / MT0 + j * (8 / MT0)) ----
   {
     constexpr int WN0 = 8 / MT0;
+    int rot0 = bid & 7;
+    while (rot0 >= KS1) rot0 -= KS1;
     const int rt = wave % MT0, wn = wave / MT0;
     const unsigned a_lane_off = (unsigned)((lane & 31) * 64 + half * 16);
     const int wins = DUAL1 ? 2 : 1;
@@ -109,20 +116,47 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
       i32x16 acc, acc2;
 #pragma unroll
       for (int r = 0; r < 16; r++) { acc[r] = 0; acc2[r] = 0; }
-      for (int s = 0; s < KS1; s++) {
-        const int8_t* pu = a.w1 + ((((size_t)s * wins) << tms1) + rt * 32) * 64;
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(pu + a_lane_off), a1 = *reinterpret_cast<const i32x4*>(pu + a_lane_off + 32);
-        const int8_t* B = xin + (size_t)s * (NP0 * 64);
+      // weight fragments PD0 slabs ahead of their MFMAs in rotating register buffers (global -> registers: an L2 round trip per slab
+      // otherwise, 4-8 slabs on the 14 x 14 maps); loads unconditional, indices clamped (see phase 1)
+      constexpr int PD0 = DUAL1 ? 2 : 4, NWF = DUAL1 ? 4 : 2;      // (two-window squeeze: 16 registers per stage -- three stages would cost the second block per CU)
+      const int8_t* pu0 = a.w1 + (size_t)(rt * 32) * 64 + a_lane_off;
+      const size_t wstep = ((size_t)wins << tms1) * 64, lo_off = (size_t)64 << tms1;
+      i32x4 wr[PD0][NWF];
+      // Every block walks the slabs from its OWN starting slab (Z/2^32 sums commute: pe.cl:43): the blocks of a launch start together, and
+      // in lockstep each step's fragment was a miss for ALL of them at once (tools/fire_timeline.py: 4.6 us for eight slabs) -- rotated, the
+      // slabs are first touched in parallel by different blocks and everybody else's later steps hit
+      auto rot_s = [&](int sidx) { int k = (sidx < KS1 - 1 ? sidx : KS1 - 1) + rot0; return k >= KS1 ? k - KS1 : k; };
+      auto load_w = [&](i32x4 (&f)[NWF], int sidx) __attribute__((always_inline)) {
+        const int8_t* pu = pu0 + (size_t)rot_s(sidx) * wstep;
+        f[0] = *reinterpret_cast<const i32x4*>(pu); f[1] = *reinterpret_cast<const i32x4*>(pu + 32);
+        if constexpr (DUAL1) { f[2] = *reinterpret_cast<const i32x4*>(pu + lo_off); f[3] = *reinterpret_cast<const i32x4*>(pu + lo_off + 32); }
+      };
+      auto step0 = [&](int sidx, const i32x4 (&f)[NWF]) __attribute__((always_inline)) {
+        const int8_t* B = xin + (size_t)rot_s(sidx) * (NP0 * 64);
         const i32x4 b0 = *reinterpret_cast<const i32x4*>(B + bm), b1 = *reinterpret_cast<const i32x4*>(B + (bm ^ 32));
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[1], b1, acc, 0, 0, 0);
         if constexpr (DUAL1) {
-          const int8_t* pl = pu + ((size_t)64 << tms1);
-          const i32x4 l0 = *reinterpret_cast<const i32x4*>(pl + a_lane_off), l1 = *reinterpret_cast<const i32x4*>(pl + a_lane_off + 32);
-          acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(l0, b0, acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(l1, b1, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[2], b0, acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[3], b1, acc2, 0, 0, 0);
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < PD0; d++) load_w(wr[d], d);
+      int sb = 0;
+      for (; sb + PD0 <= KS1; sb += PD0) {
+#pragma unroll
+        for (int d = 0; d < PD0; d++) {
+          i32x4 cur[NWF];
+#pragma unroll
+          for (int q = 0; q < NWF; q++) cur[q] = wr[d][q];
+          load_w(wr[d], sb + d + PD0);
+          step0(sb + d, cur);
         }
       }
+#pragma unroll
+      for (int d = 0; d < PD0 - 1; d++)
+        if (sb + d < KS1) step0(sb + d, wr[d]);
       int a16[16];
       if constexpr (DUAL1) {
         const int* dsh = prm + (6 << tms1) + rt * 32 + 4 * half;          // dshift[1] behind rows | lo | dshift[0]
@@ -150,8 +184,10 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wave == 0 || wave == 7) FIRE_STAMP(3);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (wave == 0 || wave == 7) FIRE_STAMP(4);
 
   // ---- phase 1: the merged expand (3x3 / pad 1, N2 output channels) from the halo tile; wave = (row tiles wm + i * WM, pixel tiles wn + j * WN)
   {
@@ -177,10 +213,26 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
       for (int j = 0; j < JW; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0;
-      for (int e = e0; e < e1; e++) {
-        const int sl = a.ent2[e];
-        const int8_t* pu = a.w2 + (((size_t)e << tms2) + ro) * 64 + (lane & 31) * 64 + half * 16;
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(pu), a1 = *reinterpret_cast<const i32x4*>(pu + 32);
+      // the entry list and the weight fragments PD entries ahead of their MFMAs, in a rotating set of register buffers; the list is walked
+      // from the block's own starting entry (see phase 0).  Every load is unconditional -- entry indices are clamped to the list's last
+      // entry -- because hipcc drains the queue, vmcnt(0), at any join behind a conditional global load.
+      // (Measured, tools/fire_timeline.py, 14 x 14 / C 512: no ring 20 us per launch, one entry ahead 16 us, two or four: the same; the
+      //  first fill hoisted to the kernel's start: the same -- the chain moves into the prologue's wait.)
+      constexpr int PD = 2;
+      const int8_t* pw = a.w2 + (size_t)ro * 64 + (lane & 31) * 64 + half * 16;
+      i32x4 ra0[PD], ra1[PD]; int rsl[PD];
+      const int n_e = e1 > e0 ? e1 - e0 : 1;
+      int rot = bid & 15;
+      while (rot >= n_e) rot -= n_e;
+      auto ent = [&](int i) { int k = (i < n_e - 1 ? i : n_e - 1) + rot; return e0 + (k >= n_e ? k - n_e : k); };
+      auto ring_load = [&](int d, int i) __attribute__((always_inline)) {
+        const int en = ent(i);
+        const int8_t* pu = pw + (((size_t)en << tms2) * 64);
+        rsl[d] = a.ent2[en]; ra0[d] = *reinterpret_cast<const i32x4*>(pu); ra1[d] = *reinterpret_cast<const i32x4*>(pu + 32);
+      };
+#pragma unroll
+      for (int d = 0; d < PD; d++) ring_load(d, d);
+      auto step = [&](int sl, const i32x4& a0, const i32x4& a1) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
           // this lane's 16-byte K segment: g = 4 sl + 2 ks + half -> (tap, plane); K padding behind tap 8 has zero weights: any address
@@ -196,7 +248,21 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
 #pragma unroll
           for (int j = 0; j < JW; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ks ? a1 : a0, bf[j], acc[j], 0, 0, 0);
         }
+      };
+      int eb = e0;
+      for (; eb + PD <= e1; eb += PD) {                    // whole groups: branch-free
+#pragma unroll
+        for (int d = 0; d < PD; d++) {
+          const int sl = rsl[d];
+          const i32x4 a0 = ra0[d], a1 = ra1[d];
+          ring_load(d, eb - e0 + d + PD);
+          step(sl, a0, a1);
+        }
       }
+#pragma unroll
+      for (int d = 0; d < PD - 1; d++)                     // the list's last e1 - eb < PD entries: fetched already
+        if (eb + d < e1) step(rsl[d], ra0[d], ra1[d]);
+      if ((wave == 0 || wave == 7) && rt == wm) FIRE_STAMP(5);          // first row tile's MFMAs issued
       const int* prm = reinterpret_cast<const int*>(hdr2 + mt * hst2);
       const int chl = ch + 16 * half;
       const rq_i32x4 nores = {0, 0, 0, 0};
@@ -212,8 +278,11 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
         if (p < n_px && chl + 16 <= a.y_nvalid)
           *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
       }
+      if ((wave == 0 || wave == 7) && rt == wm) FIRE_STAMP(6);          // ... and requantised, stores issued
     }
   }
+  if (wave == 0 || wave == 7) FIRE_STAMP(7);
+#undef FIRE_STAMP
 }
 
 // geometry of a fire launch: rows per band (halo band and band within the 8 / 4 pixel tiles the waves cover), LDS bytes

@@ -816,6 +816,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.tm1 = s0.TM; f.tm2 = s1.TM; f.B = batch; f.H = L.H; f.W = L.W; f.Cin = L.C; f.Sp = round_up(L.N, 16); f.N2 = p1->Np;
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.dbl1 = c0.g.dbl_out; f.dual1 = c0.dual;
         f.keep_mid = wp->keep_all ? 1 : 0; f.mid_cp = c0.g.y_cp; f.y_cp = c1.g.y_cp; f.y_off = c1.g.y_off; f.y_nvalid = c1.g.y_nvalid;
+        f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
         if (conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, &f, nullptr)) {
           pair_done[l + 1] = 1;
           lp.steps.push_back(st);

@@ -376,6 +376,7 @@ struct FireArgs {
   int32_t relu1, relu2, fast1, fast2, dbl1, dual1, keep_mid;
   int32_t mid_cp, y_cp, y_off, y_nvalid;
   uint32_t w_m, g_m; int32_t w_s, g_s;           // set_fast_div(W), set_fast_div(Sp / 16)
+  long long* dbg;                                // tools/fire_timeline.py: 16 wall-clock stamps per block, or null
 };
 bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, FireArgs* f, size_t* lds_out);
 int launch_conv_fire(const FireArgs& a, void* stream);      // 1: shape not instantiated / does not fit
