@@ -22,6 +22,9 @@
  *     where they lie) -- tests/test_oracle_vs_ref.py -- and against golden
  *     vectors generated from them (tests/golden/).
  *   - tf2o_mul / tf2o_conv follow device/src/pe.cl:27-49,144-180 and are checked
+ *     LIVE against the reference's own MUL / DotProduct (pe.cl compiled as C in
+ *     place: oracle/ref_pe_probe.c -> oracle/_ref/libtf2ref_pe.so; every
+ *     (feature, code) pair, wrapping 16-channel dot products) and
  *     against golden conv sums produced by the reference's Python emulator
  *     (TransForm_Kit/Quantization/debug, Conv2dInt8) on inputs without -128.
  *   - requant / relu / max-pool / stride-2 subsampling / residual add / global

@@ -53,3 +53,46 @@ def test_feature_trans_fuzz(R):
     got = np.empty((9, 114, 114), np.float32)
     O.lib().tf2o_feature_trans(plane.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p))
     np.testing.assert_array_equal(got, want)
+
+
+# ---- the device code's PE arithmetic (pe.cl:27-49), compiled in place as C (oracle/ref_pe_probe.c, oracle/Makefile `ref`) ----
+PE_SO = os.path.join(os.path.dirname(REF_SO), "libtf2ref_pe.so")
+
+
+@pytest.fixture(scope="module")
+def PE():
+    if not os.path.exists(PE_SO):
+        pytest.skip("oracle/_ref/libtf2ref_pe.so not built")
+    L = C.CDLL(PE_SO)
+    L.tf2ref_pe_mul.restype = C.c_int
+    L.tf2ref_pe_mul.argtypes = [C.c_int, C.c_int]
+    L.tf2ref_pe_dot.restype = C.c_int
+    L.tf2ref_pe_dot.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
+def test_pe_mul_every_feature_and_code(PE):
+    """tf2o_mul == the reference's own MUL (pe.cl:27-40) on ALL 256 x 256 (feature, filter code) pairs: the zero flag (bit 6), the sign flag
+    with the -128 quirk ((int8)(-x) keeps -128), five-bit shifts up to 31 with the int32 wrap of `feature << filter`."""
+    for x in range(-128, 128):
+        for code in range(256):
+            assert O.mul(x, code) == PE.tf2ref_pe_mul(x, code), (x, hex(code))
+    assert PE.tf2ref_pe_mul(-128, 0x83) == -1024 == PE.tf2ref_pe_mul(-128, 0x03) and PE.tf2ref_pe_mul(127, 0x14) == 133169152   # SURVEY.md section 8c
+
+
+def test_pe_dot_product_and_conv_core(PE):
+    """The reference's DotProduct (pe.cl:42-49: C_VECTOR = 16 MULs summed in an int, i.e. mod 2^32) against the oracle's convolution core on
+    the same 16 channels (a 1x1 layer of one output channel, bias 0): random vectors, and vectors built to overflow int32 (shift 31 / 30
+    codes on +-127 / -128 features)."""
+    assert PE.tf2ref_pe_c_vector() == 16
+    rng = np.random.default_rng(11)
+    for trial in range(3000):
+        x = rng.integers(-128, 128, 16).astype(np.int8)
+        if trial % 3 == 0:
+            codes = (rng.integers(24, 32, 16) | (rng.integers(0, 2, 16) << 7)).astype(np.uint8)        # long shifts: the sum wraps
+            x = rng.choice(np.array([-128, -127, 127], np.int8), 16)
+        else:
+            codes = rng.integers(0, 256, 16).astype(np.uint8)
+        ref = PE.tf2ref_pe_dot(x.ctypes.data, codes.ctypes.data)
+        acc = O.conv(x.reshape(16, 1, 1), codes.reshape(1, 16, 1, 1), np.zeros(1, np.int32))
+        assert int(acc.reshape(-1)[0]) == ref, (trial, x.tolist(), codes.tolist())
