@@ -24,12 +24,13 @@ def test_every_counted_wait_is_covered_on_every_path(isa_files):
         bad, report = vmcnt_check.check_file(f, verbose=False)
         assert bad == 0, "\n".join(r for r in report if r.startswith("BAD"))
         n_waits += len(report)
-    # every instantiation the launchers can select is in the assembly: 8 band kernels, 12 halo-tile kernels + the one-slab kernel
+    # every instantiation the launchers can select is in the assembly: 8 band kernels, the halo-tile kernels (with / without the 2x2 pool
+    # epilogue) + the one-slab kernel in both forms
     kernels = {}
     for f in isa_files:
         kernels.update(vmcnt_check.parse_kernels(f))
     assert sum("conv_bband_kernel" in k for k in kernels) == 8
-    assert sum("conv_c3_kernel" in k for k in kernels) >= 10 and sum("conv_c3_w9_kernel" in k for k in kernels) == 1
+    assert sum("conv_c3_kernel" in k for k in kernels) >= 10 and sum("conv_c3_w9_kernel" in k for k in kernels) == 2
     assert n_waits >= 40
 
 
