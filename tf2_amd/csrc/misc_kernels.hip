@@ -291,7 +291,7 @@ __device__ __forceinline__ void fill_image_tile(const PrepArgs& a, int8_t* img, 
           (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
     }
   } else {
-    // rows that are not 16-byte aligned (227-wide images): a wave takes a tile line at a time, four lines' loads (dword / byte per lane,
+    // rows that are not 16-byte aligned (227-wide images): a wave takes a tile line at a time, five lines' loads (dword / byte per lane,
     // a line = <= 4 coalesced loads per 256 columns) in flight before the first is quantised -- the per-element walk of the first version
     // (one dependent load per thread and trip, two divisions by run-time widths each) was 20 of that kernel's 34 us
     static_assert(NT % 64 == 0, "whole waves");
