@@ -1066,8 +1066,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const ConvArgs& ca = st.conv;
       // ... and, with a 3x3 / stride 2 pool behind a ReLU (SqueezeNet 1.1's front: stride-2 conv1 + pool1), the pool as well
       // (conv_first_pool_kernel: the conv map stays in LDS)
-      const bool plain = !L.pool_en && s0.kind == Launch::PREP && conv_first_fits(s0.prep, &R, &WS, &lds, hdr_used);
-      const bool pooled = L.pool_en && opts.first_pool && s0.kind == Launch::PREP && !ca.g.dbl_out && ca.g.y_nvalid == 64 &&
+      // (the kernels index with 32 bits: the launchers refuse batches beyond that, so the plan keeps the separate launches there)
+      const bool idx32 = (long long)batch * L.OH * L.OW * 64 < (1ll << 31) && (long long)batch * 3 * nd.image_h * nd.image_w < (1ll << 31);
+      const bool plain = idx32 && !L.pool_en && s0.kind == Launch::PREP && conv_first_fits(s0.prep, &R, &WS, &lds, hdr_used);
+      const bool pooled = idx32 && L.pool_en && opts.first_pool && s0.kind == Launch::PREP && !ca.g.dbl_out && ca.g.y_nvalid == 64 &&
                           conv_first_pool_fits(s0.prep, L.pool_S, L.pool_st, L.pool_pad, L.PH, L.PW, ca.g.relu, hdr_used, &R, &WS, &lds);
       if (plain || pooled) {
         FirstArgs& f = s0.first;
