@@ -86,6 +86,9 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   const int n_px = rows * W;
   const long long pix_base = ((long long)img * a.H + r0) * W;      // NHWC pixel index of tile pixel 0 (rows are contiguous)
 
+  long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/bneck_timeline.py: 100 MHz wall clock per phase
+#define BN_STAMP(i) do { if (dbg && (wave == 0 || wave == 7) && lane == 0) dbg[(i) + (wave == 7 ? 8 : 0)] = (long long)wall_clock64(); } while (0)
+  BN_STAMP(0);
   // ---- prologue: headers and the halo tile by LDS-DMA, residual tiles and the first weight fragments by ordinary loads ----
   {
     const int8_t* h1 = reinterpret_cast<const int8_t*>(a.hdr1) + lane * 16;
@@ -178,8 +181,10 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   };
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BN_STAMP(1);
   __builtin_amdgcn_s_barrier();                          // headers + halo tile complete in every wave
   asm volatile("" ::: "memory");
+  BN_STAMP(2);
 
   // ---- phase 1: the 3x3 over the halo tile; step e = (tap t, slab s) -----------------------------------------------------
   auto step1 = [&](auto v_c) {
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
     __builtin_amdgcn_sched_barrier(0);                   // steps stay in order: the unrolled loop must not pile up loads
   };
   bn_static_for<0, NW1 * NE1>(step1);
+  BN_STAMP(3);
   // the expand's first weight fragments and the first residual tile are on their way while the 3x3 is requantised
   // phase 2 rotates the same three buffers from index 0 again (phase 1 has consumed all of its fragments)
   Afr& g0 = f0;
@@ -251,8 +257,10 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[j][r] = 0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BN_STAMP(4);
   __builtin_amdgcn_s_barrier();                          // the mid tile is complete
   asm volatile("" ::: "memory");
+  BN_STAMP(5);
 
   // ---- phase 2: four passes of the 1x1 expand over the mid tile ------------------------------------------------------------
   int bm[NTN];
@@ -316,10 +324,13 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
       for (int j = 0; j < NTN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0;
+      if (mt == 0) BN_STAMP(6);                          // first pass requantised, stores issued
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   bn_static_for<0, kBneckPasses * NV2>(step2);
+  BN_STAMP(7);
+#undef BN_STAMP
 }
 
 size_t conv_bneck_lds_bytes(int TM, int TN, int R, int W, size_t hdr1_used, size_t hdr2_used) {

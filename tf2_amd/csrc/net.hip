@@ -991,6 +991,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       f.zero = ca.zero; f.keep_mid = wp->keep_all ? 1 : 0; f.dbl_mid = pl->off_dbl != 0; f.dbl_out = pb->off_dbl != 0;
       f.rnn = res_nonneg_single_clamp(pl->fuse_next) ? 1 : 0;
       f.B = batch; f.H = L.H; f.W = L.W; f.probe = opts.flags;
+      f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
       set_fast_div((uint32_t)L.W, &f.w_m, &f.w_s); set_fast_div((uint32_t)(L.W + 2), &f.wp_m, &f.wp_s);
       const int TN = pl->TM == 64 ? 256 : 128;      // pixel capacity of a block (wave tile 32 x 64)
       f.R = std::min(TN / L.W, L.H);

@@ -232,6 +232,7 @@ struct BneckArgs {
   int32_t probe;             // timing probes (ConvGeom::flags of the pair; read by -DTF2_PROBES builds only)
   int32_t ymid_cp, y_cp, y_off, y_nvalid, res_cp, res_off;
   uint32_t w_m, wp_m; int32_t w_s, wp_s;     // set_fast_div(W), set_fast_div(W + 2): the pixel decodes without a run-time division
+  long long* dbg;            // tools/bneck_timeline.py: 16 wall-clock stamps per block (waves 0 and 7), or null
 };
 
 // conv_bgroup.hip: an identity bottleneck of a small map (1x1 reduce C -> M, 3x3 / 1 / pad 1 M -> M, 1x1 expand M -> C + residual)
