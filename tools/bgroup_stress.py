@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stress of the group launches (TF2_AMD_BGROUP=1): many back-to-back steps at several batch sizes, logits against the plain
+"""Stress of the group launches (option bgroup=1, the default one batch at a time): many back-to-back steps at several batch sizes, logits against the plain
 launch sequence every time."""
 import os, sys, time
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of one conv_bgroup launch (TF2_AMD_BGROUP=1): per block, 100 MHz wall-clock stamps at the phase boundaries."""
+"""Phase timeline of one conv_bgroup launch (option bgroup=1, the default one batch at a time): per block, 100 MHz wall-clock stamps at the phase boundaries."""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -19,9 +19,7 @@ t = cfg.resnet50_tables()
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device=dev)
 x = torch.from_numpy(synth.synth_images(t, 32, 100)).to(dev)
-sts = streams.partitioned_streams(nfl, dev) if nfl > 1 and hasattr(streams, "partitioned_streams") else None
-if not sts:
-    sts = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else [torch.cuda.current_stream(dev)]
+sts = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else [torch.cuda.current_stream(dev)]
 rns = [network.Runner(None, net) for _ in range(nfl)]
 for st, rn in zip(sts, rns):
     with torch.cuda.stream(st):
