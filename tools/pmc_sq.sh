@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes only (instruction mix / pipe activity per conv launch); env (TF2_AMD_P ...) is inherited
+# SQ counter passes only (instruction mix / pipe activity per conv launch); the option string TF2_AMD_OPTS is inherited
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc; mkdir -p $R/gpurun_out/pmc

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a step's time go, one batch at a time and with four batches in flight?  Runs ResNet50 with all layers but one
-stage left out (probe build: TF2_AMD_SKIP_LAYERS; results wrong, durations only)."""
+stage left out (probe build: option skip_layers=lo-hi; results wrong, durations only)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
