@@ -1,0 +1,129 @@
+"""Randomised layer programs through the C-ABI: every layer of seeded random networks -- first layers of both strides with and without
+a pool, pointwise / 3x3 / strided / dilated rows, bottleneck triples with residuals, independent pools, odd map sizes and channel
+counts -- against the oracle (GPU), and (without a device) that every such program packs and yields a launch plan in both modes.
+The shapes are drawn so that the kernel SELECTION code is exercised on geometry the BASELINE networks never produce: maps that do not
+divide into tiles, channel counts that are not multiples of 64, rows that qualify for a fused launch by a hair or miss it by one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tf2_amd import config as cfg, network, synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+SEEDS = list(range(40))
+
+
+def random_program(seed: int) -> cfg.NetTables:
+    rng = np.random.default_rng(9000 + seed)
+    hw = int(rng.integers(17, 81))
+    b = cfg._B(f"fuzz{seed}", image=(3, hw, hw), first_filter=3)
+    widths = [16, 24, 32, 48, 64, 96, 128, 192, 256]
+
+    def out_hw(h, k, s, p, d=1):
+        return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+    def maybe_pool(h):
+        r = rng.random()
+        if r < 0.25 and h >= 5:
+            pad = int(rng.integers(0, 2))
+            ph = -(-(h + 2 * pad - 3) // 2) + 1                     # ceil mode
+            if (ph - 1) * 2 - pad >= h:
+                ph -= 1
+            return (3, 2, pad, ph, ph), ph
+        if r < 0.4 and h >= 4:
+            return (2, 2, 0, h // 2, h // 2), h // 2
+        return None, h
+
+    # first layer: 3x3 on the image, stride 1 or 2, pad 0 or 1, sometimes pooled
+    s0, p0 = int(rng.integers(1, 3)), int(rng.integers(0, 2))
+    if s0 == 2 and hw % 2 == 0:
+        hw += 1          # (stride-2 windows then cover every column: tf2_net_read_layer(-1) rebuilds the image from the im2col tensor, which
+                         #  holds no pixel that no window reads)
+        b.image = (3, hw, hw)
+    n0 = int(rng.choice([16, 32, 64]))
+    h = out_hw(hw, 3, s0, p0)
+    pool, hp = maybe_pool(h)
+    cur = b.conv(-1, 3, hw, hw, n0, 3, s0, p0, relu=1, pool=pool)
+    C, H = n0, hp
+    n_blocks = int(rng.integers(3, 9))
+    for _ in range(n_blocks):
+        kind = rng.choice(["pw", "c3", "c3s2", "dil", "bottleneck", "bottleneck_proj", "ipool"])
+        if kind == "pw":
+            N = int(rng.choice(widths)); pool, hp = maybe_pool(H)
+            cur = b.conv(cur, C, H, H, N, 1, 1, 0, relu=int(rng.integers(0, 2)) if pool is None else 1, pool=pool)
+            C, H = N, hp
+        elif kind == "c3":
+            N = int(rng.choice(widths)); pool, hp = maybe_pool(H)
+            cur = b.conv(cur, C, H, H, N, 3, 1, 1, relu=1, pool=pool, bias=int(rng.integers(0, 2)), bn=1)
+            C, H = N, hp
+        elif kind == "c3s2" and H >= 6:
+            N = int(rng.choice(widths))
+            cur = b.conv(cur, C, H, H, N, 3, 2, 1, relu=1)
+            C, H = N, out_hw(H, 3, 2, 1)
+        elif kind == "dil" and H >= 7:
+            N = int(rng.choice(widths))
+            cur = b.conv(cur, C, H, H, N, 3, 1, 2, relu=1, dil=2)
+            C = N
+        elif kind in ("bottleneck", "bottleneck_proj"):
+            mid = int(rng.choice([16, 32, 64, 128])); s = 2 if (kind == "bottleneck_proj" and H >= 6 and rng.random() < 0.5) else 1
+            out = C if kind == "bottleneck" else int(rng.choice(widths))
+            Ho = out_hw(H, 3, s, 1)
+            sc = cur if kind == "bottleneck" else b.conv(cur, C, H, H, out, 1, s, 0, relu=0)
+            if kind == "bottleneck" and s != 1:
+                continue
+            a = b.conv(cur, C, H, H, mid, 1, 1, 0, relu=1)
+            m = b.conv(a, mid, H, H, mid, 3, s, 1, relu=1)
+            cur = b.conv(m, mid, Ho, Ho, out, 1, 1, 0, relu=0, add=sc, add_relu=1)
+            C, H = out, Ho
+        elif kind == "ipool" and H >= 5:
+            ph = (H + 2 - 3) // 2 + 1
+            cur = b.pool_only(cur, C, H, H, (3, 2, 1, ph, ph))
+            H = ph
+    # head: global average over the final map + a classifier
+    cur = b.conv(cur, C, H, H, 64, 1, 1, 0, relu=0, endpool=1, endpool_hw=H * H) if H > 1 else cur
+    b.conv(cur, 64 if H > 1 else C, 1, 1, 10, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+def _q_and_model(t, seed):
+    q = synth.synth_q_values(t, seed, spread=int(seed % 3))
+    return q, synth.synth_model(t, q, seed)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_programs_pack_and_plan(seed):
+    """No device: the program parses, packs (mode 0) and both launch plans exist at three batch sizes; every conv row is covered by
+    exactly one launch chain (no row skipped, none issued twice)."""
+    t = random_program(seed)
+    q, model = _q_and_model(t, seed)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+    n_rows = len(cfg.build_plan(t))
+    for batch in (1, 3, 32):
+        for conc in (0, 1):
+            rows = net.describe_launches(batch, conc)
+            assert rows and all(r["grid"] >= 1 for r in rows)
+            firsts = [r["layer"] for r in rows]
+            assert firsts == sorted(firsts) and firsts[-1] <= n_rows - 1, firsts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_programs_every_layer_against_the_oracle(seed):
+    from test_gpu_parity import Rig
+    t = random_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, 0)
+    b = 1 + seed % 4
+    x = synth.synth_images(t, b, seed, kind="int8" if seed % 2 else "float")
+    want = rig.check_all_layers(x)
+    # the plan of a plain run (nothing kept), one batch at a time and as if batches were in flight
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    for conc in (0, 1):
+        got = rig.runner.run_batch(xd, concurrency=conc)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")
