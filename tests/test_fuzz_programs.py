@@ -127,3 +127,151 @@ def test_random_programs_every_layer_against_the_oracle(seed):
         got = rig.runner.run_batch(xd, concurrency=conc)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")
+
+
+# ---- the fused / specialised kernels on geometry of the test's choosing (their thresholds lowered through test-only options) -------------
+def random_body_program(seed: int) -> cfg.NetTables:
+    """VGG-like 3x3 rows (conv_c3 / conv_c3_w9, pooled and not), ResNet-like (3x3 + expand + residual) pairs (conv_bneck), a whole-window
+    layer (conv_fc with 4-bit codes) -- at map sizes and channel counts drawn at random, 64-byte-aligned channels so that the kernels
+    qualify."""
+    rng = np.random.default_rng(7000 + seed)
+    hw = int(rng.integers(20, 71))
+    b = cfg._B(f"body{seed}", image=(3, hw, hw), first_filter=3)
+    C = int(rng.choice([64, 128]))
+    pool = None
+    H = hw
+    if rng.random() < 0.5:
+        pool, H = (2, 2, 0, hw // 2, hw // 2), hw // 2
+    cur = b.conv(-1, 3, hw, hw, C, 3, 1, 1, relu=1, pool=pool, bias=1, bn=0)
+    for _ in range(int(rng.integers(2, 6))):
+        kind = rng.choice(["c3", "c3pool", "bneck", "bneck"])
+        if kind in ("c3", "c3pool"):
+            N = int(rng.choice([64, 128, 256]))
+            pool, hp = None, H
+            if kind == "c3pool" and H >= 8:
+                pool, hp = (2, 2, 0, H // 2, H // 2), H // 2
+            cur = b.conv(cur, C, H, H, N, 3, 1, 1, relu=1, pool=pool, bias=int(rng.integers(0, 2)), bn=int(rng.integers(0, 2)))
+            C, H = N, hp
+        else:
+            mid = int(rng.choice([64, 128]))
+            out = 4 * mid
+            sc = b.conv(cur, C, H, H, out, 1, 1, 0, relu=0) if C != out else cur
+            a = b.conv(cur, C, H, H, mid, 1, 1, 0, relu=1)
+            m = b.conv(a, mid, H, H, mid, 3, 1, 1, relu=1)
+            cur = b.conv(m, mid, H, H, out, 1, 1, 0, relu=0, add=sc, add_relu=1)
+            C = out
+    # a whole-window layer (k = H, pad 0 -> 1 x 1) with a long K, then the classifier
+    if H <= 9 and C * H * H >= 8 * 64:
+        cur = b.conv(cur, C, H, H, 128, H, 1, 0, relu=1, bias=1, bn=0)
+        C, H = 128, 1
+    else:
+        cur = b.conv(cur, C, H, H, 64, 1, 1, 0, relu=0, endpool=1, endpool_hw=H * H)
+        C, H = 64, 1
+    b.conv(cur, C, 1, 1, 16, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+BODY_SEEDS = list(range(24))
+_BODY_OPTS = dict(c3_min="1", c3_min256="1", bneck_min="1", fc_min="8")
+
+
+@pytest.mark.parametrize("seed", BODY_SEEDS)
+def test_random_body_programs_pack_and_plan(seed, monkeypatch):
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, **_BODY_OPTS)
+    t = random_body_program(seed)
+    q, model = _q_and_model(t, seed)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+    for batch in (1, 2, 32):
+        for conc in (0, 1):
+            assert net.describe_launches(batch, conc)
+
+
+def test_random_body_programs_reach_the_specialised_kernels(monkeypatch):
+    """(the generator is only worth its name if the kernels it aims at are selected)"""
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, **_BODY_OPTS)
+    seen = set()
+    for seed in BODY_SEEDS:
+        t = random_body_program(seed)
+        q, model = _q_and_model(t, seed)
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+        seen |= {r["kernel"].split("<")[0].split(" ")[0] for r in net.describe_launches(2, 1)}
+    assert {"conv_c3_kernel", "conv_bneck_kernel", "conv_first_kernel"} <= seen, seen
+    assert any(k.startswith("fc") for k in seen), seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", BODY_SEEDS)
+def test_random_body_programs_every_layer_against_the_oracle(seed, monkeypatch):
+    from test_gpu_parity import Rig
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, **_BODY_OPTS)
+    t = random_body_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, 0)
+    b = 1 + seed % 3
+    x = synth.synth_images(t, b, seed, kind="int8" if seed % 2 else "float")
+    want = rig.check_all_layers(x)
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    for conc in (0, 1):
+        got = rig.runner.run_batch(xd, concurrency=conc)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")
+
+
+# ---- SqueezeNet-shaped programs: fire modules of random widths on the 56 / 28 / 14 maps conv_fire.hip takes (fire=1: wherever it fits) ----
+def random_fire_program(seed: int) -> cfg.NetTables:
+    rng = np.random.default_rng(5000 + seed)
+    n1 = int(rng.choice([64, 128]))
+    fires = []
+    h = 56
+    for _ in range(int(rng.integers(2, 6))):
+        sq, ex = int(rng.choice([16, 32, 48, 64])), int(rng.choice([64, 128, 192, 256]))
+        pool_after = bool(h > 14 and rng.random() < 0.4)
+        fires.append((sq, ex, pool_after))
+        if pool_after:
+            h //= 2
+    return cfg.fire_net_tables(56, (n1, 3, 1, 1, False), tuple(fires), 40, 16, f"fire{seed}")
+
+
+FIRE_SEEDS = list(range(12))
+
+
+def test_random_fire_programs_reach_the_fire_kernel(monkeypatch):
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, fire="1")
+    shapes = set()
+    for seed in FIRE_SEEDS:
+        t = random_fire_program(seed)
+        q = synth.synth_q_values(t, 6, spread=1)                 # (bench.py's draw: one-window merged expands)
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(synth.synth_model(t, q, 6)); net.Pack(0)
+        for conc in (0, 1):
+            rows = net.describe_launches(3, conc)
+            assert rows
+            shapes |= {r["kernel"].split(" (")[0] for r in rows if "conv_fire" in r["kernel"]}
+    assert len(shapes) >= 6, shapes                              # several (map, C, S, N) instantiations / geometries
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", FIRE_SEEDS)
+def test_random_fire_programs_every_layer_against_the_oracle(seed, monkeypatch):
+    from test_gpu_parity import Rig
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, fire="1")
+    t = random_fire_program(seed)
+    q = synth.synth_q_values(t, 6, spread=1)
+    rig = Rig(t, q, synth.synth_model(t, q, 6), 0)
+    b = 1 + seed % 3
+    x = synth.synth_images(t, b, seed, kind="int8" if seed % 2 else "float")
+    want = rig.check_all_layers(x)
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    for conc in (0, 1):
+        got = rig.runner.run_batch(xd, concurrency=conc)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")

@@ -836,6 +836,10 @@ def ssd300_tables(image_hw: int = 300, num_classes: int = 21, width_div: int = 1
     return b.tables()
 
 
+SQUEEZENET11_FIRES = ((16, 64, False), (16, 64, True), (32, 128, False), (32, 128, True),
+                      (48, 192, False), (48, 192, False), (64, 256, False), (64, 256, False))
+
+
 def squeezenet11_tables(image_hw: int = 227) -> NetTables:
     """SqueezeNet 1.1 as in TransForm_Kit/Quantization/models/SqueezeNet/SqueezeNet.py:17-113
     (conv+BN everywhere except final_conv; fire = squeeze1x1 -> expand1x1 || expand3x3,
@@ -843,6 +847,12 @@ def squeezenet11_tables(image_hw: int = 227) -> NetTables:
     signed input, which the engine runs on the shift-accumulate kernel).  Concats use the reference's branch-tail encoding
     (kBranchTail/kConcatLayer/kNStart/kNEnd); a pool after a concat is
     distributed onto the branch tails as GoogLeNet's header does."""
+    return fire_net_tables(image_hw, (64, 3, 2, 0, True), SQUEEZENET11_FIRES, 1000, 128, "squeezenet1_1")
+
+
+def fire_net_tables(image_hw: int, conv1, fires, classes: int, fc_out: int, name: str) -> NetTables:
+    """A SqueezeNet-shaped program: conv1 = (N, k, stride, pad, pooled) on the 3-channel image, fire modules (squeeze, expand, pool after),
+    final conv to `classes` + global average, fc to `fc_out` (squeezenet11_tables is the 1.1 instance; tests draw others)."""
     rows: List[dict] = []
     n_concat = 0
 
@@ -852,12 +862,11 @@ def squeezenet11_tables(image_hw: int = 227) -> NetTables:
     def ceil_pool(h):
         return -(-(h - 3) // 2) + 1
 
-    H1 = (image_hw - 3) // 2 + 1
-    P1 = ceil_pool(H1)
-    add(src=("L", -1), C=3, H=image_hw, N=64, k=3, stride=2, pad=0, pool=(3, 2, 0, P1, P1), cat=None)
-    cur, C, H = ("L", 0), 64, P1
-    fires = [(16, 64, False), (16, 64, True), (32, 128, False), (32, 128, True),
-             (48, 192, False), (48, 192, False), (64, 256, False), (64, 256, False)]
+    N1, k1, s1, p1, pooled1 = conv1
+    H1 = (image_hw + 2 * p1 - k1) // s1 + 1
+    P1 = ceil_pool(H1) if pooled1 else H1
+    add(src=("L", -1), C=3, H=image_hw, N=N1, k=k1, stride=s1, pad=p1, pool=(3, 2, 0, P1, P1) if pooled1 else None, cat=None)
+    cur, C, H = ("L", 0), N1, P1
     for sq, ex, pool_after in fires:
         s = add(src=cur, C=C, H=H, N=sq, k=1, stride=1, pad=0, pool=None, cat=None)
         Ho = ceil_pool(H) if pool_after else H
@@ -867,12 +876,12 @@ def squeezenet11_tables(image_hw: int = 227) -> NetTables:
         cur, C, H = ("C", n_concat), 2 * ex, Ho
         n_concat += 1
     # final_conv (bias, no BN, NO ReLU: SqueezeNet.py:101-102) + global average, then fc 1000 -> 128 (no bias) + BN (:103-108)
-    fin = add(src=cur, C=C, H=H, N=1000, k=1, stride=1, pad=0, pool=None, cat=None, bias=1, bn=0, relu=0, endpool=H * H)
-    add(src=("L", fin), C=1000, H=1, N=128, k=1, stride=1, pad=0, pool=None, cat=None, bias=0, bn=1, relu=0)
+    fin = add(src=cur, C=C, H=H, N=classes, k=1, stride=1, pad=0, pool=None, cat=None, bias=1, bn=0, relu=0, endpool=H * H)
+    add(src=("L", fin), C=classes, H=1, N=fc_out, k=1, stride=1, pad=0, pool=None, cat=None, bias=0, bn=1, relu=0)
     n = len(rows)
     t = _blank_tables(n)
     t.update(INPUT_IMAGE_C=3, INPUT_IMAGE_H=image_hw, INPUT_IMAGE_W=image_hw, FIRST_FILTER_SIZE=3,
-             NUM_Q_LAYERS=n + 1 + n_concat, xConv1Rewrite=0, MAX_OUT_CHANNEL=1000, xName="squeezenet1_1",
+             NUM_Q_LAYERS=n + 1 + n_concat, xConv1Rewrite=0, MAX_OUT_CHANNEL=max([r["N"] for r in rows] + [r["cat"][2] for r in rows if r["cat"]]), xName=name,
              xNumConcat=n_concat)
     for i, r in enumerate(rows):
         k, s, pad = r["k"], r["stride"], r["pad"]
