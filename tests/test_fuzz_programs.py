@@ -275,3 +275,30 @@ def test_random_fire_programs_every_layer_against_the_oracle(seed, monkeypatch):
         got = rig.runner.run_batch(xd, concurrency=conc)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")
+
+
+# ---- the same random programs through the other packed forms and forced kernels --------------------------------------------------------
+_VARIANTS = [("mode", 1), ("mode", 2), ("nofast", "1"), ("nodual", "1"), ("nodbl", "1"), ("nosemi", "1"), ("sk", "1"), ("sk", "2"), ("pw", "0"),
+             ("im2col0", "0"), ("first", "0"), ("first_pool", "0"), ("dense", "0"), ("nofuse", "1"), ("share", "0"), ("no4bit", "1")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(32))
+def test_random_programs_other_packed_forms(i, monkeypatch):
+    """pack modes 1 (the north-star split: k > 1 on the shift kernel) and 2 (shift kernel everywhere), generic requantisation, Horner
+    windows, no doubled channels, forced / forbidden split-K, no pointwise kernel, plain first layers, table gathers, ...: one switch per
+    case, two random programs each."""
+    from test_gpu_parity import Rig
+    from tests.conftest import set_opts
+    name, val = _VARIANTS[i % len(_VARIANTS)]
+    seed = 100 + i
+    mode = 0
+    if name == "mode":
+        mode = val
+    else:
+        set_opts(monkeypatch, **{name: val})
+    t = random_program(seed) if i % 3 else random_body_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, mode)
+    x = synth.synth_images(t, 1 + i % 3, seed, kind="int8" if i % 2 else "float")
+    rig.check_all_layers(x)
