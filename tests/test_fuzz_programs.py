@@ -302,3 +302,20 @@ def test_random_programs_other_packed_forms(i, monkeypatch):
     rig = Rig(t, q, model, mode)
     x = synth.synth_images(t, 1 + i % 3, seed, kind="int8" if i % 2 else "float")
     rig.check_all_layers(x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 5, 8, 13, 21])
+@pytest.mark.parametrize("graph", [False, True])
+def test_random_body_programs_with_four_batches_in_flight(seed, graph, monkeypatch):
+    """The LDS-DMA kernels at drawn geometry under the load they are built for: four runners of one handle on four streams, eight rotating
+    inputs, 24 steps with no synchronisation in between (launched / replayed from HIP graphs), every step of the last four against a serial
+    run, the serial run against the oracle."""
+    from test_gpu_configs import _in_flight
+    from test_gpu_parity import Rig
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, **_BODY_OPTS)
+    t = random_body_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, 0)
+    _in_flight(rig, 3 + seed % 3, 8, 24, graph, 400 + seed)
