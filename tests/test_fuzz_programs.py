@@ -319,3 +319,24 @@ def test_random_body_programs_with_four_batches_in_flight(seed, graph, monkeypat
     q, model = _q_and_model(t, seed)
     rig = Rig(t, q, model, 0)
     _in_flight(rig, 3 + seed % 3, 8, 24, graph, 400 + seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,batch", [(2, 32), (9, 17), (16, 33), (20, 64)])
+def test_random_body_programs_at_full_batches(seed, batch, monkeypatch):
+    """... at batches that fill the chip (grids in several rounds, persistent blocks walking several tiles, conv_fc's chunks of 32 images):
+    logits of every image against the oracle, both launch plans."""
+    from test_gpu_parity import Rig
+    from tests.conftest import set_opts
+    set_opts(monkeypatch, **_BODY_OPTS)
+    t = random_body_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, 0)
+    x = synth.synth_images(t, batch, seed)
+    want = rig.ref.logits(rig.ref.run(x))
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    for conc in (0, 1):
+        got = rig.runner.run_batch(xd, concurrency=conc)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"concurrency {conc}")
