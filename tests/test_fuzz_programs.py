@@ -340,3 +340,78 @@ def test_random_body_programs_at_full_batches(seed, batch, monkeypatch):
         got = rig.runner.run_batch(xd, concurrency=conc)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"concurrency {conc}")
+
+
+# ---- inception-shaped programs: concat tensors written by branch tails, independent stride-1 pools, 5x5 and dilated branches --------------
+def random_inception_program(seed: int) -> cfg.NetTables:
+    rng = np.random.default_rng(3000 + seed)
+    hw = int(rng.integers(20, 57))
+    b = cfg._B(f"incep{seed}", image=(3, hw, hw), first_filter=3)
+    C = int(rng.choice([32, 64]))
+    H = hw
+    pool = None
+    if rng.random() < 0.5:
+        ph = -(-(hw - 3) // 2) + 1
+        pool, H = (3, 2, 0, ph, ph), ph
+    cur = b.conv(-1, 3, hw, hw, C, 3, 1, 1, relu=1, pool=pool)
+    widths = [16, 32, 48, 64, 96]
+    cid = 0
+    for _ in range(int(rng.integers(2, 5))):
+        n0 = 0
+        n1 = int(rng.choice(widths))
+        b.conv(cur, C, H, H, n1, 1, 1, 0, relu=1, cat=(cid, n0, n0 + n1)); n0 += n1
+        r2, n2 = int(rng.choice([16, 24, 32, 64])), int(rng.choice(widths))
+        a = b.conv(cur, C, H, H, r2, 1, 1, 0, relu=1)
+        b.conv(a, r2, H, H, n2, 3, 1, 1, relu=1, cat=(cid, n0, n0 + n2)); n0 += n2
+        if rng.random() < 0.6 and H >= 7:
+            r3, n3 = int(rng.choice([16, 24, 32])), int(rng.choice([16, 32, 48]))
+            a = b.conv(cur, C, H, H, r3, 1, 1, 0, relu=1)
+            if rng.random() < 0.5:
+                b.conv(a, r3, H, H, n3, 5, 1, 2, relu=1, cat=(cid, n0, n0 + n3))
+            else:
+                b.conv(a, r3, H, H, n3, 3, 1, 2, relu=1, dil=2, cat=(cid, n0, n0 + n3))
+            n0 += n3
+        if rng.random() < 0.7:
+            n4 = int(rng.choice([16, 32, 64]))
+            p = b.pool_only(cur, C, H, H, (3, 1, 1, H, H))
+            b.conv(p, C, H, H, n4, 1, 1, 0, relu=1, cat=(cid, n0, n0 + n4)); n0 += n4
+        cur, C = ("C", cid), n0
+        cid += 1
+        if rng.random() < 0.4 and H >= 8:
+            ph = -(-(H - 3) // 2) + 1
+            cur = b.pool_only(cur, C, H, H, (3, 2, 0, ph, ph))
+            H = ph
+    cur = b.conv(cur, C, H, H, 32, 1, 1, 0, relu=0, endpool=1, endpool_hw=H * H)
+    b.conv(cur, 32, 1, 1, 12, 1, 1, 0, relu=0, bn=0, bias=1)
+    return b.tables()
+
+
+INCEPTION_SEEDS = list(range(20))
+
+
+@pytest.mark.parametrize("seed", INCEPTION_SEEDS)
+def test_random_inception_programs_pack_and_plan(seed):
+    t = random_inception_program(seed)
+    q, model = _q_and_model(t, seed)
+    net = network.NetWork(t)
+    net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+    for batch in (1, 4, 32):
+        for conc in (0, 1):
+            assert net.describe_launches(batch, conc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", INCEPTION_SEEDS)
+def test_random_inception_programs_every_layer_against_the_oracle(seed):
+    from test_gpu_parity import Rig
+    t = random_inception_program(seed)
+    q, model = _q_and_model(t, seed)
+    rig = Rig(t, q, model, 0)
+    x = synth.synth_images(t, 1 + seed % 3, seed, kind="int8" if seed % 2 else "float")
+    want = rig.check_all_layers(x)
+    import torch
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    for conc in (0, 1):
+        got = rig.runner.run_batch(xd, concurrency=conc)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")

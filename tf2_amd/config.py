@@ -676,16 +676,18 @@ class _B:
         self.rewrite = rewrite
 
     def conv(self, src, C, H, W, N, k, stride=1, pad=0, relu=1, bn=1, bias=0, pool=None, add=-1,
-             add_relu=0, endpool=0, dil=1, endpool_hw=49):
+             add_relu=0, endpool=0, dil=1, endpool_hw=49, cat=None):
+        """src: a row index, -1 for the image, or ("C", k) for concat tensor k.  cat = (k, n0, n1): this row is a branch tail that writes
+        channels n0 .. n1 - 1 of concat tensor k (kBranchTail / kConcatLayer / kNStart / kNEnd)."""
         self.rows.append(dict(src=src, C=C, H=H, W=W, N=N, k=k, stride=stride, pad=pad, relu=relu, bn=bn,
                               bias=bias, pool=pool, add=add, add_relu=add_relu, endpool=endpool, dil=dil,
-                              endpool_hw=endpool_hw, ipool=0))
+                              endpool_hw=endpool_hw, ipool=0, cat=cat))
         return len(self.rows) - 1
 
     def pool_only(self, src, C, H, W, pool):
         """An independent pooling row (kIpoolEnable, as GoogLeNet's inception pools): no filter, no Q row of its own."""
         self.rows.append(dict(src=src, C=C, H=H, W=W, N=C, k=1, stride=1, pad=0, relu=0, bn=0, bias=0, pool=pool,
-                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=1))
+                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=1, cat=None))
         return len(self.rows) - 1
 
     def l2norm(self, src, C, H, W):
@@ -693,15 +695,18 @@ class _B:
         l2norm.py:19-24): per-pixel x / ||x||_2 times a per-channel float weight, requantised with its own Q row.  No
         filter; the model stream carries its C float weights."""
         self.rows.append(dict(src=src, C=C, H=H, W=W, N=C, k=1, stride=1, pad=0, relu=0, bn=0, bias=0, pool=None,
-                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=2))
+                              add=-1, add_relu=0, endpool=0, dil=1, endpool_hw=49, ipool=2, cat=None))
         return len(self.rows) - 1
 
     def tables(self) -> NetTables:
         n = len(self.rows)
         t = _blank_tables(n)
+        n_concat = 1 + max([r["cat"][0] for r in self.rows if r.get("cat")], default=-1)
         t.update(INPUT_IMAGE_C=self.image[0], INPUT_IMAGE_H=self.image[1], INPUT_IMAGE_W=self.image[2],
-                 FIRST_FILTER_SIZE=self.first_filter, NUM_Q_LAYERS=n + 1, xConv1Rewrite=self.rewrite,
-                 MAX_OUT_CHANNEL=max(r["N"] for r in self.rows), xName=self.name)
+                 FIRST_FILTER_SIZE=self.first_filter, NUM_Q_LAYERS=n + 1 + n_concat, xConv1Rewrite=self.rewrite,
+                 MAX_OUT_CHANNEL=max([r["N"] for r in self.rows] + [r["cat"][2] for r in self.rows if r.get("cat")]), xName=self.name)
+        if n_concat:
+            t.update(xNumConcat=n_concat)
         for i, r in enumerate(self.rows):
             k, s, pad, d = r["k"], r["stride"], r["pad"], r["dil"]
             oh1 = r["H"] + 2 * pad - d * (k - 1); ow1 = r["W"] + 2 * pad - d * (k - 1)
@@ -710,7 +715,11 @@ class _B:
             t["kOutputWidth"][i] = ow1; t["kOutputHeight"][i] = oh1
             t["kInputChannels"][i] = r["C"]; t["kOutputChannels"][i] = r["N"]; t["kConvStride"][i] = s
             t["kBiasEnable"][i] = r["bias"]; t["kBnEnable"][i] = r["bn"]; t["kReluEnable"][i] = r["relu"]
-            t["xDilation"][i] = d; t["kInputLayer"][i] = r["src"] + 1; t["kNEnd"][i] = r["N"]
+            t["xDilation"][i] = d; t["kNEnd"][i] = r["N"]
+            t["kInputLayer"][i] = (n + 1 + r["src"][1]) if isinstance(r["src"], tuple) else r["src"] + 1
+            if r.get("cat"):
+                cid, n0, n1 = r["cat"]
+                t["kBranchTail"][i] = 1; t["kConcatLayer"][i] = cid; t["kNStart"][i] = n0; t["kNEnd"][i] = n1
             t["kIpoolEnable"][i] = r.get("ipool", 0)
             oh, ow = (oh1 - 1) // s + 1, (ow1 - 1) // s + 1
             t["kPoolWindow"][i] = 3
