@@ -13,7 +13,7 @@ from tf2_amd import config as cfg, network, synth
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-SEEDS = list(range(40))
+SEEDS = list(range(56))
 
 
 def random_program(seed: int) -> cfg.NetTables:
@@ -50,7 +50,7 @@ def random_program(seed: int) -> cfg.NetTables:
     C, H = n0, hp
     n_blocks = int(rng.integers(3, 9))
     for _ in range(n_blocks):
-        kind = rng.choice(["pw", "c3", "c3s2", "dil", "bottleneck", "bottleneck_proj", "ipool"])
+        kind = rng.choice(["pw", "c3", "c3s2", "dil", "bottleneck", "bottleneck_proj", "ipool", "l2norm"])
         if kind == "pw":
             N = int(rng.choice(widths)); pool, hp = maybe_pool(H)
             cur = b.conv(cur, C, H, H, N, 1, 1, 0, relu=int(rng.integers(0, 2)) if pool is None else 1, pool=pool)
@@ -78,6 +78,8 @@ def random_program(seed: int) -> cfg.NetTables:
             m = b.conv(a, mid, H, H, mid, 3, s, 1, relu=1)
             cur = b.conv(m, mid, Ho, Ho, out, 1, 1, 0, relu=0, add=sc, add_relu=1)
             C, H = out, Ho
+        elif kind == "l2norm" and seed >= 40:              # (SSD's conv4_3 row; seeds below 40 keep the programs they always drew)
+            cur = b.l2norm(cur, C, H, H)
         elif kind == "ipool" and H >= 5:
             ph = (H + 2 - 3) // 2 + 1
             cur = b.pool_only(cur, C, H, H, (3, 2, 1, ph, ph))
