@@ -33,8 +33,19 @@ __device__ __forceinline__ void fire_dma16(const int8_t* src, int8_t* lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(l) : "memory", "m0");
 }
 
-// MT0: 32-row tiles of the squeeze (S <= 32: 1, else 2); DUAL1: the squeeze is a two-window layer; JW: pixel tiles per wave in the expand
-template <int MT0, bool DUAL1, int JW>
+__device__ __forceinline__ unsigned fire_pkmax(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// MT0: 32-row tiles of the squeeze (S <= 32: 1, else 2); DUAL1: the squeeze is a two-window layer; JW: pixel tiles per wave in the expand.
+// POOL: the module's 3x3 / stride 2 / pad 0 ceil-mode max pool (pool.cl:152-260 + pool_tail.cl:91-216; SqueezeNet 1.1's fire3 / fire5) in the
+// launch: a block owns PR pooled rows, i.e. the R = 2 PR + 1 expand rows under them (one row recomputed per neighbour) and their R + 2 squeeze
+// rows; the requantised expand tile goes to LDS (16-byte chunk c of pixel p at chunk c ^ (p mod chunks): conflict-free for the sixteen lanes of
+// a ds_write_b128) and the pool runs from there -- every byte is 0..127 behind the expands' ReLU (launcher-checked), so the byte-wise maximum is
+// v_pk_max_u16 on the even / odd bytes and window slots outside the map (zeros, pool.cl:119-140) are skipped.
+template <int MT0, bool DUAL1, int JW, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
   extern __shared__ __attribute__((aligned(1024))) int8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
   const int hst1 = (DUAL1 ? 28 : 20) << tms1;              // bytes of the squeeze's (single) m-tile header: rows | lo | dshift[P]
   int8_t* const hdr2 = hdr1 + hst1;
   const int hst2 = 20 << tms2;
+  int8_t* const cy = hdr2 + (size_t)(a.N2 >> tms2) * hst2;      // POOL: the expand tile [R * W pixels][N2 bytes], chunk-swizzled
 
   int bid = blockIdx.x;
   {
@@ -60,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;      // the bands of one image on one XCD (conv_bband.hip)
   }
   const int img = bid / a.tiles_per_img;
-  const int r0 = (bid - img * a.tiles_per_img) * R;
+  const int r0 = (bid - img * a.tiles_per_img) * (POOL ? 2 * a.PR : R);       // first expand row of the band
   const int rows = (H - r0) < R ? (H - r0) : R;
   const int n_px = rows * W;
   const int n_p0 = (R + 2) * W;
@@ -275,10 +287,50 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
         if (a.fast2 == 1) out = requant_tile16<false, 0, true>(a16, prm, 1 << tms2, ro + 4 * half, lo_b2, -128, nores, false, false);
         else out = requant_tile16<false, 0, false>(a16, prm, 1 << tms2, ro + 4 * half, lo_b2, -128, nores, false, a.fast2 == 2);
         const int p = (wn + j * WN) * 32 + (lane & 31);
-        if (p < n_px && chl + 16 <= a.y_nvalid)
+        if constexpr (POOL) {
+          const int nch = a.N2 >> 4;
+          if (p < n_px) *reinterpret_cast<i32x4*>(cy + (size_t)p * a.N2 + ((((chl >> 4) ^ p) & (nch - 1)) << 4)) = out;
+        }
+        if ((!POOL || a.keep_mid) && p < n_px && chl + 16 <= a.y_nvalid)
           *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
       }
       if ((wave == 0 || wave == 7) && rt == wm) FIRE_STAMP(6);          // ... and requantised, stores issued
+    }
+  }
+  if constexpr (POOL) {
+    // ---- the pool over the block's own expand tile ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int nch = a.N2 >> 4;
+    const int ph0 = (bid - img * a.tiles_per_img) * a.PR;
+    const int pr_n = (a.PH - ph0) < a.PR ? (a.PH - ph0) : a.PR;
+    const int n_out = pr_n * a.PW * nch;
+    for (int idx = tid; idx < n_out; idx += 512) {
+      const int c = idx & (nch - 1), pix = idx / nch;
+      const int pr = pix / a.PW, pw = pix - pr * a.PW;
+      unsigned me[4] = {0, 0, 0, 0}, mo[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int r = pr * 2 + i;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int col = pw * 2 + j;
+          if (col >= W) continue;
+          const int p = r * W + col;
+          const i32x4 v = *reinterpret_cast<const i32x4*>(cy + (size_t)p * a.N2 + (((c ^ p) & (nch - 1)) << 4));
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            me[q] = fire_pkmax(me[q], (unsigned)v[q] & 0x00ff00ffu);
+            mo[q] = fire_pkmax(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
+          }
+        }
+      }
+      if (c * 16 + 16 <= a.y_nvalid) {
+        const i32x4 o = {(int)(me[0] | (mo[0] << 8)), (int)(me[1] | (mo[1] << 8)), (int)(me[2] | (mo[2] << 8)), (int)(me[3] | (mo[3] << 8))};
+        *reinterpret_cast<i32x4*>(a.yp + (((size_t)img * a.PH + ph0 + pr) * a.PW + pw) * a.yp_cp + a.yp_off + c * 16) = o;
+      }
     }
   }
   if (wave == 0 || wave == 7) FIRE_STAMP(7);
@@ -286,35 +338,39 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
 }
 
 // geometry of a fire launch: rows per band (halo band and band within the 8 / 4 pixel tiles the waves cover), LDS bytes
-bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, FireArgs* f, size_t* lds_out) {
+bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, int pool, FireArgs* f, size_t* lds_out) {
   if (H != W || (W != 56 && W != 28 && W != 14) || Cin % 64 != 0 || Cin < 64 || Cin > 512 || Sp % 16 != 0 || Sp < 16 || Sp > 64) return false;
   if (N2 % 128 != 0 || N2 < 128 || N2 > 512 || (tm1 != 64 && tm1 != 128) || (tm2 != 64 && tm2 != 128)) return false;
-  const int R = W == 56 ? 2 : 4;                           // 4 x 56, 6 x 28, 6 x 14 halo pixels: 7 / 6 / 3 column tiles of 32 (bands of 4 / 4 / 2)
+  if (pool && (W < 28 || (N2 != 128 && N2 != 256))) return false;      // (pooled form: 56 / 28 wide maps, 8 or 16 chunks per pixel)
+  constexpr int kPR = 2;                                   // pooled rows per block
+  const int R = pool ? 2 * kPR + 1 : (W == 56 ? 2 : 4);    // 4 x 56, 6 x 28, 6 x 14 halo pixels: 7 / 6 / 3 column tiles of 32 (bands of 4 / 4 / 2); pooled: 7 halo rows
   const int NT0 = ((R + 2) * W + 31) / 32, NT1 = (R * W + 31) / 32;
   const int MT0 = Sp > 32 ? 2 : 1;
   if (NT0 > 8 / MT0 * 2) return false;
   const int RT = N2 / 32;
   const int WM = RT % 8 == 0 ? 8 : 4;                      // 128: 4 x 2, 256: 8 x 1, 384: 4 x 2, 512: 8 x 1
   const int WN = 8 / WM, JW = (NT1 + WN - 1) / WN;
-  if (JW > 4) return false;
+  if (JW > (pool ? 5 : 4)) return false;
   const int n_h = (R + 2) * (W + 2);
   const int tms1 = tm1 == 128 ? 7 : 6, tms2 = tm2 == 128 ? 7 : 6;
   const size_t lds = (size_t)(Cin / 64) * NT0 * 32 * 64 + (size_t)(Sp / 16) * ((n_h + 63) / 64) * 1024 + ((size_t)(dual1 ? 28 : 20) << tms1) +
-                     (size_t)(N2 >> tms2) * ((size_t)20 << tms2) + 64;
+                     (size_t)(N2 >> tms2) * ((size_t)20 << tms2) + 64 + (pool ? (size_t)R * W * N2 : 0);
   if (lds > 160 * 1024) return false;
   if (f) {
-    f->R = R; f->NT0 = NT0; f->WM = WM; f->tiles_per_img = (H + R - 1) / R;
+    const int PH = (H - 3 + 1) / 2 + 1;                    // ceil((H - 3) / 2) + 1
+    f->R = R; f->NT0 = NT0; f->WM = WM; f->tiles_per_img = pool ? (PH + kPR - 1) / kPR : (H + R - 1) / R;
+    f->PR = kPR;
     set_fast_div((uint32_t)W, &f->w_m, &f->w_s); set_fast_div((uint32_t)(Sp / 16), &f->g_m, &f->g_s);
   }
   if (lds_out) *lds_out = lds;
   return true;
 }
 
-template <int MT0, bool DUAL1, int JW>
+template <int MT0, bool DUAL1, int JW, bool POOL = false>
 static int launch_fire2(const FireArgs& a, size_t lds, hipStream_t s) {
-  auto fn = conv_fire_kernel<MT0, DUAL1, JW>;
+  auto fn = conv_fire_kernel<MT0, DUAL1, JW, POOL>;
   if (!lds_attr_once(reinterpret_cast<const void*>(fn), 160 * 1024)) return -1;
-  TF2_LAUNCH_NAME("conv_fire_kernel<%dx%d,C%d,S%d,N%d%s> (%d bands per image)", a.H, a.W, a.Cin, a.Sp, a.N2, DUAL1 ? ",dual squeeze" : "", a.tiles_per_img);
+  TF2_LAUNCH_NAME("conv_fire_kernel<%dx%d,C%d,S%d,N%d%s%s> (%d bands per image)", a.H, a.W, a.Cin, a.Sp, a.N2, DUAL1 ? ",dual squeeze" : "", POOL ? ",3x3/2 pool" : "", a.tiles_per_img);
   TF2_LAUNCH(fn, dim3(a.B * a.tiles_per_img), dim3(512), lds, s, a);
   return launch_ok() ? 0 : -1;
 }
@@ -323,9 +379,14 @@ int launch_conv_fire(const FireArgs& a0, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   FireArgs a = a0;
   size_t lds = 0;
-  if (!conv_fire_geometry(a.H, a.W, a.Cin, a.Sp, a.N2, a.tm1, a.tm2, a.dual1, &a, &lds)) return 1;
+  if (!conv_fire_geometry(a.H, a.W, a.Cin, a.Sp, a.N2, a.tm1, a.tm2, a.dual1, a.pool, &a, &lds)) return 1;
   const int NT1 = (a.R * a.W + 31) / 32, JW = (NT1 + 8 / a.WM - 1) / (8 / a.WM);
   const bool mt2 = a.Sp > 32;
+  if (a.pool) {
+    if (!a.relu2 || a.PH != (a.H - 2) / 2 + 1 || a.PW != a.PH) return 1;
+    if (mt2) return a.dual1 ? launch_fire2<2, true, 5, true>(a, lds, s) : launch_fire2<2, false, 5, true>(a, lds, s);
+    return a.dual1 ? launch_fire2<1, true, 5, true>(a, lds, s) : launch_fire2<1, false, 5, true>(a, lds, s);
+  }
 #define TF2_FIRE(J_) do { if (mt2) return a.dual1 ? launch_fire2<2, true, J_>(a, lds, s) : launch_fire2<2, false, J_>(a, lds, s); \
                           return a.dual1 ? launch_fire2<1, true, J_>(a, lds, s) : launch_fire2<1, false, J_>(a, lds, s); } while (0)
   if (JW <= 2) TF2_FIRE(2);

@@ -460,7 +460,7 @@ bool Net::fire_at(int l) const {
     if (j != l + 1 && j != l + 2 && (layers[j].src == l || layers[j].add_src == l)) return false;      // the squeeze's tensor is not written
   if (p0->TM != 64 || p0->n_mtiles != 1 || (long)p0->n_entries != p0->nslab || !(p0->n_phases == 1 || p0->dual) || p0->w_share || p0->fuse_next > 0 || p0->fused_into >= 0) return false;
   if (p1->n_phases != 1 || p1->dual || p1->w_share || (p1->TM != 64 && p1->TM != 128) || p1->Cp_in != round_up(A.N, 16) || p1->off_dbl) return false;
-  return conv_fire_geometry(A.H, A.W, A.C, round_up(A.N, 16), p1->Np, p0->TM, p1->TM, p0->dual, nullptr, nullptr) && p1->Np == layers[l + 1].N + layers[l + 2].N;
+  return conv_fire_geometry(A.H, A.W, A.C, round_up(A.N, 16), p1->Np, p0->TM, p1->TM, p0->dual, 0, nullptr, nullptr) && p1->Np == layers[l + 1].N + layers[l + 2].N;
 }
 
 // a 3x3 / stride 1 / pad 1 layer on an unsigned tensor that holds exactly C (a multiple of 64) bytes per pixel, dense one- or two-window
@@ -802,7 +802,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     }
     // a fire module (squeeze + the merged expands) as ONE launch of independent row bands (conv_fire.hip)
     if (opts.fire_mode && fire_at(l) && (opts.fire_mode == 1 || L.W >= 28) &&
-        (!layers[l + 1].pool_en || opts.fire_pool == 2 || (opts.fire_pool == 1 && L.W >= 56))) {
+        (!layers[l + 1].pool_en || opts.fire_pool >= 2 || (opts.fire_pool == 1 && L.W >= 56))) {
       Launch s0, s1;
       if (!make_conv(l, s0, false) || !make_conv(l + 1, s1, false)) return nullptr;
       const PackLayer* p1 = pack_layer(l + 1);
@@ -817,11 +817,22 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.dbl1 = c0.g.dbl_out; f.dual1 = c0.dual;
         f.keep_mid = wp->keep_all ? 1 : 0; f.mid_cp = c0.g.y_cp; f.y_cp = c1.g.y_cp; f.y_off = c1.g.y_off; f.y_nvalid = c1.g.y_nvalid;
         f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
-        if (conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, &f, nullptr)) {
+        // the pool behind the expands inside the launch where its form fits (3x3 / 2 / pad 0 in ceil mode behind a ReLU) -- one batch at a
+        // time (fire_pool=3, the default; 4: always): its blocks hold 100-108 KB of LDS, one per CU, and with batches in flight that costs
+        // more (317 k against 334-345 k img/s) than the pool launch it saves; alone it is 25.3 us against 19 + 9.2 (fire3), 12.6 against
+        // 16.2 + 6.7 (fire5): profiles/r05_experiments.txt item 22
+        const tf2_layer_desc L1 = exec_desc(l + 1);
+        f.pool = 0;
+        if (L1.pool_en && (opts.fire_pool == 4 || (opts.fire_pool == 3 && !concurrent)) && L1.pool_S == 3 && L1.pool_st == 2 && L1.pool_pad == 0 && c1.g.relu && !c1.g.dbl_out &&
+            L1.PH == (L.H - 2) / 2 + 1 && L1.PW == L1.PH && c1.g.y_nvalid == f.N2 &&
+            conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, 1, nullptr, nullptr)) {
+          const TensorPlan& to1 = T(wp->exec[l + 1].out_tensor);
+          f.pool = 1; f.PH = L1.PH; f.PW = L1.PW; f.yp = base + to1.offset; f.yp_cp = to1.Cp; f.yp_off = wp->exec[l + 1].out_off;
+        }
+        if (conv_fire_geometry(f.H, f.W, f.Cin, f.Sp, f.N2, f.tm1, f.tm2, f.dual1, f.pool, &f, nullptr)) {
           pair_done[l + 1] = 1;
           lp.steps.push_back(st);
-          const tf2_layer_desc L1 = exec_desc(l + 1);
-          if (L1.pool_en) { const TensorPlan& tc1 = T(wp->exec[l + 1].conv_tensor); pool_step(l + 1, tc1, base + tc1.offset, L1.OH, L1.OW); }
+          if (L1.pool_en && !f.pool) { const TensorPlan& tc1 = T(wp->exec[l + 1].conv_tensor); pool_step(l + 1, tc1, base + tc1.offset, L1.OH, L1.OW); }
           continue;
         }
       }

@@ -29,7 +29,7 @@ const OptSpec kOptSpecs[] = {
   {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"},
   {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
   {"fire", 1, "a fire module (squeeze + merged expands) as one launch: 0 never, 1 wherever it fits, 2 (default) on maps >= 28 wide"},
-  {"fire_pool", 1, "fire modules with a pool behind their expands as a fire launch + the pool: 0 never, 1 on maps >= 56 wide, 2 wherever fire allows"},
+  {"fire_pool", 1, "fire modules with a pool behind their expands: 0 never, 1 / 2 fire launch + pool launch (maps >= 56 wide / wherever fire allows), 3 (default) the pool inside the fire launch one batch at a time, 4 always"},
   {"first", 1, "a 3x3 / stride 1 first layer on the image in one launch with its input preparation: 1 / 0"},
   {"first_pool", 1, "... a 3x3 first layer (stride 1 / 2) with a 3x3 / 2 max pool behind its ReLU, the pool included: 1 / 0"},
   {"c3_pool", 1, "a layer's 2x2 / 2 max pool inside its conv_c3 launch: 1 / 0"},

@@ -378,8 +378,11 @@ struct FireArgs {
   int32_t mid_cp, y_cp, y_off, y_nvalid;
   uint32_t w_m, g_m; int32_t w_s, g_s;           // set_fast_div(W), set_fast_div(Sp / 16)
   long long* dbg;                                // tools/fire_timeline.py: 16 wall-clock stamps per block, or null
+  // the 3x3 / stride 2 / pad 0 (ceil mode) max pool behind the expands inside the launch: a block then owns PR pooled rows = R = 2 PR + 1 expand rows
+  int8_t* yp;                                    // the pooled concat tensor
+  int32_t pool, PH, PW, PR, yp_cp, yp_off;
 };
-bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, FireArgs* f, size_t* lds_out);
+bool conv_fire_geometry(int H, int W, int Cin, int Sp, int N2, int tm1, int tm2, int dual1, int pool, FireArgs* f, size_t* lds_out);
 int launch_conv_fire(const FireArgs& a, void* stream);      // 1: shape not instantiated / does not fit
 
 // conv_first_kernel (misc_kernels.hip): a 3x3 / stride 1 first layer on the 3-channel image in one launch -- input preparation (the im2col

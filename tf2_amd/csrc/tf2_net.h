@@ -92,7 +92,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   long bneck_min_blocks = 200;
   int fire_mode = 2;         // fire: a fire module (squeeze + merged expands) as ONE launch (conv_fire.hip): 0 never, 1 wherever it fits, 2 (default) on maps
                              // >= 28 wide (14 x 14 modules measured SLOWER fused: 64-128 blocks of long dependent chains, r05_experiments.txt item 10)
-  int fire_pool = 2;         // fire_pool: fire modules with a pool behind their expands (the pool stays a launch): 0 never, 1 on maps >= 56 wide, 2 wherever `fire` allows
+  int fire_pool = 3;         // fire_pool: fire modules with a pool behind their expands: 0 never, 1 on maps >= 56 wide (the pool stays a launch), 2 wherever `fire` allows (pool a launch), 3 (default) the pool inside the fire launch where its form fits one batch at a time / as 2 with batches in flight, 4 inside always
   int first_fuse = 1;        // first: a 3x3 / stride 1 first layer on the 3-channel image as ONE launch with its input preparation (conv_first_kernel): 1 (default) / 0
   int first_pool = 1;        // first_pool: ... and a first layer's 3x3 / 2 max pool in that launch too (conv_first_pool_kernel): 1 (default) / 0
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
