@@ -71,22 +71,18 @@ __device__ __forceinline__ C3Split c3_split(const i32x4& v, bool keep) {
   }
   return r;
 }
-__device__ __forceinline__ unsigned c3_pkmax(unsigned a, unsigned b) {
-  using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
 // rows tr / tr + 1 of one pixel column (this lane's tc) -> the 2x2 window maximum of the lane pair (tc, tc ^ 1), valid in both lanes
 __device__ __forceinline__ i32x4 c3_pool2x2(const i32x4& top, const i32x4& bot, bool bot_ok, bool self_ok, bool right_ok) {
   const C3Split a = c3_split(top, self_ok), b = c3_split(bot, self_ok && bot_ok);
   i32x4 out;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const unsigned ve = c3_pkmax(a.e[q], b.e[q]), vo = c3_pkmax(a.o[q], b.o[q]);
+    const unsigned ve = pk_max_u16(a.e[q], b.e[q]), vo = pk_max_u16(a.o[q], b.o[q]);
     // the neighbouring lane's column maxima (quad_perm [1, 0, 3, 2]); a lane whose own column lies beyond the map contributed zeros
     unsigned ne = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ve, 0xb1, 0xf, 0xf, false);
     unsigned no = (unsigned)__builtin_amdgcn_update_dpp(0, (int)vo, 0xb1, 0xf, 0xf, false);
     if (!right_ok) { ne = 0; no = 0; }
-    out[q] = (int)(c3_pkmax(ve, ne) | (c3_pkmax(vo, no) << 8));
+    out[q] = (int)(pk_max_u16(ve, ne) | (pk_max_u16(vo, no) << 8));
   }
   return out;
 }

@@ -33,12 +33,6 @@ __device__ __forceinline__ void fire_dma16(const int8_t* src, int8_t* lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(l) : "memory", "m0");
 }
 
-__device__ __forceinline__ unsigned fire_pkmax(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // MT0: 32-row tiles of the squeeze (S <= 32: 1, else 2); DUAL1: the squeeze is a two-window layer; JW: pixel tiles per wave in the expand.
 // POOL: the module's 3x3 / stride 2 / pad 0 ceil-mode max pool (pool.cl:152-260 + pool_tail.cl:91-216; SqueezeNet 1.1's fire3 / fire5) in the
 // launch: a block owns PR pooled rows, i.e. the R = 2 PR + 1 expand rows under them (one row recomputed per neighbour) and their R + 2 squeeze
@@ -322,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
           const i32x4 v = *reinterpret_cast<const i32x4*>(cy + (size_t)p * a.N2 + (((c ^ p) & (nch - 1)) << 4));
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            me[q] = fire_pkmax(me[q], (unsigned)v[q] & 0x00ff00ffu);
-            mo[q] = fire_pkmax(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
+            me[q] = pk_max_u16(me[q], (unsigned)v[q] & 0x00ff00ffu);
+            mo[q] = pk_max_u16(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
           }
         }
       }

@@ -528,11 +528,6 @@ __device__ __forceinline__ unsigned first_neg_bytes(unsigned x) {
   const unsigned t = ~x;
   return ((t & 0x7f7f7f7fu) + 0x01010101u) ^ (t & 0x80808080u);
 }
-__device__ __forceinline__ unsigned first_pkmax(unsigned a, unsigned b) {
-  unsigned r;
-  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 template <bool SRC_Q, bool DUAL>
 __global__ __launch_bounds__(512, 4) void conv_first_pool_kernel(FirstArgs f) {
@@ -650,8 +645,8 @@ __global__ __launch_bounds__(512, 4) void conv_first_pool_kernel(FirstArgs f) {
         const i32x4 v = *reinterpret_cast<const i32x4*>(cy + (size_t)p * 64 + ((g ^ ((p >> 2) & 3)) << 4));
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          me[q] = first_pkmax(me[q], (unsigned)v[q] & 0x00ff00ffu);
-          mo[q] = first_pkmax(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
+          me[q] = pk_max_u16(me[q], (unsigned)v[q] & 0x00ff00ffu);
+          mo[q] = pk_max_u16(mo[q], ((unsigned)v[q] >> 8) & 0x00ff00ffu);
         }
       }
     }

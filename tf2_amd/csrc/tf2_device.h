@@ -14,6 +14,13 @@ __device__ __forceinline__ int fast_div(int n, uint32_t m, int s) {
   return s < 0 ? n : (int)(__umulhi((unsigned)n, m) >> s);
 }
 
+// Two unsigned 16-bit maxima per register (v_pk_max_u16): the building block of the byte-wise maximum of post-ReLU bytes (0..127) in the pools
+// fused into conv launches -- even bytes (x & 0x00ff00ff) and odd bytes ((x >> 8) & 0x00ff00ff) separately, then e | o << 8.
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
 // Pull the kernel arguments a conv block needs into SGPRs at kernel entry: hipcc otherwise loads each field right
 // before its first use -- a dozen dependent scalar-load round trips spread over the prologue (measured on conv_mfma2:
 // 2.8 k -> 1.8 k cycles from block start to the first address computation, and 3.5 k -> 1.7 k for the part after it).
