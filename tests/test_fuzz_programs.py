@@ -417,3 +417,20 @@ def test_random_inception_programs_every_layer_against_the_oracle(seed):
         got = rig.runner.run_batch(xd, concurrency=conc)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"plain run, concurrency {conc}")
+
+
+def test_every_random_program_plans_at_every_batch_size():
+    """No device: both launch plans of all the generators' programs at batch 1..19 and around the powers of two up to 3000 (beyond the fused
+    first layers' 32-bit pixel indices): a plan exists, covers the rows in order and names a kernel for every launch."""
+    progs = ([(s, random_program(s)) for s in SEEDS[::4]] + [(s, random_body_program(s)) for s in BODY_SEEDS[::3]] +
+             [(s, random_fire_program(s)) for s in FIRE_SEEDS[::3]] + [(s, random_inception_program(s)) for s in INCEPTION_SEEDS[::4]])
+    for seed, t in progs:
+        q, model = _q_and_model(t, seed)
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+        for batch in list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 128, 255, 256, 700, 3000]:
+            for conc in (0, 1):
+                rows = net.describe_launches(batch, conc)
+                assert rows and all(r["kernel"] and r["grid"] >= 1 for r in rows), (seed, batch, conc)
+                layers = [r["layer"] for r in rows]
+                assert layers == sorted(layers), (seed, batch, conc, layers)
