@@ -434,3 +434,21 @@ def test_every_random_program_plans_at_every_batch_size():
                 assert rows and all(r["kernel"] and r["grid"] >= 1 for r in rows), (seed, batch, conc)
                 layers = [r["layer"] for r in rows]
                 assert layers == sorted(layers), (seed, batch, conc, layers)
+
+
+@pytest.mark.parametrize("which,seed", [("free", s) for s in range(0, 56, 3)] + [("body", s) for s in range(0, 24, 3)])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_random_programs_packed_image_emulated_on_the_cpu(which, seed, mode, monkeypatch):
+    """No device: the packed weight image of a random program (exponent windows, doubled channels, slab lists, 4-bit code layers, merged rows,
+    the im2col first layer) run through the numpy model of the kernels' data flow (tests/emu_packed.py) reproduces the oracle layer by layer --
+    mode 0 (MFMA forms) and mode 2 (the shift kernel's packed 4-bit filters)."""
+    from tests.conftest import set_opts
+    from tests.test_pack_emulation import check_net
+    if which == "body":
+        set_opts(monkeypatch, **_BODY_OPTS)
+    t = (random_program if which == "free" else random_body_program)(seed)
+    q, model = _q_and_model(t, seed)
+    x = synth.synth_images(t, 2, seed, kind="int8" if seed % 2 else "float")
+    if seed % 2:
+        x[0, :, :2, :] = -128                                    # the negate quirk (pe.cl:32-37)
+    check_net(t, q, model, x, mode)
