@@ -436,7 +436,8 @@ def test_every_random_program_plans_at_every_batch_size():
                 assert layers == sorted(layers), (seed, batch, conc, layers)
 
 
-@pytest.mark.parametrize("which,seed", [("free", s) for s in range(0, 56, 3)] + [("body", s) for s in range(0, 24, 3)])
+@pytest.mark.parametrize("which,seed", [("free", s) for s in range(0, 56, 3)] + [("body", s) for s in range(0, 24, 3)] +
+                         [("inception", s) for s in range(0, 20, 3)] + [("fire", s) for s in range(0, 12, 3)])
 @pytest.mark.parametrize("mode", [0, 2])
 def test_random_programs_packed_image_emulated_on_the_cpu(which, seed, mode, monkeypatch):
     """No device: the packed weight image of a random program (exponent windows, doubled channels, slab lists, 4-bit code layers, merged rows,
@@ -446,8 +447,11 @@ def test_random_programs_packed_image_emulated_on_the_cpu(which, seed, mode, mon
     from tests.test_pack_emulation import check_net
     if which == "body":
         set_opts(monkeypatch, **_BODY_OPTS)
-    t = (random_program if which == "free" else random_body_program)(seed)
+    t = {"free": random_program, "body": random_body_program, "inception": random_inception_program, "fire": random_fire_program}[which](seed)
     q, model = _q_and_model(t, seed)
+    if which == "fire":
+        q = synth.synth_q_values(t, 6, spread=1)                 # (one-window merged expands: the merged rows are in the packed image)
+        model = synth.synth_model(t, q, 6)
     x = synth.synth_images(t, 2, seed, kind="int8" if seed % 2 else "float")
     if seed % 2:
         x[0, :, :2, :] = -128                                    # the negate quirk (pe.cl:32-37)
