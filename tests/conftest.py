@@ -39,7 +39,8 @@ def set_opts(monkeypatch, **kw):
     """Set / change / remove (value None) options of the library's ONE option string TF2_AMD_OPTS (csrc/opts.h), cumulatively within a
     test; TF2_AMD_TEST=1 admits the test-only ones (forced kernels, disabled proofs, thresholds).  Takes effect at the next
     tf2_net_create / tf2_net_reload_options."""
-    cur = dict(item.split("=", 1) for item in os.environ.get("TF2_AMD_OPTS", "").split(",") if item)
+    from tf2_amd._lib import parse_opts
+    cur = parse_opts(os.environ.get("TF2_AMD_OPTS", ""))
     for k, v in kw.items():
         if v is None:
             cur.pop(k, None)

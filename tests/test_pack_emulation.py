@@ -254,3 +254,33 @@ def test_fc_layers_as_4bit_codes():
     check_net(t, q3, synth.synth_model(t, q3, 4), x, 0, layers={13, 14})
     assert int(pls3[13]["fc4"]) == 0
     del os.environ["TF2_AMD_OPTS"]; del os.environ["TF2_AMD_TEST"]
+
+
+def test_whole_window_layer_on_padded_channels_keeps_int8_tiles():
+    """Round-5 advice: the pack-time condition of the 4-bit form (weight_pack.cpp PackLayer::fc4) was weaker than the run-time one
+    (Net::fc_at) -- a 3 x 3 whole-window layer on a 3 x 3 x 500 tensor (Cp 512, 72 K slabs) was packed as codes that no kernel could
+    run and failed to PLAN at every batch.  Both now want C == Cp_in (whole 64-channel slabs of an unpadded tensor): C = 500 keeps its
+    int8 tiles and plans on the split-K kernel; the same net with C = 512 takes the codes and conv_fc.  No device needed."""
+    os.environ["TF2_AMD_TEST"] = "1"; os.environ["TF2_AMD_OPTS"] = "fc_min=8"
+    try:
+        for C, want_fc4 in ((500, 0), (512, 1)):
+            b = cfg._B(f"fcpad{C}", image=(3, 12, 12), first_filter=3)
+            cur = b.conv(-1, 3, 12, 12, 64, 3, 1, 1, relu=1, pool=(2, 2, 0, 6, 6), bias=1, bn=0)
+            cur = b.conv(cur, 64, 6, 6, C, 3, 1, 1, relu=1, pool=(2, 2, 0, 3, 3), bias=1, bn=0)
+            cur = b.conv(cur, C, 3, 3, 128, 3, 1, 0, relu=1, bias=1, bn=0)          # the whole-window layer: 9 * Cp / 64 = 72 slabs
+            b.conv(cur, 128, 1, 1, 16, 1, 1, 0, relu=0, bn=0, bias=1)
+            t = b.tables()
+            q = synth.synth_q_values(t, 3, spread=1)
+            model = synth.synth_model(t, q, 3)
+            x = synth.synth_images(t, 2, 3)
+            _, pls = check_net(t, q, model, x, 0, layers={2})
+            assert int(pls[2]["fc4"]) == want_fc4, (C, pls[2]["fc4"])
+            net = network.NetWork(t)
+            net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+            for batch in (1, 32, 64):
+                for conc in (0, 1):
+                    rows = net.describe_launches(batch, conc)
+                    kern = [r["kernel"] for r in rows if r["layer"] == 2]
+                    assert kern and (kern[0].startswith("fc4") == bool(want_fc4)), (C, batch, kern)
+    finally:
+        del os.environ["TF2_AMD_OPTS"]; del os.environ["TF2_AMD_TEST"]

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import sys
 import subprocess
 
@@ -147,10 +148,22 @@ EXPORTED = [
     "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_run_stats", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
+def parse_opts(text: str) -> dict:
+    """TF2_AMD_OPTS text -> {name: value} exactly as csrc/opts.cpp reads it: items separated by ',', ';' or ' ', a bare name means
+    name=1.  (An empty value, 'name=', is an error on the C side; it is kept here so that the library reports it.)"""
+    cur = {}
+    for item in re.split(r"[,; ]", text or ""):
+        if not item:
+            continue
+        name, eq, val = item.partition("=")
+        cur[name] = val if eq else "1"
+    return cur
+
+
 def set_opts(**kw) -> None:
     """Tools: set / change / remove (value None) options of TF2_AMD_OPTS (csrc/opts.h) in this process's environment, cumulatively, and
     admit the test-only ones (TF2_AMD_TEST=1).  Takes effect at the next tf2_net_create / NetWork.reload_options()."""
-    cur = dict(item.split("=", 1) for item in os.environ.get("TF2_AMD_OPTS", "").split(",") if item)
+    cur = parse_opts(os.environ.get("TF2_AMD_OPTS", ""))
     for k, v in kw.items():
         if v is None:
             cur.pop(k, None)

@@ -401,7 +401,7 @@ static int launch_sk2(const ConvArgs& a, hipStream_t s) {
 }
 
 // For 64-row packed layers with a long slab list and a grid that would not fill the chip.
-int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
   const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
@@ -413,8 +413,8 @@ int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream) {
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
   const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);
   const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
-  // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU)
-  constexpr long s3_blocks = 256;
+  // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU): s3_blocks = 256 one batch at a
+  // time; the in-flight plan passes its own threshold (Net::launch_plan: a 64 KiB block leaves room for another batch's block)
   if (w8) {
     if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
     return pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);

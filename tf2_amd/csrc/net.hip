@@ -513,6 +513,7 @@ void Net::load_options() {
   o.pw_mode = (int)opt("pw", o.pw_mode);        // register-resident pointwise kernel: 1 auto (default), 0 never
   o.sk_mode = (int)opt("sk", o.sk_mode);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   o.sk8_blocks = (long)opt("sk8", o.sk8_blocks);
+  o.sk_s3_blocks = (long)opt("sk_s3", o.sk_s3_blocks); o.sk_s3_blocks_conc = (long)opt("sk_s3_conc", o.sk_s3_blocks_conc);
   o.fc_mode = (int)opt("fc", o.fc_mode);
   o.fc_min_slabs = (int)opt("fc_min", o.fc_min_slabs);
   o.c3_mode = (int)opt("c3", o.c3_mode);
@@ -540,11 +541,13 @@ void Net::load_options() {
   if (o.bband_mode == 2) o.bband_alone_maps = 6;
   o.pair_mode = (int)opt("pair", o.pair_mode);          // 1 (default): independent neighbouring rows in one launch; 0: never
   o.stem_pool = (int)opt("stem_pool", o.stem_pool);     // 1 (default): conv1's 3x3/2 max pool inside the conv_stem launch; 0: its own launch
-  o.avg_fuse = (int)opt("avg_fuse", o.avg_fuse);        // 1 (default): a layer's global average inside its split-K launch; 0: global_avg_kernel
+  o.avg_fuse = (int)opt("avg_fuse", o.avg_fuse);        // a layer's global average inside its split-K launch: 2 (default) one batch at a time, 1 always; 0: global_avg_kernel
   o.dense_max_slabs = (int)opt("dense_max", o.dense_max_slabs);
   o.dense_mode = (int)opt("dense", o.dense_mode);       // arithmetic gather words for dense layers: 1 (default), 0 = always the header tables
   if (opt("alt_min", -1) >= 0) o.alt_min_blocks = o.alt_min_blocks_conc = (long)opt("alt_min", 0);       // smallest 128 x 128 grid that takes a layer's wide-tile alternative
   o.alt_min_blocks_conc = (long)opt("alt_min_conc", o.alt_min_blocks_conc);
+  o.alt_rows = (unsigned long long)opt("alt_rows", 0); o.noalt_rows = (unsigned long long)opt("noalt_rows", 0);
+  o.sk_rows = (unsigned long long)opt("sk_rows", 0); o.nosk_rows = (unsigned long long)opt("nosk_rows", 0);
   o.alt_narrow_blocks = (long)opt("alt_narrow", o.alt_narrow_blocks);   // a 128-row layer takes its 64-row alternative below this many 128 x 128 blocks
   o.alt_conc_mode = (int)opt("alt_conc", o.alt_conc_mode);
   o.pw_slabs = (int)opt("pw_slabs", o.pw_slabs);
@@ -636,6 +639,11 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     pa.S = L.pool_S; pa.st = L.pool_st; pa.pad = L.pool_pad; pa.C16 = round_up(L.N, 16) / 16;
     lp.steps.push_back(st);
   };
+  // the global average inside the last expand's split-K launch (conv_mfma_sk AVG: 1024 blocks of 64 x 64 tiles, one image per pixel
+  // tile) pays one batch at a time (a launch and the 7 x 7 map's round trip less); with batches in flight that launch costs 13 us of the
+  // step against 2.6 us for the same row on 208 blocks of 128 x 128 tiles + a 512-block average (round 6, profiles/r06_experiments.txt
+  // items 1-2: 94.8 -> 96.5 k img/s) -- avg_fuse = 2 (default): one batch at a time only
+  const bool avg_fuse_now = opts.avg_fuse == 1 || (opts.avg_fuse == 2 && !concurrent);
   // argument block + kernel selection of one conv layer
   auto make_conv = [&](int l, Launch& st, bool allow_alt) -> bool {
     const tf2_layer_desc L = exec_desc(l);
@@ -646,11 +654,14 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     // other batches' kernels fill the chip, so the wide form pays from a much smaller grid on.
     // The reverse on the 28x28 maps: their 128-row layers have a 64-row alternative (more blocks, split-K) for grids of a few
     // blocks (batch 1-2).
-    const PackLayer* pa = (allow_alt && !(L.endpool && opts.avg_fuse && pl->TM == 64)) ? pack_layer_alt(l) : nullptr;   // (the fused global average runs on the 64-row tiles)
+    const PackLayer* pa = (allow_alt && !(L.endpool && avg_fuse_now && pl->TM == 64)) ? pack_layer_alt(l) : nullptr;   // (the fused global average runs on the 64-row tiles)
     if (pa) {
       const long blocks128 = ((long)batch * L.OH * L.OW + 127) / 128 * (pa->Np / 128);
       if (pa->TM == 128) { if (blocks128 >= (concurrent ? opts.alt_min_blocks_conc : opts.alt_min_blocks)) pl = pa; }
       else if (blocks128 < opts.alt_narrow_blocks) pl = pa;
+      // (test-only, per-row A/B of the in-flight plan: rows forced onto / kept off their alternative tile height)
+      if (l < 64 && ((opts.alt_rows >> l) & 1)) pl = pa;
+      if (l < 64 && ((opts.noalt_rows >> l) & 1)) pl = pack_layer(l);
     }
     st.kind = Launch::CONV; st.layer = l;
     ConvArgs& ca = st.conv;
@@ -723,8 +734,11 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const bool sk = pl->TM == 64 && opts.sk_mode != 2 &&
                       (opts.sk_mode == 1 || (blocks64 <= 512 && (long)pl->n_entries * (pl->dual ? 2 : 1) >= 16L * pl->n_mtiles));
       st.sel = sk ? Launch::SEL_SK : Launch::SEL_MFMA2;
+      if (pl->TM == 64 && l < 64 && ((opts.sk_rows >> l) & 1)) st.sel = Launch::SEL_SK;              // (test-only per-row switches)
+      if (l < 64 && ((opts.nosk_rows >> l) & 1)) st.sel = Launch::SEL_MFMA2;
+      st.shape = (int)(concurrent ? opts.sk_s3_blocks_conc : opts.sk_s3_blocks);      // SEL_SK: largest grid on three ring stages
       // the layer's global average inside the launch (conv_mfma_sk AVG): 64-row tiles, one image per pixel tile
-      if (opts.avg_fuse && L.endpool && !L.pool_en && pl->TM == 64 && g.OHW <= 64 && (g.pad_h | g.pad_w) == 0 && L.concat < 0 &&
+      if (avg_fuse_now && L.endpool && !L.pool_en && pl->TM == 64 && g.OHW <= 64 && (g.pad_h | g.pad_w) == 0 && L.concat < 0 &&
           E.conv_tensor != E.out_tensor && !g.dbl_out && g.n_pix == batch * g.OHW) {
         const TensorPlan& to = T(E.out_tensor);
         ca.y = base + to.offset; g.y_cp = to.Cp; g.y_off = E.out_off; g.avg_mult = L.endpool_mult;
@@ -1135,9 +1149,9 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_SK:
           if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
             ConvArgs cd = st.conv_direct; cd.y = logits;
-            return launch_conv_mfma_sk(cd, opts.sk8_blocks, stream);
+            return launch_conv_mfma_sk(cd, opts.sk8_blocks, st.shape, stream);
           }
-          return launch_conv_mfma_sk(st.conv, opts.sk8_blocks, stream);
+          return launch_conv_mfma_sk(st.conv, opts.sk8_blocks, st.shape, stream);
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);

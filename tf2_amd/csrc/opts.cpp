@@ -2,10 +2,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <unistd.h>
 #include <map>
 #include <memory>
 #include <mutex>
 #include "opts.h"
+
+extern char** environ;
 
 namespace tf2 {
 
@@ -26,7 +30,7 @@ const OptSpec kOptSpecs[] = {
   {"nofast", 1, "pack time: generic requantisation everywhere"}, {"nosemi", 1, "pack time: no SEMI requantisation"}, {"nounit", 1, "pack time: conv1's low window as a window"},
   {"no4bit", 1, "pack time: shift-kernel layers keep int32 weights"}, {"im2col0", 1, "0: a 3x3 first layer on 3 channels keeps its plain form"},
   {"pw", 1, "conv_pw: 1 auto, 0 never"}, {"pw_slabs", 1, "conv_pw: most K slabs"}, {"pw_minpix", 1, "conv_pw: fewest pixels"},
-  {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"},
+  {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"}, {"sk_s3", 1, "largest split-K grid on three ring stages, one batch at a time"}, {"sk_s3_conc", 1, "... with batches in flight"},
   {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
   {"fire", 1, "a fire module (squeeze + merged expands) as one launch: 0 never, 1 wherever it fits, 2 (default) on maps >= 28 wide"},
   {"fire_pool", 1, "fire modules with a pool behind their expands: 0 never, 1 / 2 fire launch + pool launch (maps >= 56 wide / wherever fire allows), 3 (default) the pool inside the fire launch one batch at a time, 4 always"},
@@ -35,13 +39,15 @@ const OptSpec kOptSpecs[] = {
   {"c3_pool", 1, "a layer's 2x2 / 2 max pool inside its conv_c3 launch: 1 / 0"},
   {"c3_w9", 1, "conv_c3_w9_kernel: 0 never, 1 auto, 2 wherever allowed"},
   {"bneck_min", 1, "conv_bneck: smallest grid"}, {"stem", 1, "conv_stem: 1 auto, 0 never"}, {"stem_pool", 1, "conv1's pool in its launch"},
-  {"avg_fuse", 1, "a layer's global average in its split-K launch"}, {"pair", 1, "pair launches"},
+  {"avg_fuse", 1, "a layer's global average in its split-K launch: 0 never, 1 always, 2 (default) one batch at a time only"}, {"pair", 1, "pair launches"},
   {"bgroup_min7", 1, "smallest batch of the 7x7 group launches"}, {"bgroup_min14", 1, "... 14x14"}, {"bgroup_min28", 1, "... 28x28"}, {"bgroup_min56f", 1, "... the first 56x56 bottleneck"},
   {"bgroup_chain", 1, "identity bottlenecks per group launch"},
   {"bband_rows", 1, "band launches: rows per block with batches in flight"}, {"bband_rows_alone", 1, "... one batch at a time"},
   {"bband_min", 1, "band launches: smallest batch"}, {"bband_alone_maps", 1, "maps taking band launches one batch at a time (bit 1: 28x28, bit 2: 14x14)"},
   {"dense", 1, "arithmetic gather words"}, {"dense_max", 1, "longest slab list that takes them on multi-round grids"},
   {"alt_min", 1, "smallest grid taking a wide-tile alternative"}, {"alt_min_conc", 1, "... with batches in flight"}, {"alt_narrow", 1, "largest grid taking a narrow alternative"},
+  {"alt_rows", 1, "bit mask of rows forced onto their alternative tile height"}, {"noalt_rows", 1, "... kept off it"},
+  {"sk_rows", 1, "bit mask of 64-row-tile rows forced onto the in-block split-K kernel"}, {"nosk_rows", 1, "... kept off it"},
   {"exp", 1, "timing-probe bits (-DTF2_PROBES builds)"}, {"skip_layers", 1, "lo-hi: launches left out (-DTF2_PROBES builds)"},
   {"dbgptr", 1, "tools: device buffer for per-layer stamps"}, {"dbgptr2", 1, "tools: device buffer for per-block stamps"}, {"dbglayer", 1, "tools: the layer dbgptr2 records"},
 };
@@ -81,6 +87,7 @@ std::string opts_reload() {
       std::string name = item, val = "1";
       const size_t eq = item.find('=');
       if (eq != std::string::npos) { name = item.substr(0, eq); val = item.substr(eq + 1); }
+      if (eq != std::string::npos && val.empty()) { err = "TF2_AMD_OPTS: '" + item + "' has no value (a bare name means name=1)"; break; }
       const OptSpec* sp = find_spec(name);
       if (!sp) { err = "TF2_AMD_OPTS: unknown option '" + name + "'"; break; }
       if (sp->test_only && !test_mode) { err = "TF2_AMD_OPTS: '" + name + "' is a test-only option (set TF2_AMD_TEST=1 as well)"; break; }
@@ -96,6 +103,25 @@ std::string opts_reload() {
         if (!endp || *endp) { err = "TF2_AMD_OPTS: '" + item + "' is not name=integer"; break; }
       }
       (*snap)[name] = v;
+    }
+  }
+  // Rounds 1-4 read 56 separate TF2_AMD_* variables (TF2_AMD_BGROUP=0, TF2_AMD_ALT_CONC, ...).  A deployment that still sets one of
+  // them -- e.g. to keep the group launches off where their preconditions cannot be guaranteed -- must not silently get the default
+  // back: any TF2_AMD_* name other than the four the library reads is an error that names its replacement.
+  if (err.empty()) {
+    static const char* const kKnown[] = {"TF2_AMD_OPTS", "TF2_AMD_TEST", "TF2_AMD_LIB", "TF2_AMD_TOOL_LIB"};
+    for (char** e = environ; e && *e; e++) {
+      if (strncmp(*e, "TF2_AMD_", 8) != 0) continue;
+      const char* eqp = strchr(*e, '=');
+      const std::string nm(*e, eqp ? (size_t)(eqp - *e) : strlen(*e));
+      bool known = false;
+      for (const char* k : kKnown) known = known || nm == k;
+      if (known) continue;
+      std::string low = nm.substr(8);
+      for (char& c : low) c = (char)tolower((unsigned char)c);
+      err = "environment variable " + nm + " is no longer read: use TF2_AMD_OPTS=\"" + low + "=" + (eqp ? eqp + 1 : "1") + "\"" +
+            (find_spec(low) ? "" : " (INTEGRATION.md section 5 lists the current names)");
+      break;
     }
   }
   if (!err.empty()) return err;                           // (the previous snapshot stays)

@@ -410,7 +410,7 @@ int launch_conv_first_pool(const FirstArgs& f, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
-int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix);   // register-resident pointwise kernel takes the layer? (max_slab / min_pix: RunOpts::pw_slabs / pw_minpix)
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)

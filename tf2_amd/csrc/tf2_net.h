@@ -106,6 +106,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   long alt_min_blocks = 200;   // alt_min: smallest 128 x 128 grid that takes a wide-tile alternative, one batch at a time
   long alt_narrow_blocks = 64;     // alt_narrow
   long alt_min_blocks_conc = 90;   // alt_min_conc: the same when the caller keeps several batches in flight
+  unsigned long long alt_rows = 0, noalt_rows = 0, sk_rows = 0, nosk_rows = 0;   // test-only per-row switches (bit l = table row l)
   int alt_conc_mode = 2;       // alt_conc: 0 never assume concurrency, 1 always, 2 auto (calls on >= 2 streams among the last 8)
   int dense_max_slabs = 17;   // dense_max: layers with more K slabs than this on grids of more than one round keep the header tables
   int dense_mode = 1;      // dense: gather words of dense layers computed from the step index (1) or read from the header tables (0)
@@ -117,9 +118,10 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int bband_alone_maps = 0;   // bband_alone_maps: maps that take band launches one batch at a time too, instead of the group launches (bit 1: 28 x 28, bit 2: 14 x 14; bband=2 = both)
   int bband_min = 8;       // bband_min: smallest batch that takes them
   int pair_mode = 1;       // pair: two independent neighbouring layers (shortcut | first 1x1) in one conv_mfma2 launch
-  int avg_fuse = 1;        // avg_fuse: the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
+  int avg_fuse = 2;        // avg_fuse (0 never / 1 always / 2 one batch at a time): the global average of an end-pool layer inside its conv launch (conv_mfma_sk AVG)
   int stem_pool = 1;       // stem_pool: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (stem)
+  long sk_s3_blocks = 256, sk_s3_blocks_conc = 0;   // largest split-K grid on three ring stages (100 KiB of LDS: the block owns its CU), one batch at a time / in flight
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (sk8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };

@@ -515,10 +515,10 @@ tf2_status Net::pack(int mode) {
       // the dense window matrices: the form is used only when it reproduces them byte for byte.
       std::vector<uint8_t> nibt, lutv, clsm;
       int n_cls = 1;
-      bool fc4 = variant == 0 && mode == 0 && opt("fc4", 1) != 0 && !L.ipool && L.k == L.H && L.k == L.W && L.stride == 1 && L.dil <= 1 &&
+      bool fc4 = variant == 0 && mode == 0 && opt("fc4", 1) != 0 && !L.ipool && L.k == L.H && L.k == L.W && L.stride == 1 && L.dil == 1 &&
                  (L.pad_h | L.pad_w) == 0 && L.OH == 1 && L.OW == 1 && L.src >= 0 && L.add_src < 0 && !L.endpool && !L.pool_en && L.concat < 0 &&
                  layers[L.src].concat < 0 && l != nl - 1 && !in_signed && (P == 1 || dual) && Np % 128 == 0 && il.Cp_in % 64 == 0 &&
-                 il.Cp_in == round_up(C, 16) && Kp == Ktot && (long)entries.size() == (long)n_mtiles * nslab && nslab >= (int)opt("fc_min", 64) /* conv_fc's own threshold (RunOpts::fc_min_slabs): a layer packed this way can run nowhere else */ && fuse_next[l] <= 0 && fused_into[l] < 0;
+                 il.Cp_in == C /* (Net::fc_at: the kernel walks whole 64-channel slabs of an unpadded tensor; C = 500 on Cp 512 stays int8 tiles for the split-K kernel) */ && Kp == Ktot && (long)entries.size() == (long)n_mtiles * nslab && nslab >= (int)opt("fc_min", 64) /* conv_fc's own threshold (RunOpts::fc_min_slabs): a layer packed this way can run nowhere else */ && fuse_next[l] <= 0 && fused_into[l] < 0;
       if (fc4) {
         const int Mq = nd.max_out_channel;
         std::vector<int> Bc(il.Cp_in, 0), An(Np, -1000);

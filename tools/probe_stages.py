@@ -4,8 +4,8 @@ stage left out (probe build: option skip_layers=lo-hi; results wrong, durations 
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tf2_amd._lib import set_opts  # noqa: E402
 os.environ["TF2_AMD_LIB"] = os.path.join(ROOT, "tf2_amd", "libtf2amd_probe.so"); os.environ["TF2_AMD_TOOL_LIB"] = "1"     # (built on demand: make -C tf2_amd/csrc probe)
+from tf2_amd._lib import set_opts  # noqa: E402
 import numpy as np, torch
 from tf2_amd import config as cfg, network, synth, _lib
 t = cfg.resnet50_tables(); plan = cfg.build_plan(t)
