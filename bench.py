@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ResNet50 INT4w/INT8a images/s on N MI355X (BASELINE.json metric); `--net` runs the other BASELINE configurations
-(SqueezeNet 1.1, VGG16, SSD300-VGG: synthetic Q values and weights) through the same measurement and prints the same JSON line.
+(SqueezeNet 1.1, VGG16, SSD300-VGG: synthetic Q values and weights) and the reference's other two shipped table programs (googlenet,
+resnet50_pruned: shipped tables and Q files) through the same measurement and prints the same JSON line.
 
 One process per GPU (torchrun contract), batches sharded with no data-path collective (weak
 scaling: every rank runs `--batch` images per step); the packed weights are broadcast once
@@ -134,9 +135,13 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300"],
+    ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300", "googlenet", "resnet50_pruned"],
                     help="network: resnet50 (the headline: shipped resnet50_Q, seeded INQ weights) or another BASELINE.json configuration "
-                         "(synthetic Q values and weights); e.g. BASELINE config 4 is `--gpus 8 --net vgg16 --batch 32`")
+                         "(synthetic Q values and weights); e.g. BASELINE config 4 is `--gpus 8 --net vgg16 --batch 32`; googlenet / "
+                         "resnet50_pruned: the reference's other two shipped table programs with their shipped Q files (README.md:39,76-80)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region this many times (the first one is `value`, as before; all of them under `repeats` with min / "
+                         "median / max): a 20-step region is 7 ms -- one scheduling hiccup is several percent")
     ap.add_argument("--mode", type=int, default=0, help="0 auto (MFMA), 1 north-star split, 2 shift only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -341,6 +346,16 @@ def main():
     dt, x = timed(args.batch, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    # the same region again (device warm: no further spin-up), W warm-up steps in front of each: how far the figure of record moves
+    rep_vals = [value]
+    for _ in range(max(0, args.repeats - 1)):
+        dr, _ = timed(args.batch, args.steps, args.warmup, spin=False)
+        rep_vals.append(world * args.batch * args.steps / dr)
+    rs = sorted(rep_vals)
+    repeats = dict(values=[round(v, 1) for v in rep_vals], min=round(rs[0], 1), median=round(float(np.median(rs)), 1), max=round(rs[-1], 1),
+                   spread_pct=round(100.0 * (rs[-1] - rs[0]) / float(np.median(rs)), 2),
+                   note="`value` is values[0]; the others repeat the W + K steps back to back on the warm device"
+                        + ("; spread above 3 %: quote the median" if (rs[-1] - rs[0]) / float(np.median(rs)) > 0.03 else ""))
     per_rank = None
     if world > 1 and rank_dts:
         rates = [args.batch * args.steps / d for d in rank_dts]
@@ -471,6 +486,12 @@ def main():
                              gbps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None,
                              frac_hbm_peak=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM, 4) if v["ms"] > 0 else None)
                      for k, v in classes.items()}
+        # the literal shift-accumulate kernel (modes 1 / 2: the north-star split) is priced against ITS roof: one v_mad_i32_i24 per MAC and lane,
+        # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz x ... = 78 TMAC/s (conv_shift.hip)
+        for k, v in classes.items():
+            if any("conv_shift" in kk for kk in v["kernel"]) and v["ms"] > 0:
+                per_class[k]["tmacs"] = round(v["ops"] / 2 / (v["ms"] * 1e-3) / 1e12, 2)
+                per_class[k]["frac_valu_shift_peak"] = round(v["ops"] / 2 / (v["ms"] * 1e-3) / 1e12 / 78.0, 4)
         cv = [i for i in range(len(plan)) if kinds[i] in (1, 2)]
         n_launch = max(1, sum(1 for i in cv if nl[i] > 0))
         dom_ms = float(sum(per_layer_ms[i] for i in cv))
@@ -483,7 +504,7 @@ def main():
         return dict(per_layer_ms=per_layer_ms, nl=nl, kinds=kinds, cv=cv, n_launch=n_launch, dom_ms=dom_ms, event_scale=event_scale,
                     per_class=per_class, top_kernel=top_kernel, kernels=sorted({k for v in kern_of.values() for k in v if k.startswith("conv")}))
 
-    ROUND = "r05"
+    ROUND = "r06"
 
     def committed(name):
         """a profile of THIS round committed under profiles/ for this network / batch / kernel mode (tools/round_evidence.sh)"""
@@ -613,7 +634,7 @@ def main():
                                 spinup_note="untimed steps for spinup_ms before the W warm-up steps of every timed leg: an idle MI355X sits "
                                             "at ~150 MHz and needs ~0.4 s of load to reach 2.4 GHz (tools/clock_sample.py); the timed region is "
                                             "still exactly K steps between barrier + synchronize"),
-                    cold_start=cold, weight_broadcast=broadcast, per_rank=per_rank, roofline=roofline, cpu_baseline=cpu,
+                    repeats=repeats, cold_start=cold, weight_broadcast=broadcast, per_rank=per_rank, roofline=roofline, cpu_baseline=cpu,
                     hbm=dict(algorithmic_gbps=round(hbm_gbps, 1), frac_of_8tbps=round(hbm_gbps / PEAK_HBM, 4),
                              bytes_per_image=sum(r["bytes"] for r in lo)),
                     per_layer_class=per_class, per_layer_class_one_batch=per_class_one_batch, images_per_s_by_batch=sweep,

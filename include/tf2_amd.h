@@ -32,7 +32,8 @@ enum {
   TF2_ERR_STATE = -2,      /* call order (e.g. run before load_model)                 */
   TF2_ERR_SIZE = -3,       /* buffer too small / model stream length mismatch         */
   TF2_ERR_HIP = -4,        /* HIP runtime error (message carries hipGetErrorString)   */
-  TF2_ERR_UNSUPPORTED = -5 /* layer shape not supported by any kernel                 */
+  TF2_ERR_UNSUPPORTED = -5,/* layer shape not supported by any kernel                 */
+  TF2_ERR_GROUP = -6       /* a group launch gave up a meeting (tf2_net_poll_error)   */
 };
 
 /* One row of the network program = one row of the k* tables of <net>.h
@@ -186,6 +187,14 @@ tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void*
  * tf2_net_run_stats: out4 = {steps run, steps whose plan had group launches, steps run with the in-flight plan, steps on a stream
  * of fewer than 64 CUs} since tf2_net_create -- what a test or a server asserts its deployment against.                          */
 tf2_status tf2_net_run_stats(tf2_net* net, int64_t* out4);
+/* Group launches that cannot complete REPORT, they never trap or hang the context (round 6): a block that has polled a meeting of its
+ * image's eight members `bgroup_polls` times (1 << 24: seconds) writes a report into the workspace's error word and leaves the kernel, and
+ * so do the other members of that image; every other image of the launch and every later launch run on (the affected step's logits are
+ * garbage).  tf2_net_poll_error synchronises `stream`, reads and clears the error word of the workspace that was used for `batch` images and
+ * returns TF2_ERR_GROUP (tf2_last_error says which meeting) or TF2_OK; the report is sticky across later steps until it is polled.  A
+ * server polls where it synchronises anyway (when it reads a batch's logits).  Steps of the in-flight plan (concurrency = 1) have no group
+ * launches and nothing to report.  The reference has no counterpart (its kernels are statically scheduled, sequencer.cl). */
+tf2_status tf2_net_poll_error(tf2_net* net, int batch, void* workspace, size_t workspace_bytes, void* stream);
 /* Introspection: the kernel launches one step of `batch` images consists of, in issue order, as the library's own launch
  * plan selects them (concurrency as in tf2_run_opts: 0 or 1).  Needs a packed image, no device.  rows[i].layer = the table
  * row the launch belongs to (-1: input preparation; a fused launch carries its first row).  Returns the number of launches

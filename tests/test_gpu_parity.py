@@ -515,6 +515,47 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
 
 
+@pytest.mark.parametrize("withhold_row", [28, 47, 15, 1])
+def test_group_launch_that_cannot_meet_reports_a_status(r50, monkeypatch, withhold_row):
+    """include/tf2_amd.h promises status codes, never a dead context (round-5 review: the group kernels ended a stuck meeting with
+    __builtin_trap()).  The test-only option bgroup_withhold makes ONE block of every group launch leave at kernel entry without posting
+    its flags: the other seven members of its image give up after bgroup_polls polls, write a report into the workspace's error word and
+    return; every other image completes; the step's later launches run; tf2_net_poll_error returns TF2_ERR_GROUP once (the report is
+    sticky until polled, then cleared), and the SAME handle, workspace and HIP context then run a clean step with the oracle's logits.
+    One case per group kernel (14 x 14 chain, 7 x 7 chain, 28 x 28, the first 56 x 56 bottleneck: the block index picks a member of image 0
+    or 1 of each)."""
+    from tf2_amd._lib import Tf2Error
+    torch = _torch()
+    set_opts(monkeypatch, bgroup="1", alt_conc="0", bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1)
+    rig = Rig(*r50, 0)
+    x = synth.synth_images(rig.t, 9, 75)
+    want = rig.ref.logits(rig.ref.run(x))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    np.testing.assert_array_equal(rig.runner.run_batch(xd, concurrency=0).cpu().numpy(), want)
+    assert rig.runner.poll_error() is None
+    # block 8 * k + i is member k of image i (conv_bgroup.hip): block 17 = member 2 of image 1 -- in EVERY group launch of the step
+    set_opts(monkeypatch, bgroup_withhold=18, bgroup_polls=20000)
+    rig.net.reload_options()
+    assert any("conv_bgroup" in r["kernel"] and r["layer"] == withhold_row for r in rig.net.describe_launches(9, 0))
+    got = rig.runner.run_batch(xd, concurrency=0)           # returns TF2_OK: the failure is on the device
+    with pytest.raises(Tf2Error) as ei:
+        rig.runner.poll_error()
+    assert ei.value.status == -6 and "group launch" in str(ei.value)
+    bad = got.cpu().numpy()
+    assert (bad[1] != want[1]).any()                        # (image 1 went through a launch without one of its members)
+    assert rig.runner.poll_error() is None                  # reported once, cleared
+    # two steps without a poll in between: the report survives the next step's control-word initialisation
+    rig.runner.run_batch(xd, concurrency=0)
+    set_opts(monkeypatch, bgroup_withhold=None, bgroup_polls=None)
+    rig.net.reload_options()
+    clean = rig.runner.run_batch(xd, concurrency=0).cpu().numpy()
+    with pytest.raises(Tf2Error):
+        rig.runner.poll_error()
+    np.testing.assert_array_equal(clean, want)              # the context, the handle and the workspace are alive
+    assert rig.runner.poll_error() is None
+    np.testing.assert_array_equal(rig.runner.run_batch(xd, concurrency=0).cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("pack_switch", ["nofast", "nodbl", "nosemi"])
 def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     """The group kernels share requant_epilogue.h with everything else: the wrap-exact generic requantisation on every row

@@ -180,7 +180,13 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     assert [r["layer"] for r in bands] == [15, 18, 21, 28, 31, 34, 37, 40] and not any("conv_bband" in r["kernel"] for r in one)
     assert [r["grid"] for r in bands] == [128, 128, 224, 64, 64, 64, 64, 64] and all(r["block"] == 512 and r["lds_bytes"] + 65536 <= 160 * 1024 for r in bands)
     assert "dual reduce" in bands[0]["kernel"] and "dual reduce,dual 3x3" in bands[2]["kernel"] and "dual" not in bands[3]["kernel"]
-    assert len(many) == 33 and len(one) == 22
+    # the global average: inside the last expand's split-K launch one batch at a time; with batches in flight the expand runs on its
+    # 208-block 128 x 128 tiles and the average is a launch of its own (round 6: the 1024-block fused launch cost 13 us of the in-flight step
+    # against 2.6), and the split-K launches take two ring stages there (64 KiB of LDS: another block fits beside them)
+    assert "global average" in [r for r in one if r["layer"] == 47][0]["kernel"] and not any(r["kernel"] == "global_avg_kernel" for r in one)
+    assert [r["kernel"].split("<")[0] for r in many if r["layer"] == 52] == ["conv_mfma2_kernel", "global_avg_kernel"]
+    assert all("S2" in r["kernel"] for r in many if "conv_mfma_sk" in r["kernel"])
+    assert len(many) == 34 and len(one) == 22
     assert [r["grid"] for r in net.describe_launches(40, 0) if r["layer"] == 28] == [256, 64]     # at most 32 images per launch
     # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation (single-window and dual layers are dense)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]

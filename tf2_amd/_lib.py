@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
     L.tf2_net_run_q.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp]
     L.tf2_net_run_ex.argtypes = [vp, vp, C.c_int, vp, sz, vp, vp, C.POINTER(RunOpts)]
     L.tf2_net_run_stats.argtypes = [vp, vp]
+    L.tf2_net_poll_error.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
     L.tf2_net_describe_launches.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LaunchInfo), C.c_int, C.POINTER(C.c_int)]
     L.tf2_net_describe_workspace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TensorInfo), C.c_int, C.POINTER(C.c_int), C.POINTER(RowTensors), C.c_int]
     L.tf2_net_read_layer.argtypes = [vp, C.c_int, C.c_int, vp, vp, sz, vp]
@@ -145,7 +146,7 @@ EXPORTED = [
     "tf2_net_create", "tf2_net_destroy", "tf2_net_set_q", "tf2_net_load_model", "tf2_model4bit_decode", "tf2_net_load_model_4bit", "tf2_net_get_codes",
     "tf2_net_get_bias_bn", "tf2_net_pack", "tf2_net_packed_size", "tf2_net_packed_copy",
     "tf2_net_packed_adopt", "tf2_net_bind_device", "tf2_net_workspace_size", "tf2_net_logits_size", "tf2_net_reload_options", "tf2_net_run",
-    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_run_stats", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
+    "tf2_net_run_q", "tf2_net_run_ex", "tf2_net_run_stats", "tf2_net_poll_error", "tf2_net_describe_launches", "tf2_net_describe_workspace", "tf2_net_read_layer", "tf2_net_profile", "tf2_net_profile_read", "tf2_net_profile_loop_read", "tf2_topk"]
 
 
 def parse_opts(text: str) -> dict:

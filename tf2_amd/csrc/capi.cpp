@@ -217,6 +217,12 @@ tf2_status tf2_net_run_stats(tf2_net* net, int64_t* out4) {
   return TF2_OK;
 }
 
+tf2_status tf2_net_poll_error(tf2_net* net, int batch, void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_NET(net);
+  std::lock_guard<std::mutex> lock(net->impl.run_mutex);
+  return net->impl.poll_error(batch, workspace, workspace_bytes, stream);
+}
+
 tf2_status tf2_net_describe_launches(tf2_net* net, int batch, int concurrency, tf2_launch_info* rows, int capacity, int* n) {
   CHECK_NET(net);
   if (!n || (capacity > 0 && !rows)) { set_error("tf2_net_describe_launches: null argument"); return TF2_ERR_ARG; }

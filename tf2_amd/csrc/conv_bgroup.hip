@@ -73,11 +73,21 @@ __device__ __forceinline__ void bg_signal(unsigned* flags, int member, unsigned 
   __syncthreads();
   if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(flags + member), "v"(tag) : "memory");
 }
-// returns (block-uniform) whether every member runs on this block's XCD
-__device__ __forceinline__ bool bg_wait(const unsigned* flags, unsigned tag, int tid, int* lds_word) {
+// A meeting that does not complete (a member that never became resident: the launch preconditions of tf2_amd.h were not met) is
+// REPORTED, not trapped (round 6; rounds 3-5 ended the HIP context with __builtin_trap()): after `limit` polls the waiting block writes
+// kBgErrMagic | code into the workspace's error word (control word 1, written through to memory), gives up and leaves the kernel;
+// the other members of its group do the same, every other group completes, the stream goes on, and tf2_net_poll_error returns
+// TF2_ERR_GROUP for that step (its logits are garbage).  Control words of the workspace (net.hip / prep_zero_ctrl): [0] step counter,
+// [1] error word, [2] poll limit of this step, [3] test-only: 1 + index of a block that leaves its group at kernel entry.
+__device__ __forceinline__ void bg_report(const unsigned* epoch, unsigned code) {
+  asm volatile("global_store_dword %0, %1, off sc1" :: "v"(const_cast<unsigned*>(epoch) + 1), "v"(kBgErrMagic | (code & 0xffffu)) : "memory");
+}
+// returns (block-uniform) 1: every member runs on this block's XCD, 0: not, -1: the meeting timed out (reported; the caller returns)
+__device__ __forceinline__ int bg_wait(const unsigned* flags, unsigned tag, int tid, int* lds_word, const unsigned* epoch, int limit, unsigned code) {
   if (tid < 64) {
     int polls = 0;
     unsigned f = 0;
+    bool failed = false;
     for (;;) {
       if (tid < kBgMembers) {
         if ((polls & 3) == 3) {
@@ -91,13 +101,16 @@ __device__ __forceinline__ bool bg_wait(const unsigned* flags, unsigned tag, int
       }
       if (__builtin_amdgcn_ballot_w64((f >> 8) != (tag >> 8)) == 0) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++polls > (1 << 24)) __builtin_trap();     // members are dispatched together (ascending order): fail, do not hang
+      if (++polls > limit) { failed = true; break; }       // members are dispatched together (ascending order): report, do not hang
     }
     const bool all_here = __builtin_amdgcn_ballot_w64(tid < kBgMembers && (f & 0xff) != (tag & 0xff)) == 0;
-    if (tid == 0) *lds_word = all_here ? 1 : 0;
+    if (tid == 0) {
+      if (failed) bg_report(epoch, code);
+      *lds_word = failed ? -1 : all_here ? 1 : 0;
+    }
   }
   __syncthreads();
-  return *lds_word != 0;
+  return *lds_word;
 }
 
 // Roll call: every member posts its flag once at the start of the launch; by the time the first exchange stores are due everybody
@@ -106,8 +119,9 @@ __device__ __forceinline__ bool bg_wait(const unsigned* flags, unsigned tag, int
 __device__ __forceinline__ void bg_rollcall_post(unsigned* flags, int member, unsigned tag, int tid) {
   if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(flags + member), "v"(tag) : "memory");
 }
-// the calling WAVE reads the roll call (no block barrier): true = all eight members run on this wave's XCD
-__device__ __forceinline__ bool bg_rollcall_wave(const unsigned* flags, unsigned tag, int lane) {
+// the calling WAVE reads the roll call (no block barrier): true = all eight members run on this wave's XCD.  A roll call that times
+// out is reported and read as "not local": the block's next meeting (a block barrier) times out as well and ends the block.
+__device__ __forceinline__ bool bg_rollcall_wave(const unsigned* flags, unsigned tag, int lane, const unsigned* epoch, int limit, unsigned code) {
   int polls = 0;
   unsigned f = tag;
   for (;;) {
@@ -117,7 +131,7 @@ __device__ __forceinline__ bool bg_rollcall_wave(const unsigned* flags, unsigned
     }
     if (__builtin_amdgcn_ballot_w64((f >> 8) != (tag >> 8)) == 0) break;
     __builtin_amdgcn_s_sleep(1);
-    if (++polls > (1 << 24)) __builtin_trap();
+    if (++polls > limit) { if (lane == 0) bg_report(epoch, code); return false; }
   }
   return __builtin_amdgcn_ballot_w64((f & 0xff) != (tag & 0xff)) == 0;
 }
@@ -211,9 +225,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
     if (a.tm3 < C / kBgMembers) hdr_dma(a.hdr3, a.hdr3_bytes, c3 / a.tm3 + 1, a.tm3, 3);
     for (int s = wave; s < KS1; s += 8) w_dma(a.w1, a.tm1, mt1 * KS1 + s, ro1, work + s * 2048);
     if (kb == 0 && tid == 64 * 7) {                        // the step counter, from the memory side (wave 7 has no tile of its own)
-      unsigned e;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-      ctl[0] = (int)e;
+      i32x4 e;                                             // control words {step counter, error word, poll limit, test: withheld block + 1}
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = e[0]; ctl[4] = e[2]; ctl[5] = e[3];
     }
   }
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
   // kb > 0: the input is the previous bottleneck's output, written by all eight members: they meet at this one's roll-call row
   // (signalled behind the previous expand's stores) before the first pixel is fetched
   bool local_in = false;
-  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
+  if (kb > 0) { const int r_in = bg_wait(ctr, tag, tid, ctl + 3, a.epoch, ctl[4], 0x10u | ((unsigned)kb << 8)); if (r_in < 0) return; local_in = r_in > 0; }
 
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
     __syncthreads();                                       // headers and the reduce's weights are in LDS (pieces fetched by every wave)
     BG_STAMP(1);
     if (kb == 0) {
+      if (ctl[5] == (int)blockIdx.x + 1) return;            // (test-only: this member leaves its group; the others report and go on)
       tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);        // (the epoch word was stored before the barrier)
       bg_rollcall_post(ctr, m, tag, tid);
     }
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] += acc1[r];
       BG_STAMP(2);
-      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane, a.epoch, ctl[4], 0x01u);
       // requantise, write this member's 32 channels of mid1 (the other members read them next)
       int a16[16];
 #pragma unroll
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
   BG_STAMP(3);
   // the 3x3's weights (this member's 32 rows of all 9 x KS2 steps) on their way while the group gathers
   for (int e = wave; e < NE; e += 8) w_dma(a.w2, a.tm2, mt2 * NE + e, ro2, wreg + e * 2048);
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  const int r_m1 = bg_wait(ctr + 8, tag, tid, ctl + 1, a.epoch, ctl[4], 0x20u | ((unsigned)kb << 8)); if (r_m1 < 0) return; const bool local1 = r_m1 > 0;
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup_kernel(BGroupChain c) {
     const int8_t* rp = (a.has_res && p_ok) ? a.res + (px_img + p_lane) * a.res_cp + a.res_off + c3 + 32 * q + 16 * half : a.zero;
     rv[q] = *reinterpret_cast<const i32x4*>(rp);
   }
-  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
+  const int r_m2 = bg_wait(ctr + 16, tag, tid, ctl + 2, a.epoch, ctl[4], 0x30u | ((unsigned)kb << 8)); if (r_m2 < 0) return; const bool local2 = r_m2 > 0;
   BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
@@ -499,9 +514,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(xt + gi * 1024), 16, 0, 0);
     }
     if (tid == 64 * 7) {
-      unsigned e;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-      ctl[0] = (int)e;
+      i32x4 e;                                             // control words {step counter, error word, poll limit, test: withheld block + 1}
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = e[0]; ctl[4] = e[2]; ctl[5] = e[3];
     }
   }
   const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
@@ -509,6 +524,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   const int* const prm2 = reinterpret_cast<const int*>(hdr_lds + kBgHdrSlot);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                         // headers, reduce weights and the band's input are in LDS
+  if (ctl[5] == (int)blockIdx.x + 1) return;                // (test-only: this member leaves its group; the others report and go on)
   const unsigned tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
   bg_rollcall_post(ctr, m, tag, tid);
   bool local0 = false;
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   // =================================== phase A: reduce, 1x1 64 -> 64 (K = one slab) ===================================
   {
     const int lo_b = a.relu1 ? 0 : -128;
-    local0 = bg_rollcall_wave(ctr, tag, lane);
+    local0 = bg_rollcall_wave(ctr, tag, lane, a.epoch, ctl[4], 0x01u);
 #pragma unroll
     for (int rd = 0; rd < 2; rd++) {
       const int t = wave + 8 * rd;
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup56f_kernel(BGroupArgs a) {
   }
   bg_signal(ctr + 8, m, tag, tid);
   for (int u = wave; u < 9 * 2; u += 8) w_dma(a.w2, (size_t)(u >> 1) * 64 + 32 * (u & 1), wreg + u * 2048);      // the 3x3's weights: [tap][two 32-row tiles]
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  const int r_m1 = bg_wait(ctr + 8, tag, tid, ctl + 1, a.epoch, ctl[4], 0x20u | ((unsigned)0 << 8)); if (r_m1 < 0) return; const bool local1 = r_m1 > 0;
 
   // =================================== phase B: 3x3 / pad 1; the band's output stays in LDS ===================================
   {
@@ -768,9 +784,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
       w_dma(a.w1, (((size_t)mt1 * KS1 + s) * NW1 + win) * a.tm1 + ro1 + 32 * ctq, wreg + u * 2048);
     }
     if (kb == 0 && tid == 64 * 7) {
-      unsigned e;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-      ctl[0] = (int)e;
+      i32x4 e;                                             // control words {step counter, error word, poll limit, test: withheld block + 1}
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = e[0]; ctl[4] = e[2]; ctl[5] = e[3];
     }
   }
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
@@ -796,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
 
   // kb > 0: the input is the previous bottleneck's output: the members meet at this one's roll-call row first
   bool local_in = false;
-  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
+  if (kb > 0) { const int r_in = bg_wait(ctr, tag, tid, ctl + 3, a.epoch, ctl[4], 0x10u | ((unsigned)kb << 8)); if (r_in < 0) return; local_in = r_in > 0; }
 
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
@@ -820,6 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
     __syncthreads();                                       // headers and the reduce's weights are in LDS
     BG_STAMP(1);
     if (kb == 0) {
+      if (ctl[5] == (int)blockIdx.x + 1) return;            // (test-only: this member leaves its group; the others report and go on)
       tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
       bg_rollcall_post(ctr, m, tag, tid);
     }
@@ -862,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
               acc[q][G * 4 + r] = (int)(((unsigned)acc[q][G * 4 + r] << (d[r] & 31)) + (unsigned)accl[q][G * 4 + r]);
           }
       }
-      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane, a.epoch, ctl[4], 0x01u);
       store_mid(acc, prm1, a.tm1, ro1, a.fast1, a.relu1, a.dbl1, a.mid1);
     }
   }
@@ -876,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
       w_dma(a.w2, (((size_t)mt2 * NE + (u >> 1)) * NW2 + win) * a.tm2 + ro2 + 32 * (u & 1), wreg + u * 2048);
   };
   load_w2(0);
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  const int r_m1 = bg_wait(ctr + 8, tag, tid, ctl + 1, a.epoch, ctl[4], 0x20u | ((unsigned)kb << 8)); if (r_m1 < 0) return; const bool local1 = r_m1 > 0;
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -964,7 +981,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup28_kernel(BGroupChain c) { 
       wf[s][0] = *reinterpret_cast<const i32x4*>(p); wf[s][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
   }
-  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
+  const int r_m2 = bg_wait(ctr + 16, tag, tid, ctl + 2, a.epoch, ctl[4], 0x30u | ((unsigned)kb << 8)); if (r_m2 < 0) return; const bool local2 = r_m2 > 0;
   BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual ===================================
@@ -1110,9 +1127,9 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
 #pragma unroll
     for (int q = 0; q < 4; q++) hdr_dma(a.hdr3, a.hdr3_bytes, 4 * m + q, 2 + q);
     if (kb == 0 && tid == 64 * 7) {
-      unsigned e;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
-      ctl[0] = (int)e;
+      i32x4 e;                                             // control words {step counter, error word, poll limit, test: withheld block + 1}
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(a.epoch) : "memory");
+      ctl[0] = e[0]; ctl[4] = e[2]; ctl[5] = e[3];
     }
   }
   const int* const prm1 = reinterpret_cast<const int*>(hdr_lds);
@@ -1162,7 +1179,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
 
   // kb > 0: the input is the previous bottleneck's output: the members meet at this one's roll-call row first
   bool local_in = false;
-  if (kb > 0) local_in = bg_wait(ctr, tag, tid, ctl + 3);
+  if (kb > 0) { const int r_in = bg_wait(ctr, tag, tid, ctl + 3, a.epoch, ctl[4], 0x10u | ((unsigned)kb << 8)); if (r_in < 0) return; local_in = r_in > 0; }
 
   // =================================== phase A: reduce, 1x1 C -> M ===================================
   {
@@ -1214,6 +1231,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
     __syncthreads();                                       // every wave is done with its ring; headers (fetched by every wave) are in LDS
     BG_STAMP(1);
     if (kb == 0) {
+      if (ctl[5] == (int)blockIdx.x + 1) return;            // (test-only: this member leaves its group; the others report and go on)
       tag = ((unsigned)ctl[0] << 8) | (xcc & 0xff);
       bg_rollcall_post(ctr, m, tag, tid);
     }
@@ -1232,14 +1250,14 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
     }
     reduce_quarters(acc, wreg);
     if (kq == 0) {
-      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane);
+      if (kb == 0) local0 = bg_rollcall_wave(ctr, tag, lane, a.epoch, ctl[4], 0x01u);
       store_mid(acc, prm1, a.fast1, a.relu1, a.dbl1, a.mid1);
     }
     BG_STAMP(2);
   }
   bg_signal(ctr + 8, m, tag, tid);
   BG_STAMP(3);
-  const bool local1 = bg_wait(ctr + 8, tag, tid, ctl + 1);
+  const int r_m1 = bg_wait(ctr + 8, tag, tid, ctl + 1, a.epoch, ctl[4], 0x20u | ((unsigned)kb << 8)); if (r_m1 < 0) return; const bool local1 = r_m1 > 0;
   BG_STAMP(4);
 
   // =================================== phase B: 3x3 / pad 1, M -> M ===================================
@@ -1331,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void conv_bgroup7_kernel(BGroupChain c) {  
   auto issue3 = [&](int s, int slot) { w_dma(a.w3, ((size_t)mt3 * KS2 + s) * 64 + ro3, ring3 + slot * 2048); };
 #pragma unroll
   for (int s = 0; s < S3 - 1; s++) issue3(s, s);
-  const bool local2 = bg_wait(ctr + 16, tag, tid, ctl + 2);
+  const int r_m2 = bg_wait(ctr + 16, tag, tid, ctl + 2, a.epoch, ctl[4], 0x30u | ((unsigned)kb << 8)); if (r_m2 < 0) return; const bool local2 = r_m2 > 0;
   BG_STAMP(8);
 
   // =================================== phase C: expand, 1x1 M -> C, + residual (+ global average) ===================================

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(512, 2) void conv_fire_kernel(FireArgs a) {
       while (rot >= n_e) rot -= n_e;
       auto ent = [&](int i) { int k = (i < n_e - 1 ? i : n_e - 1) + rot; return e0 + (k >= n_e ? k - n_e : k); };
       auto ring_load = [&](int d, int i) __attribute__((always_inline)) {
-        const int en = ent(i);
+        // (an m-tile whose rows are all zero has an EMPTY list, e1 == e0: n_e is forced to 1 and the unconditional prefetch would read the
+        //  next m-tile's first entry -- or, for the last m-tile, one entry past the layer's arrays; the values are never used, the address is
+        //  clamped to the layer's last entry all the same)
+        const int en = ent(i) < a.n_ent2 ? ent(i) : a.n_ent2 - 1;
         const int8_t* pu = pw + (((size_t)en << tms2) * 64);
         rsl[d] = a.ent2[en]; ra0[d] = *reinterpret_cast<const i32x4*>(pu); ra1[d] = *reinterpret_cast<const i32x4*>(pu + 32);
       };

@@ -42,6 +42,10 @@ __device__ __forceinline__ void prep_zero_ctrl(const PrepArgs& a) {
       unsigned e = a.epoch_ptr[0] + 1u;
       if ((e & 0xffffffu) == 0) e++;
       a.epoch_ptr[0] = e;
+      // error word: sticky across steps until tf2_net_poll_error reads it; anything that is no report (a fresh or re-used buffer) is cleared
+      if (!bg_err_valid(a.epoch_ptr[1])) a.epoch_ptr[1] = 0u;
+      a.epoch_ptr[2] = (unsigned)a.bg_poll_limit;
+      a.epoch_ptr[3] = (unsigned)a.bg_withhold;
     }
     unsigned* const flags = a.epoch_ptr + 64;
     for (int i = threadIdx.x; i < a.n_flag_words; i += blockDim.x) flags[i] = 0u;
@@ -684,8 +688,12 @@ int launch_conv_first_pool(const FirstArgs& f0, void* stream) {
   if ((long long)a.B * a.OH * a.OW * 64 >= (1ll << 31) || (long long)a.B * 3 * a.H * a.W >= (1ll << 31)) return 1;
   const unsigned grid = (unsigned)(a.B * ((f.PH + PR - 1) / PR));
   TF2_LAUNCH_NAME("conv_first_pool_kernel<stride %d,%d pooled rows per block%s>", a.im_stride, PR, f.dual ? ",dual" : "");
-  if (a.src_is_q) { if (f.dual) TF2_LAUNCH((conv_first_pool_kernel<true, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_pool_kernel<true, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
-  else { if (f.dual) TF2_LAUNCH((conv_first_pool_kernel<false, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); else TF2_LAUNCH((conv_first_pool_kernel<false, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, f); }
+  // up to 78 KiB of dynamic LDS: above the 64 KiB a kernel may use without asking (every other kernel of the library beyond that asks too)
+#define TF2_FP(Q, D) do { auto fn = conv_first_pool_kernel<Q, D>; if (lds > 64 * 1024 && !lds_attr_once(reinterpret_cast<const void*>(fn))) return -1; \
+                          TF2_LAUNCH(fn, dim3(grid), dim3(512), lds, (hipStream_t)stream, f); } while (0)
+  if (a.src_is_q) { if (f.dual) TF2_FP(true, true); else TF2_FP(true, false); }
+  else { if (f.dual) TF2_FP(false, true); else TF2_FP(false, false); }
+#undef TF2_FP
   return launch_ok() ? 0 : -1;
 }
 

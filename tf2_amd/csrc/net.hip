@@ -513,6 +513,7 @@ void Net::load_options() {
   o.pw_mode = (int)opt("pw", o.pw_mode);        // register-resident pointwise kernel: 1 auto (default), 0 never
   o.sk_mode = (int)opt("sk", o.sk_mode);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   o.sk8_blocks = (long)opt("sk8", o.sk8_blocks);
+  o.bg_poll_limit = (long)opt("bgroup_polls", o.bg_poll_limit); o.bg_withhold = (long)opt("bgroup_withhold", 0);
   o.sk_s3_blocks = (long)opt("sk_s3", o.sk_s3_blocks); o.sk_s3_blocks_conc = (long)opt("sk_s3_conc", o.sk_s3_blocks_conc);
   o.fc_mode = (int)opt("fc", o.fc_mode);
   o.fc_min_slabs = (int)opt("fc_min", o.fc_min_slabs);
@@ -808,6 +809,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
         lp.steps[0].prep.n_flag_words = (int32_t)((wp->ctrl_bytes - 256) / 4);
+        lp.steps[0].prep.bg_poll_limit = (int32_t)opts.bg_poll_limit; lp.steps[0].prep.bg_withhold = (int32_t)opts.bg_withhold;
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
         lp.steps.push_back(st);
@@ -825,7 +827,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         FireArgs& f = st.fire;
         const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv;
         f.x = c0.x; f.mid = c0.y; f.y = c1.y; f.w1 = c0.w; f.w2 = c1.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr2_bytes = c1.hdr_bytes;
-        f.ent2 = reinterpret_cast<const int32_t*>(pk + p1->off_entries); f.dir2 = reinterpret_cast<const int32_t*>(pk + p1->off_dir);
+        f.ent2 = reinterpret_cast<const int32_t*>(pk + p1->off_entries); f.dir2 = reinterpret_cast<const int32_t*>(pk + p1->off_dir); f.n_ent2 = (int32_t)p1->n_entries;
         f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
         f.tm1 = s0.TM; f.tm2 = s1.TM; f.B = batch; f.H = L.H; f.W = L.W; f.Cin = L.C; f.Sp = round_up(L.N, 16); f.N2 = p1->Np;
         f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.dbl1 = c0.g.dbl_out; f.dual1 = c0.dual;
@@ -910,6 +912,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         // the step's first kernel (input preparation) advances the step counter
         lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
         lp.steps[0].prep.n_flag_words = (int32_t)((wp->ctrl_bytes - 256) / 4);
+        lp.steps[0].prep.bg_poll_limit = (int32_t)opts.bg_poll_limit; lp.steps[0].prep.bg_withhold = (int32_t)opts.bg_withhold;
         bg_used++; lp.n_groups++;
         pair_done[l + 1] = 1; pair_done[l + 2] = 1;
         // the 14 x 14 stage's identity bottlenecks follow one another: the groups of the previous launch carry on with this one
@@ -1335,6 +1338,36 @@ tf2_status Net::run(const void* images, bool images_are_q, int batch, void* ws, 
                             (size_t)LL.N, rows, hipMemcpyDeviceToDevice, s));
   }
   return TF2_OK;
+}
+
+// Did a group launch of a step on this workspace give up a meeting (conv_bgroup.hip bg_report)?  Reads the workspace's error word
+// (synchronises the stream), clears it, TF2_ERR_GROUP with the report decoded if it was set.  The plan's workspace layout is a
+// function of the batch alone, so the caller names the batch the workspace was used for.
+tf2_status Net::poll_error(int batch, void* ws, size_t ws_bytes, void* stream) {
+  if (!packed_valid || !packed_dev) { set_error("tf2_net_poll_error: no packed model bound"); return TF2_ERR_STATE; }
+  if (batch <= 0 || !ws) { set_error("tf2_net_poll_error: bad argument"); return TF2_ERR_ARG; }
+  const WorkPlan* wp = nullptr;
+  {
+    const WorkPlan* a = plan(batch, false);
+    auto itk = plans.find(std::make_pair(batch, 1));
+    if (itk != plans.end() && ws_bytes >= itk->second.total_bytes) wp = &itk->second;
+    else wp = a;
+  }
+  if (ws_bytes < wp->total_bytes) { set_error("tf2_net_poll_error: workspace too small for this batch"); return TF2_ERR_SIZE; }
+  if (!wp->ctrl_bytes) { HIP_OK(hipStreamSynchronize((hipStream_t)stream)); return TF2_OK; }      // no group launch can run on it
+  unsigned word = 0;
+  unsigned* dev = reinterpret_cast<unsigned*>((uint8_t*)ws + wp->ctrl_off) + 1;
+  HIP_OK(hipMemcpyAsync(&word, dev, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  if (!bg_err_valid(word)) return TF2_OK;
+  HIP_OK(hipMemsetAsync(dev, 0, 4, (hipStream_t)stream));
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  const unsigned code = word & 0xffffu, meet = code & 0xff, kb = code >> 8;
+  set_error(std::string("a group launch gave up a meeting of its eight blocks per image (") +
+            (meet == 0x01 ? "roll call" : meet == 0x10 ? "input of a chained bottleneck" : meet == 0x20 ? "first meeting" : "second meeting") +
+            ", bottleneck " + std::to_string(kb) + " of its launch): the members were not resident together -- the step's logits are not valid; "
+            "see the group-launch preconditions in tf2_amd.h (>= 64 CUs on the stream, at most four concurrent callers) or set TF2_AMD_OPTS=bgroup=0");
+  return TF2_ERR_GROUP;
 }
 
 void Net::drain_profile() {

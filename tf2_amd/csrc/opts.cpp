@@ -42,6 +42,8 @@ const OptSpec kOptSpecs[] = {
   {"avg_fuse", 1, "a layer's global average in its split-K launch: 0 never, 1 always, 2 (default) one batch at a time only"}, {"pair", 1, "pair launches"},
   {"bgroup_min7", 1, "smallest batch of the 7x7 group launches"}, {"bgroup_min14", 1, "... 14x14"}, {"bgroup_min28", 1, "... 28x28"}, {"bgroup_min56f", 1, "... the first 56x56 bottleneck"},
   {"bgroup_chain", 1, "identity bottlenecks per group launch"},
+  {"bgroup_polls", 1, "group launches: polls of a meeting before it is reported as failed (default 1 << 24)"},
+  {"bgroup_withhold", 1, "group launches: 1 + index of a block that leaves its group at kernel entry (the failure path of tf2_net_poll_error)"},
   {"bband_rows", 1, "band launches: rows per block with batches in flight"}, {"bband_rows_alone", 1, "... one batch at a time"},
   {"bband_min", 1, "band launches: smallest batch"}, {"bband_alone_maps", 1, "maps taking band launches one batch at a time (bit 1: 28x28, bit 2: 14x14)"},
   {"dense", 1, "arithmetic gather words"}, {"dense_max", 1, "longest slab list that takes them on multi-round grids"},

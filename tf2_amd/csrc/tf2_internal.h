@@ -295,6 +295,15 @@ struct BBandArgs {
 // consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
 // conv_bgroup7_kernel: the groups run them back to back)
 constexpr int kBgMaxChain = 5;
+// the error word of a workspace (control word 1): kBgErrMagic | code once a group launch gave up a meeting (conv_bgroup.hip bg_report);
+// code = meeting (0x01 roll call, 0x10 input of a chained bottleneck, 0x20 / 0x30 the two meetings) | bottleneck of the chain << 8
+constexpr unsigned kBgErrMagic = 0xE77E0000u;
+// (exactly 20 of the 2^32 words are reports: what a fresh or re-used buffer holds at that offset is not mistaken for one)
+__host__ __device__ inline bool bg_err_valid(unsigned w) {
+  const unsigned meet = w & 0xffu, kb = (w >> 8) & 0xffu;
+  return (w & 0xffff0000u) == kBgErrMagic && (meet == 0x01u || meet == 0x10u || meet == 0x20u || meet == 0x30u) && kb < 5u;
+}
+
 struct BGroupChain {
   int32_t n;
   BGroupArgs b[kBgMaxChain];
@@ -354,6 +363,8 @@ struct PrepArgs {
   int32_t q0;                 // runtime (negated) Q of image channel 0
   int32_t src_is_q;           // 1: source already int8
   int32_t xonly;              // 1 (rewrite form only): 32 bytes of x per pixel, no xneg half (conv_stem.hip)
+  int32_t bg_poll_limit;      // control word 2 of this step: polls after which a group launch's meeting is reported as failed (conv_bgroup.hip)
+  int32_t bg_withhold;        // control word 3 (test-only): 1 + index of a group-launch block that leaves its group at kernel entry, 0 = none
   unsigned* epoch_ptr;        // side job of the step's first kernel: the workspace's step counter += 1 (the value the flags of the
                               // step's conv_bgroup launches carry) and its n_flag_words flag words (256 bytes behind it) cleared, or null
   int32_t n_flag_words;
@@ -369,6 +380,7 @@ struct FireArgs {
   const int32_t* hdr1; const int32_t* hdr2;      // header images (hdr2: one per m-tile, stride hdr2_bytes)
   const int32_t* ent2;       // merged expand: slab id of every entry (PackLayer::off_entries)
   const int32_t* dir2;       // merged expand: [m-tile][2] first / end entry (PackLayer::off_dir, one window)
+  int32_t n_ent2;            // merged expand: entries of the layer (the unconditional prefetch of an EMPTY m-tile is clamped to the last one)
   const int8_t* zero;        // zero page
   const int8_t* zero2;       // the expand's pad row (the stored form of x = 0 of the squeeze's output tensor)
   int32_t hdr2_bytes, tm1, tm2;

@@ -122,6 +122,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int stem_pool = 1;       // stem_pool: fuse the first layer's 3x3 / stride 2 max pool into the conv_stem launch
   int stem_mode = 1;       // conv_stem.hip for the executed first layer: 1 auto (default), 0 never (stem)
   long sk_s3_blocks = 256, sk_s3_blocks_conc = 0;   // largest split-K grid on three ring stages (100 KiB of LDS: the block owns its CU), one batch at a time / in flight
+  long bg_poll_limit = 1 << 24, bg_withhold = 0;   // group launches: polls of a meeting before it is reported as failed (bgroup_polls); test-only bgroup_withhold
   long sk8_blocks = 128;   // largest split-K grid that takes the 8-wave form (sk8)
   long long* dbg = nullptr; long long* dbg2 = nullptr; int dbg_layer = -1;
 };
@@ -194,6 +195,7 @@ struct Net {
   int recent_pos = 0;
   void load_options();
   size_t logits_bytes(int batch) const;
+  tf2_status poll_error(int batch, void* ws, size_t ws_bytes, void* stream);
   tf2_status run(const void* images, bool images_are_q, int batch, void* ws, size_t ws_bytes,
                  int8_t* logits, void* stream, int concurrency = -1, void* mark_event = nullptr, int mark_after_layer = -1);
   int issue(const Launch& st, const LaunchPlan* lp, const void* images, bool images_are_q, int8_t* logits, void* stream);

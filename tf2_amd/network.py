@@ -263,6 +263,15 @@ class Runner:
                                              self._logits.data_ptr(), stream, C.byref(o)))
         return self._logits
 
+    def poll_error(self, batch: int = None):
+        """Did a group launch of a step on this runner's workspace give up a meeting (tf2_net_poll_error)?  Synchronises the current
+        stream; raises Tf2Error (status TF2_ERR_GROUP = -6) once per report, else returns None.  batch: the batch the workspace was last
+        used for (default: the runner's current one)."""
+        import torch
+        net = self.network
+        stream = torch.cuda.current_stream(net.device).cuda_stream
+        _lib.check(_lib.lib().tf2_net_poll_error(net._h, int(batch or self._ws_batch[0]), self._ws.data_ptr(), self._ws.numel(), stream))
+
     def run_split(self, images, parts: int = 2):
         """One batch as `parts` sub-batches on concurrent HIP streams (fork from / join to the current stream): the
         small-map layers of a batch are bound by their own launch-to-drain latency, not by throughput, so two halves

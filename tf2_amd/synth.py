@@ -152,6 +152,16 @@ def bench_network(name: str):
         t = cfg.resnet50_tables()
         qv = np.loadtxt(os.path.join(root, "tests", "golden", "resnet50_Q"), dtype=np.int32)
         return t, qv, 0, "ResNet50", "54-layer TF2 table program, shipped resnet50_Q, seeded INQ weights"
+    if name in ("googlenet", "resnet50_pruned"):
+        # the reference's other two shipped networks (cnn.h:29-35: compile-time selection of googlenet.h / resnet50_pruned.h): the tables
+        # dumped from the shipped headers and the shipped Q files (tests/golden/, oracle/gen_golden.py), seeded INQ weights
+        import json
+        g = os.path.join(root, "tests", "golden")
+        t = cfg.NetTables(json.load(open(os.path.join(g, f"tables_{name}.json"))))
+        t.setdefault("xConv1Rewrite", 1)          # (the headers describe conv1 in its executed 3x3 form over the space-to-depth image, model_loader.cpp:244-257)
+        qv = np.loadtxt(os.path.join(g, f"{name}_Q"), dtype=np.int32)
+        disp = {"googlenet": "GoogLeNet", "resnet50_pruned": "pruned ResNet50"}[name]
+        return t, qv, 0, disp, f"the reference's shipped {name}.h table program and {name}_Q, seeded INQ weights"
     mk, disp, seed = {"squeezenet": (cfg.squeezenet11_tables, "SqueezeNet 1.1", 6), "vgg16": (cfg.vgg16_tables, "VGG16", 1),
                       "ssd300": (cfg.ssd300_tables, "SSD300-VGG", 3)}[name]
     t = mk()
