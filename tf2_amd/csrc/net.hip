@@ -432,7 +432,7 @@ bool Net::bband_at(int l, int rows) const {
   {
     const PackLayer* p0 = pack_layer(l); const PackLayer* p1 = pack_layer(l + 1);
     if (!p0 || !p1) return false;
-    if (!conv_bband_shape_ok(A.H, A.W, A.C, A.N, std::min(conv_bband_pick_rows(A.W, A.N, p0->dual, p1->dual, rows), A.H))) return false;
+    if (!conv_bband_shape_ok(A.H, A.W, A.C, A.N, std::min(conv_bband_pick_rows(A.W, A.N, p0->dual, p1->dual, rows, opts.bband_rows_dd), A.H))) return false;
   }
   if (out_Cp[A.src] != A.C) return false;                  // the input tensor holds exactly C bytes per pixel
   for (int k = l; k <= l + 2; k++) {
@@ -537,6 +537,7 @@ void Net::load_options() {
   o.bband_mode = (int)opt("bband", o.bband_mode);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
   o.bband_rows = (int)opt("bband_rows", o.bband_rows);
   o.bband_rows_alone = (int)opt("bband_rows_alone", o.bband_rows_alone);
+  o.bband_rows_dd = (int)opt("bband_rows_dd", o.bband_rows_dd);
   o.bband_min = (int)opt("bband_min", o.bband_min);
   o.bband_alone_maps = (int)opt("bband_alone_maps", o.bband_alone_maps);
   if (o.bband_mode == 2) o.bband_alone_maps = 6;
@@ -870,7 +871,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
           f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
           f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
           f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
-          f.B = batch; f.H = L.H; f.W = L.W; f.R = std::min(conv_bband_pick_rows(L.W, L.N, c0.dual, c1.dual, band_rows), L.H);
+          f.B = batch; f.H = L.H; f.W = L.W; f.R = std::min(conv_bband_pick_rows(L.W, L.N, c0.dual, c1.dual, band_rows, opts.bband_rows_dd), L.H);
           f.tiles_per_img = (L.H + f.R - 1) / f.R;
           f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
           f.keep_mid = wp->keep_all ? 1 : 0;

@@ -45,6 +45,7 @@ const OptSpec kOptSpecs[] = {
   {"bgroup_polls", 1, "group launches: polls of a meeting before it is reported as failed (default 1 << 24)"},
   {"bgroup_withhold", 1, "group launches: 1 + index of a block that leaves its group at kernel entry (the failure path of tf2_net_poll_error)"},
   {"bband_rows", 1, "band launches: rows per block with batches in flight"}, {"bband_rows_alone", 1, "... one batch at a time"},
+  {"bband_rows_dd", 1, "band launches: most rows per block of a 28x28 bottleneck with two-window reduce and 3x3 (default 7; rounds 4-5: 4)"},
   {"bband_min", 1, "band launches: smallest batch"}, {"bband_alone_maps", 1, "maps taking band launches one batch at a time (bit 1: 28x28, bit 2: 14x14)"},
   {"dense", 1, "arithmetic gather words"}, {"dense_max", 1, "longest slab list that takes them on multi-round grids"},
   {"alt_min", 1, "smallest grid taking a wide-tile alternative"}, {"alt_min_conc", 1, "... with batches in flight"}, {"alt_narrow", 1, "largest grid taking a narrow alternative"},

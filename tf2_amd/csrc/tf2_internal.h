@@ -431,7 +431,7 @@ bool conv_bgroup_shape_ok(int HW, int C, int M);
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream);     // n_chain > 1: 14 x 14 only
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R);
-int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted);     // rows per band used when `wanted` are asked for
+int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted, int rows_dd);     // rows per band used when `wanted` are asked for
 bool conv_bband_windows_ok(int M, int dual1, int dual2);     // the instantiated (reduce, 3x3) window forms
 int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream);        // 1: shape not instantiated / does not fit
 int launch_conv_bneck(const BneckArgs& a, int TM, int TN, void* stream);      // 1: shape not instantiated / does not fit

@@ -114,6 +114,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int bgroup_chain = 5;             // consecutive identity bottlenecks of the 28 x 28 / 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // bgroup_min7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
   int bband_mode = 1;      // bband: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
+  int bband_rows_dd = 7;                      // most rows per band of a 28 x 28 bottleneck whose reduce AND 3x3 are two-window layers (rounds 4-5: 4)
   int bband_rows = 7, bband_rows_alone = 2;   // bband_rows / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
   int bband_alone_maps = 0;   // bband_alone_maps: maps that take band launches one batch at a time too, instead of the group launches (bit 1: 28 x 28, bit 2: 14 x 14; bband=2 = both)
   int bband_min = 8;       // bband_min: smallest batch that takes them
