@@ -613,6 +613,13 @@ int launch_conv_bband(const BBandArgs& a, int C, int M, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!conv_bband_shape_ok(a.H, a.W, C, M, a.R) || !conv_bband_windows_ok(M, a.dual1, a.dual2)) return 1;
   if (a.H != a.W || a.W != (M == 256 ? 14 : M == 128 ? 28 : 56)) return 1;        // (the kernel's compile-time map side)
+#ifdef TF2_PROBES
+  // (timing probe: the 7-row bands with one column tile fewer in the 3x3 / expand phases -- the pixels behind 32 * NT1 are then NOT computed)
+  if (a.probe == 1) {
+    if (M == 256 && a.W == 14 && a.R == 7) return launch_bband<256, 8, 1, 4, 3, 4>(a, s);
+    if (M == 128 && a.W == 28 && a.R == 7) return launch_bband<128, 8, 2, 8, 6, 2>(a, s);
+  }
+#endif
   if (M == 256 && a.W == 14) {
     if (a.R == 7) return launch_bband<256, 8, 1, 4, 4, 4>(a, s);      // 126 / 98 pixels
     if (a.R == 4) return launch_bband<256, 8, 1, 3, 2, 4>(a, s);      // 84 / 56

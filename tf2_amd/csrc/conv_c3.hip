@@ -591,10 +591,10 @@ bool conv_c3_pick_tile_pool(int H, int W, int* TH, int* TW) {
   return (*TH + 2) * (*TW + 2) <= kC3HaloPx;
 }
 
-bool conv_c3_shape_ok(int H, int W, int C, int Np) {
+bool conv_c3_shape_ok(int H, int W, int C, int Np, int min_hw) {
   int th, tw;
   if (C % 64 != 0 || C < 64 || C > 1024 || Np % 64 != 0) return false;
-  if (H < 14 || W < 14) return false;                      // (small maps: too few tiles to fill the chip, the ring / split-K kernels stay)
+  if (H < min_hw || W < min_hw) return false;              // (policy, Net::c3_at: 14 -- on small maps the ring / split-K kernels stay; the launcher itself takes any map >= 3 x 3)
   return conv_c3_pick_tile(H, W, &th, &tw);
 }
 
@@ -667,14 +667,14 @@ static int launch_c3_w9(const C3Args& a, hipStream_t s) {
 // the one-slab kernel: mode 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests).
 // Decided when the launch plan is built (C3Args::w9): tf2_net_describe_launches and every later step name the same kernel.
 bool conv_c3_takes_w9(const C3Args& a, int mode) {
-  return mode && a.tmk == 64 && a.C == 64 && !a.dual && !a.dbg && conv_c3_shape_ok(a.H, a.W, a.C, a.M) &&
+  return mode && a.tmk == 64 && a.C == 64 && !a.dual && !a.dbg && conv_c3_shape_ok(a.H, a.W, a.C, a.M, 3) &&
          (mode == 2 || (long)a.B * a.tiles_per_img * (a.M / 64) / std::max(1, tf2_cu_count()) >= 8);
 }
 
 int launch_conv_c3(const C3Args& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.w9) return launch_c3_w9(a, s);
-  if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M) || (a.tm != 64 && a.tm != 128)) return 1;
+  if (!conv_c3_shape_ok(a.H, a.W, a.C, a.M, 3) || (a.tm != 64 && a.tm != 128)) return 1;
   const int ks = a.C / 64;
   if ((a.tmk != 64 && a.tmk != 128 && a.tmk != 256) || a.M % a.tmk != 0 || (a.tmk == 256 && a.dual)) return 1;
   const bool m128 = a.tmk == 128;

@@ -47,8 +47,11 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 // OHW are dead), the requantised + residual-added outputs are summed over the valid pixels in the wave (__shfl_xor over the 32
 // lanes of a half), the two pixel halves meet in LDS, and the block stores its 64 averaged channels of that image -- the conv
 // map itself never reaches memory and the global_avg_kernel launch disappears.
+// The body is a device function of (argument block, block index, grid size), as in conv_mfma2.hip: ONE launch can carry two independent
+// rows of the same instantiation (conv_mfma_sk_pair_kernel below, round 6: at batch 1 the shortcut convolution of stages 4 and 5 and the
+// first 1x1 of the stage's first bottleneck are both split-K launches of a few dozen blocks -- one launch boundary less each).
 template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int blk_x, const int nblk_x) {
   static_assert(!AVG || NWV == 4, "the fused global average runs with four waves");
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   TF2_PRELOAD_CONV_ARGS(a);          // every kernel argument in SGPRs after two scalar-load round trips (tf2_device.h)
   TF2_PROBE_WORD(g.flags);
   if (prb & kProbeExit0) return;
+  if ((prb & kProbeQuarterBlocks) && (blk_x & 3)) return;      // (probe: a quarter of the launch's footprint at the same block latency)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
   int* const ghw = goff + a_max_ent * 4;
   int8_t* const ring = lds + wave * RING;
 
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
+  const int nblk = nblk_x;
+  int bid = blk_x;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
     n_ent = ee[1] - ee[0];
   }
   if (prb & kProbeExit1) { if (n_ent == 0x7eadbeef) ay[0] = 1; return; }
+  if ((prb & kProbeQuarterK) && n_ent >= 16) n_ent >>= 2;                // (probe: a quarter of the K walk at the same footprint)
   const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
   const int n_mine = n_virt > wave ? (n_virt - wave + NWV - 1) / NWV : 0;     // (virtual) entries wave, wave+NWV, ...
   // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
@@ -376,6 +381,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kerne
 }
 
 template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
+  conv_mfma_sk_body<S, PADCHK, DUAL, NWV, DENSE, AVG>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two independent layers of the same instantiation in one launch: blocks [0, n0) work on the first argument block, the rest on the second
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_pair_kernel(ConvArgs a0, ConvArgs a1, int n0) {
+  const int b = (int)blockIdx.x;
+  if (b < n0) conv_mfma_sk_body<S, PADCHK, DUAL, NWV, DENSE, false>(a0, b, n0);
+  else conv_mfma_sk_body<S, PADCHK, DUAL, NWV, DENSE, false>(a1, b - n0, (int)gridDim.x - n0);
+}
+
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
 static int launch_sk4(const ConvArgs& a, hipStream_t s) {
   constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
   const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
@@ -400,31 +418,66 @@ static int launch_sk2(const ConvArgs& a, hipStream_t s) {
   return a.dense ? launch_sk3<S, PADCHK, DUAL, NWV, true>(a, s) : launch_sk3<S, PADCHK, DUAL, NWV, false>(a, s);
 }
 
-// For 64-row packed layers with a long slab list and a grid that would not fill the chip.
-int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+// The instantiation a layer takes (64-row packed layers with a long slab list and a grid that would not fill the chip).
+struct SkVariant { int S, pad, dual, nwv, dense, avg; bool operator==(const SkVariant& o) const { return S == o.S && pad == o.pad && dual == o.dual && nwv == o.nwv && dense == o.dense && avg == o.avg; } };
+static SkVariant sk_variant(const ConvArgs& a, long sk8_blocks, long s3_blocks) {
   const long blocks = (long)((a.g.n_pix + 63) / 64) * a.n_mtiles;
-  const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
-  if (a.g.avg_mult) {                                 // global average fused (net.hip checked: 1x1-style unpadded layer, OHW <= 64)
-    if (pad) return -1;
-    return a.dual ? launch_sk2<2, false, true, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
-  }
+  const int pad = (a.g.pad_h | a.g.pad_w) != 0, dual = a.dual != 0, dense = a.dense != 0;
+  if (a.g.avg_mult) return {2, pad, dual, 4, dense, 1};     // global average fused (net.hip checked: 1x1-style unpadded layer, OHW <= 64)
   // 8-way split only for grids far below one block per CU (7x7 maps at batch 32: measured 16.0 -> 14.7 us) -- at 392
   // blocks its 136 KiB of LDS (one block per CU) costs more than the shorter K walk saves (14.0 -> 17.8 us)
   const long n_virt = (long)a.ent0 * (a.dual ? 2 : 1);
-  const bool w8 = blocks <= sk8_blocks && n_virt >= 16;
+  if (blocks <= sk8_blocks && n_virt >= 16) return {2, pad, dual, 8, dense, 0};
   // three ring stages only for grids of at most one block per CU (their 100 KiB of LDS take the CU): s3_blocks = 256 one batch at a
   // time; the in-flight plan passes its own threshold (Net::launch_plan: a 64 KiB block leaves room for another batch's block)
-  if (w8) {
-    if (a.dual) return pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
-    return pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);
+  return {blocks <= s3_blocks ? 3 : 2, pad, dual, 4, dense, 0};
+}
+
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const SkVariant v = sk_variant(a, sk8_blocks, s3_blocks);
+  if (v.avg) {
+    if (v.pad) return -1;
+    return v.dual ? launch_sk2<2, false, true, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
   }
-  if (a.dual) {
-    if (blocks <= s3_blocks) return pad ? launch_sk2<3, true, true, 4>(a, s) : launch_sk2<3, false, true, 4>(a, s);
-    return pad ? launch_sk2<2, true, true, 4>(a, s) : launch_sk2<2, false, true, 4>(a, s);
+  if (v.nwv == 8) {
+    if (v.dual) return v.pad ? launch_sk2<2, true, true, 8>(a, s) : launch_sk2<2, false, true, 8>(a, s);
+    return v.pad ? launch_sk2<2, true, false, 8>(a, s) : launch_sk2<2, false, false, 8>(a, s);
   }
-  if (blocks <= s3_blocks) return pad ? launch_sk2<3, true, false, 4>(a, s) : launch_sk2<3, false, false, 4>(a, s);
-  return pad ? launch_sk2<2, true, false, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
+  if (v.S == 3) {
+    if (v.dual) return v.pad ? launch_sk2<3, true, true, 4>(a, s) : launch_sk2<3, false, true, 4>(a, s);
+    return v.pad ? launch_sk2<3, true, false, 4>(a, s) : launch_sk2<3, false, false, 4>(a, s);
+  }
+  if (v.dual) return v.pad ? launch_sk2<2, true, true, 4>(a, s) : launch_sk2<2, false, true, 4>(a, s);
+  return v.pad ? launch_sk2<2, true, false, 4>(a, s) : launch_sk2<2, false, false, 4>(a, s);
+}
+
+// ---- pair launch: two independent rows that take the SAME unpadded, dense, two-stage instantiation ---------------------------------
+bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks) {
+  const SkVariant v0 = sk_variant(a0, sk8_blocks, s3_blocks), v1 = sk_variant(a1, sk8_blocks, s3_blocks);
+  return v0 == v1 && !v0.avg && !v0.pad && v0.dense && v0.S == 2;
+}
+
+template <bool DUAL, int NWV>
+static int launch_sk_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
+  constexpr int S = 2;
+  constexpr int RING_ALL = (NWV * S * 8192 > NWV * 16384) ? NWV * S * 8192 : NWV * 16384;
+  const size_t lds = (size_t)RING_ALL + (size_t)(a0.hdr_bytes > a1.hdr_bytes ? a0.hdr_bytes : a1.hdr_bytes) + 64;
+  auto fn = conv_mfma_sk_pair_kernel<S, false, DUAL, NWV, true>;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
+  if (lds > 160 * 1024) return -3;
+  const int n0 = ((a0.g.n_pix + 63) / 64) * a0.n_mtiles, n1 = ((a1.g.n_pix + 63) / 64) * a1.n_mtiles;
+  TF2_LAUNCH_NAME("conv_mfma_sk_pair_kernel<S%d,%s%d waves,dense> (%d + %d blocks)", S, DUAL ? "dual," : "", NWV, n0, n1);
+  TF2_LAUNCH(fn, dim3(n0 + n1), dim3(NWV * 64), lds, s, a0, a1, n0);
+  return launch_ok() ? 0 : -1;
+}
+
+int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!conv_mfma_sk_pair_eligible(a0, a1, sk8_blocks, s3_blocks)) return 1;
+  const SkVariant v = sk_variant(a0, sk8_blocks, s3_blocks);
+  if (v.nwv == 8) return v.dual ? launch_sk_pair2<true, 8>(a0, a1, s) : launch_sk_pair2<false, 8>(a0, a1, s);
+  return v.dual ? launch_sk_pair2<true, 4>(a0, a1, s) : launch_sk_pair2<false, 4>(a0, a1, s);
 }
 
 }  // namespace tf2

@@ -475,7 +475,7 @@ bool Net::c3_at(int l) const {
   if (pl->fuse_next > 0 || pl->fused_into >= 0) return false;
   const bool one_window = pl->n_phases == 1 && !pl->dual, dual = pl->n_phases == 2 && pl->dual;
   if (!one_window && !dual) return false;
-  return conv_c3_shape_ok(L.H, L.W, L.C, pl->Np);
+  return conv_c3_shape_ok(L.H, L.W, L.C, pl->Np, opts.c3_min_hw);
 }
 
 // a layer whose input is ONE filter window per image (k x k / pad 0 on a k x k map), K long, at batch <= 32, not the network's last
@@ -509,7 +509,7 @@ bool Net::stem_selected(int batch) const {
 void Net::load_options() {
   RunOpts o;
   // (the snapshot of TF2_AMD_OPTS was taken by the caller: tf2_net_create / tf2_net_reload_options, opts.h)
-  o.flags |= (int)opt("exp", 0) & 0xff8;    // timing-probe bits of the -DTF2_PROBES build (tf2_device.h kProbe*, tools/probe_run.py); nothing in the product reads them
+  o.flags |= (int)opt("exp", 0) & 0x7ff8;    // timing-probe bits of the -DTF2_PROBES build (tf2_device.h kProbe*, tools/probe_run.py); nothing in the product reads them
   o.pw_mode = (int)opt("pw", o.pw_mode);        // register-resident pointwise kernel: 1 auto (default), 0 never
   o.sk_mode = (int)opt("sk", o.sk_mode);        // 0 auto, 1 force the in-block split-K kernel for every 64-row layer, 2 never
   o.sk8_blocks = (long)opt("sk8", o.sk8_blocks);
@@ -538,6 +538,7 @@ void Net::load_options() {
   o.bband_rows = (int)opt("bband_rows", o.bband_rows);
   o.bband_rows_alone = (int)opt("bband_rows_alone", o.bband_rows_alone);
   o.bband_rows_dd = (int)opt("bband_rows_dd", o.bband_rows_dd);
+  o.c3_min_hw = (int)opt("c3_min_hw", o.c3_min_hw);
   o.bband_min = (int)opt("bband_min", o.bband_min);
   o.bband_alone_maps = (int)opt("bband_alone_maps", o.bband_alone_maps);
   if (o.bband_mode == 2) o.bband_alone_maps = 6;
@@ -875,6 +876,9 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
           f.tiles_per_img = (L.H + f.R - 1) / f.R;
           f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = c2.g.has_res;
           f.keep_mid = wp->keep_all ? 1 : 0;
+#ifdef TF2_PROBES
+          if (opts.flags & 16384) f.probe = 1;              // (probe, conv_bband.hip: one column tile fewer in phases 1-2)
+#endif
           f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
           f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = c2.g.dbl_out;
           f.dual1 = c0.dual; f.dual2 = c1.dual;
@@ -1036,6 +1040,16 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         fused_done[l + 1] = 1; pair_done[l + 1] = 1;
       }
     }
+    // ... the same for two split-K rows (small batches: a stage's shortcut convolution and the first 1x1 of its first bottleneck on the
+    // 14 x 14 / 7 x 7 maps are both split-K launches of a few dozen blocks; round 6: batch-1 latency, two launches less)
+    if (opts.pair_mode && !fuse_now && !profiling_pairs_off && st.sel == Launch::SEL_SK && !st.avg_fused && l + 1 < nl - 1 && pair_candidate(l) && !(l >= 2 && pair_candidate(l - 1))) {
+      Launch sb;
+      if (!make_conv(l + 1, sb, true)) return nullptr;
+      if (sb.sel == Launch::SEL_SK && !sb.avg_fused && sb.shape == st.shape && conv_mfma_sk_pair_eligible(st.conv, sb.conv, opts.sk8_blocks, st.shape)) {
+        st.conv2 = sb.conv; st.sel = Launch::SEL_SKPAIR;
+        fused_done[l + 1] = 1; pair_done[l + 1] = 1;
+      }
+    }
     if (l == 0 && stem) {
       const ConvArgs& ca = st.conv;
       StemArgs& f = st.stem;
@@ -1159,6 +1173,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
         case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_SKPAIR: return launch_conv_mfma_sk_pair(st.conv, st.conv2, opts.sk8_blocks, st.shape, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_C3: return launch_conv_c3(st.c3, stream);
         case Launch::SEL_FIRE: return launch_conv_fire(st.fire, stream);

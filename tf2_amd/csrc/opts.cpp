@@ -31,7 +31,7 @@ const OptSpec kOptSpecs[] = {
   {"no4bit", 1, "pack time: shift-kernel layers keep int32 weights"}, {"im2col0", 1, "0: a 3x3 first layer on 3 channels keeps its plain form"},
   {"pw", 1, "conv_pw: 1 auto, 0 never"}, {"pw_slabs", 1, "conv_pw: most K slabs"}, {"pw_minpix", 1, "conv_pw: fewest pixels"},
   {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"}, {"sk_s3", 1, "largest split-K grid on three ring stages, one batch at a time"}, {"sk_s3_conc", 1, "... with batches in flight"},
-  {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
+  {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min_hw", 1, "conv_c3: smallest map side (default 14)"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
   {"fire", 1, "a fire module (squeeze + merged expands) as one launch: 0 never, 1 wherever it fits, 2 (default) on maps >= 28 wide"},
   {"fire_pool", 1, "fire modules with a pool behind their expands: 0 never, 1 / 2 fire launch + pool launch (maps >= 56 wide / wherever fire allows), 3 (default) the pool inside the fire launch one batch at a time, 4 always"},
   {"first", 1, "a 3x3 / stride 1 first layer on the image in one launch with its input preparation: 1 / 0"},

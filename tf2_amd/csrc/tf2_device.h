@@ -50,6 +50,7 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 // change in duration is of interest (which pipe binds a layer).  In the product build prb is the constant 0.
 constexpr int kProbeNoB = 8, kProbeNoA = 16, kProbeNoMfma = 32, kProbeNoEpi = 64, kProbeNoPad = 128, kProbeNoBar = 256,
               kProbeNoStore = 2048 /* conv_pw / conv_bneck / conv_stem: keep the arithmetic, skip the output stores */,
+              kProbeQuarterBlocks = 4096 /* conv_mfma_sk: three of four blocks return at entry */, kProbeQuarterK = 8192 /* conv_mfma_sk: a quarter of the slab list */,
               kProbeExit0 = 512 /* return at kernel entry */, kProbeExit1 = 1024 /* return once the header's scalar words are there */;
 #ifdef TF2_PROBES
 #define TF2_PROBE_WORD(f) const int prb = (f)

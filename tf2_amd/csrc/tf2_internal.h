@@ -203,7 +203,7 @@ struct C3Args {
 bool conv_c3_takes_w9(const C3Args& a, int mode);      // mode = RunOpts::c3_w9: 0 never, 1 where a block walks at least eight tiles, 2 wherever allowed
 bool conv_c3_pick_tile(int H, int W, int* TH, int* TW);
 bool conv_c3_pick_tile_pool(int H, int W, int* TH, int* TW);
-bool conv_c3_shape_ok(int H, int W, int C, int Np);
+bool conv_c3_shape_ok(int H, int W, int C, int Np, int min_hw);
 int launch_conv_c3(const C3Args& a, void* stream);
 #ifdef TF2_CHECK_DMA
 void conv_bband_check_counts(unsigned long long out[2]);      // -DTF2_CHECK_DMA builds only (vm_track.h)
@@ -290,6 +290,7 @@ struct BBandArgs {
   int32_t dbl1, dbl2, dbl3;        // the layer's output tensor has doubled channels
   int32_t dual1, dual2;            // the reduce / the 3x3 is a two-window layer (entries [hi rows | lo rows])
   int32_t res_cp, res_off, y_cp, y_off;
+  int32_t probe;                   // -DTF2_PROBES builds only (timing experiments of the launcher)
 };
 
 // consecutive identity bottlenecks of the 28 x 28, 14 x 14 or 7 x 7 maps in one launch (conv_bgroup28_kernel / conv_bgroup_kernel /
@@ -422,7 +423,9 @@ int launch_conv_first_pool(const FirstArgs& f, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
-int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
+int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream);
+bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks);      // two independent split-K rows in one launch (same instantiation)
+int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix);   // register-resident pointwise kernel takes the layer? (max_slab / min_pix: RunOpts::pw_slabs / pw_minpix)
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)

@@ -45,7 +45,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_SKPAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -99,6 +99,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
   int c3_mode = 1;           // c3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
+  int c3_min_hw = 14;        // c3_min_hw: smallest map side that takes conv_c3
   long c3_min_blocks = 96;   // c3_min: smallest grid that takes it
   int fc_mode = 1;           // fc: whole-window layers at batch <= 32 on conv_fc.hip
   int fc_min_slabs = 64;     // fc_min: shortest K (64-byte slabs) that takes it

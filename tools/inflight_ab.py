@@ -17,13 +17,15 @@ ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--serial", type=int, default=1, help="also time one batch at a time")
+ap.add_argument("--prio", type=str, default="", help="comma-separated stream priorities (torch: -1 high, 0 normal), e.g. -1,0,0,0")
 a = ap.parse_args()
 settings = a.set or ["bband=0", "bband=1"]
 t = cfg.resnet50_tables()
 qv = np.loadtxt(os.path.join(ROOT, "tests/golden/resnet50_Q"), dtype=np.int32)
 net = network.NetWork(t); net.Init(synth.synth_model(t, qv, 0), synth.q_text(qv), device="cuda:0")
 x = torch.from_numpy(synth.synth_images(t, a.batch, 1)).to("cuda:0")
-sts = [torch.cuda.Stream(device="cuda:0") for _ in range(a.inflight)]
+prio = [int(v) for v in a.prio.split(",")] if a.prio else [0] * a.inflight
+sts = [torch.cuda.Stream(device="cuda:0", priority=prio[i % len(prio)]) for i in range(a.inflight)]
 # device spin-up (an idle MI355X needs ~0.4 s of load to reach its clock)
 m = torch.randn(4096, 4096, device="cuda:0", dtype=torch.float16)
 t_end = time.perf_counter() + 0.6
