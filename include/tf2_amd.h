@@ -180,7 +180,8 @@ tf2_status tf2_net_run_ex(tf2_net* net, const void* images_dev, int batch, void*
  *  - one batch at a time: selected only for concurrency == 0, stated or inferred.  A caller that STATES concurrency = 0 on more than
  *    four streams of one device at once (or drives more than four handles that way) breaks the contract: each XCD has 32
  *    one-block slots, four concurrent group kernels always leave room for one complete group, a fifth need not -- a meeting
- *    that does not complete within 2^24 polls traps (the context is lost, as after any GPU fault) instead of hanging.  With
+ *    that does not complete within 2^24 polls is given up and REPORTED (tf2_net_poll_error below: the step's logits are garbage, the
+ *    context, the stream and every later step are intact; rounds 3-5 trapped here).  With
  *    concurrency = -1 (tf2_net_run) the library sees the several streams in its call history and never selects them there.
  *  - the workspace bytes behind the tensors (step counter, flags) are the library's; they are re-initialised by every step.
  * The batches-in-flight plan (concurrency = 1) has none of this: its fused launches (conv_bband.hip) exchange nothing between blocks.

@@ -43,11 +43,14 @@ def test_bench_line_fields():
     o = r["one_batch"]
     assert o["launches_per_step"] < r["launches_per_step"] and o["kernel_us_per_step"] > 0 and "conv_bgroup_kernel" in o["kernels"]
     assert d["per_layer_class_one_batch"]
-    # the committed rocprofv3 summaries of the same workload (profiles/r05_rocprof_b32[_conc1]_summary.json, tools/round_evidence.sh)
+    # the committed rocprofv3 summaries of the same workload (profiles/r06_rocprof_b32[_conc1]_summary.json, tools/round_evidence.sh)
     # agree with the live HIP-event figures
     for blk in (r, o):
         if blk.get("kernel_us_per_step_rocprof"):
             assert abs(blk["kernel_us_per_step_rocprof"] - blk["kernel_us_per_step"]) / blk["kernel_us_per_step"] < 0.10, (blk["kernel_us_per_step_rocprof"], blk["kernel_us_per_step"])
+    # the K-step region repeated (round 6): `value` is the first repetition, min / median / max beside it
+    rp = d["repeats"]
+    assert len(rp["values"]) >= 5 and rp["values"][0] == d["value"] and rp["min"] <= rp["median"] <= rp["max"]
     assert d["cold_start"]["value"] > 0 and d["weight_broadcast"]["ms"] is None and d["per_rank"] is None        # one GPU: no collective ran
 
 

@@ -175,10 +175,10 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in groups if r["layer"] == 47][0]["kernel"]
     assert not any("conv_bgroup" in r["kernel"] for r in many)
     # with batches in flight the identity bottlenecks of stages 3 and 4 are ONE band launch each (conv_bband.hip: no exchange between
-    # blocks -- two-window reduce on stage 3, the last one's 3x3 two-window as well and in 4-row bands), stage 5 keeps its separate launches
+    # blocks -- two-window reduce on stage 3, the last one's 3x3 two-window as well; 7-row bands everywhere since round 6), stage 5 keeps its separate launches
     bands = [r for r in many if "conv_bband" in r["kernel"]]
     assert [r["layer"] for r in bands] == [15, 18, 21, 28, 31, 34, 37, 40] and not any("conv_bband" in r["kernel"] for r in one)
-    assert [r["grid"] for r in bands] == [128, 128, 224, 64, 64, 64, 64, 64] and all(r["block"] == 512 and r["lds_bytes"] + 65536 <= 160 * 1024 for r in bands)
+    assert [r["grid"] for r in bands] == [128, 128, 128, 64, 64, 64, 64, 64] and all(r["block"] == 512 and r["lds_bytes"] + 65536 <= 160 * 1024 for r in bands)
     assert "dual reduce" in bands[0]["kernel"] and "dual reduce,dual 3x3" in bands[2]["kernel"] and "dual" not in bands[3]["kernel"]
     # the global average: inside the last expand's split-K launch one batch at a time; with batches in flight the expand runs on its
     # 208-block 128 x 128 tiles and the average is a launch of its own (round 6: the 1024-block fused launch cost 13 us of the in-flight step
@@ -192,8 +192,11 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     ring = [r for r in one if "conv_mfma" in r["kernel"]]
     assert ring and all("dense" in r["kernel"] and "tables" not in r["kernel"] for r in ring)
     assert all(0 < r["grid"] and r["block"] in (256, 512) and 0 <= r["lds_bytes"] <= 160 * 1024 for r in one)
-    # batch 1: small grids, the split-K kernel on the 64-row layers
-    assert any("conv_mfma_sk" in r["kernel"] for r in net.describe_launches(1, 0))
+    # batch 1: small grids, the split-K kernel on the 64-row layers; the shortcut convolution of stages 4 / 5 and the first 1x1 of the stage's first
+    # bottleneck -- independent rows, the same split-K instantiation -- share a launch (round 6: 53 launches instead of 55)
+    b1 = net.describe_launches(1, 0)
+    assert any("conv_mfma_sk" in r["kernel"] for r in b1)
+    assert [r["layer"] for r in b1 if "conv_mfma_sk_pair_kernel" in r["kernel"]] == [24, 43] and len(b1) == 53 and not any(r["layer"] in (25, 44) for r in b1)
     with pytest.raises(_lib.Tf2Error):
         net.describe_launches(0, 0)
 
@@ -377,6 +380,25 @@ def test_option_string_is_parsed_once_and_checked(monkeypatch):
     monkeypatch.setenv("TF2_AMD_TEST", "1")
     net.reload_options()
     monkeypatch.setenv("TF2_AMD_OPTS", "bband")                           # a bare name = 1
+    net.reload_options()
+    # round-5 advice: the separators the C parser documents (',', ';', ' ') and bare flags, through the Python helpers as well; 'name=' is an error
+    monkeypatch.setenv("TF2_AMD_OPTS", "nodbl;fc=0 bband=2,share=1")
+    net.reload_options()
+    assert _lib.parse_opts("nodbl;fc=0 bband=2,share=1") == {"nodbl": "1", "fc": "0", "bband": "2", "share": "1"}
+    _lib.set_opts(c3=0)
+    assert _lib.parse_opts(os.environ["TF2_AMD_OPTS"])["c3"] == "0" and _lib.parse_opts(os.environ["TF2_AMD_OPTS"])["nodbl"] == "1"
+    net.reload_options()
+    monkeypatch.setenv("TF2_AMD_OPTS", "share=")
+    with pytest.raises(_lib.Tf2Error, match="no value"):
+        net.reload_options()
+    # ... and the 56 variables of rounds 1-4 are not silently ignored any more: the error names the replacement
+    monkeypatch.setenv("TF2_AMD_OPTS", "bband=1")
+    monkeypatch.setenv("TF2_AMD_BGROUP", "0")
+    with pytest.raises(_lib.Tf2Error, match=r'TF2_AMD_BGROUP is no longer read: use TF2_AMD_OPTS="bgroup=0"'):
+        net.reload_options()
+    with pytest.raises(_lib.Tf2Error, match="no longer read"):
+        network.NetWork(t)
+    monkeypatch.delenv("TF2_AMD_BGROUP")
     net.reload_options()
     csrc = os.path.join(ROOT, "tf2_amd", "csrc")
     for f in os.listdir(csrc):

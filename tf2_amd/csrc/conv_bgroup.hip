@@ -14,7 +14,7 @@
 // written through (sc1 stores), read from the XCD's L2 when the whole group sits on one XCD (the normal placement) and from the
 // memory side otherwise, and between the layers the eight members meet at eight epoch-tagged flag words per image and layer
 // (bg_signal / bg_wait below; blocks are dispatched in ascending order, so the members of a group become resident together;
-// a stuck wait traps instead of hanging).  No ring shared between waves and no
+// a stuck wait is reported through the workspace's error word and ends the block, bg_report).  No ring shared between waves and no
 // block barrier inside a K loop:
 //   reduce : every wave streams its own 32 pixels x 64 channels and the member's 32 weight rows through a private 3-stage
 //            LDS-DMA ring (counted vmcnt waits only);

@@ -2,12 +2,12 @@
 # Round evidence on the GPU box.  Everything that feeds `roofline` is taken from processes that run ONLY batch-N steps, one batch at
 # a time on one stream (tools/steps_only.py), once per LAUNCH PLAN: --conc 1 = the plan bench.py's timed region runs with batches in
 # flight (top level of `roofline`), --conc 0 = the one-batch-at-a-time plan (`roofline.one_batch`).  Per plan: rocprofv3 kernel stats +
-# per-launch trace (-> profiles/r05_rocprof_[<net>_]b32[_conc1]_summary.json, r05_trace_launches_[<net>_]b32[_conc1].json) and the PMC
-# passes (HBM traffic, instruction mix; launch -> row mapping from tf2_net_describe_launches -> r05_pmc_conv_[<net>_]b32[_conc1].json).
-# Round 5: the same for the other BASELINE.json networks (vgg16, ssd300, squeezenet).  Outputs under gpurun_out/evidence/ (copied to
-# profiles/r05_* by hand).  Usage: round_evidence.sh [nets, default "resnet50 vgg16 ssd300 squeezenet"] [bench: 1 = also the bench lines]
+# per-launch trace (-> profiles/r06_rocprof_[<net>_]b32[_conc1]_summary.json, r06_trace_launches_[<net>_]b32[_conc1].json) and the PMC
+# passes (HBM traffic, instruction mix; launch -> row mapping from tf2_net_describe_launches -> r06_pmc_conv_[<net>_]b32[_conc1].json).
+# Round 5: the same for the other BASELINE.json networks (vgg16, ssd300, squeezenet); round 6: and for the reference's other two shipped networks (googlenet, resnet50_pruned).  Outputs under gpurun_out/evidence/ (copied to
+# profiles/r06_* by hand).  Usage: round_evidence.sh [nets, default "resnet50 vgg16 ssd300 squeezenet"] [bench: 1 = also the bench lines]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; mkdir -p $O
-NETS=${1:-"resnet50 vgg16 ssd300 squeezenet"}; BENCH=${2:-1}
+NETS=${1:-"resnet50 vgg16 ssd300 squeezenet googlenet resnet50_pruned"}; BENCH=${2:-1}
 cd /tmp && export TMPDIR=/tmp
 for NET in $NETS; do
   T=""; [ $NET != resnet50 ] && T="${NET}_"
@@ -30,11 +30,16 @@ for NET in $NETS; do
   done
   cd /tmp
 done
+# the summaries bench.py attaches to its lines (rocprof_summary / traffic), into profiles/ of THIS copy of the tree before the bench legs
+for f in $O/rocprof_*_summary.json $O/trace_launches_*.json $O/pmc_conv_*.json $O/rocprof_kernel_stats_*.csv; do
+  [ -s $f ] && cp $f $R/profiles/r06_$(basename $f)
+done
 [ "$BENCH" = "1" ] || exit 0
 cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
 timeout 300 python bench.py --no-cpu --steps 100 --warmup 10 --extra-batches "" > $O/bench_s100.log 2>&1; tail -1 $O/bench_s100.log > $O/bench_s100.json
-for NET in squeezenet vgg16 ssd300; do
+for NET in squeezenet vgg16 ssd300 googlenet resnet50_pruned; do
   timeout 600 python bench.py --net $NET --steps 20 --warmup 5 --extra-batches "" --cpu-seconds 6 > $O/bench_$NET.log 2>&1; tail -1 $O/bench_$NET.log > $O/bench_$NET.json
 done
+timeout 600 python bench.py --mode 1 --steps 10 --warmup 3 --cpu-seconds 4 --extra-batches "" > $O/bench_mode1.log 2>&1; tail -1 $O/bench_mode1.log > $O/bench_mode1.json
 tail -c 600 $O/bench_default.json; echo

@@ -17,7 +17,7 @@ ap.add_argument("--conc", type=int, default=0, help="launch plan: 0 one batch at
 ap.add_argument("--spinup-ms", type=float, default=600.0,
                 help="keep the device busy this long with torch matrix products first (other kernel names: they do not enter the tf2 rows "
                      "of the profile): an idle MI355X needs ~0.4 s of load to reach its engine clock (tools/clock_sample.py)")
-ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300"])
+ap.add_argument("--net", default="resnet50", choices=["resnet50", "squeezenet", "vgg16", "ssd300", "googlenet", "resnet50_pruned"])
 ap.add_argument("--meta", default=None, help="write {batch, steps, launches} here")
 a = ap.parse_args()
 t, qv, seed, net_name, _ = synth.bench_network(a.net)
