@@ -576,6 +576,44 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
 
 
 
+@pytest.mark.parametrize("form", ["in_flight", "alone", "single_window", "generic"])
+def test_first_bottleneck_as_one_launch_of_row_bands(r50, monkeypatch, form):
+    """conv_bfirst.hip (round 6): rows 1-4 -- projection shortcut | reduce, 3x3, expand + residual from the shortcut, on the 56 x 56 maps -- as
+    ONE launch of independent 4-row bands at two blocks per CU: the band's input stays in LDS for the reduce (halo rows recomputed) and the
+    shortcut, the shortcut tile is the residual of the expand's epilogue, none of the three inner maps exists (keep_all: all written, so every
+    layer can be read back).  The default with batches in flight; bfirst=2 one batch at a time as well (instead of the group launch).  Two-window
+    rows (the shipped Q file) and one-window rows (a Q file without per-channel spread: the other instantiation), FAST and generic
+    requantisation.  Every layer against the oracle at batch 2 and 5, batch-33 logits of repeated runs on the liveness-planned workspace,
+    and against the plain launches."""
+    alone = form == "alone"
+    set_opts(monkeypatch, bfirst="2" if alone else "1", bfirst_min="1", alt_conc="0" if alone else "1")
+    if form == "generic":
+        set_opts(monkeypatch, nofast="1")
+    t, q, model = r50
+    if form == "single_window":
+        q = synth.synth_q_values(t, 5, spread=0)
+        model = synth.synth_model(t, q, 0)
+    rig = Rig(t, q, model, 0)
+    launches = rig.net.describe_launches(32, 0 if alone else 1)
+    mine = [r for r in launches if "conv_bfirst" in r["kernel"]]
+    assert [r["layer"] for r in mine] == [1] and mine[0]["grid"] == 32 * 14 and mine[0]["lds_bytes"] <= 80 * 1024
+    assert ("dual" in mine[0]["kernel"]) == (form != "single_window")
+    assert not any(r["layer"] in (2, 3, 4) for r in launches)
+    x2 = synth.synth_images(rig.t, 2, 95, kind="int8")
+    x2[0, :, :5, :] = -128
+    rig.check_all_layers(x2)
+    rig.check_all_layers(synth.synth_images(rig.t, 5, 96))
+    x = synth.synth_images(rig.t, 33, 97)
+    first = rig.run(x, keep_all=False).copy()
+    np.testing.assert_array_equal(first[[0, 17, 32]], rig.ref.logits(rig.ref.run(x[[0, 17, 32]])))
+    for _ in range(5):
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
+    set_opts(monkeypatch, bfirst="0")
+    plain = Rig(t, q, model, 0)
+    assert not any("conv_bfirst" in r["kernel"] for r in plain.net.describe_launches(32, 0 if alone else 1))
+    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
+
+
 @pytest.mark.parametrize("rows,conc", [("7", "1"), ("4", "1"), ("2", "0")])
 def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc):
     """conv_bband.hip: the identity bottlenecks of stage 3 (rows 15-23: two-window reduce, the last one's 3x3 two-window too) and stage 4

@@ -202,17 +202,19 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
     }
   // Group launches (conv_bgroup.hip: rows l .. l + 2 in one launch, images at different layers at the same time): what the launch
   // reads stays live to its last row, what it writes exists from its first
-  if (packed_valid && (opts.bgroup_mode || opts.bband_mode))
+  if (packed_valid && (opts.bgroup_mode || opts.bband_mode || opts.bfirst_mode))
     for (int l = 0; l + 2 < nl; l++) {
-      if (opts.bgroup_mode && bgroup_first_at(l)) {
+      if ((opts.bgroup_mode || opts.bfirst_mode) && bgroup_first_at(l)) {          // (conv_bgroup56f_kernel or conv_bfirst_kernel: rows l .. l + 3)
         TensorPlan& tin = wp.tensors[wp.exec[l].in_tensor];
         tin.last_use = std::max(tin.last_use, l + 3);
         TensorPlan& tm1 = wp.tensors[wp.exec[l + 1].out_tensor];
         tm1.last_use = std::max(tm1.last_use, l + 3);
         for (size_t t = 0; t < wp.tensors.size(); t++)
           if (born[t] > l && born[t] <= l + 3) born[t] = l;
-        if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
-        wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;
+        if (opts.bgroup_mode) {
+          if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
+          wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;
+        }
         l += 3;
         continue;
       }
@@ -534,6 +536,8 @@ void Net::load_options() {
   o.bgroup_min56f = (int)opt("bgroup_min56f", o.bgroup_min56f);
   o.bgroup_chain = (int)opt("bgroup_chain", o.bgroup_chain);
   o.bgroup_mode = (int)opt("bgroup", o.bgroup_mode);     // 1: identity bottlenecks of the small maps as group launches (conv_bgroup.hip), one batch at a time
+  o.bfirst_mode = (int)opt("bfirst", o.bfirst_mode);     // the first 56 x 56 bottleneck as one launch of row bands (conv_bfirst.hip): 0 never, 1 with batches in flight, 2 always
+  o.bfirst_min = (int)opt("bfirst_min", o.bfirst_min);
   o.bband_mode = (int)opt("bband", o.bband_mode);        // identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 with batches in flight, 2 always
   o.bband_rows = (int)opt("bband_rows", o.bband_rows);
   o.bband_rows_alone = (int)opt("bband_rows_alone", o.bband_rows_alone);
@@ -784,7 +788,38 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
     const PackLayer* pl = pack_layer(l);
     if (pl->fused_into >= 0 && fused_done[l]) continue;      // computed by the launch of layer pl->fused_into (conv_bneck.hip)
     if (pair_done[l]) continue;                              // computed by the pair launch of layer l - 1 (or a group launch)
-    // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch (conv_bgroup56f_kernel)
+    // the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as ONE launch of independent row bands at two blocks per
+    // CU (conv_bfirst.hip, round 6): the form for batches in flight (bfirst=2: one batch at a time as well, instead of the group launch)
+    if (opts.bfirst_mode && (concurrent || opts.bfirst_mode == 2) && bgroup_first_at(l) && batch >= opts.bfirst_min) {
+      Launch ss, s0, s1, s2;
+      if (!make_conv(l, ss, false) || !make_conv(l + 1, s0, false) || !make_conv(l + 2, s1, false) || !make_conv(l + 3, s2, false)) return nullptr;
+      if (ss.conv.dense && s0.conv.dense && s1.conv.dense && s2.conv.dense && s0.TM == 64 && s1.TM == 64 && s2.TM == 64 && !s1.conv.dual &&
+          s0.conv.dual == s2.conv.dual && ss.conv.dual == s0.conv.dual) {
+        Launch st; st.kind = Launch::CONV; st.sel = Launch::SEL_BFIRST; st.layer = l;
+        BGroupArgs& f = st.bgroup;
+        const ConvArgs& cs = ss.conv; const ConvArgs& c0 = s0.conv; const ConvArgs& c1 = s1.conv; const ConvArgs& c2 = s2.conv;
+        f.x = c0.x; f.mid1 = c0.y; f.mid2 = c1.y; f.y = c2.y; f.res = nullptr;
+        f.w1 = c0.w; f.w2 = c1.w; f.w3 = c2.w; f.hdr1 = c0.hdr; f.hdr2 = c1.hdr; f.hdr3 = c2.hdr;
+        f.hdr1_bytes = c0.hdr_bytes; f.hdr2_bytes = c1.hdr_bytes; f.hdr3_bytes = c2.hdr_bytes;
+        f.tm1 = s0.TM; f.tm2 = s1.TM; f.tm3 = s2.TM;
+        f.zero = (const int8_t*)(pk + zero_off); f.zero2 = c1.zero;
+        f.epoch = nullptr; f.ctr = nullptr; f.img0 = 0;
+        f.B = batch;
+        f.relu1 = c0.g.relu; f.relu2 = c1.g.relu; f.relu3 = c2.g.relu; f.add_relu = c2.g.add_relu; f.has_res = 1;
+        f.fast1 = c0.g.fast; f.fast2 = c1.g.fast; f.fast3 = c2.g.fast;
+        f.dbl1 = c0.g.dbl_out; f.dbl2 = c1.g.dbl_out; f.dbl3 = 0;
+        f.dual1 = c0.dual; f.dual2 = 0; f.dual3 = c2.dual;
+        f.avg_mult = 0; f.res_cp = 0; f.res_off = 0;
+        f.y_cp = c2.g.y_cp; f.y_off = c2.g.y_off;
+        f.ws = cs.w; f.hdrs = cs.hdr; f.hdrs_bytes = cs.hdr_bytes; f.tms = ss.TM; f.relu_s = cs.g.relu; f.fast_s = cs.g.fast;
+        f.ys = cs.y; f.ys_cp = cs.g.y_cp; f.keep_s = wp->keep_all ? 1 : 0;
+        f.dbg = (opts.dbg2 && opts.dbg_layer == l) ? opts.dbg2 : nullptr;
+        pair_done[l + 1] = 1; pair_done[l + 2] = 1; pair_done[l + 3] = 1;
+        lp.steps.push_back(st);
+        continue;
+      }
+    }
+    // ... the same rows as a group launch (conv_bgroup56f_kernel), one batch at a time
     if (opts.bgroup_mode && !concurrent && wp->ctrl_bytes && groups_fit && bgroup_first_at(l) && batch >= opts.bgroup_min56f &&
         256 + (size_t)(bg_used + 1) * ((batch + 7) / 8 * 8) * 128 <= wp->ctrl_bytes) {
       Launch ss, s0, s1, s2;
@@ -1179,6 +1214,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
         case Launch::SEL_FIRE: return launch_conv_fire(st.fire, stream);
         case Launch::SEL_FC: return launch_conv_fc(st.fc, stream);
         case Launch::SEL_BGROUPF: return launch_conv_bgroup_first(st.bgroup, stream);
+        case Launch::SEL_BFIRST: return launch_conv_bfirst(st.bgroup, stream);
         case Launch::SEL_BGROUP:
           if (!st.bg_chain.empty()) return launch_conv_bgroup(st.bg_chain.data(), (int)st.bg_chain.size(), st.bg_hw, st.bg_c, st.bg_m, stream);
           return launch_conv_bgroup(&st.bgroup, 1, st.bg_hw, st.bg_c, st.bg_m, stream);

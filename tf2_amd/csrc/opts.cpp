@@ -19,6 +19,7 @@ const OptSpec kOptSpecs[] = {
   // ---- product options ----
   {"alt_conc", 0, "how Net::run decides that batches are in flight: 0 never, 1 always, 2 (default) the caller's tf2_net_run_ex statement, else calls on >= 2 streams among the last eight"},
   {"bgroup", 0, "group launches (conv_bgroup.hip: eight co-resident blocks per image that meet inside the kernel) one batch at a time: 1 (default) / 0"},
+  {"bfirst", 0, "the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand + residual) as one launch of independent row bands (conv_bfirst.hip): 0 never, 1 (default) with batches in flight, 2 one batch at a time as well"},
   {"bband", 0, "band launches (conv_bband.hip) of identity bottlenecks: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well"},
   {"c3", 0, "3x3 / 1 / pad 1 layers of big maps on conv_c3.hip: 1 (default), 0 the ring kernel; 2 / 3 force 64- / 128-channel blocks (tests)"},
   {"fc", 0, "whole-window layers at batch <= 32 on conv_fc.hip (weight stream): 1 (default) / 0"},
@@ -46,7 +47,7 @@ const OptSpec kOptSpecs[] = {
   {"bgroup_withhold", 1, "group launches: 1 + index of a block that leaves its group at kernel entry (the failure path of tf2_net_poll_error)"},
   {"bband_rows", 1, "band launches: rows per block with batches in flight"}, {"bband_rows_alone", 1, "... one batch at a time"},
   {"bband_rows_dd", 1, "band launches: most rows per block of a 28x28 bottleneck with two-window reduce and 3x3 (default 7; rounds 4-5: 4)"},
-  {"bband_min", 1, "band launches: smallest batch"}, {"bband_alone_maps", 1, "maps taking band launches one batch at a time (bit 1: 28x28, bit 2: 14x14)"},
+  {"bfirst_min", 1, "conv_bfirst: smallest batch"}, {"bband_min", 1, "band launches: smallest batch"}, {"bband_alone_maps", 1, "maps taking band launches one batch at a time (bit 1: 28x28, bit 2: 14x14)"},
   {"dense", 1, "arithmetic gather words"}, {"dense_max", 1, "longest slab list that takes them on multi-round grids"},
   {"alt_min", 1, "smallest grid taking a wide-tile alternative"}, {"alt_min_conc", 1, "... with batches in flight"}, {"alt_narrow", 1, "largest grid taking a narrow alternative"},
   {"alt_rows", 1, "bit mask of rows forced onto their alternative tile height"}, {"noalt_rows", 1, "... kept off it"},

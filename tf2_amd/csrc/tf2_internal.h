@@ -433,6 +433,10 @@ size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
 int launch_conv_bgroup(const BGroupArgs* chain, int n_chain, int HW, int C, int M, void* stream);     // n_chain > 1: 14 x 14 only
 int launch_conv_bgroup_first(const BGroupArgs& a, void* stream);            // rows shortcut | reduce, 3x3, expand of the 56 x 56 stage
+// conv_bfirst.hip: the same four rows as ONE launch of independent row bands at two blocks per CU (no meetings: the form for batches in
+// flight); takes a BGroupArgs (ctr / epoch / img0 unused; keep_s: the three inner tensors are written as well).  1: not instantiated
+int launch_conv_bfirst(const BGroupArgs& a, void* stream);
+size_t conv_bfirst_lds_bytes(int dual);
 bool conv_bband_shape_ok(int H, int W, int C, int M, int R);
 int conv_bband_pick_rows(int W, int M, int dual1, int dual2, int wanted, int rows_dd);     // rows per band used when `wanted` are asked for
 bool conv_bband_windows_ok(int M, int dual1, int dual2);     // the instantiated (reduce, 3x3) window forms

@@ -45,7 +45,7 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_SKPAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_SKPAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BFIRST, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
@@ -114,6 +114,8 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int bgroup_mode = 1;     // bgroup (default on): identity bottlenecks of the 14 x 14 maps in one launch, eight blocks per image (conv_bgroup.hip); one batch at a time only
   int bgroup_chain = 5;             // consecutive identity bottlenecks of the 28 x 28 / 14 x 14 / 7 x 7 maps per group launch (1: one launch each)
   int bgroup_min7 = 12, bgroup_min14 = 12, bgroup_min28 = 12, bgroup_min56f = 12;   // bgroup_min7 / _MIN14 / _MIN28 / _MIN56F: smallest batch that takes them (a group is 8 CUs per image whatever the batch)
+  int bfirst_mode = 2;     // bfirst: the first bottleneck of the 56 x 56 stage (shortcut | reduce, 3x3, expand) as one launch of independent row bands (conv_bfirst.hip): 0 never, 1 (default) with batches in flight, 2 one batch at a time as well (instead of the group launch)
+  int bfirst_min = 12;     // bfirst_min: smallest batch that takes it (14 blocks per image)
   int bband_mode = 1;      // bband: identity bottlenecks as band launches (conv_bband.hip): 0 never, 1 (default) with batches in flight, 2 also one batch at a time (instead of the group launches)
   int bband_rows_dd = 7;                      // most rows per band of a 28 x 28 bottleneck whose reduce AND 3x3 are two-window layers (rounds 4-5: 4)
   int bband_rows = 7, bband_rows_alone = 2;   // bband_rows / _ROWS_ALONE: output rows per block (several batches in flight / one batch at a time)
