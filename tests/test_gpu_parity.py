@@ -496,6 +496,7 @@ def test_group_launches_of_the_identity_bottlenecks(r50, monkeypatch, chain):
     set_opts(monkeypatch, bgroup_min14="1")
     set_opts(monkeypatch, bgroup_min28="1")
     set_opts(monkeypatch, bgroup_min56f="1")
+    set_opts(monkeypatch, bfirst="1")               # (rows 1-4 on their GROUP launch: since round 6 the default takes conv_bfirst.hip in both plans)
     set_opts(monkeypatch, alt_conc="0")
     rig = Rig(*r50, 0)
     rows = rig.net.describe_launches(32, 0)
@@ -526,7 +527,7 @@ def test_group_launch_that_cannot_meet_reports_a_status(r50, monkeypatch, withho
     or 1 of each)."""
     from tf2_amd._lib import Tf2Error
     torch = _torch()
-    set_opts(monkeypatch, bgroup="1", alt_conc="0", bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1)
+    set_opts(monkeypatch, bgroup="1", alt_conc="0", bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1, bfirst="1")
     rig = Rig(*r50, 0)
     x = synth.synth_images(rig.t, 9, 75)
     want = rig.ref.logits(rig.ref.run(x))
@@ -562,7 +563,7 @@ def test_group_launches_with_other_packed_forms(r50, monkeypatch, pack_switch):
     (nofast), plain instead of doubled channels (nodbl: more two-window rows -- some bottlenecks then fall back to
     separate launches, by the library's own eligibility rules), no SEMI rows.  Every layer against the oracle, group launches on."""
     set_opts(monkeypatch, **{pack_switch: "1"})
-    set_opts(monkeypatch, bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1)
+    set_opts(monkeypatch, bgroup_min7=1, bgroup_min14=1, bgroup_min28=1, bgroup_min56f=1, bfirst="1")
     set_opts(monkeypatch, alt_conc="0")
     rig = Rig(*r50, 0)
     groups = [r["kernel"] for r in rig.net.describe_launches(3, 0) if "conv_bgroup" in r["kernel"]]

@@ -162,14 +162,21 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # fused pairs (conv_bneck) carry their first row; with batches in flight the 128-channel pairs run unfused
     fused_one = {r["layer"] for r in one if "conv_bneck" in r["kernel"]}
     fused_many = {r["layer"] for r in many if "conv_bneck" in r["kernel"]}
-    assert fused_one == {6, 9} and fused_many == {3, 6, 9}          # (the 128-channel pairs belong to group launches one batch at a time)
+    assert fused_one == {6, 9} and fused_many == {6, 9}             # (the 128-channel pairs belong to group launches one batch at a time; rows 3-4 to conv_bfirst)
+    # round 6: rows 1-4 (projection shortcut | reduce, 3x3, expand + residual on the 56 x 56 maps) are ONE launch of independent 4-row bands
+    # at two blocks per CU in BOTH plans (conv_bfirst.hip: 14 bands per image, under 80 KB of LDS; bfirst=1 keeps the group launch of the
+    # one-batch plan, bfirst=0 the separate launches)
+    for plan_rows in (one, many):
+        bf = [r for r in plan_rows if "conv_bfirst" in r["kernel"]]
+        assert [r["layer"] for r in bf] == [1] and bf[0]["grid"] == 32 * 14 and bf[0]["block"] == 512 and 2 * bf[0]["lds_bytes"] <= 160 * 1024
+        assert "dual" in bf[0]["kernel"] and not any(r["layer"] in (2, 3, 4) for r in plan_rows)
     # independent neighbouring rows in one launch: the shortcut convolution of stages 3 and 4 (and, with the wide tiles of the
     # several-streams plan, stage 5) next to the first 1x1 of the stage's first bottleneck
     assert {r["layer"] for r in one if "pair" in r["kernel"]} == {11, 24} and {r["layer"] for r in many if "pair" in r["kernel"]} == {11, 24, 43}
     # one batch at a time the identity bottlenecks of stages 3 and 5 are ONE launch each (conv_bgroup.hip: rows 15-17 ..., 47-49, 50-52),
     # the five of stage 4 (rows 28-42) ONE launch together
     groups = [r for r in one if "conv_bgroup" in r["kernel"]]
-    assert [r["layer"] for r in groups] == [1, 15, 21, 28, 47] and all(r["grid"] == 256 and r["block"] == 512 for r in groups)
+    assert [r["layer"] for r in groups] == [15, 21, 28, 47] and all(r["grid"] == 256 and r["block"] == 512 for r in groups)
     assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 15][0]["kernel"] and "dual 3x3" in [r for r in groups if r["layer"] == 21][0]["kernel"]
     assert "x 5 bottlenecks" in [r for r in groups if r["layer"] == 28][0]["kernel"]
     assert "x 2 bottlenecks" in [r for r in groups if r["layer"] == 47][0]["kernel"] and "global average" in [r for r in groups if r["layer"] == 47][0]["kernel"]
@@ -186,7 +193,7 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     assert "global average" in [r for r in one if r["layer"] == 47][0]["kernel"] and not any(r["kernel"] == "global_avg_kernel" for r in one)
     assert [r["kernel"].split("<")[0] for r in many if r["layer"] == 52] == ["conv_mfma2_kernel", "global_avg_kernel"]
     assert all("S2" in r["kernel"] for r in many if "conv_mfma_sk" in r["kernel"])
-    assert len(many) == 34 and len(one) == 22
+    assert len(many) == 32 and len(one) == 22
     assert [r["grid"] for r in net.describe_launches(40, 0) if r["layer"] == 28] == [256, 64]     # at most 32 images per launch
     # every ring-kernel launch of ResNet-50 takes the arithmetic-gather instantiation (single-window and dual layers are dense)
     ring = [r for r in one if "conv_mfma" in r["kernel"]]

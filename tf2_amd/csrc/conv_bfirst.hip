@@ -15,14 +15,14 @@
 //   * reduce -> requantised straight into the 3x3's halo tile in LDS (borders and rows outside the image keep the stored form of
 //     x = 0, sequencer.cl:287); 3x3 from that tile (a tap = a shifted address, conv_bneck's scheme) -> requantised into the expand's
 //     B tile in LDS;
-//   * per 64-channel pass of the output: the SHORTCUT tile of the wave's 32 channels x 64 pixels first (K = 64: two MFMAs per window
-//     and column tile), requantised with its own header rows into 16 NHWC bytes per lane and column tile -- exactly the form the
+//   * expand: a wave owns 32 of the 256 output channels (weights of expand and shortcut resident in registers) and sweeps the band's
+//     seven column tiles in pairs: the SHORTCUT tile first (K = 64: two MFMAs per window and column tile), requantised with its own header rows into 16 NHWC bytes per lane and column tile -- exactly the form the
 //     expand's epilogue takes a residual in --, then the expand and the epilogue; 16-byte NHWC stores.  The shortcut's map never
 //     exists (with keep_s it is written, for tf2_net_read_layer), nor do the reduce's and the 3x3's;
 //   * weights global -> registers (a lane's MFMA fragment = 16 contiguous bytes of its row), the next phase's fragments in flight
 //     while the current one is requantised; two-window layers are swept window by window into ONE accumulator with the Horner shift
 //     in between (128 registers: two blocks per CU);
-//   * LDS: input 22 KB + halo 22 KB + B tile 16 KB + header images 17.3 KB = 77.3 KB.
+//   * LDS: input 22 KB + halo 22 KB + B tile 14 KB + header images 17.3 KB = 75.3 KB.
 //
 // HBM per batch of 32: 9.6 MB read + 25.7 MB written instead of 48 + 68.  Bit-identical to the four separate launches (same
 // Z/2^32 sums, same requantisation: requant_epilogue.h; tests/test_gpu_parity.py).
@@ -49,7 +49,7 @@ __device__ __forceinline__ void bf_static_for(F& fn) {
 namespace {
 constexpr int kBfHW = 56, kBfR = 4, kBfLead = 8;
 constexpr int kBfNT0 = (kBfLead + (kBfR + 2) * kBfHW + 31) / 32;        // 11 tiles of 32 input pixels (8 lead pixels: band pixel 0 = tile 2)
-constexpr int kBfNT1 = 8;                                               // column tiles of the band (7 hold pixels)
+constexpr int kBfNT1 = 7;                                               // column tiles of the band
 constexpr int kBfHalo = ((kBfR + 2) * (kBfHW + 2) + 15) / 16 * 16;      // 352 halo pixels
 __host__ __device__ constexpr int bf_hdr_bytes(int windows, int rows) { return (5 + windows) * rows * 4; }
 __host__ __device__ constexpr size_t bf_lds_bytes(bool dual) {
@@ -147,18 +147,18 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     const int8_t* p = a.w2 + (size_t)(tap * 64 + wm * 32) * 64 + a_lane_off;
     f.k[0] = *reinterpret_cast<const i32x4*>(p); f.k[1] = *reinterpret_cast<const i32x4*>(p + 32);
   };
-  auto load_ws = [&](Afr& f, int mt) __attribute__((always_inline)) {
-    const int ch = mt * 64 + wm * 32;
+  auto load_ws = [&](Afr& f) __attribute__((always_inline)) {      // the wave's 32 output channels of phase 3
+    const int ch = wave * 32;
 #pragma unroll
     for (int win = 0; win < NWIN; win++) {
       const int8_t* p = a.ws + (((size_t)(ch / a.tms) * NWIN + win) * a.tms + ch % a.tms) * 64 + a_lane_off;
       f.k[win][0] = *reinterpret_cast<const i32x4*>(p); f.k[win][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
   };
-  auto load_w3 = [&](Afr& f, int mt) __attribute__((always_inline)) {
+  auto load_w3 = [&](Afr& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int win = 0; win < NWIN; win++) {
-      const int8_t* p = a.w3 + (((size_t)mt * NWIN + win) * 64 + wm * 32) * 64 + a_lane_off;
+      const int8_t* p = a.w3 + (((size_t)(wave >> 1) * NWIN + win) * 64 + (wave & 1) * 32) * 64 + a_lane_off;
       f.k[win][0] = *reinterpret_cast<const i32x4*>(p); f.k[win][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
   };
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     bf_static_for<0, 9>(step);
   }
   BF_STAMP(3);
-  load_ws(wsf, 0);                                       // the first pass's shortcut fragments travel while the 3x3 is requantised
+  load_ws(wsf);                                          // phase 3's shortcut fragments travel while the 3x3 is requantised
   {
     const int* const prm2 = reinterpret_cast<const int*>(hdr2);
     const int lo_b = a.relu2 ? 0 : -128;
@@ -283,124 +283,119 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int p = (wn * 2 + j) * 32 + frow;
-        *reinterpret_cast<i32x4*>(mid2 + (wn * 2 + j) * 2048 + frow * 64 + (((chl >> 4) ^ ((frow >> 2) & 3)) << 4)) = outs[j];
+        if (wn * 2 + j < NT1)                              // (the wave grid's eighth column tile holds no pixel)
+          *reinterpret_cast<i32x4*>(mid2 + (wn * 2 + j) * 2048 + frow * 64 + (((chl >> 4) ^ ((frow >> 2) & 3)) << 4)) = outs[j];
         if (a.keep_s && p < NPB) *reinterpret_cast<i32x4*>(a.mid2 + (px_band + p) * 64 + chl) = outs[j];
       }
     };
     if (a.fast2 == 1) to_mid2(std::true_type{}); else to_mid2(std::false_type{});
   }
+  load_w3(wf);                                           // (the expand's: they have the first shortcut tiles' time)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // the expand's B tile is complete
   asm volatile("" ::: "memory");
   BF_STAMP(4);
 
-  // ---- phase 3: four passes of 64 output channels: shortcut tile -> residual, expand + residual -> y ---------------------------------
+  // ---- phase 3: shortcut tile -> residual, expand + residual -> y -------------------------------------------------------------------
+  // Wave w owns output channels [32 w, 32 w + 32) -- its expand and shortcut fragments stay in registers for the whole phase -- and sweeps
+  // the band's SEVEN column tiles in pairs (2 + 2 + 2 + 1: every wave does the same 7 tiles of work; four 64-channel passes over the wave
+  // grid of phase 2 made waves 0-2 of a SIMD row compute an eighth, empty tile's worth beside a half-loaded fourth)
   {
     const int lo_s = a.relu_s ? 0 : -128, lo_b = a.relu3 ? 0 : -128, rlo = a.add_relu ? 0 : -128;
-    const int8_t* const Bs = xt + 2 * 2048 + (wn * 2) * 2048;          // band pixel 0 = LDS pixel 64 = tile 2
-    const int8_t* const Be = mid2 + (wn * 2) * 2048;
+    const int ch = wave * 32;
+    const int* const pm = reinterpret_cast<const int*>(hdr3 + (ch >> 6) * H64);
+    const int ro3 = ch & 63;
+    const int* const ps = reinterpret_cast<const int*>(hdrS + (ch / a.tms) * (bf_hdr_bytes(NWIN, 1) * a.tms));
+    const int ros = ch % a.tms;
     // (wave-uniform base + a 32-bit lane offset: the scalar-base form of global_store, no 64-bit address pair held per column tile)
-    int8_t* const yb = a.y + px_band * a.y_cp + a.y_off;
-    int8_t* const ysb = a.ys + px_band * a.ys_cp;
-    unsigned yo[2], yso[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int p = (wn * 2 + j) * 32 + frow;
-      yo[j] = (unsigned)(p * a.y_cp + wm * 32 + 16 * half);
-      yso[j] = (unsigned)(p * a.ys_cp + wm * 32 + 16 * half);
-    }
-#pragma unroll 1
-    for (int mt = 0; mt < 4; mt++) {
-      load_w3(wf, mt);
-      const int ch = mt * 64 + wm * 32;
-      i32x4 rs[2];
-      // the shortcut convolution of the wave's tile (1x1 64 -> 256 on the band's input), requantised: the residual
+    int8_t* const yb = a.y + px_band * a.y_cp + a.y_off + ch;
+    int8_t* const ysb = a.ys + px_band * a.ys_cp + ch;
+    const unsigned yo = (unsigned)(frow * a.y_cp + 16 * half), yso = (unsigned)(frow * a.ys_cp + 16 * half);
+    auto tiles = [&](auto nj_c, int t0) __attribute__((always_inline)) {
+      constexpr int NJ = decltype(nj_c)::value;
+      i32x4 rs[NJ];
+      // the shortcut convolution of the tiles (1x1 64 -> 256 on the band's input: LDS pixel 64 = band pixel 0), requantised: the residual
       {
-        const int* const ps = reinterpret_cast<const int*>(hdrS + (ch / a.tms) * (bf_hdr_bytes(NWIN, 1) * a.tms));
-        const int ros = ch % a.tms;
-        i32x4 b0[2], b1[2];
+        const int8_t* const Bs = xt + (2 + t0) * 2048;
+        i32x4 b0[NJ], b1[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
           b0[j] = *reinterpret_cast<const i32x4*>(Bs + j * 2048 + fr0); b1[j] = *reinterpret_cast<const i32x4*>(Bs + j * 2048 + (fr0 ^ 32));
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[j][r] = 0;
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
           acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf.k[0][0], b0[j], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf.k[0][1], b1[j], acc[j], 0, 0, 0);
         }
         if constexpr (DUAL) {
-          window_shift(acc, std::integral_constant<int, 2>{}, ps, a.tms, ros);
+          window_shift(acc, nj_c, ps, a.tms, ros);
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
+          for (int j = 0; j < NJ; j++) {
             acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf.k[NWIN - 1][0], b0[j], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf.k[NWIN - 1][1], b1[j], acc[j], 0, 0, 0);
           }
         }
         auto to_res = [&](auto fast_c) __attribute__((always_inline)) {
           constexpr bool FAST = decltype(fast_c)::value;
-          int a16s[2][16];
-          i32x4 nores_j[2];
+          int a16s[NJ][16];
+          i32x4 nores_j[NJ];
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
+          for (int j = 0; j < NJ; j++) {
             nores_j[j] = nores;
 #pragma unroll
             for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
           }
-          requant_tiles16<2, false, 1, FAST>(a16s, rs, ps, a.tms, ros + 4 * half, lo_s, -128, nores_j, false, a.fast_s == 2);
+          requant_tiles16<NJ, false, 1, FAST>(a16s, rs, ps, a.tms, ros + 4 * half, lo_s, -128, nores_j, false, a.fast_s == 2);
         };
         if (a.fast_s == 1) to_res(std::true_type{}); else to_res(std::false_type{});
         if (a.keep_s) {
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const int p = (wn * 2 + j) * 32 + frow;
-            if (p < NPB) *reinterpret_cast<i32x4*>(ysb + (yso[j] + (unsigned)(mt * 64))) = rs[j];
-          }
+          for (int j = 0; j < NJ; j++) *reinterpret_cast<i32x4*>(ysb + (yso + (unsigned)((t0 + j) * 32 * a.ys_cp))) = rs[j];
         }
       }
-      if (mt + 1 < 4) load_ws(wsf, mt + 1);              // (behind the shortcut's MFMAs: the next pass's fragments travel during the expand)
       // the expand (1x1 64 -> 256 on the 3x3's tile) + residual
       {
-        const int* const pm = reinterpret_cast<const int*>(hdr3 + mt * H64);
-        i32x4 b0[2], b1[2];
+        const int8_t* const Be = mid2 + t0 * 2048;
+        i32x4 b0[NJ], b1[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
           b0[j] = *reinterpret_cast<const i32x4*>(Be + j * 2048 + fr0); b1[j] = *reinterpret_cast<const i32x4*>(Be + j * 2048 + (fr0 ^ 32));
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[j][r] = 0;
         }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
           acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf.k[0][0], b0[j], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf.k[0][1], b1[j], acc[j], 0, 0, 0);
         }
         if constexpr (DUAL) {
-          window_shift(acc, std::integral_constant<int, 2>{}, pm, 64, wm * 32);
+          window_shift(acc, nj_c, pm, 64, ro3);
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
+          for (int j = 0; j < NJ; j++) {
             acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf.k[NWIN - 1][0], b0[j], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf.k[NWIN - 1][1], b1[j], acc[j], 0, 0, 0);
           }
         }
         auto epilogue = [&](auto fast_c) __attribute__((always_inline)) {
           constexpr bool FAST = decltype(fast_c)::value;
-          int a16s[2][16];
-          i32x4 outs[2];
+          int a16s[NJ][16];
+          i32x4 outs[NJ];
 #pragma unroll
-          for (int j = 0; j < 2; j++)
+          for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
-          requant_tiles16<2, true, 1, FAST>(a16s, outs, pm, 64, wm * 32 + 4 * half, lo_b, rlo, rs, false, a.fast3 == 2);
+          requant_tiles16<NJ, true, 1, FAST>(a16s, outs, pm, 64, ro3 + 4 * half, lo_b, rlo, rs, false, a.fast3 == 2);
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const int p = (wn * 2 + j) * 32 + frow;
-            if (p < NPB) *reinterpret_cast<i32x4*>(yb + (yo[j] + (unsigned)(mt * 64))) = outs[j];
-          }
+          for (int j = 0; j < NJ; j++) *reinterpret_cast<i32x4*>(yb + (yo + (unsigned)((t0 + j) * 32 * a.y_cp))) = outs[j];
         };
         if (a.fast3 == 1) epilogue(std::true_type{}); else epilogue(std::false_type{});
       }
-    }
+    };
+#pragma unroll 1
+    for (int t0 = 0; t0 < 6; t0 += 2) tiles(std::integral_constant<int, 2>{}, t0);
+    tiles(std::integral_constant<int, 1>{}, 6);
   }
   BF_STAMP(5);
 #undef BF_STAMP

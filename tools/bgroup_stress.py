@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tf2_amd._lib import set_opts  # noqa: E402
-set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1");      # every batch size takes the group launches here
+set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1"); set_opts(bfirst="1");      # every batch size takes the group launches here
 import torch
 from tf2_amd import config as cfg, network, synth
 t = cfg.resnet50_tables()

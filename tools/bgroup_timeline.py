@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tf2_amd._lib import set_opts  # noqa: E402
-set_opts(bgroup="1"); set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1");
+set_opts(bgroup="1"); set_opts(bgroup_min7="1"); set_opts(bgroup_min14="1"); set_opts(bgroup_min28="1"); set_opts(bgroup_min56f="1"); set_opts(bfirst="1");
 import torch
 from tf2_amd import config as cfg, network, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--layer", type=int, default=31)
