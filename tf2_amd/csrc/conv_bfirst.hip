@@ -264,7 +264,6 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     bf_static_for<0, 9>(step);
   }
   BF_STAMP(3);
-  load_ws(wsf);                                          // phase 3's shortcut fragments travel while the 3x3 is requantised
   {
     const int* const prm2 = reinterpret_cast<const int*>(hdr2);
     const int lo_b = a.relu2 ? 0 : -128;
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     };
     if (a.fast2 == 1) to_mid2(std::true_type{}); else to_mid2(std::false_type{});
   }
-  load_w3(wf);                                           // (the expand's: they have the first shortcut tiles' time)
+  load_ws(wsf); load_w3(wf);                             // phase 3's fragments (behind the hand-over: in front of it they cost it 25 spilled registers)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // the expand's B tile is complete
   asm volatile("" ::: "memory");
