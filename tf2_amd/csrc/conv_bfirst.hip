@@ -289,7 +289,6 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     };
     if (a.fast2 == 1) to_mid2(std::true_type{}); else to_mid2(std::false_type{});
   }
-  load_ws(wsf); load_w3(wf);                             // phase 3's fragments (behind the hand-over: in front of it they cost it 25 spilled registers)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // the expand's B tile is complete
   asm volatile("" ::: "memory");
@@ -309,10 +308,15 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
     // (wave-uniform base + a 32-bit lane offset: the scalar-base form of global_store, no 64-bit address pair held per column tile)
     int8_t* const yb = a.y + px_band * a.y_cp + a.y_off + ch;
     int8_t* const ysb = a.ys + px_band * a.ys_cp + ch;
-    const unsigned yo = (unsigned)(frow * a.y_cp + 16 * half), yso = (unsigned)(frow * a.ys_cp + 16 * half);
+    const unsigned yo = (unsigned)(frow * a.y_cp + 16 * half);
     auto tiles = [&](auto nj_c, int t0) __attribute__((always_inline)) {
       constexpr int NJ = decltype(nj_c)::value;
       i32x4 rs[NJ];
+      // (the wave's fragments come from the packed image again for every tile pair -- L2-resident, read-only: the shortcut's here, the
+      //  expand's behind the shortcut's MFMAs -- instead of staying in registers: held, the compiler parked sixteen of the 32 in scratch,
+      //  and spilled registers are DIRTY lines that reach HBM: 84 bytes per lane made 17 MB written + 16 MB fetched per launch in the PMC
+      //  passes, half of the kernel's traffic)
+      load_ws(wsf);
       // the shortcut convolution of the tiles (1x1 64 -> 256 on the band's input: LDS pixel 64 = band pixel 0), requantised: the residual
       {
         const int8_t* const Bs = xt + (2 + t0) * 2048;
@@ -336,6 +340,7 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
             acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf.k[NWIN - 1][1], b1[j], acc[j], 0, 0, 0);
           }
         }
+        load_w3(wf);                                       // (arrives while the shortcut is requantised)
         auto to_res = [&](auto fast_c) __attribute__((always_inline)) {
           constexpr bool FAST = decltype(fast_c)::value;
           int a16s[NJ][16];
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
         if (a.fast_s == 1) to_res(std::true_type{}); else to_res(std::false_type{});
         if (a.keep_s) {
 #pragma unroll
-          for (int j = 0; j < NJ; j++) *reinterpret_cast<i32x4*>(ysb + (yso + (unsigned)((t0 + j) * 32 * a.ys_cp))) = rs[j];
+          for (int j = 0; j < NJ; j++) *reinterpret_cast<i32x4*>(ysb + (unsigned)(((t0 + j) * 32 + frow) * a.ys_cp + 16 * half)) = rs[j];
         }
       }
       // the expand (1x1 64 -> 256 on the 3x3's tile) + residual
