@@ -115,18 +115,6 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
       __builtin_amdgcn_global_load_lds(TF2_GLOBAL_PTR(src), TF2_LDS_PTR(mid1 + s * slabb + grp * 1024), 16, 0, 0);
     }
   }
-  // residual tile of pass mt (16 contiguous NHWC bytes per lane and pixel tile); loaded one pass ahead
-  auto load_res = [&](i32x4 (&rv)[NTN], int mt) {
-#pragma unroll
-    for (int j = 0; j < NTN; j++) {
-      const int p = wn * WTN + j * 32 + (lane & 31);
-      const int chl = mt * TM + wm * 32 + 16 * half;
-      const bool ok = a.has_res && p < n_px && chl + 16 <= a.y_nvalid;
-      const int8_t* rp = ok ? a.res + (size_t)(pix_base + p) * a.res_cp + a.res_off + chl : a.zero;
-      rv[j] = *reinterpret_cast<const i32x4*>(rp);
-    }
-  };
-
   // per-lane B addresses inside the halo tile: pixel p = (r, c) -> halo pixel h0 + dh * (W + 2) + dw for tap (dh, dw), byte
   // address h * 64 + ((chunk ^ ((h >> 2) & 3)) << 4); the second K half (ks = 1) is the same address ^ 32 (chunk 2 + half =
   // half ^ 2 under the swizzle).  Recomputed per step (4 VALU per address) rather than kept in 18 registers.
@@ -150,11 +138,6 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   auto load_a1 = [&](Afr& f, int v) {
     const int win = v / NE1, e = v - win * NE1;
     const int8_t* p = a.w1 + (size_t)e * A1_BYTES + win * (TM * 64) + a_row_off;
-    f.k[0] = *reinterpret_cast<const i32x4*>(p); f.k[1] = *reinterpret_cast<const i32x4*>(p + 32);
-  };
-  auto load_a2 = [&](Afr& f, int mt, int v) {           // v over (window, slab) of pass mt
-    const int win = v / NSL, sl = v - win * NSL;
-    const int8_t* p = a.w2 + (size_t)(mt * NSL + sl) * A2_BYTES + win * (TM * 64) + a_row_off;
     f.k[0] = *reinterpret_cast<const i32x4*>(p); f.k[1] = *reinterpret_cast<const i32x4*>(p + 32);
   };
   Afr f0, f1, f2;                                        // weight fragments: two steps ahead of the MFMAs (PF = 2)
@@ -213,16 +196,6 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   };
   bn_static_for<0, NW1 * NE1>(step1);
   BN_STAMP(3);
-  // the expand's first weight fragments and the first residual tile are on their way while the 3x3 is requantised
-  // phase 2 rotates the same three buffers from index 0 again (phase 1 has consumed all of its fragments)
-  Afr& g0 = f0;
-  Afr& g1 = f1;
-  Afr& g2 = f2;
-  load_a2(g0, 0, 0);
-  if (PF == 2 && kBneckPasses * (NW2 * NSL) > 1) load_a2(g1, 1 / (NW2 * NSL), 1 % (NW2 * NSL));
-  i32x4 res0[NTN], res1[NTN];
-  load_res(res0, 0);
-
   // ---- hand-over: requantise the 3x3 (window combine, pe.cl:185-203, ReLU) into the mid tile -------------------------------
   {
     const int lo_bound = a.relu1 ? 0 : -128;
@@ -262,73 +235,136 @@ __global__ __launch_bounds__(512, 4) void conv_bneck_kernel(BneckArgs a) {
   asm volatile("" ::: "memory");
   BN_STAMP(5);
 
-  // ---- phase 2: four passes of the 1x1 expand over the mid tile ------------------------------------------------------------
-  int bm[NTN];
+  // ---- phase 2: the 1x1 expand over the mid tile -------------------------------------------------------------------------------
+  // Round 6 (conv_bfirst's scheme): a wave owns 32 of the 4 TM output channels per GROUP pass (wave w: channels 32 (w + 8 g) ..; one
+  // pass at TM = 64, two at 128) with that group's weight fragments resident in registers, and sweeps the block's column tiles that
+  // hold pixels in pairs -- a run-time loop, residual tiles one pair ahead.  (Rounds 2-5: four statically unrolled passes of TM
+  // channels over the WM x WN wave grid of phase 1 -- an eighth, empty column tile's worth of work per pass on 56 x 56 maps, four times
+  // the code, 52-88 bytes of scratch per lane whose write-back showed up as 10 MB of HBM writes per launch.)
+  {
+    constexpr int NGRP = (kBneckPasses * TM) / 256;
+    static_assert(NGRP * 256 == kBneckPasses * TM, "eight waves x 32 channels per group pass");
+    const int lo_bound2 = a.relu2 ? 0 : -128;
+    const int rlo = a.add_relu ? 0 : -128;
+    const int n_t = (n_px + 31) >> 5;                      // column tiles that hold pixels
+    const int frow = lane & 31;
+    const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);
+    struct Afr2 { i32x4 k[NW2][NSL][2]; };
+#pragma unroll 1
+    for (int gp = 0; gp < NGRP; gp++) {
+      const int ch = (wave + 8 * gp) * 32;                 // first of the wave's 32 output channels
+      const int mt = ch / TM, ro = ch - mt * TM;
+      // (the group's weight fragments come from the packed image again for every tile pair -- L2-resident, read-only -- instead of staying
+      //  in registers: held, the compiler parks part of them in scratch, and spilled registers are dirty lines that reach HBM)
+      const int8_t* const wgrp = a.w2 + (size_t)(mt * NSL) * A2_BYTES + ro * 64;
+      const unsigned w_lane = (unsigned)(frow * 64 + half * 16);
+      auto load_wf = [&](Afr2& f) __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < NTN; j++) {
-    const int row = wn * WTN + j * 32 + (lane & 31);
-    bm[j] = row * 64 + ((half ^ ((row >> 2) & 3)) << 4);
-  }
-  const int lo_bound2 = a.relu2 ? 0 : -128;
-  const int rlo = a.add_relu ? 0 : -128;
-  constexpr int NV2 = NW2 * NSL;                         // virtual steps per pass
-  auto step2 = [&](auto u_c) {
-    constexpr int u = decltype(u_c)::value;
-    constexpr int mt = u / NV2, v = u % NV2, win = v / NSL, s = v % NSL;
-    Afr& cur = PF == 2 ? (u % 3 == 0 ? g0 : u % 3 == 1 ? g1 : g2) : ((u & 1) ? g1 : g0);
-    Afr& nxt = PF == 2 ? ((u + 2) % 3 == 0 ? g0 : (u + 2) % 3 == 1 ? g1 : g2) : ((u & 1) ? g0 : g1);
-    if (u + PF < kBneckPasses * NV2 && !(prb & kProbeNoA)) load_a2(nxt, (u + PF) / NV2, (u + PF) % NV2);
-    if (v == 0 && mt + 1 < kBneckPasses) { if (mt & 1) load_res(res0, mt + 1); else load_res(res1, mt + 1); }
-    if (win == 1 && s == 0) window_shift(reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(prm2) + (size_t)mt * a.hdr2_used) + kPrmWordsPerRow * TM);
-    const int8_t* B = mid2 + s * (TN * 64);
+        for (int win = 0; win < NW2; win++)
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      i32x4 bf[NTN];
+          for (int sl = 0; sl < NSL; sl++) {
+            const int8_t* p = wgrp + sl * A2_BYTES + win * (TM * 64) + w_lane;
+            f.k[win][sl][0] = *reinterpret_cast<const i32x4*>(p); f.k[win][sl][1] = *reinterpret_cast<const i32x4*>(p + 32);
+          }
+      };
+      const int* const pm = reinterpret_cast<const int*>(reinterpret_cast<const int8_t*>(prm2) + (size_t)mt * a.hdr2_used);
+      const int chl = ch + 16 * half;
+      const bool ch_ok = chl + 16 <= a.y_nvalid;
+      // (kernel-argument base + ONE 32-bit offset per lane: the scalar-base form of global loads / stores; the block's part of the offset is
+      //  wave-uniform and pinned to a scalar register -- as 64-bit lane addresses these were eight of the registers the compiler spilled)
+      const unsigned res_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)pix_base * (unsigned)a.res_cp + (unsigned)a.res_off + (unsigned)ch));
+      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)pix_base * (unsigned)a.y_cp + (unsigned)a.y_off + (unsigned)ch));
+      const unsigned reso = (unsigned)(frow * a.res_cp + 16 * half), yo = (unsigned)(frow * a.y_cp + 16 * half);
+      auto load_res2 = [&](i32x4 (&rv)[2], int t0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < NTN; j++) bf[j] = *reinterpret_cast<const i32x4*>(B + (bm[j] ^ (ks << 5)));
-#pragma unroll
-      for (int j = 0; j < NTN; j++) {
-        if (prb & kProbeNoMfma) { asm volatile("" :: "v"(cur.k[ks]), "v"(bf[j])); continue; }
-        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.k[ks], bf[j], acc[j], 0, 0, 0);
-      }
-    }
-    if (v == NV2 - 1 && !(prb & kProbeNoEpi)) {
-      int* const pm = reinterpret_cast<int*>(reinterpret_cast<int8_t*>(prm2) + (size_t)mt * a.hdr2_used);
-      const int chl = mt * TM + wm * 32 + 16 * half;
-      i32x4 (&rv)[NTN] = (mt & 1) ? res1 : res0;
-      auto epilogue = [&](auto has_res_c, auto fast_c, auto rnn_c) {
-        constexpr bool HAS_RES = decltype(has_res_c)::value;
-        constexpr bool FAST = decltype(fast_c)::value;
-        constexpr bool RNN = decltype(rnn_c)::value;        // the residual is a post-ReLU tensor and the sum is clamped to [0, 127]: one clamp (requant_epilogue.h)
-        int a16s[NTN][16];
-        i32x4 outs[NTN];
-#pragma unroll
-        for (int j = 0; j < NTN; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) a16s[j][r] = acc[j][r];
-        requant_tiles16<NTN, HAS_RES, 1, FAST, RNN>(a16s, outs, pm, TM, wm * 32 + 4 * half, lo_bound2, rlo, rv, a.dbl_out != 0, a.fast2 == 2);
-#pragma unroll
-        for (int j = 0; j < NTN; j++) {
-          const i32x4 out = outs[j];
-          const int p = wn * WTN + j * 32 + (lane & 31);
-          if (prb & kProbeNoStore) { asm volatile("" :: "v"(out)); continue; }
-          if (p < n_px && chl + 16 <= a.y_nvalid)
-            *reinterpret_cast<i32x4*>(a.y + (size_t)(pix_base + p) * a.y_cp + a.y_off + chl) = out;
+        for (int j = 0; j < 2; j++) {
+          const int p = (t0 + j) * 32 + frow;
+          const bool ok = a.has_res && p < n_px && ch_ok;
+          const int8_t* rp = ok ? a.res + (res_u + reso + (unsigned)((t0 + j) * 32 * a.res_cp)) : a.zero;
+          rv[j] = *reinterpret_cast<const i32x4*>(rp);
         }
       };
+      // (the epilogue's form -- residual, FAST rows, single clamp -- is chosen ONCE per group pass, outside the tile loop: five forms inside
+      //  the loop body kept their common lane values alive across all of them, in scratch)
+      auto sweep = [&](auto has_res_c, auto fast_c, auto rnn_c) __attribute__((always_inline)) {
+      auto tiles = [&](auto nj_c, int t0, const i32x4 (&rv2)[2]) __attribute__((always_inline)) {
+        constexpr int NJ = decltype(nj_c)::value;
+        Afr2 wf;
+        load_wf(wf);
+        i32x16 ac[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) ac[j][r] = 0;
+#pragma unroll
+        for (int win = 0; win < NW2; win++) {
+          if (win == 1) {
+            const int* dsh = pm + (kPrmWordsPerRow + 1) * TM + ro + 4 * half;
+#pragma unroll
+            for (int G = 0; G < 4; G++) {
+              const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) ac[j][G * 4 + r] = (int)((unsigned)ac[j][G * 4 + r] << (d[r] & 31));
+            }
+          }
+#pragma unroll
+          for (int sl = 0; sl < NSL; sl++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+              i32x4 bf[NJ];
+#pragma unroll
+              for (int j = 0; j < NJ; j++) bf[j] = *reinterpret_cast<const i32x4*>(mid2 + sl * (TN * 64) + (t0 + j) * 2048 + (fr0 ^ (ks << 5)));
+#pragma unroll
+              for (int j = 0; j < NJ; j++) {
+                if (prb & kProbeNoMfma) { asm volatile("" :: "v"(wf.k[win][sl][ks]), "v"(bf[j])); continue; }
+                ac[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf.k[win][sl][ks], bf[j], ac[j], 0, 0, 0);
+              }
+            }
+        }
+        if (prb & kProbeNoEpi) { asm volatile("" :: "v"(ac[0])); return; }
+        i32x4 rv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) rv[j] = rv2[j];
+        {
+          constexpr bool HAS_RES = decltype(has_res_c)::value;
+          constexpr bool FAST = decltype(fast_c)::value;
+          constexpr bool RNN = decltype(rnn_c)::value;        // the residual is a post-ReLU tensor and the sum is clamped to [0, 127]: one clamp (requant_epilogue.h)
+          int a16s[NJ][16];
+          i32x4 outs[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) a16s[j][r] = ac[j][r];
+          requant_tiles16<NJ, HAS_RES, 1, FAST, RNN>(a16s, outs, pm, TM, ro + 4 * half, lo_bound2, rlo, rv, a.dbl_out != 0, a.fast2 == 2);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) {
+            const int p = (t0 + j) * 32 + frow;
+            if (prb & kProbeNoStore) { asm volatile("" :: "v"(outs[j])); continue; }
+            if (p < n_px && ch_ok) *reinterpret_cast<i32x4*>(a.y + (y_u + yo + (unsigned)((t0 + j) * 32 * a.y_cp))) = outs[j];
+          }
+        }
+      };
+      i32x4 ra[2], rb[2];
+      load_res2(ra, 0);
+      int t0 = 0;
+#pragma unroll 1
+      for (; t0 + 2 <= n_t; t0 += 2) {
+        load_res2(rb, t0 + 2);                              // the next pair's residual tiles (past the block's pixels: the zero page)
+        tiles(std::integral_constant<int, 2>{}, t0, ra);
+#pragma unroll
+        for (int j = 0; j < 2; j++) ra[j] = rb[j];
+      }
+      if (t0 < n_t) tiles(std::integral_constant<int, 1>{}, t0, ra);
+      };
       if (a.fast2 == 1) {
-        if (a.has_res) { if (a.rnn) epilogue(std::true_type{}, std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::true_type{}, std::false_type{}); }
-        else epilogue(std::false_type{}, std::true_type{}, std::false_type{});
-      } else { if (a.has_res) epilogue(std::true_type{}, std::false_type{}, std::false_type{}); else epilogue(std::false_type{}, std::false_type{}, std::false_type{}); }
-#pragma unroll
-      for (int j = 0; j < NTN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0;
-      if (mt == 0) BN_STAMP(6);                          // first pass requantised, stores issued
+        if (a.has_res) { if (a.rnn) sweep(std::true_type{}, std::true_type{}, std::true_type{}); else sweep(std::true_type{}, std::true_type{}, std::false_type{}); }
+        else sweep(std::false_type{}, std::true_type{}, std::false_type{});
+      } else { if (a.has_res) sweep(std::true_type{}, std::false_type{}, std::false_type{}); else sweep(std::false_type{}, std::false_type{}, std::false_type{}); }
+      if (gp == 0) BN_STAMP(6);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  bn_static_for<0, kBneckPasses * NV2>(step2);
+  }
   BN_STAMP(7);
 #undef BN_STAMP
 }
