@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-DMA_KERNELS = ("conv_bband_kernel", "conv_c3_kernel", "conv_c3_w9_kernel", "fc_partial_kernel", "fc4_partial_kernel", "conv_fire_kernel", "conv_first_kernel")
+DMA_KERNELS = ("conv_bband_kernel", "conv_bfirst_kernel", "conv_bneck_kernel", "conv_c3_kernel", "conv_c3_w9_kernel", "fc_partial_kernel", "fc4_partial_kernel", "conv_fire_kernel", "conv_first_kernel")
 BATCHES = (1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 31, 32, 33, 48, 63, 64)
 
 
