@@ -70,3 +70,21 @@ def test_no_vmcnt_literal_left_in_the_dma_kernels():
         lits = [m.group(1) for m in re.finditer(r"s_waitcnt[^\"]*vmcnt\((\d+)\)", src)]
         assert all(v == "0" for v in lits), (f, lits)
         assert "vm_wait<" in src
+
+
+def test_the_two_block_per_cu_bottleneck_kernels_compile_without_scratch(isa_files):
+    """Round 6: spilled registers are HBM traffic -- a lane's private segment is written back as dirty lines and partly re-fetched.  conv_bfirst's
+    84 bytes were 17 MB written + 16 MB fetched per launch (half of the kernel's traffic in the PMC passes), conv_bneck's 52-80 bytes the 10.5-11.5 MB
+    by which its WRITE_SIZE exceeded its output; without them +0.9 % and +1.0-1.6 % img/s with batches in flight (profiles/r06_experiments.txt item 18).
+    The compiled listing of the shipped sources with the shipped flags: conv_bfirst (both instantiations) and the 64-channel shapes of conv_bneck
+    (the ones ResNet-50 launches) stay at a private segment of 0 (one shape: three registers)."""
+    isa_dir = os.path.dirname(isa_files[0])
+    seg = {}
+    for src in ("conv_bfirst", "conv_bneck"):
+        txt = open(os.path.join(isa_dir, src + ".s")).read()
+        for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", txt):
+            seg[m.group(1)] = int(m.group(2))
+    bfirst = {k: v for k, v in seg.items() if "conv_bfirst_kernel" in k}
+    assert len(bfirst) == 2 and all(v == 0 for v in bfirst.values()), bfirst
+    bneck64 = {k: v for k, v in seg.items() if "conv_bneck_kernelILi2ELi4ELi2E" in k}
+    assert len(bneck64) == 4 and all(v <= 12 for v in bneck64.values()) and sum(v == 0 for v in bneck64.values()) >= 2, bneck64
