@@ -92,6 +92,15 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension was not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C tf2_amd/csrc`). tf2_amd has no CPU fallback by design.")
+    # The HIP runtime of the process must be ONE: PyTorch-ROCm ships its own libamdhip64, and libtf2amd.so loaded BEFORE torch binds the
+    # system copy under /opt/rocm instead -- a later torch import then brings the second runtime, and the library's first launch reports
+    # "no ROCm-capable device is detected" (seen with build() + smoke() in one process, round 6).  Loading torch first makes the
+    # dynamic loader resolve libtf2amd.so's HIP symbols against the runtime torch loaded.  (Hosts without torch -- the C++ shim of
+    # INTEGRATION.md section 3 -- link one runtime anyway.)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     L.tf2_build_kind.restype = C.c_int
     kind = L.tf2_build_kind()
