@@ -615,6 +615,49 @@ def test_first_bottleneck_as_one_launch_of_row_bands(r50, monkeypatch, form):
     np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
 
 
+@pytest.mark.parametrize("form", ["in_flight", "alone", "single_window", "generic", "split_k_rows"])
+def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form):
+    """conv_pwk.hip (round 6): 1x1 rows of 128 .. 512 input channels (ResNet-50's 256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512, 512 -> 256 |
+    1024 / 2, 256 -> 1024, 512 -> 2048) with a pixel tile's whole K extent resident in LDS: the activations are fetched once for every output
+    channel, a wave owns 32 channels per pass, two-window rows are swept window by window into one accumulator set.  The default with batches
+    in flight (rows of >= 4096 pixels), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0; split_k_rows: the rows the
+    in-block split-K kernel would take as well), stride 1 and 2, with and without residual, one- and two-window packing, FAST and generic
+    requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one / two / four / eight blocks per pixel tile;
+    every layer against the oracle, batch-33 logits of repeated runs on the liveness-planned workspace, and against the plain launches."""
+    alone = form == "alone"
+    set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", alt_conc="0" if alone else "1")
+    if form == "split_k_rows":
+        set_opts(monkeypatch, pwk_sk="1")
+    if form == "generic":
+        set_opts(monkeypatch, nofast="1")
+    t, q, model = r50
+    if form == "single_window":
+        q = synth.synth_q_values(t, 5, spread=0)
+        model = synth.synth_model(t, q, 0)
+    rig = Rig(t, q, model, 0)
+    conc = 0 if alone else 1
+    mine = {r["layer"]: r["kernel"] for r in rig.net.describe_launches(33, conc) if "conv_pwk" in r["kernel"]}
+    assert {5, 8, 11, 12, 14, 24, 25, 27} <= set(mine), mine
+    if form == "split_k_rows":
+        assert {46, 49} <= set(mine), mine
+    assert any("blocks per tile" in k for k in mine.values()) and any("blocks per tile" not in k for k in mine.values())
+    if form != "single_window":
+        assert any("dual" in k for k in mine.values()) and any("single" in k for k in mine.values())
+    x2 = synth.synth_images(rig.t, 2, 101, kind="int8")
+    x2[0, :, :5, :] = -128
+    rig.check_all_layers(x2)
+    rig.check_all_layers(synth.synth_images(rig.t, 5, 102))
+    x = synth.synth_images(rig.t, 33, 103)
+    first = rig.run(x, keep_all=False).copy()
+    np.testing.assert_array_equal(first[[0, 17, 32]], rig.ref.logits(rig.ref.run(x[[0, 17, 32]])))
+    for _ in range(5):
+        np.testing.assert_array_equal(rig.run(x, keep_all=False), first)
+    set_opts(monkeypatch, pwk="0")
+    plain = Rig(t, q, model, 0)
+    assert not any("conv_pwk" in r["kernel"] for r in plain.net.describe_launches(33, conc))
+    np.testing.assert_array_equal(plain.run(x, keep_all=False), first)
+
+
 @pytest.mark.parametrize("rows,conc", [("7", "1"), ("4", "1"), ("2", "0")])
 def test_band_launches_of_the_identity_bottlenecks(r50, monkeypatch, rows, conc):
     """conv_bband.hip: the identity bottlenecks of stage 3 (rows 15-23: two-window reduce, the last one's 3x3 two-window too) and stage 4

@@ -559,6 +559,9 @@ void Net::load_options() {
   o.alt_conc_mode = (int)opt("alt_conc", o.alt_conc_mode);
   o.pw_slabs = (int)opt("pw_slabs", o.pw_slabs);
   o.pw_minpix = (long)opt("pw_minpix", o.pw_minpix);
+  o.pwk_mode = (int)opt("pwk", o.pwk_mode);
+  o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
+  o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
   o.dbg2 = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr2", 0);
   o.dbg_layer = (int)opt("dbglayer", -1);
@@ -652,7 +655,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
   // items 1-2: 94.8 -> 96.5 k img/s) -- avg_fuse = 2 (default): one batch at a time only
   const bool avg_fuse_now = opts.avg_fuse == 1 || (opts.avg_fuse == 2 && !concurrent);
   // argument block + kernel selection of one conv layer
-  auto make_conv = [&](int l, Launch& st, bool allow_alt) -> bool {
+  auto make_conv0 = [&](int l, Launch& st, bool allow_alt) -> bool {
     const tf2_layer_desc L = exec_desc(l);
     const LayerExec& E = wp->exec[l];
     const PackLayer* pl = pack_layer(l);
@@ -753,10 +756,24 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       } else
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
       if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, opts.pw_slabs, opts.pw_minpix)) st.sel = Launch::SEL_PW;
+      // short-K pointwise rows with the pixel tile's whole K extent resident in LDS (conv_pwk.hip, round 6)
+      if (opts.pwk_mode && (concurrent || opts.pwk_mode == 2) && !st.avg_fused && (st.sel == Launch::SEL_MFMA2 || (st.sel == Launch::SEL_SK && opts.pwk_sk)) &&
+          L.k == 1 && !pl->w_share && L.concat < 0 && conv_pwk_eligible(ca, pl->TM, L.k, dense ? 1 : 0, opts.pwk_minpix)) st.sel = Launch::SEL_PWK;
     } else if (pl->kind == KIND_SHIFT) {
       st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {
       set_error("layer " + std::to_string(l) + " has no packed kernel"); return false;
+    }
+    return true;
+  };
+  // (conv_pwk reads a layer's OWN weight tiles: a 1x1 row whose wide-tile alternative shares the main entry's tiles is tried again on
+  //  the main entry)
+  auto make_conv = [&](int l, Launch& st, bool allow_alt) -> bool {
+    if (!make_conv0(l, st, allow_alt)) return false;
+    if (allow_alt && opts.pwk_mode && (concurrent || opts.pwk_mode == 2) && exec_desc(l).k == 1 && !st.avg_fused &&
+        (st.sel == Launch::SEL_MFMA2 || (st.sel == Launch::SEL_SK && opts.pwk_sk))) {
+      Launch s2;
+      if (make_conv0(l, s2, false) && s2.sel == Launch::SEL_PWK) st = s2;
     }
     return true;
   };
@@ -1199,6 +1216,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
     case Launch::CONV:
       switch (st.sel) {
         case Launch::SEL_PW: return launch_conv_pw(st.conv, st.TM, stream);
+        case Launch::SEL_PWK: return launch_conv_pwk(st.conv, st.TM, stream);
         case Launch::SEL_SK:
           if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
             ConvArgs cd = st.conv_direct; cd.y = logits;

@@ -428,6 +428,8 @@ bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8
 int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix);   // register-resident pointwise kernel takes the layer? (max_slab / min_pix: RunOpts::pw_slabs / pw_minpix)
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
+bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix);   // short-K pointwise kernel (conv_pwk.hip) takes the layer?
+int launch_conv_pwk(const ConvArgs& a, int TM, void* stream);
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
