@@ -617,9 +617,9 @@ def test_first_bottleneck_as_one_launch_of_row_bands(r50, monkeypatch, form):
 
 @pytest.mark.parametrize("form", ["in_flight", "alone", "single_window", "generic", "split_k_rows"])
 def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form):
-    """conv_pwk.hip (round 6): 1x1 rows of 128 .. 512 input channels (ResNet-50's 256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512, 512 -> 256 |
-    1024 / 2, 256 -> 1024, 512 -> 2048) with a pixel tile's whole K extent resident in LDS: the activations are fetched once for every output
-    channel, a wave owns 32 channels per pass, two-window rows are swept window by window into one accumulator set.  The default with batches
+    """conv_pwk.hip (round 6): 1x1 rows of 128 or 256 input channels (ResNet-50's 256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512, 256 -> 1024)
+    with the block's pixels resident in LDS (fetched once for every output channel) and a wave's weight fragments resident in registers per
+    pass of 32 channels; two-window rows are swept window by window into one accumulator set.  The default with batches
     in flight (rows of >= 4096 pixels), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0; split_k_rows: the rows the
     in-block split-K kernel would take as well), stride 1 and 2, with and without residual, one- and two-window packing, FAST and generic
     requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one / two / four / eight blocks per pixel tile;
@@ -637,9 +637,9 @@ def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form)
     rig = Rig(t, q, model, 0)
     conc = 0 if alone else 1
     mine = {r["layer"]: r["kernel"] for r in rig.net.describe_launches(33, conc) if "conv_pwk" in r["kernel"]}
-    assert {5, 8, 11, 12, 14, 24, 25, 27} <= set(mine), mine
+    assert {5, 8, 11, 12, 14, 27} <= set(mine), mine
     if form == "split_k_rows":
-        assert {46, 49} <= set(mine), mine
+        assert {30, 33} <= {r["layer"] for r in rig.net.describe_launches(2, conc) if "conv_pwk" in r["kernel"]}
     assert any("blocks per tile" in k for k in mine.values()) and any("blocks per tile" not in k for k in mine.values())
     if form != "single_window":
         assert any("dual" in k for k in mine.values()) and any("single" in k for k in mine.values())
