@@ -622,7 +622,7 @@ def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form)
     pass of 32 channels; two-window rows are swept window by window into one accumulator set.  The default with batches
     in flight (rows of >= 4096 pixels), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0; split_k_rows: the rows the
     in-block split-K kernel would take as well), stride 1 and 2, with and without residual, one- and two-window packing, FAST and generic
-    requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one / two / four / eight blocks per pixel tile;
+    requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one to eight channel parts per pixel tile, one to three tiles per block;
     every layer against the oracle, batch-33 logits of repeated runs on the liveness-planned workspace, and against the plain launches."""
     alone = form == "alone"
     set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", alt_conc="0" if alone else "1")
@@ -640,7 +640,7 @@ def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form)
     assert {5, 8, 11, 12, 14, 27} <= set(mine), mine
     if form == "split_k_rows":
         assert {30, 33} <= {r["layer"] for r in rig.net.describe_launches(2, conc) if "conv_pwk" in r["kernel"]}
-    assert any("blocks per tile" in k for k in mine.values()) and any("blocks per tile" not in k for k in mine.values())
+    assert any("x 1 channel parts" in k for k in mine.values()) and any("x 4 channel parts" in k for k in mine.values())
     if form != "single_window":
         assert any("dual" in k for k in mine.values()) and any("single" in k for k in mine.values())
     x2 = synth.synth_images(rig.t, 2, 101, kind="int8")

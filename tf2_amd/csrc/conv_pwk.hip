@@ -8,18 +8,20 @@
 //
 // First form (git history: the pixel tile's K extent in LDS, weight fragments global -> registers ONE K step ahead, passes over the
 // channel groups inside a loop over pixel tiles): bit-exact and 40-60 % SLOWER per launch than the ring kernel -- every K step of every
-// (tile, pass) waited for an L2 round trip that a 4-MFMA step cannot cover (profiles/r06_experiments.txt item 21).  This form turns
-// the loops inside out (conv_pw.hip's order with the B operand in LDS):
+// (tile, pass) waited for an L2 round trip that a 4-MFMA step cannot cover (profiles/r06_experiments.txt item 21).  Second form (git
+// history too): weights of a pass resident in registers, ALL the block's pixels loaded first, then computed: 20-45 % slower than the
+// ring kernel -- a one-round grid loads in phase and computes in phase, HBM idle while the chip computes.  This form (conv_pw.hip's
+// loop order with the B operand streamed through LDS):
 //
-//   * a block owns T pixel tiles of 128 pixels (T * K <= 64 KB): ALL their K slabs go global -> LDS once by LDS-DMA
-//     ([tile][slab][pixel][64] swizzled), one wait, one barrier -- two blocks per CU cover each other's load;
-//   * a pass = WM channel groups of 32 (waves along channels) x 8 / WM pixel groups; at the start of a pass a wave loads ALL its weight
-//     fragments (32 rows x K x windows: 16 .. 64 registers) -- ONE L2 round trip per pass, issued behind the previous pass's last MFMA
-//     so that the epilogue covers it -- and then sweeps its column tiles with no memory instruction but ds_read in the K loop;
+//   * a block owns WM x 32 output channels (channel part `part` of the layer) for its whole life: a wave's weight fragments (32 rows x K x
+//     windows: 16 .. 64 registers) and its header rows are fetched ONCE, beside the first tile's DMAs;
+//   * it walks a stream of 128-pixel tiles (tile = stream, stream + n_streams, ..): a tile's K slabs go global -> LDS by LDS-DMA
+//     ([slab][pixel][64] swizzled) into one of two buffers, the next tile's DMAs are issued right behind the barrier that hands over the
+//     current one; no memory instruction but ds_read in the K loop; the channel parts of one tile run on the same XCD (ids n_streams apart);
 //   * two-window layers are swept window by window into ONE accumulator set with the Horner shift in between;
-//   * a wave's 32 header rows (requantisation parameters, final shifts, Horner shifts) are copied per pass into its own 1 KB of LDS in
-//     the form requant_epilogue.h reads (an m-tile image of 32 rows); residual tiles are loaded in front of a column group's MFMAs,
-//     16-byte NHWC stores; addresses = kernel-argument base + one 32-bit offset.
+//   * a wave's 32 header rows (requantisation parameters, final shifts, Horner shifts) sit in its own 1 KB of LDS in the form
+//     requant_epilogue.h reads (an m-tile image of 32 rows); residual tiles are loaded in front of a column group's MFMAs, 16-byte NHWC
+//     stores; addresses = kernel-argument base + one 32-bit offset.
 //
 // Arithmetic, packed image and epilogue are conv_mfma2.hip's (pe.cl:27-43 shift-accumulate as exponent-window int8 GEMMs, pe.cl:185-203
 // requantisation, relu.cl:54, feature_writer.cl:88-122 residual); bit-identical to it (tests/test_gpu_parity.py runs both forms).
@@ -39,28 +41,27 @@ using i32x16 = int __attribute__((ext_vector_type(16)));
 #define TF2_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 namespace {
-constexpr int kPwkPixBytes = 64 * 1024;                  // the block's pixels: T tiles x 128 pixels x K bytes
 constexpr int kPwkHdrSlot = 1024;                        // a wave's 32 header rows (rows | lo | dshift[2]: 7 x 32 words = 896 bytes)
 
 // LDS-DMA hidden from the compiler's wait-count pass (conv_bband.hip bb_dma16): the only wait for these is the vmcnt(0) in front of
-// the block's one barrier, written out below
+// a tile's barrier, written out below
 __device__ __forceinline__ void pwk_dma16(const int8_t* base, unsigned off, int8_t* lds_dst) {
   const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)TF2_LDS_PTR(lds_dst));
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 }  // namespace
 
-// KS: 64-byte K slabs of the layer (2 or 4); WM: channel groups of 32 per pass (waves along channels; 4 / WM pixel groups).
+// KS: 64-byte K slabs of the layer (2 or 4); WM: channel groups of 32 of a block (waves along channels; 4 / WM pixel groups).
 // Four waves per block, two blocks per CU: two waves per SIMD with 256 registers each -- the resident fragments (up to 64 registers)
 // beside two accumulator sets and the epilogue's temporaries (eight waves at 128 registers parked 160-470 bytes per lane in scratch)
 template <int KS, int WM, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int T, int csplit) {
-  constexpr int WN = 4 / WM;
+__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams) {
+  constexpr int WN = 4 / WM, CT = 4 / WN;                // a wave's 32-pixel column tiles of a 128-pixel tile
   constexpr int NWIN = DUAL ? 2 : 1, NV = KS * NWIN;      // K steps of a column tile: (window, slab)
-  constexpr int NJ = 2;                                  // column tiles (accumulator sets) per wave at a time, beside NV * 8 fragment registers
+  constexpr int NJ = 2;                                  // column tiles (accumulator sets) per wave at a time
   constexpr int TILE = KS * 128 * 64;                    // bytes of one 128-pixel tile: [slab][pixel][64]
-  static_assert(WM * WN == 4 && TILE <= kPwkPixBytes, "wave grid / tile");
-  __shared__ __attribute__((aligned(1024))) int8_t pixb[kPwkPixBytes];
+  static_assert(WM * WN == 4 && CT % NJ == 0 && TILE <= 32 * 1024, "wave grid / tile");
+  __shared__ __attribute__((aligned(1024))) int8_t pixb[2][TILE];
   __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
 
   const ConvGeom g = a.g;
@@ -69,24 +70,19 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
   const int wm = wave % WM, wn = wave / WM;
   const int half = lane >> 5, frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);        // a lane's fragment of pixel frow of a [32][64] tile, K half 0
-  // (csplit blocks share a pixel-tile group: block part cp runs passes [cp, cp + 1) * n_pass / csplit -- small maps with many output channels)
-  const int cpart = (int)blockIdx.x % csplit;
-  const int n_pass = a.Np / (32 * WM) / csplit, pass0 = cpart * n_pass;
-  const int t0 = ((int)blockIdx.x / csplit) * T;         // first 128-pixel tile of the block
-  const int nt = n_tiles - t0 < T ? n_tiles - t0 : T;    // its tiles (>= 1: the launcher's grid)
-  const int n_ct = 4 * nt;                               // its 32-pixel column tiles
+  const int part = (int)blockIdx.x / n_streams, stream = (int)blockIdx.x - part * n_streams;
+  const int ch = (part * WM + wm) * 32;                  // first of the wave's 32 output channels
   const int tms = tm == 128 ? 7 : 6;
-  const unsigned a_lane_off = (unsigned)(frow * 64 + half * 16);
   int* const prm = reinterpret_cast<int*>(hdrb[wave]);
 
-  // ---- the block's pixels -> LDS: units u = wave, wave + 8, ..: (tile, slab, 16-pixel group) -------------------------------------------
-  {
-    const bool contiguous = g.stride == 1 && g.OHW == g.H * g.W;        // output pixel index == input pixel index
-    const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
-    const int n_units = nt * (KS * 8);
-    for (int u = wave; u < n_units; u += 4) {
-      const int i = u / (KS * 8), r = u - i * (KS * 8), s = r >> 3, grp = r & 7;
-      const int pg = (t0 + i) * 128 + grp * 16;
+  // ---- a tile's pixels -> LDS: units u = wave, wave + 4, ..: (slab, 16-pixel group); every wave issues 2 KS DMAs per tile ------------
+  const bool contiguous = g.stride == 1 && g.OHW == g.H * g.W;          // output pixel index == input pixel index
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
+  auto issue_tile = [&](int t, int8_t* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2 * KS; q++) {
+      const int u = wave + 4 * q, s = u >> 3, grp = u & 7;
+      const int pg = t * 128 + grp * 16;
       const int p = pg + drow;
       unsigned off;
       const int8_t* base = a.x;
@@ -101,52 +97,46 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
         }
         off = (unsigned)ip * (unsigned)g.Cp_in + (unsigned)(s * 64 + chunk * 16);
       } else {
-        off = (unsigned)(chunk * 16);
+        off = (unsigned)(s * 64 + chunk * 16);             // (a group straddling the end reads the layer's first pixel instead: never stored)
       }
-      // (pixels past the launch: the zero page -- a different base, so the whole wave-instruction takes it only when every lane is out;
-      //  a group straddling the end reads the layer's first pixel instead: never stored)
-      if (pg >= g.n_pix) base = a.zero;
-      else if (p >= g.n_pix) off = (unsigned)(s * 64 + chunk * 16);
-      pwk_dma16(base, off, pixb + i * TILE + s * (128 * 64) + grp * 1024);
+      // (a group wholly past the launch: the zero page -- a different base, wave-uniform)
+      if (pg >= g.n_pix) { base = a.zero; off = (unsigned)(chunk * 16); }
+      pwk_dma16(base, off, buf + s * (128 * 64) + grp * 1024);
     }
-  }
+  };
+  int t = stream;
+  if (t >= n_tiles) return;
+  long long* const dbg = a.dbg2 ? a.dbg2 + (size_t)blockIdx.x * 16 : nullptr;       // tools/pwk_timeline.py: 100 MHz wall clock per phase
+#define PWK_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
+  PWK_STAMP(0);
+  issue_tile(t, pixb[0]);
 
-  // weight fragments of a pass: K step v = (window, slab), 16 contiguous bytes of the lane's row per K half
-  struct Afr { i32x4 k[NV][2]; };
-  auto load_a = [&](Afr& f, int ch) __attribute__((always_inline)) {
+  // the wave's weight fragments: K step v = (window, slab), 16 contiguous bytes of the lane's row per K half
+  i32x4 fa[NV][2];
+  {
     const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
-    const int8_t* const wrow = a.w + (size_t)(mt * KS) * (NWIN << tms) * 64 + (size_t)ro * 64 + a_lane_off;
+    const int8_t* const wrow = a.w + (size_t)(mt * KS) * (NWIN << tms) * 64 + (size_t)ro * 64 + (size_t)(frow * 64 + half * 16);
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       const int win = v / KS, sl = v - win * KS;
       const int8_t* p = wrow + ((size_t)(sl * NWIN + win) << tms) * 64;
-      f.k[v][0] = *reinterpret_cast<const i32x4*>(p); f.k[v][1] = *reinterpret_cast<const i32x4*>(p + 32);
+      fa[v][0] = *reinterpret_cast<const i32x4*>(p); fa[v][1] = *reinterpret_cast<const i32x4*>(p + 32);
     }
-  };
-  // a wave's 32 header rows as an m-tile image of 32 rows in its LDS slot: rows {bias | dbl, alpha, addend64} | lo | dshift[P].
-  // rows: 32 x 16 bytes = lanes 0..31; lo: 32 words = lanes 32..39 (16 bytes each); dshift[p]: lanes 40..47, 48..55
-  int hdst = -1;
-  if (lane < 32) hdst = lane * 16;
-  else if (lane < 40) hdst = 32 * 16 + (lane - 32) * 16;
-  else if (lane < 40 + 8 * NWIN) hdst = (5 + ((lane - 40) >> 3)) * 32 * 4 + ((lane - 40) & 7) * 16;
-  auto load_hdr = [&](int ch) __attribute__((always_inline)) -> i32x4 {
-    const int mt = ch >> tms, ro = ch & ((1 << tms) - 1);
+    // its 32 header rows as an m-tile image of 32 rows in its LDS slot: rows {bias | dbl, alpha, addend64} | lo | dshift[P].
+    // rows: 32 x 16 bytes = lanes 0..31; lo: 32 words = lanes 32..39 (16 bytes each); dshift[p]: lanes 40..47, 48..55
     const int8_t* hsrc = reinterpret_cast<const int8_t*>(a.hdr) + (size_t)mt * a.hdr_bytes;
     const int TMr = 1 << tms;
-    const int8_t* src = hsrc;                              // (lanes without a piece read the m-tile's first bytes: never written)
-    if (lane < 32) src = hsrc + (size_t)(ro + lane) * 16;
-    else if (lane < 40) src = hsrc + (size_t)(4 * TMr + ro) * 4 + (lane - 32) * 16;
-    else if (lane < 40 + 8 * NWIN) src = hsrc + (size_t)((5 + ((lane - 40) >> 3)) * TMr + ro) * 4 + ((lane - 40) & 7) * 16;
-    return *reinterpret_cast<const i32x4*>(src);
-  };
-
-  // the first pass's fragments and header rows travel beside the pixel DMAs
-  Afr fa;
-  load_a(fa, (pass0 * WM + wm) * 32);
-  i32x4 hv = load_hdr((pass0 * WM + wm) * 32);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+    int hdst = -1;
+    const int8_t* src = hsrc;
+    if (lane < 32) { src = hsrc + (size_t)(ro + lane) * 16; hdst = lane * 16; }
+    else if (lane < 40) { src = hsrc + (size_t)(4 * TMr + ro) * 4 + (lane - 32) * 16; hdst = 32 * 16 + (lane - 32) * 16; }
+    else if (lane < 40 + 8 * NWIN) {
+      const int pz = (lane - 40) >> 3, k = (lane - 40) & 7;
+      src = hsrc + (size_t)((5 + pz) * TMr + ro) * 4 + k * 16; hdst = (5 + pz) * 32 * 4 + k * 16;
+    }
+    const i32x4 hv = *reinterpret_cast<const i32x4*>(src);
+    if (hdst >= 0) *reinterpret_cast<i32x4*>(hdrb[wave] + hdst) = hv;
+  }
 
   // (the epilogue's form -- residual, FAST rows -- is chosen ONCE, outside the loops: four forms inside the loop body kept their common
   //  lane values alive across all of them, in scratch -- conv_bneck's lesson)
@@ -156,24 +146,32 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
     const int lo_bound = g.relu ? 0 : -128, rlo = g.add_relu ? 0 : -128;
     const unsigned reso = (unsigned)(frow * g.res_cp + 16 * half);
     const unsigned yo = (unsigned)(frow * g.y_cp + 16 * half);
+    const int chl = ch + 16 * half;
+    const bool ch_ok = chl + 16 <= g.y_nvalid;
+    int it = 0;
 #pragma unroll 1
-    for (int ps = 0; ps < n_pass; ps++) {
-      const int ch = ((pass0 + ps) * WM + wm) * 32;        // first of the wave's 32 output channels of this pass
-      if (hdst >= 0) *reinterpret_cast<i32x4*>(hdrb[wave] + hdst) = hv;
-      const int chl = ch + 16 * half;
-      const bool ch_ok = chl + 16 <= g.y_nvalid;
-      const unsigned res_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t0 * 128) * (unsigned)g.res_cp + (unsigned)g.res_off + (unsigned)ch));
-      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t0 * 128) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
-#pragma unroll 1
-      for (int k0 = wn; k0 < n_ct; k0 += WN * NJ) {        // this wave's column tiles k0, k0 + WN (NJ at a time)
+    for (; t < n_tiles; t += n_streams, it++) {
+      // tile t landed in every wave (and every store / load this wave issued before); nobody reads the other buffer any more
+      if (it < 3) PWK_STAMP(1 + 3 * it);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (it < 3) PWK_STAMP(2 + 3 * it);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (it < 3) PWK_STAMP(3 + 3 * it);
+      if (t + n_streams < n_tiles) issue_tile(t + n_streams, pixb[(it + 1) & 1]);
+      const int8_t* const B0 = pixb[it & 1];
+      const unsigned res_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.res_cp + (unsigned)g.res_off + (unsigned)ch));
+      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
+#pragma unroll
+      for (int k0 = 0; k0 < CT; k0 += NJ) {                // this wave's column tiles wn * CT + k0 .. + NJ
         // the group's residual tiles (16 contiguous NHWC bytes per lane and column tile) land during its MFMAs
         i32x4 rvs[NJ];
         bool okj[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-          const int tj = k0 + j * WN;
-          const int p = t0 * 128 + tj * 32 + frow;
-          okj[j] = tj < n_ct && p < g.n_pix && ch_ok;
+          const int tj = wn * CT + k0 + j;
+          const int p = t * 128 + tj * 32 + frow;
+          okj[j] = p < g.n_pix && ch_ok;
           const int8_t* rp = (HAS_RES && okj[j]) ? a.res + (res_u + reso + (unsigned)(tj * 32 * g.res_cp)) : a.zero;
           rvs[j] = *reinterpret_cast<const i32x4*>(rp);
         }
@@ -182,19 +180,14 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
         for (int j = 0; j < NJ; j++)
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[j][r] = 0;
-        const int8_t* Bj[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const int tj = (k0 + j * WN) & (kPwkPixBytes / TILE * 4 - 1);      // (a column tile past the block's: some resident tile, never stored)
-          Bj[j] = pixb + (tj >> 2) * TILE + (tj & 3) * 2048;
-        }
+        const int8_t* const Bw = B0 + (wn * CT + k0) * 2048;
         // B fragments one K step ahead of their MFMAs, no further (sched_barrier: left alone, the scheduler hoists all NV * 2 * NJ reads
         // -- up to 128 registers -- in front of the first MFMA)
         i32x4 bfc[2][NJ], bfn[2][NJ];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-          for (int j = 0; j < NJ; j++) bfc[ks][j] = *reinterpret_cast<const i32x4*>(Bj[j] + (fr0 ^ (ks << 5)));
+          for (int j = 0; j < NJ; j++) bfc[ks][j] = *reinterpret_cast<const i32x4*>(Bw + j * 2048 + (fr0 ^ (ks << 5)));
 #pragma unroll
         for (int v = 0; v < NV; v++) {
           if (v + 1 < NV) {
@@ -202,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bj[j] + sn * (128 * 64) + (fr0 ^ (ks << 5)));
+              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (128 * 64) + j * 2048 + (fr0 ^ (ks << 5)));
           }
           if (DUAL && v == KS) {
             // Horner step between the windows: acc <<= dshift[1][row]  (weight_pack.cpp: hi window first); the slot's image has 32 rows
@@ -219,17 +212,12 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #pragma unroll
           for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa.k[v][ks], bfc[ks][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[v][ks], bfc[ks][j], acc[j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) bfc[ks][j] = bfn[ks][j];
-        }
-        // behind the pass's last MFMA: the next pass's fragments and header rows -- the epilogue below covers their round trip
-        if (k0 + WN * NJ >= n_ct && ps + 1 < n_pass) {
-          load_a(fa, ch + 32 * WM);
-          hv = load_hdr(ch + 32 * WM);
         }
         // ---- epilogue of the group ------------------------------------------------------------------------------------------------
         i32x4 outs[NJ];
@@ -241,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
         requant_tiles16<NJ, HAS_RES, 1, FAST>(a16s, outs, prm, 32, 4 * half, lo_bound, rlo, rvs, g.dbl_out != 0, g.fast == 2);
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-          const int tj = k0 + j * WN;
+          const int tj = wn * CT + k0 + j;
           if (okj[j]) *reinterpret_cast<i32x4*>(a.y + (y_u + yo + (unsigned)(tj * 32 * g.y_cp))) = outs[j];
         }
       }
@@ -249,11 +237,18 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
   };
   if (g.fast == 1) { if (g.has_res) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
+  if (dbg) {
+    PWK_STAMP(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PWK_STAMP(11);
+    if (tid == 0) dbg[12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+#undef PWK_STAMP
 }
 
 // Does the layer qualify?  1x1 / pad 0 / stride 1 or 2 (any dilation of a 1x1 is the plain layer), dense entries (every m-tile holds
 // slabs 0 .. nslab - 1 in order, one window or dual) in the layer's OWN tiles (no shared storage), K = 2 or 4 slabs, output channels a
-// multiple of the 32 x WM a pass covers, no fused global average.
+// multiple of the 32 x WM a block covers, no fused global average.
 static int pwk_wm(int Np) { return Np % 128 == 0 ? 4 : Np % 64 == 0 ? 2 : 0; }
 bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix) {
   const ConvGeom& g = a.g;
@@ -269,28 +264,24 @@ bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix
   return g.n_pix >= min_pix;
 }
 
-static int g_pwk_tiles = 0;                              // pwk_t (test-only): tiles per block, 0 = the launcher's choice
-void conv_pwk_set_tiles(int t) { g_pwk_tiles = t; }
+static int g_pwk_slots = 512;                            // pwk_slots (test-only): blocks the grid aims at (two per CU)
+void conv_pwk_set_tiles(int t) { g_pwk_slots = t > 0 ? t : 512; }
 
 template <int KS, int WM, bool DUAL>
 static int launch_pwk2(const ConvArgs& a, int TM, hipStream_t s) {
   auto fn = conv_pwk_kernel<KS, WM, DUAL>;
   const int n_tiles = (a.g.n_pix + 127) / 128;
-  const int n_pass = a.Np / (32 * WM);
-  // blocks per pixel-tile group: the channel passes split over 2 / 4 / 8 blocks while the launch has fewer than two blocks per CU
-  // (the group's activations are then fetched once per part: L2); tiles per block: as many as fit the 64 KB while the grid keeps ~400 blocks
-  int max_split = 1;
-  while (n_pass % (max_split * 2) == 0 && max_split < 8) max_split *= 2;
-  int T = kPwkPixBytes / (KS * 128 * 64);
-  while (T > 1 && (long)((n_tiles + T - 1) / T) * max_split < 384) T >>= 1;
-  if (g_pwk_tiles > 0 && g_pwk_tiles <= kPwkPixBytes / (KS * 128 * 64)) T = g_pwk_tiles;
-  const int tb = (n_tiles + T - 1) / T;
-  int csplit = 1;
-  while (tb * csplit * 2 <= 512 && csplit < max_split) csplit *= 2;
-  const int grid = tb * csplit;
-  TF2_LAUNCH_NAME("conv_pwk_kernel<%d slabs,%d channel groups,%s> (%d pixels per block%s)", KS, WM, DUAL ? "dual" : "single", 128 * T,
-                  csplit == 1 ? "" : csplit == 2 ? ", 2 blocks per tile" : csplit == 4 ? ", 4 blocks per tile" : ", 8 blocks per tile");
-  TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a, n_tiles, TM, T, csplit);
+  const int parts = a.Np / (32 * WM);                     // channel parts: blocks that share a pixel tile (its activations come from L2 then)
+  // tile streams: every block walks the same number of tiles (+- 1), ~two blocks per CU in all; a multiple of 8 where parts share tiles
+  // (block ids n_streams apart then sit on one XCD)
+  const int want = std::max(1, g_pwk_slots / parts);
+  const int per = (n_tiles + want - 1) / want;
+  int n_streams = (n_tiles + per - 1) / per;
+  if (parts > 1 && n_streams >= 8) n_streams = std::min((n_streams + 7) & ~7, n_tiles);
+  const int grid = n_streams * parts;
+  TF2_LAUNCH_NAME("conv_pwk_kernel<%d slabs,%d channel groups,%s> (%d streams of %d..%d tiles x %d channel parts)", KS, WM, DUAL ? "dual" : "single",
+                  n_streams, n_tiles / n_streams, (n_tiles + n_streams - 1) / n_streams, parts);
+  TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a, n_tiles, TM, n_streams);
   return launch_ok() ? 0 : -1;
 }
 

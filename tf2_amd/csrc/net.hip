@@ -562,7 +562,7 @@ void Net::load_options() {
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
-  conv_pwk_set_tiles((int)opt("pwk_t", 0));
+  conv_pwk_set_tiles((int)opt("pwk_slots", 0));
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
   o.dbg2 = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr2", 0);
   o.dbg_layer = (int)opt("dbglayer", -1);
