@@ -208,6 +208,38 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
         net.describe_launches(0, 0)
 
 
+def test_short_k_pointwise_option_changes_exactly_its_rows(golden_dir, monkeypatch):
+    """pwk (conv_pwk.hip, default 0): with pwk=1 the in-flight plan sends ResNet-50's dense 1x1 rows of 128 / 256 input channels and >= 4096 pixels --
+    5, 8, 11 | 12 (the pair splits into two launches), 14, 27 -- to the kernel that keeps a block's weight fragments in registers and streams pixel tiles
+    through two LDS buffers; a row whose wide-tile alternative shares its main entry's weight tiles (27) is taken on the main entry.  Nothing else moves,
+    the one-batch plan only with pwk=2.  No device needed."""
+    from tests.conftest import set_opts
+    t = cfg.resnet50_tables()
+    q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
+    model = synth.synth_model(t, q, 0)
+
+    def plans():
+        net = network.NetWork(t)
+        net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
+        return net.describe_launches(32, 1), net.describe_launches(32, 0)
+    many0, one0 = plans()
+    assert not any("conv_pwk" in r["kernel"] for r in many0 + one0)
+    set_opts(monkeypatch, pwk="1")
+    many1, one1 = plans()
+    mine = {r["layer"]: r for r in many1 if "conv_pwk" in r["kernel"]}
+    assert sorted(mine) == [5, 8, 11, 12, 14, 27] and [(r["layer"], r["kernel"]) for r in one1] == [(r["layer"], r["kernel"]) for r in one0]
+    assert all(r["block"] == 256 and 380 <= r["grid"] <= 520 for r in mine.values()), mine
+    assert "4 slabs,2 channel groups,dual" in mine[5]["kernel"] and "x 1 channel parts" in mine[5]["kernel"] and "of 2..2 tiles" in mine[5]["kernel"]
+    assert "2 slabs,4 channel groups,single" in mine[14]["kernel"] and "x 4 channel parts" in mine[14]["kernel"]
+    assert "x 8 channel parts" in mine[27]["kernel"]
+    others0 = [(r["layer"], r["kernel"], r["grid"]) for r in many0 if r["layer"] not in (5, 8, 11, 12, 14, 27)]
+    others1 = [(r["layer"], r["kernel"], r["grid"]) for r in many1 if r["layer"] not in (5, 8, 11, 12, 14, 27)]
+    assert others0 == others1 and len(many1) == len(many0) + 1
+    set_opts(monkeypatch, pwk="2")
+    _, one2 = plans()
+    assert {5, 8} <= {r["layer"] for r in one2 if "conv_pwk" in r["kernel"]}
+
+
 def test_launch_selection_of_the_vgg_style_networks(monkeypatch):
     """The other BASELINE configurations' plans, without a device: a 3x3 first layer on the 3-channel image runs as a pointwise layer
     over the im2col image the input kernel writes (Net::init); the 3x3 / 1 / pad 1 body layers of maps >= 14 x 14 take conv_c3.hip

@@ -88,3 +88,12 @@ def test_the_two_block_per_cu_bottleneck_kernels_compile_without_scratch(isa_fil
     assert len(bfirst) == 2 and all(v == 0 for v in bfirst.values()), bfirst
     bneck64 = {k: v for k, v in seg.items() if "conv_bneck_kernelILi2ELi4ELi2E" in k}
     assert len(bneck64) == 4 and all(v <= 12 for v in bneck64.values()) and sum(v == 0 for v in bneck64.values()) >= 2, bneck64
+
+
+def test_the_short_k_pointwise_kernel_compiles_without_scratch(isa_files):
+    """conv_pwk.hip: every instantiation (2 / 4 K slabs x 2 / 4 channel groups x one / two windows) at a private segment of 0 -- its first forms
+    (eight waves at 128 registers beside up to 64 resident fragment registers) parked 160-470 bytes per lane; four waves per block at <= 256 registers."""
+    txt = open(os.path.join(os.path.dirname(isa_files[0]), "conv_pwk.s")).read()
+    seg = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", txt)}
+    mine = {k: v for k, v in seg.items() if "conv_pwk_kernel" in k}
+    assert len(mine) == 8 and all(v == 0 for v in mine.values()), mine
