@@ -55,7 +55,7 @@ __device__ __forceinline__ void pwk_dma16(const int8_t* base, unsigned off, int8
 // Four waves per block, two blocks per CU: two waves per SIMD with 256 registers each -- the resident fragments (up to 64 registers)
 // beside two accumulator sets and the epilogue's temporaries (eight waves at 128 registers parked 160-470 bytes per lane in scratch)
 template <int KS, int WM, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams) {
+__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams, int pipe) {
   constexpr int WN = 4 / WM, CT = 4 / WN;                // a wave's 32-pixel column tiles of a 128-pixel tile
   constexpr int NWIN = DUAL ? 2 : 1, NV = KS * NWIN;      // K steps of a column tile: (window, slab)
   constexpr int NJ = 2;                                  // column tiles (accumulator sets) per wave at a time
@@ -235,6 +235,119 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
       }
     }
   };
+  // ---- FAST rows without a residual: a column group's requantisation rides between the NEXT group's MFMAs (one wave keeps the matrix pipe
+  // and the VALU busy at once: two waves per SIMD that start together would otherwise contend for the one, then for the other) ------------
+  auto run_pipe = [&](auto dbl_c) __attribute__((always_inline)) {
+    constexpr bool DBL = decltype(dbl_c)::value;
+    const int lo_bound = g.relu ? 0 : -128;
+    const unsigned yo = (unsigned)(frow * g.y_cp + 16 * half);
+    const bool ch_ok = ch + 16 * half + 16 <= g.y_nvalid;
+    const rq_i32x4* const rowp = reinterpret_cast<const rq_i32x4*>(prm) + 4 * half;
+    const rq_i32x4 nolo = {0, 0, 0, 0};
+    int pend[NJ][16];
+    unsigned pd[NJ][4];
+    unsigned pend_off[NJ];
+    bool pend_ok[NJ];
+    bool has_pend = false;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { pend_off[j] = 0; pend_ok[j] = false; }
+    // rows 4 G .. 4 G + 3 (of the lane's sixteen) of the pending group -> their four packed bytes
+    auto epi_rows = [&](int G) __attribute__((always_inline)) {
+      rq_i32x4 pr4[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) pr4[r] = rowp[8 * G + r];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) pd[j][G] = rq_rows4<true, DBL, false>(pend[j], G, pr4, nolo, lo_bound);
+    };
+    auto epi_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        auto s02 = __builtin_amdgcn_permlane32_swap(pd[j][0], pd[j][2], false, false);
+        auto s13 = __builtin_amdgcn_permlane32_swap(pd[j][1], pd[j][3], false, false);
+        const i32x4 out = {(int)s02[0], (int)s02[1], (int)s13[0], (int)s13[1]};
+        if (pend_ok[j]) *reinterpret_cast<i32x4*>(a.y + pend_off[j]) = out;
+      }
+    };
+    int it = 0;
+#pragma unroll 1
+    for (; t < n_tiles; t += n_streams, it++) {
+      if (it < 3) PWK_STAMP(1 + 3 * it);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (it < 3) PWK_STAMP(2 + 3 * it);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (it < 3) PWK_STAMP(3 + 3 * it);
+      if (t + n_streams < n_tiles) issue_tile(t + n_streams, pixb[(it + 1) & 1]);
+      const int8_t* const B0 = pixb[it & 1];
+      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
+#pragma unroll
+      for (int k0 = 0; k0 < CT; k0 += NJ) {
+        i32x16 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[j][r] = 0;
+        const int8_t* const Bw = B0 + (wn * CT + k0) * 2048;
+        i32x4 bfc[2][NJ], bfn[2][NJ];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++) bfc[ks][j] = *reinterpret_cast<const i32x4*>(Bw + j * 2048 + (fr0 ^ (ks << 5)));
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          if (v + 1 < NV) {
+            const int sn = (v + 1) % KS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (128 * 64) + j * 2048 + (fr0 ^ (ks << 5)));
+          }
+          if (DUAL && v == KS) {
+            const int* dsh = prm + (kPrmWordsPerRow + 1) * 32 + 4 * half;
+#pragma unroll
+            for (int G = 0; G < 4; G++) {
+              const i32x4 d = *reinterpret_cast<const i32x4*>(dsh + 8 * G);
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) acc[j][G * 4 + r] = (int)((unsigned)acc[j][G * 4 + r] << (d[r] & 31));
+            }
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[v][ks], bfc[ks][j], acc[j], 0, 0, 0);
+          // the pending group's rows behind this step's MFMAs: 4 row groups over NV steps
+          if (has_pend) {
+            if constexpr (NV >= 4) { if (v % (NV / 4) == 0) epi_rows(v / (NV / 4)); }
+            else { epi_rows(2 * v); epi_rows(2 * v + 1); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bfc[ks][j] = bfn[ks][j];
+        }
+        if (has_pend) epi_store();
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int tj = wn * CT + k0 + j;
+#pragma unroll
+          for (int r = 0; r < 16; r++) pend[j][r] = acc[j][r];
+          pend_ok[j] = t * 128 + tj * 32 + frow < g.n_pix && ch_ok;
+          pend_off[j] = y_u + yo + (unsigned)(tj * 32 * g.y_cp);
+        }
+        has_pend = true;
+      }
+    }
+    if (has_pend) {
+#pragma unroll
+      for (int G = 0; G < 4; G++) epi_rows(G);
+      epi_store();
+    }
+  };
+  if (g.fast == 1 && !g.has_res && pipe) { if (g.dbl_out) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
+  else
   if (g.fast == 1) { if (g.has_res) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
   if (dbg) {
@@ -265,7 +378,9 @@ bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix
 }
 
 static int g_pwk_slots = 512;                            // pwk_slots (test-only): blocks the grid aims at (two per CU)
+static int g_pwk_pipe = 1;                               // pwk_pipe (test-only): 0 = no requantisation between the next group's MFMAs
 void conv_pwk_set_tiles(int t) { g_pwk_slots = t > 0 ? t : 512; }
+void conv_pwk_set_pipe(int p) { g_pwk_pipe = p; }
 
 template <int KS, int WM, bool DUAL>
 static int launch_pwk2(const ConvArgs& a, int TM, hipStream_t s) {
@@ -281,7 +396,7 @@ static int launch_pwk2(const ConvArgs& a, int TM, hipStream_t s) {
   const int grid = n_streams * parts;
   TF2_LAUNCH_NAME("conv_pwk_kernel<%d slabs,%d channel groups,%s> (%d streams of %d..%d tiles x %d channel parts)", KS, WM, DUAL ? "dual" : "single",
                   n_streams, n_tiles / n_streams, (n_tiles + n_streams - 1) / n_streams, parts);
-  TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a, n_tiles, TM, n_streams);
+  TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a, n_tiles, TM, n_streams, g_pwk_pipe);
   return launch_ok() ? 0 : -1;
 }
 

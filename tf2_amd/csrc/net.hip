@@ -563,6 +563,7 @@ void Net::load_options() {
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   conv_pwk_set_tiles((int)opt("pwk_slots", 0));
+  conv_pwk_set_pipe((int)opt("pwk_pipe", 1));
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
   o.dbg2 = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr2", 0);
   o.dbg_layer = (int)opt("dbglayer", -1);

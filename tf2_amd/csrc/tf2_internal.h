@@ -430,6 +430,7 @@ bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, in
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
 bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix);   // short-K pointwise kernel (conv_pwk.hip) takes the layer?
 int launch_conv_pwk(const ConvArgs& a, int TM, void* stream);
+void conv_pwk_set_pipe(int p);     // pwk_pipe (test-only): 0 = the plain epilogue for every row
 void conv_pwk_set_tiles(int t);    // pwk_slots (test-only): blocks a launch aims at, 0 = 512 (two per CU)
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
