@@ -617,15 +617,16 @@ def test_first_bottleneck_as_one_launch_of_row_bands(r50, monkeypatch, form):
 
 @pytest.mark.parametrize("form", ["in_flight", "alone", "single_window", "generic", "split_k_rows"])
 def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form):
-    """conv_pwk.hip (round 6): 1x1 rows of 128 or 256 input channels (ResNet-50's 256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512, 256 -> 1024)
+    """conv_pwk.hip (round 6): 1x1 rows of 128, 256 or 512 input channels (ResNet-50's 256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512, 512 -> 256 | 1024 / 2,
+    256 -> 1024, 512 -> 2048)
     with the block's pixels resident in LDS (fetched once for every output channel) and a wave's weight fragments resident in registers per
     pass of 32 channels; two-window rows are swept window by window into one accumulator set.  The default with batches
-    in flight (rows of >= 4096 pixels), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0; split_k_rows: the rows the
+    in flight (rows of >= 4096 pixels; pwk=0: the ring kernel), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0, pwk_slabs=8: the 512-channel rows too, which the default leaves to the ring kernel; split_k_rows: the rows the
     in-block split-K kernel would take as well), stride 1 and 2, with and without residual, one- and two-window packing, FAST and generic
     requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one to eight channel parts per pixel tile, one to three tiles per block;
     every layer against the oracle, batch-33 logits of repeated runs on the liveness-planned workspace, and against the plain launches."""
     alone = form == "alone"
-    set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", alt_conc="0" if alone else "1")
+    set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", pwk_slabs="8", alt_conc="0" if alone else "1")
     if form == "split_k_rows":
         set_opts(monkeypatch, pwk_sk="1")
     if form == "generic":
@@ -637,10 +638,14 @@ def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form)
     rig = Rig(t, q, model, 0)
     conc = 0 if alone else 1
     mine = {r["layer"]: r["kernel"] for r in rig.net.describe_launches(33, conc) if "conv_pwk" in r["kernel"]}
-    assert {5, 8, 11, 12, 14, 27} <= set(mine), mine
+    assert {5, 8, 11, 14, 24, 27} <= set(mine) and "conv_pwk_pair_kernel" in mine[11] and "conv_pwk_pair_kernel<8 slabs" in mine[24] and 12 not in mine, mine
     if form == "split_k_rows":
         assert {30, 33} <= {r["layer"] for r in rig.net.describe_launches(2, conc) if "conv_pwk" in r["kernel"]}
     assert any("x 1 channel parts" in k for k in mine.values()) and any("x 4 channel parts" in k for k in mine.values())
+    set_opts(monkeypatch, pair="0" if form == "generic" else None)       # (one form with rows 11 and 12 as launches of their own)
+    if form == "generic":
+        rig.net.reload_options()
+        assert {11, 12} <= {r["layer"] for r in rig.net.describe_launches(33, conc) if "conv_pwk_kernel" in r["kernel"]}
     if form != "single_window":
         assert any("dual" in k for k in mine.values()) and any("single" in k for k in mine.values())
     x2 = synth.synth_images(rig.t, 2, 101, kind="int8")

@@ -173,6 +173,7 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # independent neighbouring rows in one launch: the shortcut convolution of stages 3 and 4 (and, with the wide tiles of the
     # several-streams plan, stage 5) next to the first 1x1 of the stage's first bottleneck
     assert {r["layer"] for r in one if "pair" in r["kernel"]} == {11, 24} and {r["layer"] for r in many if "pair" in r["kernel"]} == {11, 24, 43}
+    assert {r["layer"] for r in many if "conv_pwk_pair" in r["kernel"]} == {11}              # (round 6: the in-flight plan's 256-channel pair on conv_pwk.hip)
     # one batch at a time the identity bottlenecks of stages 3 and 5 are ONE launch each (conv_bgroup.hip: rows 15-17 ..., 47-49, 50-52),
     # the five of stage 4 (rows 28-42) ONE launch together
     groups = [r for r in one if "conv_bgroup" in r["kernel"]]
@@ -209,10 +210,11 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
 
 
 def test_short_k_pointwise_option_changes_exactly_its_rows(golden_dir, monkeypatch):
-    """pwk (conv_pwk.hip, default 0): with pwk=1 the in-flight plan sends ResNet-50's dense 1x1 rows of 128 / 256 input channels and >= 4096 pixels --
-    5, 8, 11 | 12 (the pair splits into two launches), 14, 27 -- to the kernel that keeps a block's weight fragments in registers and streams pixel tiles
-    through two LDS buffers; a row whose wide-tile alternative shares its main entry's weight tiles (27) is taken on the main entry.  Nothing else moves,
-    the one-batch plan only with pwk=2.  No device needed."""
+    """pwk (conv_pwk.hip, default 1: with batches in flight): the in-flight plan sends ResNet-50's dense 1x1 rows of 128 / 256 input channels and
+    >= 4096 pixels -- 5, 8, 11 | 12 (one launch of two rows, like the ring kernel's pair), 14, 27 -- to the kernel that keeps a block's weight fragments
+    in registers and streams pixel tiles through two LDS buffers; a row whose wide-tile alternative shares its main entry's weight tiles (27) is taken on
+    the main entry; pwk_slabs=8 adds the 512-channel rows (24 | 25: measured slower, not the default).  pwk=0 gives the ring-kernel plan back, nothing else
+    moves; the one-batch plan takes it only with pwk=2.  No device needed."""
     from tests.conftest import set_opts
     t = cfg.resnet50_tables()
     q = np.loadtxt(os.path.join(golden_dir, "resnet50_Q"), dtype=np.int32)
@@ -222,20 +224,27 @@ def test_short_k_pointwise_option_changes_exactly_its_rows(golden_dir, monkeypat
         net = network.NetWork(t)
         net.Quantization(synth.q_text(q)); net.LoadModel(model); net.Pack(0)
         return net.describe_launches(32, 1), net.describe_launches(32, 0)
-    many0, one0 = plans()
-    assert not any("conv_pwk" in r["kernel"] for r in many0 + one0)
-    set_opts(monkeypatch, pwk="1")
     many1, one1 = plans()
     mine = {r["layer"]: r for r in many1 if "conv_pwk" in r["kernel"]}
-    assert sorted(mine) == [5, 8, 11, 12, 14, 27] and [(r["layer"], r["kernel"]) for r in one1] == [(r["layer"], r["kernel"]) for r in one0]
-    assert all(r["block"] == 256 and 380 <= r["grid"] <= 520 for r in mine.values()), mine
-    assert "4 slabs,2 channel groups,dual" in mine[5]["kernel"] and "x 1 channel parts" in mine[5]["kernel"] and "of 2..2 tiles" in mine[5]["kernel"]
+    assert sorted(mine) == [5, 8, 11, 14, 27] and not any("conv_pwk" in r["kernel"] for r in one1)
+    assert "conv_pwk_pair_kernel" in mine[11]["kernel"] and not any(r["layer"] == 12 for r in many1)
+    assert all(r["block"] == 256 and 190 <= r["grid"] <= 260 for r in mine.values()), mine       # about one block per CU, 3-7 tiles each
+    assert "4 slabs,2 channel groups,dual" in mine[5]["kernel"] and "x 1 channel parts" in mine[5]["kernel"] and "of 4..4 tiles" in mine[5]["kernel"]
     assert "2 slabs,4 channel groups,single" in mine[14]["kernel"] and "x 4 channel parts" in mine[14]["kernel"]
     assert "x 8 channel parts" in mine[27]["kernel"]
-    others0 = [(r["layer"], r["kernel"], r["grid"]) for r in many0 if r["layer"] not in (5, 8, 11, 12, 14, 27)]
-    others1 = [(r["layer"], r["kernel"], r["grid"]) for r in many1 if r["layer"] not in (5, 8, 11, 12, 14, 27)]
-    assert others0 == others1 and len(many1) == len(many0) + 1
-    set_opts(monkeypatch, pwk="2")
+    set_opts(monkeypatch, pwk="0")
+    many0, one0 = plans()
+    assert not any("conv_pwk" in r["kernel"] for r in many0 + one0)
+    assert [(r["layer"], r["kernel"]) for r in one1] == [(r["layer"], r["kernel"]) for r in one0]
+    rows = (5, 8, 11, 14, 27)
+    others0 = [(r["layer"], r["kernel"], r["grid"]) for r in many0 if r["layer"] not in rows]
+    others1 = [(r["layer"], r["kernel"], r["grid"]) for r in many1 if r["layer"] not in rows]
+    assert others0 == others1 and len(many1) == len(many0)
+    set_opts(monkeypatch, pwk="1", pwk_slabs="8")
+    many8, _ = plans()
+    k8 = {r["layer"]: r["kernel"] for r in many8 if "conv_pwk" in r["kernel"]}
+    assert sorted(k8) == [5, 8, 11, 14, 24, 27] and "conv_pwk_pair_kernel<8 slabs" in k8[24] and not any(r["layer"] == 25 for r in many8)
+    set_opts(monkeypatch, pwk="2", pwk_slabs=None)
     _, one2 = plans()
     assert {5, 8} <= {r["layer"] for r in one2 if "conv_pwk" in r["kernel"]}
 

@@ -49,20 +49,22 @@ __device__ __forceinline__ void pwk_dma16(const int8_t* base, unsigned off, int8
   const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)TF2_LDS_PTR(lds_dst));
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
+__host__ __device__ constexpr int pwk_tile_px(int ks) { return ks <= 4 ? 128 : 64; }      // pixels of a tile (32 KB at most)
 }  // namespace
 
-// KS: 64-byte K slabs of the layer (2 or 4); WM: channel groups of 32 of a block (waves along channels; 4 / WM pixel groups).
+// KS: 64-byte K slabs of the layer (2, 4 or 8); WM: channel groups of 32 of a block (waves along channels; 4 / WM pixel groups).
 // Four waves per block, two blocks per CU: two waves per SIMD with 256 registers each -- the resident fragments (up to 64 registers)
 // beside two accumulator sets and the epilogue's temporaries (eight waves at 128 registers parked 160-470 bytes per lane in scratch)
 template <int KS, int WM, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams, int pipe) {
-  constexpr int WN = 4 / WM, CT = 4 / WN;                // a wave's 32-pixel column tiles of a 128-pixel tile
+__device__ __forceinline__ void conv_pwk_body(const ConvArgs& a, const int n_tiles, const int tm, const int n_streams, const int pipe, const int bid,
+                                              int8_t (*pixb)[pwk_tile_px(KS) * KS * 64], int8_t (*hdrb)[1024]) {
+  constexpr int TP = pwk_tile_px(KS);                    // pixels of a tile: 128 (K <= 256), 64 (K = 512)
+  constexpr int WN = 4 / WM, CT = TP / 32 / WN;          // a wave's 32-pixel column tiles of a tile
   constexpr int NWIN = DUAL ? 2 : 1, NV = KS * NWIN;      // K steps of a column tile: (window, slab)
   constexpr int NJ = 2;                                  // column tiles (accumulator sets) per wave at a time
-  constexpr int TILE = KS * 128 * 64;                    // bytes of one 128-pixel tile: [slab][pixel][64]
-  static_assert(WM * WN == 4 && CT % NJ == 0 && TILE <= 32 * 1024, "wave grid / tile");
-  __shared__ __attribute__((aligned(1024))) int8_t pixb[2][TILE];
-  __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
+  constexpr int TILE = KS * TP * 64;                     // bytes of one tile: [slab][pixel][64]
+  constexpr int NG = TP / 16, UPW = KS * NG / 4;         // 16-pixel groups of a tile; DMA units (slab, group) per wave
+  static_assert(WM * WN == 4 && CT >= NJ && CT % NJ == 0 && TILE <= 32 * 1024 && (KS * NG) % 4 == 0, "wave grid / tile");
 
   const ConvGeom g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
   const int wm = wave % WM, wn = wave / WM;
   const int half = lane >> 5, frow = lane & 31;
   const int fr0 = frow * 64 + ((half ^ ((frow >> 2) & 3)) << 4);        // a lane's fragment of pixel frow of a [32][64] tile, K half 0
-  const int part = (int)blockIdx.x / n_streams, stream = (int)blockIdx.x - part * n_streams;
+  const int part = bid / n_streams, stream = bid - part * n_streams;
   const int ch = (part * WM + wm) * 32;                  // first of the wave's 32 output channels
   const int tms = tm == 128 ? 7 : 6;
   int* const prm = reinterpret_cast<int*>(hdrb[wave]);
@@ -80,9 +82,9 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3), drow = lane >> 2;
   auto issue_tile = [&](int t, int8_t* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 2 * KS; q++) {
-      const int u = wave + 4 * q, s = u >> 3, grp = u & 7;
-      const int pg = t * 128 + grp * 16;
+    for (int q = 0; q < UPW; q++) {
+      const int u = wave + 4 * q, s = u / NG, grp = u % NG;
+      const int pg = t * TP + grp * 16;
       const int p = pg + drow;
       unsigned off;
       const int8_t* base = a.x;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
       }
       // (a group wholly past the launch: the zero page -- a different base, wave-uniform)
       if (pg >= g.n_pix) { base = a.zero; off = (unsigned)(chunk * 16); }
-      pwk_dma16(base, off, buf + s * (128 * 64) + grp * 1024);
+      pwk_dma16(base, off, buf + s * (TP * 64) + grp * 1024);
     }
   };
   int t = stream;
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
       if (it < 3) PWK_STAMP(3 + 3 * it);
       if (t + n_streams < n_tiles) issue_tile(t + n_streams, pixb[(it + 1) & 1]);
       const int8_t* const B0 = pixb[it & 1];
-      const unsigned res_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.res_cp + (unsigned)g.res_off + (unsigned)ch));
-      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
+      const unsigned res_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * TP) * (unsigned)g.res_cp + (unsigned)g.res_off + (unsigned)ch));
+      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * TP) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
 #pragma unroll
       for (int k0 = 0; k0 < CT; k0 += NJ) {                // this wave's column tiles wn * CT + k0 .. + NJ
         // the group's residual tiles (16 contiguous NHWC bytes per lane and column tile) land during its MFMAs
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
           const int tj = wn * CT + k0 + j;
-          const int p = t * 128 + tj * 32 + frow;
+          const int p = t * TP + tj * 32 + frow;
           okj[j] = p < g.n_pix && ch_ok;
           const int8_t* rp = (HAS_RES && okj[j]) ? a.res + (res_u + reso + (unsigned)(tj * 32 * g.res_cp)) : a.zero;
           rvs[j] = *reinterpret_cast<const i32x4*>(rp);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (128 * 64) + j * 2048 + (fr0 ^ (ks << 5)));
+              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (TP * 64) + j * 2048 + (fr0 ^ (ks << 5)));
           }
           if (DUAL && v == KS) {
             // Horner step between the windows: acc <<= dshift[1][row]  (weight_pack.cpp: hi window first); the slot's image has 32 rows
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
       if (it < 3) PWK_STAMP(3 + 3 * it);
       if (t + n_streams < n_tiles) issue_tile(t + n_streams, pixb[(it + 1) & 1]);
       const int8_t* const B0 = pixb[it & 1];
-      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * 128) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
+      const unsigned y_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(t * TP) * (unsigned)g.y_cp + (unsigned)g.y_off + (unsigned)ch));
 #pragma unroll
       for (int k0 = 0; k0 < CT; k0 += NJ) {
         i32x16 acc[NJ];
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (128 * 64) + j * 2048 + (fr0 ^ (ks << 5)));
+              for (int j = 0; j < NJ; j++) bfn[ks][j] = *reinterpret_cast<const i32x4*>(Bw + sn * (TP * 64) + j * 2048 + (fr0 ^ (ks << 5)));
           }
           if (DUAL && v == KS) {
             const int* dsh = prm + (kPrmWordsPerRow + 1) * 32 + 4 * half;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
           const int tj = wn * CT + k0 + j;
 #pragma unroll
           for (int r = 0; r < 16; r++) pend[j][r] = acc[j][r];
-          pend_ok[j] = t * 128 + tj * 32 + frow < g.n_pix && ch_ok;
+          pend_ok[j] = t * TP + tj * 32 + frow < g.n_pix && ch_ok;
           pend_off[j] = y_u + yo + (unsigned)(tj * 32 * g.y_cp);
         }
         has_pend = true;
@@ -346,10 +348,14 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
       epi_store();
     }
   };
-  if (g.fast == 1 && !g.has_res && pipe) { if (g.dbl_out) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
-  else
+  bool piped = false;
+  if constexpr (NV * 8 <= 64) {
+    if (g.fast == 1 && !g.has_res && pipe) { piped = true; if (g.dbl_out) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
+  }
+  if (!piped) {
   if (g.fast == 1) { if (g.has_res) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
   else { if (g.has_res) run(std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}); }
+  }
   if (dbg) {
     PWK_STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -359,6 +365,24 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 #undef PWK_STAMP
 }
 
+template <int KS, int WM, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams, int pipe) {
+  __shared__ __attribute__((aligned(1024))) int8_t pixb[2][pwk_tile_px(KS) * KS * 64];
+  __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
+  conv_pwk_body<KS, WM, DUAL>(a, n_tiles, tm, n_streams, pipe, (int)blockIdx.x, pixb, hdrb);
+}
+
+// two independent rows of one instantiation in one launch (conv_mfma2_pair_kernel's scheme: a stage's shortcut convolution beside the first
+// 1x1 of its first bottleneck -- same input, no dependence): blocks [0, n0) work on the first argument block, the rest on the second
+template <int KS, int WM, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_pwk_pair_kernel(ConvArgs a0, ConvArgs a1, int n_tiles0, int tm0, int n_streams0, int n_tiles1, int tm1, int n_streams1,
+                                                               int pipe, int n0) {
+  __shared__ __attribute__((aligned(1024))) int8_t pixb[2][pwk_tile_px(KS) * KS * 64];
+  __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
+  if ((int)blockIdx.x < n0) conv_pwk_body<KS, WM, DUAL>(a0, n_tiles0, tm0, n_streams0, pipe, (int)blockIdx.x, pixb, hdrb);
+  else conv_pwk_body<KS, WM, DUAL>(a1, n_tiles1, tm1, n_streams1, pipe, (int)blockIdx.x - n0, pixb, hdrb);
+}
+
 // Does the layer qualify?  1x1 / pad 0 / stride 1 or 2 (any dilation of a 1x1 is the plain layer), dense entries (every m-tile holds
 // slabs 0 .. nslab - 1 in order, one window or dual) in the layer's OWN tiles (no shared storage), K = 2 or 4 slabs, output channels a
 // multiple of the 32 x WM a block covers, no fused global average.
@@ -366,37 +390,58 @@ static int pwk_wm(int Np) { return Np % 128 == 0 ? 4 : Np % 64 == 0 ? 2 : 0; }
 bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix) {
   const ConvGeom& g = a.g;
   if (k != 1 || (g.pad_h | g.pad_w) != 0 || (g.stride != 1 && g.stride != 2) || g.avg_mult) return false;
-  if (!dense || (TM != 64 && TM != 128) || (a.nslab != 2 && a.nslab != 4) || g.Cp_in != a.nslab * 64) return false;
+  if (!dense || (TM != 64 && TM != 128) || (a.nslab != 2 && a.nslab != 4 && a.nslab != 8) || g.Cp_in != a.nslab * 64) return false;
   if (a.n_phases > 2 || (a.n_phases == 2 && !a.dual)) return false;
   const int wins = a.dual ? 2 : 1;
   if (a.w_sub_step || a.e_mt_shr || a.e_mt_shl || a.w_ent_bytes != wins * TM * 64 || a.w_win_stride != TM * 64) return false;
   const int wm = pwk_wm(a.Np);
   if (!wm || a.Np % TM != 0) return false;
+  if (a.nslab == 8 && wm != 4) return false;              // (K = 512: 64-pixel tiles, four channel groups x one pixel group)
   if ((long long)g.n_pix * g.y_cp >= (1ll << 32) || (long long)g.H * g.W * (g.n_pix / std::max(1, g.OHW)) * g.Cp_in >= (1ll << 32)) return false;
   if (g.has_res && (long long)g.n_pix * g.res_cp >= (1ll << 32)) return false;
   return g.n_pix >= min_pix;
 }
 
-static int g_pwk_slots = 512;                            // pwk_slots (test-only): blocks the grid aims at (two per CU)
+static int g_pwk_slots = 256;                            // pwk_slots (test-only): blocks a launch aims at (one per CU: 3-5 tiles per block amortise a block's first-operand wait; 512 measured 0.7 % slower in flight)
 static int g_pwk_pipe = 1;                               // pwk_pipe (test-only): 0 = no requantisation between the next group's MFMAs
-void conv_pwk_set_tiles(int t) { g_pwk_slots = t > 0 ? t : 512; }
+void conv_pwk_set_tiles(int t) { g_pwk_slots = t > 0 ? t : 256; }
 void conv_pwk_set_pipe(int p) { g_pwk_pipe = p; }
+
+// tile streams of a layer: every block walks the same number of tiles (+- 1), ~`slots` blocks in all; a multiple of 8 where channel parts share
+// tiles (block ids n_streams apart then sit on one XCD)
+static int pwk_streams(const ConvArgs& a, int WM, int slots, int* n_tiles_out, int* parts_out) {
+  const int tp = pwk_tile_px(a.nslab);
+  const int n_tiles = (a.g.n_pix + tp - 1) / tp;
+  const int parts = a.Np / (32 * WM);                     // channel parts: blocks that share a pixel tile (its activations come from L2 then)
+  const int want = std::max(1, slots / parts);
+  const int per = (n_tiles + want - 1) / want;
+  int n_streams = (n_tiles + per - 1) / per;
+  if (parts > 1 && n_streams >= 8) n_streams = std::min((n_streams + 7) & ~7, n_tiles);
+  *n_tiles_out = n_tiles; *parts_out = parts;
+  return n_streams;
+}
 
 template <int KS, int WM, bool DUAL>
 static int launch_pwk2(const ConvArgs& a, int TM, hipStream_t s) {
   auto fn = conv_pwk_kernel<KS, WM, DUAL>;
-  const int n_tiles = (a.g.n_pix + 127) / 128;
-  const int parts = a.Np / (32 * WM);                     // channel parts: blocks that share a pixel tile (its activations come from L2 then)
-  // tile streams: every block walks the same number of tiles (+- 1), ~two blocks per CU in all; a multiple of 8 where parts share tiles
-  // (block ids n_streams apart then sit on one XCD)
-  const int want = std::max(1, g_pwk_slots / parts);
-  const int per = (n_tiles + want - 1) / want;
-  int n_streams = (n_tiles + per - 1) / per;
-  if (parts > 1 && n_streams >= 8) n_streams = std::min((n_streams + 7) & ~7, n_tiles);
+  int n_tiles, parts;
+  const int n_streams = pwk_streams(a, WM, g_pwk_slots, &n_tiles, &parts);
   const int grid = n_streams * parts;
   TF2_LAUNCH_NAME("conv_pwk_kernel<%d slabs,%d channel groups,%s> (%d streams of %d..%d tiles x %d channel parts)", KS, WM, DUAL ? "dual" : "single",
                   n_streams, n_tiles / n_streams, (n_tiles + n_streams - 1) / n_streams, parts);
   TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a, n_tiles, TM, n_streams, g_pwk_pipe);
+  return launch_ok() ? 0 : -1;
+}
+
+template <int KS, int WM, bool DUAL>
+static int launch_pwk_pair2(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1, hipStream_t s) {
+  auto fn = conv_pwk_pair_kernel<KS, WM, DUAL>;
+  int nt0, p0, nt1, p1;
+  // the launch aims at the same number of blocks as one row would: each row at half
+  const int ns0 = pwk_streams(a0, WM, g_pwk_slots / 2, &nt0, &p0), ns1 = pwk_streams(a1, WM, g_pwk_slots / 2, &nt1, &p1);
+  const int n0 = ns0 * p0, grid = n0 + ns1 * p1;
+  TF2_LAUNCH_NAME("conv_pwk_pair_kernel<%d slabs,%d channel groups,%s> (%d x %d + %d x %d blocks)", KS, WM, DUAL ? "dual" : "single", ns0, p0, ns1, p1);
+  TF2_LAUNCH(fn, dim3(grid), dim3(256), 0, s, a0, a1, nt0, TM0, ns0, nt1, TM1, ns1, g_pwk_pipe, n0);
   return launch_ok() ? 0 : -1;
 }
 
@@ -406,10 +451,31 @@ int launch_conv_pwk(const ConvArgs& a, int TM, void* stream) {
   const bool dual = a.dual != 0;
 #define TF2_PWK(KS_, WM_) do { return dual ? launch_pwk2<KS_, WM_, true>(a, TM, s) : launch_pwk2<KS_, WM_, false>(a, TM, s); } while (0)
 #define TF2_PWK_KS(KS_) do { if (wm == 4) TF2_PWK(KS_, 4); if (wm == 2) TF2_PWK(KS_, 2); } while (0)
+  if (a.nslab == 8 && wm == 4) TF2_PWK(8, 4);
   if (a.nslab == 4) TF2_PWK_KS(4);
   if (a.nslab == 2) TF2_PWK_KS(2);
 #undef TF2_PWK_KS
 #undef TF2_PWK
+  return 1;
+}
+
+// two rows in one launch: the same instantiation (K slabs, channel groups per block, windows)
+bool conv_pwk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1) {
+  return a0.nslab == a1.nslab && pwk_wm(a0.Np) == pwk_wm(a1.Np) && (a0.dual != 0) == (a1.dual != 0) && !a0.dbg2 && !a1.dbg2;
+}
+
+int launch_conv_pwk_pair(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!conv_pwk_pair_eligible(a0, a1)) return 1;
+  const int wm = pwk_wm(a0.Np);
+  const bool dual = a0.dual != 0;
+#define TF2_PWKP(KS_, WM_) do { return dual ? launch_pwk_pair2<KS_, WM_, true>(a0, TM0, a1, TM1, s) : launch_pwk_pair2<KS_, WM_, false>(a0, TM0, a1, TM1, s); } while (0)
+#define TF2_PWKP_KS(KS_) do { if (wm == 4) TF2_PWKP(KS_, 4); if (wm == 2) TF2_PWKP(KS_, 2); } while (0)
+  if (a0.nslab == 8 && wm == 4) TF2_PWKP(8, 4);
+  if (a0.nslab == 4) TF2_PWKP_KS(4);
+  if (a0.nslab == 2) TF2_PWKP_KS(2);
+#undef TF2_PWKP_KS
+#undef TF2_PWKP
   return 1;
 }
 

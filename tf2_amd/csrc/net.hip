@@ -562,6 +562,7 @@ void Net::load_options() {
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
+  o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
   conv_pwk_set_tiles((int)opt("pwk_slots", 0));
   conv_pwk_set_pipe((int)opt("pwk_pipe", 1));
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
@@ -760,7 +761,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, opts.pw_slabs, opts.pw_minpix)) st.sel = Launch::SEL_PW;
       // short-K pointwise rows with the pixel tile's whole K extent resident in LDS (conv_pwk.hip, round 6)
       if (opts.pwk_mode && (concurrent || opts.pwk_mode == 2) && !st.avg_fused && (st.sel == Launch::SEL_MFMA2 || (st.sel == Launch::SEL_SK && opts.pwk_sk)) &&
-          L.k == 1 && !pl->w_share && L.concat < 0 && conv_pwk_eligible(ca, pl->TM, L.k, dense ? 1 : 0, opts.pwk_minpix)) st.sel = Launch::SEL_PWK;
+          L.k == 1 && !pl->w_share && L.concat < 0 && pl->nslab <= opts.pwk_max_slabs && conv_pwk_eligible(ca, pl->TM, L.k, dense ? 1 : 0, opts.pwk_minpix)) st.sel = Launch::SEL_PWK;
     } else if (pl->kind == KIND_SHIFT) {
       st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {
@@ -1094,6 +1095,15 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         fused_done[l + 1] = 1; pair_done[l + 1] = 1;
       }
     }
+    // ... two conv_pwk rows of one instantiation (rows 11 | 12 with pwk=1)
+    if (opts.pair_mode && !fuse_now && !profiling_pairs_off && st.sel == Launch::SEL_PWK && pair_candidate(l) && !(l >= 2 && pair_candidate(l - 1))) {
+      Launch sb;
+      if (!make_conv(l + 1, sb, true)) return nullptr;
+      if (sb.sel == Launch::SEL_PWK && conv_pwk_pair_eligible(st.conv, sb.conv)) {
+        st.conv2 = sb.conv; st.TM2 = sb.TM; st.sel = Launch::SEL_PWKPAIR;
+        fused_done[l + 1] = 1; pair_done[l + 1] = 1;
+      }
+    }
     // ... the same for two split-K rows (small batches: a stage's shortcut convolution and the first 1x1 of its first bottleneck on the
     // 14 x 14 / 7 x 7 maps are both split-K launches of a few dozen blocks; round 6: batch-1 latency, two launches less)
     if (opts.pair_mode && !fuse_now && !profiling_pairs_off && st.sel == Launch::SEL_SK && !st.avg_fused && l + 1 < nl - 1 && pair_candidate(l) && !(l >= 2 && pair_candidate(l - 1))) {
@@ -1219,6 +1229,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
       switch (st.sel) {
         case Launch::SEL_PW: return launch_conv_pw(st.conv, st.TM, stream);
         case Launch::SEL_PWK: return launch_conv_pwk(st.conv, st.TM, stream);
+        case Launch::SEL_PWKPAIR: return launch_conv_pwk_pair(st.conv, st.TM, st.conv2, st.TM2, stream);
         case Launch::SEL_SK:
           if (logits && lp->logits_direct >= 0 && &st == &lp->steps[lp->logits_direct]) {
             ConvArgs cd = st.conv_direct; cd.y = logits;

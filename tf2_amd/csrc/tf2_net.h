@@ -45,9 +45,10 @@ struct WorkPlan {
 // One prepared kernel launch of a step (net.hip launch_plan): argument block + kernel selection.
 struct Launch {
   enum Kind { PREP, CONV, POOL, AVG, L2N } kind = CONV;
-  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_PWK, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_SKPAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BFIRST, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
+  enum Sel { SEL_MFMA2, SEL_SK, SEL_PW, SEL_PWK, SEL_PWKPAIR, SEL_SHIFT, SEL_BNECK, SEL_STEM, SEL_PAIR, SEL_SKPAIR, SEL_BGROUP, SEL_BGROUPF, SEL_BFIRST, SEL_BBAND, SEL_C3, SEL_FC, SEL_FIRST, SEL_FIRE } sel = SEL_MFMA2;
   int layer = -1;
   int TM = 0, signed_in = 0, mul24 = 0, shape = 0;
+  int TM2 = 0;               // SEL_PWKPAIR: the second layer's tile height
   int avg_fused = 0;         // the conv launch computes the layer's global average itself (no AVG step follows)
   ConvArgs conv{};
   ConvArgs conv2{};          // SEL_PAIR: the second (independent) layer of the launch, table row layer + 1
@@ -98,8 +99,9 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
-  int pwk_mode = 0;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
+  int pwk_mode = 1;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
   long pwk_minpix = 4096;    // pwk_minpix: fewest output pixels
+  int pwk_max_slabs = 4;     // pwk_slabs: most K slabs of a conv_pwk row (2, 4 or 8; 8 = the 512-channel rows too: 256 registers, no overlapped epilogue -- 1.3 % slower in flight than the ring kernel's pair)
   int pwk_sk = 0;            // pwk_sk: 1 = rows that would take the in-block split-K kernel as well
   int c3_mode = 1;           // c3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
   int c3_min_hw = 14;        // c3_min_hw: smallest map side that takes conv_c3
