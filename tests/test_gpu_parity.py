@@ -621,12 +621,12 @@ def test_short_k_pointwise_rows_with_the_k_extent_in_lds(r50, monkeypatch, form)
     256 -> 1024, 512 -> 2048)
     with the block's pixels resident in LDS (fetched once for every output channel) and a wave's weight fragments resident in registers per
     pass of 32 channels; two-window rows are swept window by window into one accumulator set.  The default with batches
-    in flight (rows of >= 4096 pixels; pwk=0: the ring kernel), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0, pwk_slabs=8: the 512-channel rows too, which the default leaves to the ring kernel; split_k_rows: the rows the
+    in flight (rows of >= 4096 pixels; pwk=0: the ring kernel), pwk=2 one batch at a time as well.  Here every eligible row (pwk_minpix=0, pwk_units=0: rows of any size; pwk_slabs=8: the 512-channel rows too, which the default leaves to the ring kernel; split_k_rows: the rows the
     in-block split-K kernel would take as well), stride 1 and 2, with and without residual, one- and two-window packing, FAST and generic
     requantisation, ragged pixel counts (batch 2 / 5: tiles that straddle the end), one to eight channel parts per pixel tile, one to three tiles per block;
     every layer against the oracle, batch-33 logits of repeated runs on the liveness-planned workspace, and against the plain launches."""
     alone = form == "alone"
-    set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", pwk_slabs="8", alt_conc="0" if alone else "1")
+    set_opts(monkeypatch, pwk="2" if alone else "1", pwk_minpix="0", pwk_units="0", pwk_slabs="8", alt_conc="0" if alone else "1")
     if form == "split_k_rows":
         set_opts(monkeypatch, pwk_sk="1")
     if form == "generic":

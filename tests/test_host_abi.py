@@ -211,9 +211,10 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
 
 def test_short_k_pointwise_option_changes_exactly_its_rows(golden_dir, monkeypatch):
     """pwk (conv_pwk.hip, default 1: with batches in flight): the in-flight plan sends ResNet-50's dense 1x1 rows of 128 / 256 input channels and
-    >= 4096 pixels -- 5, 8, 11 | 12 (one launch of two rows, like the ring kernel's pair), 14, 27 -- to the kernel that keeps a block's weight fragments
-    in registers and streams pixel tiles through two LDS buffers; a row whose wide-tile alternative shares its main entry's weight tiles (27) is taken on
-    the main entry; pwk_slabs=8 adds the 512-channel rows (24 | 25: measured slower, not the default).  pwk=0 gives the ring-kernel plan back, nothing else
+    enough (tile, channel part) units that a block walks several tiles -- 5, 8, 11 | 12 (one launch of two rows, like the ring kernel's pair), 14 -- to the
+    kernel that keeps a block's weight fragments in registers and streams pixel tiles through two LDS buffers; pwk_units=0 adds the rows of fewer tiles
+    (27: its wide-tile alternative shares the main entry's weight tiles, so it is taken on the main entry), pwk_slabs=8 the 512-channel rows (24 | 25) --
+    both measured slower than the ring kernel, not the default.  pwk=0 gives the ring-kernel plan back, nothing else
     moves; the one-batch plan takes it only with pwk=2.  No device needed."""
     from tests.conftest import set_opts
     t = cfg.resnet50_tables()
@@ -226,25 +227,25 @@ def test_short_k_pointwise_option_changes_exactly_its_rows(golden_dir, monkeypat
         return net.describe_launches(32, 1), net.describe_launches(32, 0)
     many1, one1 = plans()
     mine = {r["layer"]: r for r in many1 if "conv_pwk" in r["kernel"]}
-    assert sorted(mine) == [5, 8, 11, 14, 27] and not any("conv_pwk" in r["kernel"] for r in one1)
+    assert sorted(mine) == [5, 8, 11, 14] and not any("conv_pwk" in r["kernel"] for r in one1)
     assert "conv_pwk_pair_kernel" in mine[11]["kernel"] and not any(r["layer"] == 12 for r in many1)
     assert all(r["block"] == 256 and 190 <= r["grid"] <= 260 for r in mine.values()), mine       # about one block per CU, 3-7 tiles each
     assert "4 slabs,2 channel groups,dual" in mine[5]["kernel"] and "x 1 channel parts" in mine[5]["kernel"] and "of 4..4 tiles" in mine[5]["kernel"]
     assert "2 slabs,4 channel groups,single" in mine[14]["kernel"] and "x 4 channel parts" in mine[14]["kernel"]
-    assert "x 8 channel parts" in mine[27]["kernel"]
     set_opts(monkeypatch, pwk="0")
     many0, one0 = plans()
     assert not any("conv_pwk" in r["kernel"] for r in many0 + one0)
     assert [(r["layer"], r["kernel"]) for r in one1] == [(r["layer"], r["kernel"]) for r in one0]
-    rows = (5, 8, 11, 14, 27)
+    rows = (5, 8, 11, 14)
     others0 = [(r["layer"], r["kernel"], r["grid"]) for r in many0 if r["layer"] not in rows]
     others1 = [(r["layer"], r["kernel"], r["grid"]) for r in many1 if r["layer"] not in rows]
     assert others0 == others1 and len(many1) == len(many0)
-    set_opts(monkeypatch, pwk="1", pwk_slabs="8")
+    set_opts(monkeypatch, pwk="1", pwk_slabs="8", pwk_units="0")
     many8, _ = plans()
     k8 = {r["layer"]: r["kernel"] for r in many8 if "conv_pwk" in r["kernel"]}
     assert sorted(k8) == [5, 8, 11, 14, 24, 27] and "conv_pwk_pair_kernel<8 slabs" in k8[24] and not any(r["layer"] == 25 for r in many8)
-    set_opts(monkeypatch, pwk="2", pwk_slabs=None)
+    assert "x 8 channel parts" in k8[27]
+    set_opts(monkeypatch, pwk="2", pwk_slabs=None, pwk_units=None)
     _, one2 = plans()
     assert {5, 8} <= {r["layer"] for r in one2 if "conv_pwk" in r["kernel"]}
 

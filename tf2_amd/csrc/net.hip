@@ -565,6 +565,7 @@ void Net::load_options() {
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
   conv_pwk_set_tiles((int)opt("pwk_slots", 0));
   conv_pwk_set_pipe((int)opt("pwk_pipe", 1));
+  conv_pwk_set_min_units((int)opt("pwk_units", 512));
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);
   o.dbg2 = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr2", 0);
   o.dbg_layer = (int)opt("dbglayer", -1);
