@@ -91,12 +91,10 @@ def test_the_two_block_per_cu_bottleneck_kernels_compile_without_scratch(isa_fil
 
 
 def test_the_short_k_pointwise_kernel_compiles_without_scratch(isa_files):
-    """conv_pwk.hip: every instantiation of 2 / 4 K slabs (x 2 / 4 channel groups x one / two windows) and the one-window K = 512 one at a private segment of 0 -- its first forms
+    """conv_pwk.hip: every instantiation (2 / 4 K slabs x 2 / 4 channel groups, 8 slabs x 4; one / two windows; single and pair launches) at a private segment of 0 -- its first forms
     (eight waves at 128 registers beside up to 64 resident fragment registers) parked 160-470 bytes per lane; four waves per block at <= 256 registers."""
     txt = open(os.path.join(os.path.dirname(isa_files[0]), "conv_pwk.s")).read()
     seg = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", txt)}
     mine = {k: v for k, v in seg.items() if "conv_pwk_" in k}
     assert len(mine) == 20, mine                                  # (2 / 4 slabs x 2 / 4 channel groups + 8 slabs x 4) x one / two windows, single and pair launches
-    k512_dual = {k: v for k, v in mine.items() if "ILi8ELi4ELb1E" in k}
-    assert len(k512_dual) == 2 and all(v <= 32 for v in k512_dual.values()), k512_dual        # (128 fragment registers: eight words parked)
-    assert all(v == 0 for k, v in mine.items() if k not in k512_dual), mine
+    assert all(v == 0 for v in mine.values()), mine           # (the two-window K = 512 ones take 293 registers: one block per CU, launch bounds (256, 1))

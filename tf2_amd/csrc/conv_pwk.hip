@@ -349,7 +349,7 @@ __device__ __forceinline__ void conv_pwk_body(const ConvArgs& a, const int n_til
     }
   };
   bool piped = false;
-  if constexpr (NV * 8 <= 64) {
+  if constexpr (NV * 8 <= 128) {
     if (g.fast == 1 && !g.has_res && pipe) { piped = true; if (g.dbl_out) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
   }
   if (!piped) {
@@ -366,7 +366,7 @@ __device__ __forceinline__ void conv_pwk_body(const ConvArgs& a, const int n_til
 }
 
 template <int KS, int WM, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams, int pipe) {
+__global__ __launch_bounds__(256, KS * (DUAL ? 2 : 1) > 8 ? 1 : 2) void conv_pwk_kernel(ConvArgs a, int n_tiles, int tm, int n_streams, int pipe) {
   __shared__ __attribute__((aligned(1024))) int8_t pixb[2][pwk_tile_px(KS) * KS * 64];
   __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
   conv_pwk_body<KS, WM, DUAL>(a, n_tiles, tm, n_streams, pipe, (int)blockIdx.x, pixb, hdrb);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwk_kernel(ConvArgs a, int n_tile
 // two independent rows of one instantiation in one launch (conv_mfma2_pair_kernel's scheme: a stage's shortcut convolution beside the first
 // 1x1 of its first bottleneck -- same input, no dependence): blocks [0, n0) work on the first argument block, the rest on the second
 template <int KS, int WM, bool DUAL>
-__global__ __launch_bounds__(256, 2) void conv_pwk_pair_kernel(ConvArgs a0, ConvArgs a1, int n_tiles0, int tm0, int n_streams0, int n_tiles1, int tm1, int n_streams1,
+__global__ __launch_bounds__(256, KS * (DUAL ? 2 : 1) > 8 ? 1 : 2) void conv_pwk_pair_kernel(ConvArgs a0, ConvArgs a1, int n_tiles0, int tm0, int n_streams0, int n_tiles1, int tm1, int n_streams1,
                                                                int pipe, int n0) {
   __shared__ __attribute__((aligned(1024))) int8_t pixb[2][pwk_tile_px(KS) * KS * 64];
   __shared__ __attribute__((aligned(16))) int8_t hdrb[4][kPwkHdrSlot];
