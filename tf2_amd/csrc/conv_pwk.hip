@@ -1,30 +1,37 @@
-// conv_pwk.hip -- pointwise (1x1, unpadded, stride 1 or 2) INT8 convolution of SHORT K (128 or 256 input channels) with the WEIGHTS of a
-// wave's 32 output channels resident in registers and the block's pixels resident in LDS (gfx950).  Round 6.
+// conv_pwk.hip -- pointwise (1x1, unpadded, stride 1 or 2) INT8 convolution of SHORT K (128 or 256 input channels; 512 built, not the plan's
+// choice) by PERSISTENT blocks of four waves: the weights of a wave's 32 output channels resident in registers, pixel tiles streamed
+// through two LDS buffers (gfx950).  Round 6; the in-flight plan's kernel for ResNet-50 rows 5, 8, 11 | 12, 14 (option `pwk`).
 //
-// Why: with batches in flight the step waits for epilogue / VALU work first (tools/probe_pipes_inflight.py: -12.6 % without the
-// epilogues' arithmetic, -2.3 % without the MFMAs), and the ring kernel spends 12-14.5 VALU instructions per output on exactly these
-// rows -- ResNet-50's 256 -> 64, 256 -> 128 | 512, 128 -> 512, 256 -> 1024 layers -- where the requantisation needs 4-7: a 128 x 128
-// tile with two or four K steps pays a block prologue, gather arithmetic and DMA issue per step that so few steps do not amortise.
+// Why: with batches in flight a launch costs the other three batches what it HOLDS -- registers x time first.  The ring kernel runs these
+// rows (256 -> 64, 256 -> 128 | 512 / 2, 128 -> 512) as 392-1568 blocks of eight waves at 128 registers, each living ~9 us of which a third
+// is block prologue and first-operand latency, and spends 12-14.5 VALU instructions per output where the requantisation needs 4-7.  This
+// kernel runs them as 196-240 blocks of four waves at ~200 registers that walk 3-5 tiles each: a half to a third of the register-file
+// time, 6.5 VALU per output.  Alone its launches are SLOWER than the ring kernel's (13.0 against 10.4 us on row 5, 18.1 against 12.3 on
+// row 14); in flight the step gains 1.9 % (profiles/r06_experiments.txt item 21: four earlier forms, the rows it lost on, block timelines).
 //
-// First form (git history: the pixel tile's K extent in LDS, weight fragments global -> registers ONE K step ahead, passes over the
-// channel groups inside a loop over pixel tiles): bit-exact and 40-60 % SLOWER per launch than the ring kernel -- every K step of every
-// (tile, pass) waited for an L2 round trip that a 4-MFMA step cannot cover (profiles/r06_experiments.txt item 21).  Second form (git
-// history too): weights of a pass resident in registers, ALL the block's pixels loaded first, then computed: 20-45 % slower than the
-// ring kernel -- a one-round grid loads in phase and computes in phase, HBM idle while the chip computes.  This form (conv_pw.hip's
-// loop order with the B operand streamed through LDS):
+// Forms that did not make it (git history): (a) the pixel tile's K extent in LDS, weight fragments global -> registers ONE K step ahead,
+// channel passes inside the tile loop -- every K step waited for an L2 round trip that four MFMAs cannot cover (40-60 % slower per launch);
+// (b) a pass's fragments in registers, ALL the block's pixels loaded first, then computed -- a one-round grid loads in phase and computes
+// in phase (20-45 % slower); (c) this structure at two blocks per CU and one launch per row -- level with the ring kernel; (g) deeper B /
+// parameter prefetch -- 25-70 more registers, slower alone and in flight.  The form kept (conv_pw.hip's loop order, B streamed through LDS):
 //
 //   * a block owns WM x 32 output channels (channel part `part` of the layer) for its whole life: a wave's weight fragments (32 rows x K x
 //     windows: 16 .. 64 registers) and its header rows are fetched ONCE, beside the first tile's DMAs;
 //   * it walks a stream of 128-pixel tiles (tile = stream, stream + n_streams, ..): a tile's K slabs go global -> LDS by LDS-DMA
 //     ([slab][pixel][64] swizzled) into one of two buffers, the next tile's DMAs are issued right behind the barrier that hands over the
 //     current one; no memory instruction but ds_read in the K loop; the channel parts of one tile run on the same XCD (ids n_streams apart);
+//     the grid aims at ONE block per CU (pwk_slots 256); rows taken only where a block walks several tiles (pwk_units);
 //   * two-window layers are swept window by window into ONE accumulator set with the Horner shift in between;
+//   * FAST rows without a residual requantise a column group BETWEEN the next group's MFMAs (run_pipe: one wave keeps the matrix pipe and
+//     the VALU busy at once); the other rows requantise behind their own MFMAs, residual tiles loaded in front of them;
 //   * a wave's 32 header rows (requantisation parameters, final shifts, Horner shifts) sit in its own 1 KB of LDS in the form
-//     requant_epilogue.h reads (an m-tile image of 32 rows); residual tiles are loaded in front of a column group's MFMAs, 16-byte NHWC
-//     stores; addresses = kernel-argument base + one 32-bit offset.
+//     requant_epilogue.h reads (an m-tile image of 32 rows); 16-byte NHWC stores; addresses = kernel-argument base + one 32-bit offset;
+//   * two independent rows of one instantiation (a stage's shortcut convolution | the first 1x1 of its first bottleneck) share a launch
+//     (conv_pwk_pair_kernel).
 //
 // Arithmetic, packed image and epilogue are conv_mfma2.hip's (pe.cl:27-43 shift-accumulate as exponent-window int8 GEMMs, pe.cl:185-203
-// requantisation, relu.cl:54, feature_writer.cl:88-122 residual); bit-identical to it (tests/test_gpu_parity.py runs both forms).
+// requantisation, relu.cl:54, feature_writer.cl:88-122 residual); bit-identical to it (tests/test_gpu_parity.py runs both forms; the whole
+// GPU suite passes with the kernel forced onto every eligible row of every network: profiles/r06_pytest_gpu_pwk_everywhere.log).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -53,8 +60,9 @@ __host__ __device__ constexpr int pwk_tile_px(int ks) { return ks <= 4 ? 128 : 6
 }  // namespace
 
 // KS: 64-byte K slabs of the layer (2, 4 or 8); WM: channel groups of 32 of a block (waves along channels; 4 / WM pixel groups).
-// Four waves per block, two blocks per CU: two waves per SIMD with 256 registers each -- the resident fragments (up to 64 registers)
-// beside two accumulator sets and the epilogue's temporaries (eight waves at 128 registers parked 160-470 bytes per lane in scratch)
+// Four waves per block at up to 256 registers (launch bounds (256, 2); the two-window K = 512 instantiation (256, 1): 293) -- the resident
+// fragments (up to 64 registers) beside two accumulator sets, the pending group and the epilogue's temporaries (eight waves at 128 registers
+// parked 160-470 bytes per lane in scratch)
 template <int KS, int WM, bool DUAL>
 __device__ __forceinline__ void conv_pwk_body(const ConvArgs& a, const int n_tiles, const int tm, const int n_streams, const int pipe, const int bid,
                                               int8_t (*pixb)[pwk_tile_px(KS) * KS * 64], int8_t (*hdrb)[1024]) {
