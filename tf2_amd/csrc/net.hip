@@ -563,6 +563,7 @@ void Net::load_options() {
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
+  o.pwk_rows = (unsigned long long)opt("pwk_rows", 0); o.nopwk_rows = (unsigned long long)opt("nopwk_rows", 0);
   conv_pwk_set_tiles((int)opt("pwk_slots", 0));
   conv_pwk_set_pipe((int)opt("pwk_pipe", 1));
   conv_pwk_set_min_units((int)opt("pwk_units", 512));
@@ -760,9 +761,12 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       } else
       // register-resident pointwise kernel (conv_pw.hip) where the layer qualifies and no other kernel is forced
       if (opts.pw_mode && L.k == 1 && opts.sk_mode != 1 && !pl->w_share && conv_pw_eligible(ca, pl->TM, pl->nslab, L.k, dense ? 1 : 0, opts.pw_slabs, opts.pw_minpix)) st.sel = Launch::SEL_PW;
-      // short-K pointwise rows with the pixel tile's whole K extent resident in LDS (conv_pwk.hip, round 6)
+      // short-K pointwise rows on persistent four-wave blocks (conv_pwk.hip, round 6)
       if (opts.pwk_mode && (concurrent || opts.pwk_mode == 2) && !st.avg_fused && (st.sel == Launch::SEL_MFMA2 || (st.sel == Launch::SEL_SK && opts.pwk_sk)) &&
-          L.k == 1 && !pl->w_share && L.concat < 0 && pl->nslab <= opts.pwk_max_slabs && conv_pwk_eligible(ca, pl->TM, L.k, dense ? 1 : 0, opts.pwk_minpix)) st.sel = Launch::SEL_PWK;
+          L.k == 1 && !pl->w_share && L.concat < 0 && !(l < 64 && ((opts.nopwk_rows >> l) & 1))) {
+        const bool forced = l < 64 && ((opts.pwk_rows >> l) & 1);
+        if ((forced || pl->nslab <= opts.pwk_max_slabs) && conv_pwk_eligible(ca, pl->TM, L.k, dense ? 1 : 0, opts.pwk_minpix, forced)) st.sel = Launch::SEL_PWK;
+      }
     } else if (pl->kind == KIND_SHIFT) {
       st.sel = Launch::SEL_SHIFT; st.shape = pl->fast;      // fast on a shift layer: packed 4-bit filters
     } else {

@@ -428,7 +428,7 @@ bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8
 int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form
 bool conv_pw_eligible(const ConvArgs& a, int TM, int nslab, int k, int dense, int max_slab, long min_pix);   // register-resident pointwise kernel takes the layer? (max_slab / min_pix: RunOpts::pw_slabs / pw_minpix)
 int launch_conv_pw(const ConvArgs& a, int TM, void* stream);
-bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix);   // short-K pointwise kernel (conv_pwk.hip) takes the layer?
+bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix, bool force = false);   // short-K pointwise kernel (conv_pwk.hip) takes the layer?
 int launch_conv_pwk(const ConvArgs& a, int TM, void* stream);
 bool conv_pwk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1);   // two independent rows of one instantiation in one conv_pwk launch?
 int launch_conv_pwk_pair(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1, void* stream);

@@ -102,6 +102,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int pwk_mode = 1;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
   long pwk_minpix = 4096;    // pwk_minpix: fewest output pixels
   int pwk_max_slabs = 4;     // pwk_slabs: most K slabs of a conv_pwk row (2, 4 or 8; 8 = the 512-channel rows too: 256 registers, no overlapped epilogue -- 1.3 % slower in flight than the ring kernel's pair)
+  unsigned long long pwk_rows = 0, nopwk_rows = 0;   // test-only per-row switches (bit l = table row l): rows taken whatever pwk_units / pwk_minpix / pwk_slabs say, rows kept off
   int pwk_sk = 0;            // pwk_sk: 1 = rows that would take the in-block split-K kernel as well
   int c3_mode = 1;           // c3: 3x3 / 1 / pad 1 layers of big maps on conv_c3.hip (halo tile in LDS) instead of the ring kernel
   int c3_min_hw = 14;        // c3_min_hw: smallest map side that takes conv_c3
