@@ -419,7 +419,7 @@ bool conv_pwk_eligible(const ConvArgs& a, int TM, int k, int dense, long min_pix
 
 static int g_pwk_slots = 256;                            // pwk_slots (test-only): blocks a launch aims at (one per CU: 3-5 tiles per block amortise a block's first-operand wait; 512 measured 0.7 % slower in flight)
 static int g_pwk_pipe = 1;                               // pwk_pipe (test-only): 0 = no requantisation between the next group's MFMAs
-void conv_pwk_set_tiles(int t) { g_pwk_slots = t > 0 ? t : 256; }
+void conv_pwk_set_slots(int t) { g_pwk_slots = t > 0 ? t : 256; }
 void conv_pwk_set_pipe(int p) { g_pwk_pipe = p; }
 
 // tile streams of a layer: every block walks the same number of tiles (+- 1), ~`slots` blocks in all; a multiple of 8 where channel parts share

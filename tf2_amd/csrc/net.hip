@@ -564,7 +564,7 @@ void Net::load_options() {
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
   o.pwk_rows = (unsigned long long)opt("pwk_rows", 0); o.nopwk_rows = (unsigned long long)opt("nopwk_rows", 0);
-  conv_pwk_set_tiles((int)opt("pwk_slots", 0));
+  conv_pwk_set_slots((int)opt("pwk_slots", 0));
   conv_pwk_set_pipe((int)opt("pwk_pipe", 1));
   conv_pwk_set_min_units((int)opt("pwk_units", 512));
   o.dbg = (long long*)(uintptr_t)(unsigned long long)opt("dbgptr", 0);

@@ -434,7 +434,7 @@ bool conv_pwk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1);   // two in
 int launch_conv_pwk_pair(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1, void* stream);
 void conv_pwk_set_min_units(int u);   // pwk_units: fewest (tile, channel part) units of a conv_pwk row (default 512: two tiles per block and more)
 void conv_pwk_set_pipe(int p);     // pwk_pipe (test-only): 0 = the plain epilogue for every row
-void conv_pwk_set_tiles(int t);    // pwk_slots (test-only): blocks a launch aims at, 0 = 256 (one per CU)
+void conv_pwk_set_slots(int t);    // pwk_slots (test-only): blocks a launch aims at, 0 = 256 (one per CU)
 int launch_conv_shift(const ConvArgs& a, int signed_in, int mul24, int packed4, void* stream);   // packed4: a.w = 4-bit codes, a.w2 = A | B (weight_pack.cpp)
 size_t conv_shift_lds_bytes(int taps, int signed_in, int packed4);
 bool conv_bgroup_shape_ok(int HW, int C, int M);
