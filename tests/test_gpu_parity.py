@@ -233,6 +233,35 @@ def test_resnet50_stem_blocks_with_and_without_minus128(r50_rig):
     r50_rig.check_all_layers(x, layers={0, 53})
 
 
+@pytest.mark.parametrize("conc", ["1", "0"])
+def test_minus128_flags_from_the_input_preparation(r50, monkeypatch, conc):
+    """Round 6: where a step starts as prep_rewrite3_rows_kernel | conv_stem_pool_kernel | conv_bfirst_kernel (batch >= 12, both launch plans), the input
+    preparation reports per image whether a quantised element is -128 (runner.cpp:158-164 clamps to it; pe.cl:32-37 negates (int8)(-x) there), the
+    stem's blocks read their image's word instead of scanning their input tile, and conv_bfirst clears the words for the next step.  A sequence of
+    steps on ONE workspace -- no -128 anywhere, a small saturated patch in one image, another image saturated everywhere, clean again, float and
+    int8 sources -- every step's conv1 output and logits against the oracle, and against the library with the hand-over off (q128=0)."""
+    set_opts(monkeypatch, alt_conc=conc)
+    rig = Rig(*r50, 0)
+    t = rig.t
+    B = 16
+    clean = synth.synth_images(t, B, 211)
+    patch = clean.copy(); patch[5, :, 60:64, 150:170] = -1000.0
+    full = clean.copy(); full[9] = -1000.0; full[0, 1, 0, 0] = -1000.0
+    q8 = synth.synth_images(t, B, 212, kind="int8"); q8[3, 2, 223, 220:] = -128
+    got = []
+    for x in (clean, patch, clean, full, q8, clean):
+        logits = rig.run(x, keep_all=True).copy()
+        outs = rig.ref.run(x[[0, 3, 5, 9]])
+        np.testing.assert_array_equal(rig.runner.read_layer(0, B)[[0, 3, 5, 9]], outs[0])
+        np.testing.assert_array_equal(logits[[0, 3, 5, 9]], rig.ref.logits(outs))
+        got.append(logits)
+    np.testing.assert_array_equal(got[0], got[2]); np.testing.assert_array_equal(got[0], got[5])
+    set_opts(monkeypatch, q128="0")
+    plain = Rig(*r50, 0)
+    for x, want in zip((clean, patch, full, q8), (got[0], got[1], got[3], got[4])):
+        np.testing.assert_array_equal(plain.run(x, keep_all=True), want)
+
+
 def test_resnet50_full_batch32_logits_and_properties(r50_rig):
     """BASELINE batch: all 32 logits rows against the oracle; batch invariance (row i of the
     batch run == the same image run alone); determinism."""

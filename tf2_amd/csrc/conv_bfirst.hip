@@ -99,6 +99,9 @@ __global__ __launch_bounds__(512, 4) void conv_bfirst_kernel(BGroupArgs a) {
   long long* const dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;       // tools/block timelines: 100 MHz wall clock per phase
 #define BF_STAMP(i) do { if (dbg && tid == 0) dbg[i] = (long long)wall_clock64(); } while (0)
   BF_STAMP(0);
+  // (side job: this step's -128 flags of the input preparation -- PrepArgs::q128, read by conv_stem_pool_kernel, the launch in front of this
+  //  one -- are cleared for the next step: BGroupArgs::ctr carries them here, B words)
+  if (a.ctr && blockIdx.x == 0 && tid < a.B) a.ctr[tid] = 0u;
 
   // ---- prologue ---------------------------------------------------------------------------------------------------------------
   // LDS-DMA: lane l of an instruction fills pixel row l >> 2, 16-byte slot l & 3 of a 16-pixel group; with the XOR swizzle slot c'

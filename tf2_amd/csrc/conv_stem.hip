@@ -535,6 +535,7 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
   int in_rows = (cr0 + R + 2 <= a.H ? cr0 + R + 2 : a.H) - ir0;
   if (in_rows < 0) in_rows = 0;
   const int n_valid = in_rows * W;
+  const unsigned q128_word = a.q128 ? a.q128[img] : 0u;       // (read ahead of the prologue's wait)
 
   {
     const int8_t* hs = reinterpret_cast<const int8_t*>(a.hdr) + lane * 16;
@@ -561,7 +562,11 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (adbg2) ts1 = (long long)__builtin_readcyclecounter();
-  {
+  bool quirk;
+  if (a.q128) {
+    // the step's input preparation has told, per image, whether an element is -128 (PrepArgs::q128): no scan of the tile, no second barrier
+    quirk = __builtin_amdgcn_readfirstlane((int)q128_word) != 0;
+  } else {
     unsigned hit = 0;
     for (int o = tid * 16; o < halo_bytes; o += 512 * 16) {
       const i32x4 v = *reinterpret_cast<const i32x4*>(halo + o);
@@ -572,11 +577,11 @@ __global__ __launch_bounds__(512, 4) void conv_stem_pool_kernel(StemArgs a) {
       }
     }
     if (__builtin_amdgcn_ballot_w64(hit != 0) != 0 && lane == 0) *flag = 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    quirk = __builtin_amdgcn_readfirstlane(*flag) != 0;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  const bool quirk = __builtin_amdgcn_readfirstlane(*flag) != 0;
   if (adbg2) ts2 = (long long)__builtin_readcyclecounter();
 
   const int8_t* const a_base = wts + half * 512 + (lane & 31) * 16;

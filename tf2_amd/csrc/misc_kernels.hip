@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
   }
   // 15 (channel, row) lines of W elements, 4 elements per thread and pass
   const int w4 = a.W >> 2;                                 // W % 4 == 0 (launcher-checked)
+  int hit128 = 0;
   for (int i = tid; i < 15 * w4; i += 256) {
     const int line = i / w4, x4 = i - line * w4;
     const int ci = line / 5, rr = line - ci * 5;
@@ -231,9 +232,13 @@ __global__ __launch_bounds__(256) void prep_rewrite3_rows_kernel(PrepArgs a) {
         for (int j = 0; j < 4; j++) q[j] = quant_input(v[j], trans);
       }
     }
+    hit128 |= (q[0] == -128) | (q[1] == -128) | (q[2] == -128) | (q[3] == -128);
     *reinterpret_cast<unsigned*>(&img[ci][rr][kPadL + x4 * 4]) =
         (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
   }
+  // an element of this image quantised to -128: conv_stem_pool_kernel takes the (int8)(-x) != -x path for the image's blocks without
+  // scanning its input tile (every image row is seen by the blocks that own its output rows, so no -128 escapes)
+  if (a.q128 && __builtin_amdgcn_ballot_w64(hit128 != 0) != 0 && (tid & 63) == 0) atomicOr(a.q128 + b, 1u);
   __syncthreads();
   // one thread per output pixel: sub-channel k of image channel ci = pad3[2 oh + roff][2 ow + coff] (feature_trans)
   const int rsel = tid / a.OW;                             // 0 or 1: which of the block's two output rows
@@ -816,6 +821,13 @@ static inline int grid_for(long long total, int block = 256) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// launch_prep_input's choice of prep_rewrite3_rows_kernel (net.hip hands PrepArgs::q128 / StemArgs::q128 out only then)
+bool prep_takes_rows_kernel(const PrepArgs& a) {
+  const long long pixels = (long long)a.B * a.OH * a.OW;
+  return a.rewrite == 1 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31) &&
+         a.xonly && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2;
+}
+
 int launch_prep_input(const PrepArgs& a, void* stream) {
   const long long pixels = (long long)a.B * a.OH * a.OW;
   if (a.rewrite == 2 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
@@ -844,7 +856,7 @@ int launch_prep_input(const PrepArgs& a, void* stream) {
   }
   if (a.rewrite == 1 && a.C == 3 && a.half == 32 && a.y_cp == 64 && pixels * 64 < (1ll << 31) && (long long)a.B * 3 * a.H * a.W < (1ll << 31)) {
     const unsigned grid = (unsigned)((pixels + 255) / 256);
-    if (a.xonly && a.W % 4 == 0 && a.W <= 248 && 2 * a.OW <= 256 && a.OH == a.H / 2 + 2 && a.OW == a.W / 2 + 2) {
+    if (prep_takes_rows_kernel(a)) {
       const unsigned gridr = (unsigned)(a.B * ((a.OH + 1) / 2));
       TF2_LAUNCH_NAME("prep_rewrite3_rows_kernel");
       if (a.src_is_q) TF2_LAUNCH((prep_rewrite3_rows_kernel<true>), dim3(gridr), dim3(256), 0, (hipStream_t)stream, a);

@@ -215,6 +215,7 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
           if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
           wp.ctrl_bytes += (size_t)((batch + 7) / 8 * 8) * 128;
         }
+        if (opts.bfirst_mode && opts.q128_flags && !wp.ctrl_bytes) wp.ctrl_bytes = 256;      // (the control header: the -128 flags of launch_plan)
         l += 3;
         continue;
       }
@@ -560,6 +561,7 @@ void Net::load_options() {
   o.pw_slabs = (int)opt("pw_slabs", o.pw_slabs);
   o.pw_minpix = (long)opt("pw_minpix", o.pw_minpix);
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
+  o.q128_flags = (int)opt("q128", o.q128_flags);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
@@ -1211,6 +1213,17 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       aa.y_cp = to.Cp; aa.y_off = E.out_off; aa.C = round_up(L.N, 16); aa.mult = L.endpool_mult;
       lp.steps.push_back(sa);
     }
+  }
+  // The -128 flags of the input preparation (round 6): where the step starts as [prep_rewrite3_rows_kernel][conv_stem_pool_kernel][conv_bfirst_kernel],
+  // the preparation reports per image whether a quantised element is -128 (words 16 .. 16 + batch of the workspace's control header), the stem's
+  // blocks read their image's word instead of scanning their input tile behind a second barrier (0.9 of a block's 9.8 us), and conv_bfirst --
+  // the launch behind the stem -- clears the words for the next step.  A fresh (or re-used) workspace may hold anything there: a non-zero word
+  // only sends the first step's blocks down the path that is exact for every image.
+  if (opts.q128_flags && lp.steps.size() >= 3 && wp->ctrl_bytes >= 256 && batch <= 48 && lp.steps[0].kind == Launch::PREP && lp.steps[0].sel != Launch::SEL_FIRST &&
+      prep_takes_rows_kernel(lp.steps[0].prep) && lp.steps[1].kind == Launch::CONV && lp.steps[1].sel == Launch::SEL_STEM && lp.steps[1].stem.yp &&
+      lp.steps[1].layer == 0 && lp.steps[2].kind == Launch::CONV && lp.steps[2].sel == Launch::SEL_BFIRST && !lp.steps[2].bgroup.ctr) {
+    unsigned* const q = reinterpret_cast<unsigned*>(base + wp->ctrl_off) + 16;
+    lp.steps[0].prep.q128 = q; lp.steps[1].stem.q128 = q; lp.steps[2].bgroup.ctr = q;
   }
   launch_plans.push_back(std::move(lp));
   return &launch_plans.back();

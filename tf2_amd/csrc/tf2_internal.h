@@ -331,6 +331,8 @@ struct StemArgs {
   int32_t PH, PW, yp_cp, yp_off;
   int32_t pk;                // pooled rows per block (2 * pk + 1 conv rows)
   uint32_t ow_m, pw_m; int32_t ow_s, pw_s;     // set_fast_div(OW), set_fast_div(PW)
+  const unsigned* q128;      // conv_stem_pool_kernel: per image, != 0 when the image holds a -128 (written by the step's input preparation: PrepArgs::q128), or
+                             // null: the block scans its own input tile
 };
 
 struct PoolArgs {
@@ -369,6 +371,8 @@ struct PrepArgs {
   unsigned* epoch_ptr;        // side job of the step's first kernel: the workspace's step counter += 1 (the value the flags of the
                               // step's conv_bgroup launches carry) and its n_flag_words flag words (256 bytes behind it) cleared, or null
   int32_t n_flag_words;
+  unsigned* q128;             // prep_rewrite3_rows_kernel only: per image, |= 1 when a quantised element is -128 (conv_stem_pool_kernel then skips its own scan of
+                              // the input tile; conv_bfirst_kernel clears the words behind it), or null
 };
 
 // conv_fire.hip: a fire module (squeeze 1x1, then the merged expand1x1 | expand3x3 layer) in one launch of independent row bands
@@ -455,6 +459,7 @@ size_t conv_stem_lds_bytes(int nwin, int R, int W, size_t hdr_used);
 size_t conv_stem_pool_lds_bytes(int pk, int W, int OW, size_t hdr_used);
 int launch_maxpool(const PoolArgs& a, void* stream);
 int launch_global_avg(const AvgArgs& a, void* stream);
+bool prep_takes_rows_kernel(const PrepArgs& a);      // launch_prep_input runs prep_rewrite3_rows_kernel (the one that reports -128s through PrepArgs::q128)
 int launch_prep_input(const PrepArgs& a, void* stream);
 int launch_l2norm(const L2NormArgs& a, void* stream);
 const char* device_last_error();

@@ -99,6 +99,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
+  int q128_flags = 1;        // q128: the input preparation tells conv_stem_pool_kernel per image whether a -128 is there (no scan of the input tile) where the step starts prep | stem + pool | conv_bfirst: 1 (default) / 0
   int pwk_mode = 1;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
   long pwk_minpix = 4096;    // pwk_minpix: fewest output pixels
   int pwk_max_slabs = 4;     // pwk_slabs: most K slabs of a conv_pwk row (2, 4 or 8; 8 = the 512-channel rows too: 256 registers, no overlapped epilogue -- 1.3 % slower in flight than the ring kernel's pair)
