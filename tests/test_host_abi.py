@@ -204,7 +204,11 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     # bottleneck -- independent rows, the same split-K instantiation -- share a launch (round 6: 53 launches instead of 55)
     b1 = net.describe_launches(1, 0)
     assert any("conv_mfma_sk" in r["kernel"] for r in b1)
-    assert [r["layer"] for r in b1 if "conv_mfma_sk_pair_kernel" in r["kernel"]] == [24, 43] and len(b1) == 53 and not any(r["layer"] in (25, 44) for r in b1)
+    assert [r["layer"] for r in b1 if "conv_mfma_sk_pair_kernel" in r["kernel"]] == [24, 43] and not any(r["layer"] in (25, 44) for r in b1)
+    # ... and so do rows 1 | 2 and 11 | 12 on the ring kernel's 64-row four-wave shape (round 6: row 1 has a 64-row alternative for these grids): 51 launches, 340 us
+    small_pairs = [r for r in b1 if "conv_mfma2_pair_kernel<2x2 waves of 32x32" in r["kernel"]]
+    assert [r["layer"] for r in small_pairs] == [1, 11] and small_pairs[0]["grid"] == 196 + 49 and small_pairs[0]["block"] == 256 and len(b1) == 51
+    assert not any(r["layer"] in (2, 12) for r in b1)
     with pytest.raises(_lib.Tf2Error):
         net.describe_launches(0, 0)
 

@@ -557,14 +557,37 @@ static int launch_pair2(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
   return launch_ok() ? 0 : -1;
 }
 
-bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
-  if (TM0 != 128 || TM1 != 128 || a0.dense != a1.dense || a0.dual != a1.dual) return false;
-  if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
-    return true;
+// ... and the 64-row four-wave shape of the small grids (batch 1-4: ResNet-50 rows 1 | 2 on the 56 x 56 maps, round 6)
+template <bool DUAL, bool DENSE>
+static int launch_pair2_small(const ConvArgs& a0, const ConvArgs& a1, hipStream_t s) {
+  constexpr int TM = 64, TN = 64, S = 4;
+  constexpr int STAGE = ((DUAL ? 2 : 1) * TM + TN) * 64;
+  const size_t lds = (size_t)S * STAGE + (size_t)(a0.hdr_bytes > a1.hdr_bytes ? a0.hdr_bytes : a1.hdr_bytes) + 64;
+  auto fn = conv_mfma2_pair_kernel<2, 2, 32, 32, 4, 4, false, DUAL, DENSE>;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
+  if (lds > 160 * 1024) return -3;
+  const int n0 = ((a0.g.n_pix + TN - 1) / TN) * a0.n_mtiles, n1 = ((a1.g.n_pix + TN - 1) / TN) * a1.n_mtiles;
+  TF2_LAUNCH_NAME("conv_mfma2_pair_kernel<2x2 waves of 32x32,S4,%s%s> (%d + %d blocks)", DUAL ? "dual," : "", DENSE ? "dense" : "tables", n0, n1);
+  TF2_LAUNCH(fn, dim3(n0 + n1), dim3(256), lds, s, a0, a1, n0);
+  return launch_ok() ? 0 : -1;
 }
 
-int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream) {
+// both rows take the same instantiation when launched alone (launch_conv_mfma2's choice): 128-row tiles, or 64-row tiles on grids that take
+// the four-wave shape
+static bool pair_small_shape(const ConvArgs& a) { return (long)((a.g.n_pix + 255) / 256) * a.n_mtiles < 384; }
+bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1) {
+  if (TM0 != TM1 || (TM0 != 128 && TM0 != 64) || a0.dense != a1.dense || a0.dual != a1.dual) return false;
+  if ((a0.g.pad_h | a0.g.pad_w | a1.g.pad_h | a1.g.pad_w) != 0) return false;
+  if (TM0 == 64 && !(pair_small_shape(a0) && pair_small_shape(a1))) return false;
+  return true;
+}
+
+int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, int TM, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (TM == 64) {
+    if (a0.dense) return a0.dual ? launch_pair2_small<true, true>(a0, a1, s) : launch_pair2_small<false, true>(a0, a1, s);
+    return a0.dual ? launch_pair2_small<true, false>(a0, a1, s) : launch_pair2_small<false, false>(a0, a1, s);
+  }
   if (a0.dense) return a0.dual ? launch_pair2<true, true>(a0, a1, s) : launch_pair2<false, true>(a0, a1, s);
   return a0.dual ? launch_pair2<true, false>(a0, a1, s) : launch_pair2<false, false>(a0, a1, s);
 }

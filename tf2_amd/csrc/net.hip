@@ -1256,7 +1256,7 @@ int Net::issue(const Launch& st, const LaunchPlan* lp, const void* images, bool 
           return launch_conv_mfma_sk(st.conv, opts.sk8_blocks, st.shape, stream);
         case Launch::SEL_MFMA2: return launch_conv_mfma2(st.conv, st.TM, stream);
         case Launch::SEL_BNECK: return launch_conv_bneck(st.bneck, st.TM, st.shape, stream);
-        case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, stream);
+        case Launch::SEL_PAIR: return launch_conv_mfma2_pair(st.conv, st.conv2, st.TM, stream);
         case Launch::SEL_SKPAIR: return launch_conv_mfma_sk_pair(st.conv, st.conv2, opts.sk8_blocks, st.shape, stream);
         case Launch::SEL_BBAND: return launch_conv_bband(st.bband, st.bg_c, st.bg_m, stream);
         case Launch::SEL_C3: return launch_conv_c3(st.c3, stream);

@@ -426,7 +426,7 @@ int launch_conv_first_pool(const FirstArgs& f, void* stream);
 // kernel launchers (tf2_kernels.hip)
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
-int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, void* stream);
+int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, int TM, void* stream);     // (TM: both rows' tile height, 128 or 64)
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream);
 bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks);      // two independent split-K rows in one launch (same instantiation)
 int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form

@@ -282,7 +282,7 @@ tf2_status Net::pack(int mode) {
       // 128-row layer on a 28x28 map, for the tiny grids of batch 1-2 (never for the second half of a fused pair; the first
       // half keeps its one-m-tile entry for the fused launch and gets the narrow one for its own)
       const bool wide = p0.kind == KIND_MFMA && p0.TM == 64 && p0.Np % 128 == 0 && p0.Np >= 256 && L.OH * L.OW >= 16 /* not the 1x1-map FC rows: their grid never fills the chip */ && p0.fuse_next <= 0 && p0.fused_into < 0;
-      const bool narrow = p0.kind == KIND_MFMA && p0.TM == 128 && p0.fused_into < 0 && L.OH * L.OW <= 784;
+      const bool narrow = p0.kind == KIND_MFMA && p0.TM == 128 && p0.fused_into < 0 && L.OH * L.OW <= 3136;      // (round 6: 56 x 56 too -- ResNet-50 row 1 then shares its batch-1 launch with row 2)
       if (!(wide || narrow)) break;
       alt_TM = wide ? 128 : 64;
       pl = PackLayer{}; pl.fused_into = -1; pl.merged_into = -1; pl.merge_next = merge_next[l];
