@@ -449,6 +449,44 @@ def test_input_quantisation_ties_and_extremes(r50_rig):
     np.testing.assert_array_equal(rig.runner.read_layer(-1, 2), want)
 
 
+@pytest.mark.parametrize("blocks,kmax", [("8", "8"), ("64", "8"), ("64", "2")])
+def test_split_k_over_blocks_of_the_small_grids(r50, monkeypatch, blocks, kmax):
+    """conv_mfma_sk.hip KSP (round 6): split-K launches of a few blocks (batch 1: the 7 x 7 maps' 3x3 and 2048 -> 512 rows, eight blocks that each stream
+    150-300 KB of weights) split K over BLOCKS as well -- ks_parts blocks per output tile leave their 64 x 64 int32 partial tiles in the scratch area
+    (write-through stores, acknowledged), draw a device-scope ticket, and the block that draws the tile's last one adds the parts up (loads past its
+    caches) and requantises; the ticket words are cleared by the step's first kernel.  Every layer against the oracle at batch 1 / 2 / 3 (sk_kb_blocks=64:
+    the 14 x 14 and 28 x 28 rows as well, padded and two-window instantiations, 2 / 4 / 8 parts), 200 graph replays of a batch-1 step, four runners at
+    once on their own workspaces, and against sk_kb=0."""
+    set_opts(monkeypatch, sk_kb_blocks=blocks, sk_kb_max=kmax)
+    rig = Rig(*r50, 0)
+    mine = [r for r in rig.net.describe_launches(1, 0) if "K over" in r["kernel"]]
+    assert {45, 48, 51} <= {r["layer"] for r in mine} and (blocks == "8" or len(mine) >= 12)
+    for b, seed in ((1, 301), (2, 302), (3, 303)):
+        rig.check_all_layers(synth.synth_images(rig.t, b, seed, kind="int8" if b == 2 else "float"))
+    torch = _torch()
+    x1 = synth.synth_images(rig.t, 1, 304)
+    want = rig.ref.logits(rig.ref.run(x1))
+    xg = torch.from_numpy(x1).to("cuda:0")
+    fn = rig.runner.capture(xg, concurrency=0)
+    for _ in range(200):
+        fn()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rig.runner._logits.cpu().numpy(), want)
+    runners = [network.Runner(None, rig.net) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for i in range(100):
+        for r, s in zip(runners, streams):
+            with torch.cuda.stream(s):
+                r.run_batch(xg, concurrency=0)
+    torch.cuda.synchronize()
+    for r in runners:
+        np.testing.assert_array_equal(r._logits.cpu().numpy(), want)
+    set_opts(monkeypatch, sk_kb="0")
+    plain = Rig(*r50, 0)
+    assert not any("K over" in r["kernel"] for r in plain.net.describe_launches(1, 0))
+    np.testing.assert_array_equal(plain.run(x1, keep_all=False), want)
+
+
 @pytest.mark.parametrize("sk8", ["0", "100000"])
 def test_resnet50_split_k_forced(r50, monkeypatch, sk8):
     """4-way and 8-way in-block split-K (sk8 = largest grid that takes the 8-wave form)."""

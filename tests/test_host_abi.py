@@ -209,6 +209,10 @@ def test_describe_launches_is_the_librarys_own_selection(golden_dir):
     small_pairs = [r for r in b1 if "conv_mfma2_pair_kernel<2x2 waves of 32x32" in r["kernel"]]
     assert [r["layer"] for r in small_pairs] == [1, 11] and small_pairs[0]["grid"] == 196 + 49 and small_pairs[0]["block"] == 256 and len(b1) == 51
     assert not any(r["layer"] in (2, 12) for r in b1)
+    # ... and the 8-block split-K launches of the 7 x 7 maps split K over blocks as well (round 6: 64 blocks, the last ticket of a tile finishes it)
+    kb = {r["layer"]: r for r in b1 if "K over 8 blocks" in r["kernel"]}
+    assert sorted(kb) == [45, 47, 48, 50, 51] and all(r["grid"] == 64 for r in kb.values())
+    assert not any("K over" in r["kernel"] for r in net.describe_launches(2, 0)) and not any("K over" in r["kernel"] for r in one + many)
     with pytest.raises(_lib.Tf2Error):
         net.describe_launches(0, 0)
 

@@ -50,8 +50,9 @@ __device__ __forceinline__ void sk_wait_vmcnt() {
 // The body is a device function of (argument block, block index, grid size), as in conv_mfma2.hip: ONE launch can carry two independent
 // rows of the same instantiation (conv_mfma_sk_pair_kernel below, round 6: at batch 1 the shortcut convolution of stages 4 and 5 and the
 // first 1x1 of the stage's first bottleneck are both split-K launches of a few dozen blocks -- one launch boundary less each).
-template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG, bool KSP = false>
 __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int blk_x, const int nblk_x) {
+  static_assert(!KSP || (DENSE && !AVG), "K split over blocks: dense layers, no fused average");
   static_assert(!AVG || NWV == 4, "the fused global average runs with four waves");
   constexpr int TM = 64, TN = 64;
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, STAGE = A_BYTES + B_BYTES;   // per wave: 8 KiB
@@ -81,6 +82,10 @@ __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int b
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, within = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
+  // KSP: ks_parts consecutive ids (one XCD, mostly) share an output tile
+  int kpart = 0, kparts = 1;
+  if (KSP) { kparts = a.ks_parts; const int t = bid / kparts; kpart = bid - t * kparts; bid = t; }
+  const int tile_lin = bid;
   const int ntile = fast_div_u(bid, mt_m, mt_s);                 // bid / n_mtiles
   const int mtile = bid - ntile * a_n_mtiles;
   const int px0 = AVG ? ntile * g.OHW : ntile * TN;           // AVG: tile = image `ntile`, local pixels 0 .. OHW - 1
@@ -88,7 +93,11 @@ __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int b
   // this m-tile's {first, end} entry: the last two words of steps[] in its header image (weight_pack.cpp)
   typedef const __attribute__((address_space(4))) int __attribute__((ext_vector_type(2)))* cvec2_p;
   int e_begin, n_ent;
-  if (DENSE) { n_ent = a_nslab; e_begin = ((mtile << a_e_shl) >> a_e_shr) * n_ent; }
+  int ent_off = 0;                                             // KSP: first slab of this block's part of the list
+  if (DENSE) {
+    n_ent = a_nslab; e_begin = ((mtile << a_e_shl) >> a_e_shr) * n_ent;
+    if (KSP) { ent_off = kpart * n_ent / kparts; n_ent = (kpart + 1) * n_ent / kparts - ent_off; }
+  }
   else {
     const auto ee = *(cvec2_p)(unsigned long long)(ahdr + (size_t)mtile * (size_t)(a_hdr_bytes >> 2) + kPrmWordsPerRow * TM + P * TM + a_max_ent - 2);
     e_begin = ee[0];
@@ -99,7 +108,7 @@ __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int b
   const int n_virt = DUAL ? 2 * n_ent : n_ent;                         // DUAL: (entry, window) pairs
   const int n_mine = n_virt > wave ? (n_virt - wave + NWV - 1) / NWV : 0;     // (virtual) entries wave, wave+NWV, ...
   // list index of this wave's k-th item: entry, and for DUAL the fixed window h = wave & 1
-  auto ent_of = [&](int k) { const int v = wave + NWV * k; return DUAL ? (v >> 1) : v; };
+  auto ent_of = [&](int k) { const int v = wave + NWV * k; return ent_off + (DUAL ? (v >> 1) : v); };
 
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // see conv_mfma2.hip
   const int a_lane_off = (lane >> 2) * 64 + chunk * 16;
@@ -324,6 +333,48 @@ __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int b
     }
   }
 
+  // ---- KSP: this block's 64 x 64 partial tile -> memory; the block that draws the tile's last ticket adds the parts up -------------
+  // (no block waits for another: stores written through (sc0 sc1) and acknowledged, then ONE device-scope ticket per block; the last
+  //  one reads the others' parts past its caches.  (hi << d) + lo is linear in the parts: every block combines its own windows first.)
+  if (KSP) {
+    i32x4* const mine = reinterpret_cast<i32x4*>(a.ks_part) + ((size_t)(tile_lin * kparts + kpart) * 4 + wave) * 256;
+#pragma unroll
+    for (int G = 0; G < 4; G++)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(mine + G * 64 + lane), "v"(sum[G]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // waves 0-3 (the others have left): every part of the tile is in memory
+    int* const tk = reinterpret_cast<int*>(lds);               // (the reduction operands are consumed)
+    if (tid == 0) *tk = (int)__hip_atomic_fetch_add(a.ks_ctr + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *tk;
+    if (ticket != kparts - 1) return;
+    // (the other parts four at a time: sixteen loads in flight per wait -- one part per wait made seven dependent round trips past the caches)
+    const i32x4* const base_w = reinterpret_cast<const i32x4*>(a.ks_part) + ((size_t)tile_lin * kparts * 4 + wave) * 256 + lane;
+    for (int p0 = 0; p0 < kparts; p0 += 4) {
+      i32x4 v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        // (this block's own part and parts past the end: its own part again, added with weight 0)
+        const int p = p0 + q;
+        const int pp = (p < kparts && p != kpart) ? p : kpart;
+#pragma unroll
+        for (int G = 0; G < 4; G++)
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[q][G]) : "v"(base_w + (size_t)pp * 1024 + G * 64) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int p = p0 + q;
+        if (p < kparts && p != kpart) {
+#pragma unroll
+          for (int G = 0; G < 4; G++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sum[G][r] = (int)((unsigned)sum[G][r] + (unsigned)v[q][G][r]);
+        }
+      }
+    }
+  }
+
   // ---- epilogue for this wave's 32x32 sub-tile (see conv_mfma2.hip for the arithmetic) ----------
   const int lo_bound = g.relu ? 0 : -128;
   const int rlo = g.add_relu ? 0 : -128;
@@ -380,9 +431,9 @@ __device__ __forceinline__ void conv_mfma_sk_body(const ConvArgs& a, const int b
   }
 }
 
-template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG>
+template <int S, bool PADCHK, bool DUAL, int NWV, bool DENSE, bool AVG, bool KSP = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_mfma_sk_kernel(ConvArgs a) {
-  conv_mfma_sk_body<S, PADCHK, DUAL, NWV, DENSE, AVG>(a, (int)blockIdx.x, (int)gridDim.x);
+  conv_mfma_sk_body<S, PADCHK, DUAL, NWV, DENSE, AVG, KSP>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // two independent layers of the same instantiation in one launch: blocks [0, n0) work on the first argument block, the rest on the second
@@ -433,8 +484,32 @@ static SkVariant sk_variant(const ConvArgs& a, long sk8_blocks, long s3_blocks) 
   return {blocks <= s3_blocks ? 3 : 2, pad, dual, 4, dense, 0};
 }
 
+// K split over blocks as well (ConvArgs::ks_parts > 1; Net::launch_plan's choice for grids of a few blocks with long slab lists): the
+// eight-wave two-stage dense instantiation, ks_parts blocks per output tile
+template <bool PADCHK, bool DUAL>
+static int launch_sk_ksp(const ConvArgs& a, hipStream_t s) {
+  constexpr int NWV = 8, S = 2;
+  constexpr int RING_ALL = NWV * 16384;
+  const size_t lds = (size_t)RING_ALL + (size_t)a.hdr_bytes + 64;
+  auto fn = conv_mfma_sk_kernel<S, PADCHK, DUAL, NWV, true, false, true>;
+  if (!lds_attr_once(reinterpret_cast<const void*>(fn))) return -1;
+  if (lds > 160 * 1024) return -3;
+  const int ntiles = (a.g.n_pix + 63) / 64;
+  TF2_LAUNCH_NAME("conv_mfma_sk_kernel<S%d,%s%s%d waves,dense,K over %d blocks>", S, PADCHK ? "pad," : "", DUAL ? "dual," : "", NWV, a.ks_parts);
+  TF2_LAUNCH(fn, dim3(ntiles * a.n_mtiles * a.ks_parts), dim3(NWV * 64), lds, s, a);
+  return launch_ok() ? 0 : -1;
+}
+
+bool conv_mfma_sk_ksplit_eligible(const ConvArgs& a) { return a.dense && !a.g.avg_mult && !a.g.y_tail; }
+
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (a.ks_parts > 1) {
+    if (!conv_mfma_sk_ksplit_eligible(a)) return -1;
+    const bool pad = (a.g.pad_h | a.g.pad_w) != 0;
+    if (a.dual) return pad ? launch_sk_ksp<true, true>(a, s) : launch_sk_ksp<false, true>(a, s);
+    return pad ? launch_sk_ksp<true, false>(a, s) : launch_sk_ksp<false, false>(a, s);
+  }
   const SkVariant v = sk_variant(a, sk8_blocks, s3_blocks);
   if (v.avg) {
     if (v.pad) return -1;

@@ -309,6 +309,11 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
   }
   wp.ctrl_off = (top + 255) / 256 * 256 + 256;
   wp.ctrl_bytes = (wp.ctrl_bytes + 255) / 256 * 256;
+  // split-K over blocks (launch_plan: grids of at most sk_kb_blocks blocks): 1024 ticket words behind the group flags, cleared with them
+  if (packed_valid && opts.sk_kb && batch <= 8) {
+    if (!wp.ctrl_bytes) wp.ctrl_bytes = 256;
+    wp.ks_ctr_off = wp.ctrl_off + wp.ctrl_bytes; wp.ks_ctr_bytes = 4096; wp.ctrl_bytes += wp.ks_ctr_bytes;
+  }
   // partial sums of the conv_fc launches (one at a time: the largest)
   wp.scratch_off = wp.ctrl_off + wp.ctrl_bytes;
   wp.scratch_bytes = 0;
@@ -318,6 +323,11 @@ const WorkPlan* Net::plan(int batch, bool keep_all) {
       if (pl && (opts.fc_mode || pl->fc4) && fc_at(l, batch)) wp.scratch_bytes = std::max(wp.scratch_bytes, conv_fc_scratch_bytes(pl->Np, pl->nslab, pl->dual, batch));
     }
   wp.scratch_bytes = (wp.scratch_bytes + 255) / 256 * 256;
+  if (wp.ks_ctr_bytes) {                                   // partial tiles: sk_kb_blocks x sk_kb_max x 16 KB behind the conv_fc partial sums
+    wp.ks_part_off = wp.scratch_off + wp.scratch_bytes;
+    wp.ks_part_bytes = (size_t)std::max(1, opts.sk_kb_blocks) * std::max(1, opts.sk_kb_max) * 16384;
+    wp.scratch_bytes += wp.ks_part_bytes;
+  }
   wp.total_bytes = wp.scratch_off + wp.scratch_bytes;
   auto res = plans.emplace(key, std::move(wp));
   return &res.first->second;
@@ -562,6 +572,7 @@ void Net::load_options() {
   o.pw_minpix = (long)opt("pw_minpix", o.pw_minpix);
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
   o.q128_flags = (int)opt("q128", o.q128_flags);
+  o.sk_kb = (int)opt("sk_kb", o.sk_kb); o.sk_kb_blocks = (int)opt("sk_kb_blocks", o.sk_kb_blocks); o.sk_kb_max = (int)opt("sk_kb_max", o.sk_kb_max);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
@@ -1224,6 +1235,32 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       lp.steps[1].layer == 0 && lp.steps[2].kind == Launch::CONV && lp.steps[2].sel == Launch::SEL_BFIRST && !lp.steps[2].bgroup.ctr) {
     unsigned* const q = reinterpret_cast<unsigned*>(base + wp->ctrl_off) + 16;
     lp.steps[0].prep.q128 = q; lp.steps[1].stem.q128 = q; lp.steps[2].bgroup.ctr = q;
+  }
+  // Split-K launches of a few blocks (batch 1-4: the 7 x 7 and 14 x 14 maps -- 8 or 16 blocks that each stream 150-300 KB of weights) split K over
+  // BLOCKS as well (round 6, conv_mfma_sk.hip KSP): ks_parts blocks per output tile, partial tiles through the scratch area, the block that draws the
+  // tile's last ticket finishes.  The ticket words sit behind the group flags and are cleared with them by the step's first kernel.
+  if (opts.sk_kb && wp->ks_ctr_bytes && !lp.steps.empty() && lp.steps[0].kind == Launch::PREP) {
+    size_t ctr_used = 0;
+    for (size_t i = 1; i < lp.steps.size(); i++) {
+      Launch& st = lp.steps[i];
+      if (st.kind != Launch::CONV || st.sel != Launch::SEL_SK || st.avg_fused || (int)i == lp.logits_direct) continue;
+      ConvArgs& c = st.conv;
+      if (!conv_mfma_sk_ksplit_eligible(c)) continue;
+      const long blocks = (long)((c.g.n_pix + 63) / 64) * c.n_mtiles;
+      if (blocks > opts.sk_kb_blocks) continue;
+      const int n_virt = c.nslab * (c.dual ? 2 : 1);
+      int kb = 1;
+      while (kb * 2 <= opts.sk_kb_max && n_virt / (kb * 2) >= 8 && c.nslab / (kb * 2) >= 1) kb *= 2;
+      if (kb < 2 || (size_t)blocks * kb * 16384 > wp->ks_part_bytes || (ctr_used + blocks) * 4 > wp->ks_ctr_bytes) continue;
+      c.ks_parts = kb;
+      c.ks_part = reinterpret_cast<int32_t*>(base + wp->ks_part_off);
+      c.ks_ctr = reinterpret_cast<unsigned*>(base + wp->ks_ctr_off) + ctr_used;
+      ctr_used += (size_t)blocks;
+    }
+    if (ctr_used) {
+      lp.steps[0].prep.epoch_ptr = reinterpret_cast<unsigned*>(base + wp->ctrl_off);
+      lp.steps[0].prep.n_flag_words = (int32_t)((wp->ctrl_bytes - 256) / 4);
+    }
   }
   launch_plans.push_back(std::move(lp));
   return &launch_plans.back();

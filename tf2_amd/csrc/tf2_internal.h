@@ -154,6 +154,11 @@ struct ConvArgs {
   int32_t w_ent_bytes, w_win_stride, w_half_stride, w_sub_step;
   int32_t e_mt_shl, e_mt_shr;
   int32_t dense;             // 1: arithmetic gather (conv_mfma2 / conv_mfma_sk DENSE instantiations)
+  // conv_mfma_sk, K split over BLOCKS as well (round 6; small grids with long K: batch 1-4): ks_parts blocks share an output tile, each walks a part of the
+  // slab list and leaves its 64 x 64 int32 partial tile in ks_part[(tile * ks_parts + part)]; the block that draws the last ticket of ks_ctr[tile] adds them
+  // up and requantises.  ks_ctr words are zero when the launch starts (cleared by the step's first kernel: PrepArgs::epoch_ptr / n_flag_words)
+  int32_t ks_parts;          // 0 / 1: off
+  int32_t* ks_part; unsigned* ks_ctr;
   int32_t cslabs;            // Cp_in / 64
   uint32_t cs_m; int32_t cs_s; // set_fast_div(cslabs)
   uint32_t kk_m; int32_t kk_s; // set_fast_div(k)
@@ -427,6 +432,7 @@ int launch_conv_first_pool(const FirstArgs& f, void* stream);
 int launch_conv_mfma2(const ConvArgs& a, int TM, void* stream);
 bool conv_mfma2_pair_eligible(const ConvArgs& a0, int TM0, const ConvArgs& a1, int TM1);     // two independent layers, one launch
 int launch_conv_mfma2_pair(const ConvArgs& a0, const ConvArgs& a1, int TM, void* stream);     // (TM: both rows' tile height, 128 or 64)
+bool conv_mfma_sk_ksplit_eligible(const ConvArgs& a);     // the split-K kernel can split this layer's K over blocks as well (ConvArgs::ks_parts)
 int launch_conv_mfma_sk(const ConvArgs& a, long sk8_blocks, long s3_blocks, void* stream);
 bool conv_mfma_sk_pair_eligible(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks);      // two independent split-K rows in one launch (same instantiation)
 int launch_conv_mfma_sk_pair(const ConvArgs& a0, const ConvArgs& a1, long sk8_blocks, long s3_blocks, void* stream);   // sk8_blocks: largest grid that takes the 8-wave form

@@ -39,6 +39,8 @@ struct WorkPlan {
   int final_tensor = -1;
   size_t scratch_off = 0, scratch_bytes = 0;   // partial sums of conv_fc launches (behind the control area; never zeroed)
   size_t ctrl_off = 0, ctrl_bytes = 0;   // group counters of conv_bgroup launches (two words per image and launch)
+  size_t ks_ctr_off = 0, ks_ctr_bytes = 0;       // ticket words of the split-K-over-blocks launches (the tail of the control area: cleared by the step's first kernel)
+  size_t ks_part_off = 0, ks_part_bytes = 0;     // their partial tiles (part of the scratch area, one launch at a time)
   size_t total_bytes = 0;
 };
 
@@ -99,6 +101,9 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
+  int sk_kb = 1;             // sk_kb: split-K launches of at most sk_kb_blocks blocks (batch 1-4: the 7 x 7 and 14 x 14 maps) split K over blocks as well: 1 (default) / 0
+  int sk_kb_blocks = 8;      // sk_kb_blocks: largest grid (64 x 64 output tiles) that takes it (the 7 x 7 maps at batch 1: -3 us per 3x3 row; 16-block grids -- the 14 x 14 maps -- measured 0.3-1.4 us SLOWER: the exchange costs ~3 us)
+  int sk_kb_max = 8;         // sk_kb_max: most blocks per output tile
   int q128_flags = 1;        // q128: the input preparation tells conv_stem_pool_kernel per image whether a -128 is there (no scan of the input tile) where the step starts prep | stem + pool | conv_bfirst: 1 (default) / 0
   int pwk_mode = 1;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
   long pwk_minpix = 4096;    // pwk_minpix: fewest output pixels
