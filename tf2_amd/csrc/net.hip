@@ -572,6 +572,7 @@ void Net::load_options() {
   o.pw_minpix = (long)opt("pw_minpix", o.pw_minpix);
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
   o.q128_flags = (int)opt("q128", o.q128_flags);
+  o.stem_pk_small = (int)opt("stem_pk_small", o.stem_pk_small);
   o.sk_kb = (int)opt("sk_kb", o.sk_kb); o.sk_kb_blocks = (int)opt("sk_kb_blocks", o.sk_kb_blocks); o.sk_kb_max = (int)opt("sk_kb_max", o.sk_kb_max);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
@@ -1158,6 +1159,10 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
         for (int k = 1; k <= 8; k++)
           if (2 * conv_stem_pool_lds_bytes(k, L.W, L.OW, (size_t)f.hdr_used) <= 160 * 1024) pk = k;
         if (pk >= 2) {
+          // small batches: fewer pooled rows per block while the grid has fewer than ~192 blocks (batch 1: 19 bands x 2 channel halves = 38 blocks of 7 conv
+          // rows on 256 CUs; with one pooled row per block 112 blocks of 3 -- a third more conv rows in all, a shorter chain: round 6, stem_pk_small)
+          if (opts.stem_pk_small)
+            while (pk > 1 && (long)batch * 2 * ((L.PH + pk - 1) / pk) < 192) pk--;
           const TensorPlan& to = T(E.out_tensor);
           f.yp = base + to.offset; f.PH = L.PH; f.PW = L.PW; f.yp_cp = to.Cp; f.yp_off = E.out_off; f.pk = pk;
           f.bands_per_img = (L.PH + pk - 1) / pk; f.R = 2 * pk + 1;

@@ -101,6 +101,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int c3_pool = 1;           // c3_pool: a layer's 2x2 / 2 max pool inside its conv_c3 launch (tiles of TH x 32 pixels): 1 (default) / 0 its own launch
   int c3_w9 = 1;             // c3_w9: conv_c3_w9_kernel 0 never, 1 (default) where a block walks at least eight tiles, 2 wherever the layer allows it (tests)
   int pw_slabs = 1; long pw_minpix = 8192;     // conv_pw eligibility: most K slabs, fewest pixels
+  int stem_pk_small = 1;     // stem_pk_small: conv_stem_pool_kernel at small batches with fewer pooled rows per block (a grid of >= ~192 blocks): 1 (default) / 0
   int sk_kb = 1;             // sk_kb: split-K launches of at most sk_kb_blocks blocks (batch 1-4: the 7 x 7 and 14 x 14 maps) split K over blocks as well: 1 (default) / 0
   int sk_kb_blocks = 8;      // sk_kb_blocks: largest grid (64 x 64 output tiles) that takes it (the 7 x 7 maps at batch 1: -3 us per 3x3 row; 16-block grids -- the 14 x 14 maps -- measured 0.3-1.4 us SLOWER: the exchange costs ~3 us)
   int sk_kb_max = 8;         // sk_kb_max: most blocks per output tile
