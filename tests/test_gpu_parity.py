@@ -457,7 +457,7 @@ def test_split_k_over_blocks_of_the_small_grids(r50, monkeypatch, blocks, kmax):
     caches) and requantises; the ticket words are cleared by the step's first kernel.  Every layer against the oracle at batch 1 / 2 / 3 (sk_kb_blocks=64:
     the 14 x 14 and 28 x 28 rows as well, padded and two-window instantiations, 2 / 4 / 8 parts), 200 graph replays of a batch-1 step, four runners at
     once on their own workspaces, and against sk_kb=0."""
-    set_opts(monkeypatch, sk_kb_blocks=blocks, sk_kb_max=kmax)
+    set_opts(monkeypatch, sk_kb_blocks=blocks, sk_kb_max=kmax, sk_kb_min="2")
     rig = Rig(*r50, 0)
     mine = [r for r in rig.net.describe_launches(1, 0) if "K over" in r["kernel"]]
     assert {45, 48, 51} <= {r["layer"] for r in mine} and (blocks == "8" or len(mine) >= 12)

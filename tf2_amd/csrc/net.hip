@@ -573,7 +573,7 @@ void Net::load_options() {
   o.pwk_mode = (int)opt("pwk", o.pwk_mode);
   o.q128_flags = (int)opt("q128", o.q128_flags);
   o.stem_pk_small = (int)opt("stem_pk_small", o.stem_pk_small);
-  o.sk_kb = (int)opt("sk_kb", o.sk_kb); o.sk_kb_blocks = (int)opt("sk_kb_blocks", o.sk_kb_blocks); o.sk_kb_max = (int)opt("sk_kb_max", o.sk_kb_max);
+  o.sk_kb = (int)opt("sk_kb", o.sk_kb); o.sk_kb_blocks = (int)opt("sk_kb_blocks", o.sk_kb_blocks); o.sk_kb_max = (int)opt("sk_kb_max", o.sk_kb_max); o.sk_kb_min = (int)opt("sk_kb_min", o.sk_kb_min);
   o.pwk_minpix = (long)opt("pwk_minpix", o.pwk_minpix);
   o.pwk_sk = (int)opt("pwk_sk", o.pwk_sk);
   o.pwk_max_slabs = (int)opt("pwk_slabs", o.pwk_max_slabs);
@@ -1256,7 +1256,7 @@ const LaunchPlan* Net::launch_plan(int batch, const WorkPlan* wp, void* ws, bool
       const int n_virt = c.nslab * (c.dual ? 2 : 1);
       int kb = 1;
       while (kb * 2 <= opts.sk_kb_max && n_virt / (kb * 2) >= 8 && c.nslab / (kb * 2) >= 1) kb *= 2;
-      if (kb < 2 || (size_t)blocks * kb * 16384 > wp->ks_part_bytes || (ctr_used + blocks) * 4 > wp->ks_ctr_bytes) continue;
+      if (kb < 2 || kb < opts.sk_kb_min || (size_t)blocks * kb * 16384 > wp->ks_part_bytes || (ctr_used + blocks) * 4 > wp->ks_ctr_bytes) continue;
       c.ks_parts = kb;
       c.ks_part = reinterpret_cast<int32_t*>(base + wp->ks_part_off);
       c.ks_ctr = reinterpret_cast<unsigned*>(base + wp->ks_ctr_off) + ctr_used;

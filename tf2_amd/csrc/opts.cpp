@@ -31,7 +31,7 @@ const OptSpec kOptSpecs[] = {
   {"nofast", 1, "pack time: generic requantisation everywhere"}, {"nosemi", 1, "pack time: no SEMI requantisation"}, {"nounit", 1, "pack time: conv1's low window as a window"},
   {"no4bit", 1, "pack time: shift-kernel layers keep int32 weights"}, {"im2col0", 1, "0: a 3x3 first layer on 3 channels keeps its plain form"},
   {"pw", 1, "conv_pw: 1 auto, 0 never"}, {"pw_slabs", 1, "conv_pw: most K slabs"}, {"pw_minpix", 1, "conv_pw: fewest pixels"},
-  {"sk_kb", 1, "split-K launches of a few blocks split K over blocks as well (batch 1-4): 1 (default) / 0"}, {"sk_kb_blocks", 1, "... largest grid that takes it (default 8)"}, {"sk_kb_max", 1, "... most blocks per output tile (default 8)"}, {"stem_pk_small", 1, "conv_stem_pool_kernel at small batches: fewer pooled rows per block (>= ~192 blocks): 1 (default) / 0"}, {"q128", 1, "the input preparation reports -128s per image to conv_stem_pool_kernel (no scan of its input tile): 1 (default) / 0"}, {"pwk", 1, "conv_pwk (1x1 rows of 128 / 256 / 512 input channels: a block's weight fragments resident in registers, pixel tiles streamed through LDS): 0 never, 1 (default) with batches in flight, 2 one batch at a time as well"}, {"pwk_minpix", 1, "conv_pwk: fewest pixels"}, {"pwk_sk", 1, "conv_pwk: split-K rows as well"}, {"pwk_rows", 1, "bit mask of rows forced onto conv_pwk where the kernel can run them at all"}, {"nopwk_rows", 1, "... kept off it"}, {"pwk_slabs", 1, "conv_pwk: most K slabs of a row (2, 4 or 8)"}, {"pwk_units", 1, "conv_pwk: fewest (tile, channel part) units of a row (default 512)"}, {"pwk_pipe", 1, "conv_pwk: 0 = no requantisation between the next column group's MFMAs"}, {"pwk_slots", 1, "conv_pwk: blocks a launch aims at (0: 256, one per CU)"},
+  {"sk_kb", 1, "split-K launches of a few blocks split K over blocks as well (batch 1-4): 1 (default) / 0"}, {"sk_kb_blocks", 1, "... largest grid that takes it (default 8)"}, {"sk_kb_max", 1, "... most blocks per output tile (default 8)"}, {"sk_kb_min", 1, "... fewest (default 8: only slab lists long enough for eight parts)"}, {"stem_pk_small", 1, "conv_stem_pool_kernel at small batches: fewer pooled rows per block (>= ~192 blocks): 1 (default) / 0"}, {"q128", 1, "the input preparation reports -128s per image to conv_stem_pool_kernel (no scan of its input tile): 1 (default) / 0"}, {"pwk", 1, "conv_pwk (1x1 rows of 128 / 256 / 512 input channels: a block's weight fragments resident in registers, pixel tiles streamed through LDS): 0 never, 1 (default) with batches in flight, 2 one batch at a time as well"}, {"pwk_minpix", 1, "conv_pwk: fewest pixels"}, {"pwk_sk", 1, "conv_pwk: split-K rows as well"}, {"pwk_rows", 1, "bit mask of rows forced onto conv_pwk where the kernel can run them at all"}, {"nopwk_rows", 1, "... kept off it"}, {"pwk_slabs", 1, "conv_pwk: most K slabs of a row (2, 4 or 8)"}, {"pwk_units", 1, "conv_pwk: fewest (tile, channel part) units of a row (default 512)"}, {"pwk_pipe", 1, "conv_pwk: 0 = no requantisation between the next column group's MFMAs"}, {"pwk_slots", 1, "conv_pwk: blocks a launch aims at (0: 256, one per CU)"},
   {"sk", 1, "split-K kernel: 0 auto, 1 forced, 2 never"}, {"sk8", 1, "largest split-K grid in the 8-wave form"}, {"sk_s3", 1, "largest split-K grid on three ring stages, one batch at a time"}, {"sk_s3_conc", 1, "... with batches in flight"},
   {"fc_min", 1, "conv_fc: shortest K in slabs"}, {"c3_min", 1, "conv_c3: smallest grid"}, {"c3_min_hw", 1, "conv_c3: smallest map side (default 14)"}, {"c3_min256", 1, "conv_c3: smallest grid of 256-channel blocks"},
   {"fire", 1, "a fire module (squeeze + merged expands) as one launch: 0 never, 1 wherever it fits, 2 (default) on maps >= 28 wide"},

@@ -105,6 +105,7 @@ struct RunOpts {           // run-time switches, read from the TF2_AMD_OPTS snap
   int sk_kb = 1;             // sk_kb: split-K launches of at most sk_kb_blocks blocks (batch 1-4: the 7 x 7 and 14 x 14 maps) split K over blocks as well: 1 (default) / 0
   int sk_kb_blocks = 8;      // sk_kb_blocks: largest grid (64 x 64 output tiles) that takes it (the 7 x 7 maps at batch 1: -3 us per 3x3 row; 16-block grids -- the 14 x 14 maps -- measured 0.3-1.4 us SLOWER: the exchange costs ~3 us)
   int sk_kb_max = 8;         // sk_kb_max: most blocks per output tile
+  int sk_kb_min = 8;         // sk_kb_min: fewest -- the slab list must be long enough for that many parts of eight wave items (two parts of a short list cost GoogLeNet's batch-1 step 25 us)
   int q128_flags = 1;        // q128: the input preparation tells conv_stem_pool_kernel per image whether a -128 is there (no scan of the input tile) where the step starts prep | stem + pool | conv_bfirst: 1 (default) / 0
   int pwk_mode = 1;          // pwk: short-K pointwise rows (2 .. 8 slabs) on conv_pwk.hip (the pixel tile's whole K extent resident in LDS) instead of the ring kernel: 0 never, 1 (default) with batches in flight, 2 one batch at a time as well
   long pwk_minpix = 4096;    // pwk_minpix: fewest output pixels
