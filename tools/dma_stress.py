@@ -23,7 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-DMA_KERNELS = ("conv_bband_kernel", "conv_bfirst_kernel", "conv_bneck_kernel", "conv_c3_kernel", "conv_c3_w9_kernel", "fc_partial_kernel", "fc4_partial_kernel", "conv_fire_kernel", "conv_first_kernel")
+DMA_KERNELS = ("conv_bband_kernel", "conv_bfirst_kernel", "conv_bneck_kernel", "conv_c3_kernel", "conv_c3_w9_kernel", "fc_partial_kernel", "fc4_partial_kernel", "conv_fire_kernel", "conv_first_kernel",
+               "conv_pwk_kernel", "conv_pwk_pair_kernel")      # (round 6: the persistent pointwise kernel's hand-written DMA waits)
+KSP_MARK = "K over"                                           # ... and the split-K launches that exchange partial tiles between blocks (conv_mfma_sk KSP)
 BATCHES = (1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 31, 32, 33, 48, 63, 64)
 
 
@@ -65,7 +67,7 @@ def main():
             seen = set()
             for B in BATCHES:
                 for conc in (1, 0):
-                    rows = [r for r in net.describe_launches(B, conc) if r["kernel"].startswith(DMA_KERNELS)]
+                    rows = [r for r in net.describe_launches(B, conc) if r["kernel"].startswith(DMA_KERNELS) or KSP_MARK in r["kernel"]]
                     keys = {(r["kernel"].split(" (")[0], r["grid"]) for r in rows}
                     if not keys - seen:
                         continue
